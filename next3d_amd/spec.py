@@ -1,0 +1,179 @@
+"""Parameter / buffer inventory of the Next3D TriPlaneGenerator and seeded synthetic weights.
+
+The names and shapes reproduce the reference module tree (training_avatar_texture/
+triplane_next3d.py:63-109 and the constructors it calls) so that a reference ``state_dict`` /
+``misc.copy_params_and_buffers(require_all=True)`` (gen_samples_next3d.py:154) maps one-to-one
+onto this package's generator.  tests/golden/ref_state_dict_spec.txt holds the list produced
+by the reference's own constructors; tests/test_spec.py diffs the two.
+
+There is no network and no pretrained pickle (README.md:40 is a Drive link), so benchmarks and
+parity tests run on *seeded synthetic* weights: `synthetic_state_dict(seed)`.
+"""
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+W_DIM = 512
+Z_DIM = 512
+C_DIM = 25
+PLANE_RES = 256
+N_VERTS, N_UVS, N_FACES = 5023, 5118, 9976          # FLAME topology (data/demo/demo.obj)
+
+
+def channels_dict(img_resolution, channel_base=32768, channel_max=512):
+    log2 = int(np.log2(img_resolution))
+    return {2 ** i: min(channel_base // 2 ** i, channel_max) for i in range(2, log2 + 1)}
+
+
+def _fir():
+    f = torch.tensor([1., 3., 3., 1.])
+    f = torch.outer(f, f)
+    return f / f.sum()
+
+
+def _mapping(spec, p, num_ws):
+    spec[f'{p}.w_avg'] = ((W_DIM,), 'w_avg')
+    spec[f'{p}.embed.weight'] = ((W_DIM, C_DIM), 'randn')
+    spec[f'{p}.embed.bias'] = ((W_DIM,), 'bias')
+    spec[f'{p}.fc0.weight'] = ((W_DIM, Z_DIM + W_DIM), 'randn_lr')     # stored / lr_multiplier (0.01)
+    spec[f'{p}.fc0.bias'] = ((W_DIM,), 'bias')
+    spec[f'{p}.fc1.weight'] = ((W_DIM, W_DIM), 'randn_lr')
+    spec[f'{p}.fc1.bias'] = ((W_DIM,), 'bias')
+
+
+def _synth_layer(spec, p, ic, oc, res, k=3):
+    spec[f'{p}.weight'] = ((oc, ic, k, k), 'randn')
+    spec[f'{p}.noise_strength'] = ((), 'noise_strength')
+    spec[f'{p}.bias'] = ((oc,), 'bias')
+    spec[f'{p}.resample_filter'] = ((4, 4), 'fir')
+    spec[f'{p}.noise_const'] = ((res, res), 'randn')
+    spec[f'{p}.affine.weight'] = ((ic, W_DIM), 'randn')
+    spec[f'{p}.affine.bias'] = ((ic,), 'affine_bias')
+
+
+def _torgb(spec, p, ic, oc):
+    spec[f'{p}.weight'] = ((oc, ic, 1, 1), 'randn')
+    spec[f'{p}.bias'] = ((oc,), 'bias')
+    spec[f'{p}.affine.weight'] = ((ic, W_DIM), 'randn')
+    spec[f'{p}.affine.bias'] = ((ic,), 'affine_bias')
+
+
+def _block(spec, p, ic, oc, res, img_channels):
+    if ic == 0:
+        spec[f'{p}.const'] = ((oc, res, res), 'randn')
+    spec[f'{p}.resample_filter'] = ((4, 4), 'fir')
+    if ic != 0:
+        _synth_layer(spec, f'{p}.conv0', ic, oc, res)
+    _synth_layer(spec, f'{p}.conv1', oc, oc, res)
+    _torgb(spec, f'{p}.torgb', oc, img_channels)
+
+
+def _conv2d_layer(spec, p, ic, oc, k, bias=True):
+    spec[f'{p}.weight'] = ((oc, ic, k, k), 'randn')
+    if bias:
+        spec[f'{p}.bias'] = ((oc,), 'bias')
+    spec[f'{p}.resample_filter'] = ((4, 4), 'fir')
+
+
+def _synthesis(spec, p, img_channels, img_resolution=PLANE_RES):
+    cd = channels_dict(img_resolution)
+    for res in sorted(cd):
+        _block(spec, f'{p}.b{res}', cd[res // 2] if res > 4 else 0, cd[res], res, img_channels)
+    return cd
+
+
+def _styleunet(spec, p, img_channels, cond_channels, in_size, final_size):
+    cd = _synthesis(spec, p, img_channels)
+    enc_res = [2 ** i for i in range(int(np.log2(in_size)), int(np.log2(final_size)) - 1, -1)]
+    for i, res in enumerate(enc_res[:-1]):
+        e = f'{p}.encoder.{i}'
+        spec[f'{e}.resample_filter'] = ((4, 4), 'fir')
+        _conv2d_layer(spec, f'{e}.fromrgb', cond_channels, cd[res], 1, bias=False)
+        _conv2d_layer(spec, f'{e}.conv1', cd[res], cd[res], 3)
+        _conv2d_layer(spec, f'{e}.conv2', cd[res], cd[res // 2], 3)
+    for i, res in enumerate(enc_res[::-1]):
+        nc = cd[res]
+        _conv2d_layer(spec, f'{p}.fusion.{i}', nc * 2 if res > final_size else nc, nc, 3)
+
+
+def build_spec():
+    """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator."""
+    spec = OrderedDict()
+    # texture_backbone: StyleGAN2 256², 32 ch (triplane_next3d.py:63)
+    _synthesis(spec, 'texture_backbone.synthesis', 32)
+    _mapping(spec, 'texture_backbone.mapping', 14)
+    # mouth_backbone: StyleUNet 64² -> 256², final 4 (:64)
+    _styleunet(spec, 'mouth_backbone.synthesis', 32, 32, 64, 4)
+    _mapping(spec, 'mouth_backbone.mapping', 14)
+    # backbone: StyleGAN2 256², 96 ch, mapping broadcasts to 28 ws (:65)
+    _synthesis(spec, 'backbone.synthesis', 96)
+    _mapping(spec, 'backbone.mapping', 28)
+    # superresolution: SuperresolutionHybrid8XDC (superresolution.py:264-277)
+    spec['superresolution.block0.resample_filter'] = ((4, 4), 'fir')
+    _synth_layer(spec, 'superresolution.block0.conv0', 32, 256, 256)
+    _synth_layer(spec, 'superresolution.block0.conv1', 256, 256, 256)
+    _torgb(spec, 'superresolution.block0.torgb', 256, 3)
+    spec['superresolution.block1.resample_filter'] = ((4, 4), 'fir')
+    _synth_layer(spec, 'superresolution.block1.conv0', 256, 128, 512)
+    _synth_layer(spec, 'superresolution.block1.conv1', 128, 128, 512)
+    _torgb(spec, 'superresolution.block1.torgb', 128, 3)
+    # decoder: OSGDecoder (triplane_next3d.py:353-357)
+    spec['decoder.net.0.weight'] = ((64, 32), 'randn')
+    spec['decoder.net.0.bias'] = ((64,), 'bias')
+    spec['decoder.net.2.weight'] = ((33, 64), 'randn')
+    spec['decoder.net.2.bias'] = ((33,), 'bias')
+    # mesh buffers (:86-103)
+    n_dense = 2 * (PLANE_RES - 1 - 2 - 2) * (PLANE_RES - 1 - 5 - 5)
+    spec['dense_faces'] = ((1, n_dense, 3), 'mesh')
+    spec['faces'] = ((1, N_FACES, 3), 'mesh')
+    spec['raw_uvcoords'] = ((1, N_UVS, 2), 'mesh')
+    spec['uvcoords'] = ((1, N_UVS, 3), 'mesh')
+    spec['uvfaces'] = ((1, N_FACES, 3), 'mesh')
+    spec['face_uvcoords'] = ((1, N_FACES, 3, 3), 'mesh')
+    # neural_blending: StyleUNet 256² -> 256², final 32 (:109)
+    _styleunet(spec, 'neural_blending.synthesis', 32, 32, 256, 32)
+    _mapping(spec, 'neural_blending.mapping', 14)
+    return spec
+
+
+_INT_BUFFERS = ('dense_faces', 'faces', 'uvfaces')
+
+
+def _seed_for(name, seed):
+    h = hashlib.sha256(f'{seed}:{name}'.encode()).digest()
+    return int.from_bytes(h[:7], 'little')
+
+
+def synthetic_state_dict(seed=0, only=None):
+    """Seeded synthetic weights (CPU fp32).  Distributions follow the reference initialisers
+    (randn weights, affine bias 1) except that biases, noise_strength and w_avg — zero at init in
+    the reference — get small seeded non-zero values so those code paths are exercised
+    (SURVEY.md §8c).  Each tensor has its own generator, so any subset is reproducible.
+    Mesh buffers are NOT produced here (see next3d_amd.mesh.mesh_buffers)."""
+    out = OrderedDict()
+    for name, (shape, kind) in build_spec().items():
+        if kind == 'mesh' or (only is not None and not only(name)):
+            continue
+        if kind == 'fir':
+            out[name] = _fir()
+            continue
+        g = torch.Generator().manual_seed(_seed_for(name, seed))
+        r = torch.randn(shape, generator=g, dtype=torch.float32)
+        if kind == 'randn':
+            t = r
+        elif kind == 'randn_lr':
+            t = r / 0.01
+        elif kind == 'bias':
+            t = 0.1 * r
+        elif kind == 'affine_bias':
+            t = 1.0 + 0.1 * r
+        elif kind == 'noise_strength':
+            t = 0.1 * r
+        elif kind == 'w_avg':
+            t = 0.25 * r
+        else:
+            raise KeyError(kind)
+        out[name] = t
+    return out

@@ -1,0 +1,166 @@
+"""oracle/networks.py — CPU fp32 restatement of the StyleGAN2 / StyleUNet / SR networks
+(TEST INFRASTRUCTURE).  Functional style: every function takes the flat state dict `P`
+(reference parameter names) and a dotted `prefix`.  Paths relative to /root/reference;
+`tat/` = training_avatar_texture/.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+FIR = ops.setup_filter((1, 3, 3, 1))
+_LRELU_GAIN = float(np.sqrt(2))
+
+
+def channels_dict(img_resolution, channel_base=32768, channel_max=512):
+    """tat/networks_stylegan2.py:613-614."""
+    log2 = int(np.log2(img_resolution))
+    return {2 ** i: min(channel_base // 2 ** i, channel_max) for i in range(2, log2 + 1)}
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    """tat/networks_stylegan2.py:27-29."""
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def mapping_network(P, prefix, z, c, num_ws, num_layers=2, truncation_psi=1.0, truncation_cutoff=None,
+                    lr_multiplier=0.01):
+    """tat/networks_stylegan2.py:233-268 (MappingNetwork.forward)."""
+    x = normalize_2nd_moment(z.to(torch.float32))
+    y = ops.fully_connected(c.to(torch.float32), P[f'{prefix}.embed.weight'], P[f'{prefix}.embed.bias'])
+    x = torch.cat([x, normalize_2nd_moment(y)], dim=1)
+    for i in range(num_layers):
+        x = ops.fully_connected(x, P[f'{prefix}.fc{i}.weight'], P[f'{prefix}.fc{i}.bias'],
+                                activation='lrelu', lr_multiplier=lr_multiplier)
+    x = x.unsqueeze(1).repeat(1, num_ws, 1)
+    if truncation_psi != 1:
+        w_avg = P[f'{prefix}.w_avg']
+        if truncation_cutoff is None:
+            x = w_avg.lerp(x, truncation_psi)
+        else:
+            x[:, :truncation_cutoff] = w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+    return x
+
+
+def conv2d_layer(P, prefix, x, kernel_size, activation='linear', up=1, down=1, conv_clamp=None, gain=1.0):
+    """tat/networks_stylegan2.py:173-183 (Conv2dLayer.forward)."""
+    weight = P[f'{prefix}.weight']
+    bias = P.get(f'{prefix}.bias')
+    w = weight * (1.0 / np.sqrt(weight.shape[1] * kernel_size ** 2))
+    x = ops.conv2d_resample(x, w, f=FIR, up=up, down=down, padding=kernel_size // 2, flip_weight=(up == 1))
+    act_gain = ops.ACTIVATIONS[activation][2] * gain
+    act_clamp = conv_clamp * gain if conv_clamp is not None else None
+    return ops.bias_act(x, bias, act=activation, gain=act_gain, clamp=act_clamp)
+
+
+def synthesis_layer(P, prefix, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0):
+    """tat/networks_stylegan2.py:311-330 (SynthesisLayer.forward)."""
+    styles = ops.fully_connected(w, P[f'{prefix}.affine.weight'], P[f'{prefix}.affine.bias'])
+    noise = None
+    if noise_mode == 'const':
+        noise = P[f'{prefix}.noise_const'] * P[f'{prefix}.noise_strength']
+    x = ops.modulated_conv2d(x, P[f'{prefix}.weight'], styles, noise=noise, up=up, padding=1,
+                             resample_filter=FIR, flip_weight=(up == 1))
+    act_clamp = conv_clamp * gain if conv_clamp is not None else None
+    return ops.bias_act(x, P[f'{prefix}.bias'], act='lrelu', gain=_LRELU_GAIN * gain, clamp=act_clamp)
+
+
+def torgb_layer(P, prefix, x, w, conv_clamp=None):
+    """tat/networks_stylegan2.py:353-357 (ToRGBLayer.forward)."""
+    weight = P[f'{prefix}.weight']
+    styles = ops.fully_connected(w, P[f'{prefix}.affine.weight'], P[f'{prefix}.affine.bias'])
+    styles = styles * (1.0 / np.sqrt(weight.shape[1] * weight.shape[2] ** 2))
+    x = ops.modulated_conv2d(x, weight, styles, demodulate=False)
+    return ops.bias_act(x, P[f'{prefix}.bias'], clamp=conv_clamp)
+
+
+def synthesis_block(P, prefix, x, img, ws, in_channels, noise_mode='const', conv_clamp=None):
+    """tat/networks_stylegan2.py:544-588 (SynthesisBlock.forward), 'skip' architecture, fp32."""
+    w_iter = iter(ws.unbind(dim=1))
+    if in_channels == 0:
+        x = P[f'{prefix}.const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+        x = synthesis_layer(P, f'{prefix}.conv1', x, next(w_iter), noise_mode=noise_mode, conv_clamp=conv_clamp)
+    else:
+        x = synthesis_layer(P, f'{prefix}.conv0', x, next(w_iter), up=2, noise_mode=noise_mode, conv_clamp=conv_clamp)
+        x = synthesis_layer(P, f'{prefix}.conv1', x, next(w_iter), noise_mode=noise_mode, conv_clamp=conv_clamp)
+    if img is not None:
+        img = ops.upsample2d(img, FIR)
+    y = torgb_layer(P, f'{prefix}.torgb', x, next(w_iter), conv_clamp=conv_clamp)
+    img = img + y if img is not None else y
+    return x, img
+
+
+def _split_ws(ws, block_resolutions):
+    """tat/networks_stylegan2.py:632-640: first block has 1 conv, the others 2; +1 torgb each."""
+    out, idx = [], 0
+    for res in block_resolutions:
+        nconv = 1 if res == 4 else 2
+        out.append(ws.narrow(1, idx, nconv + 1))
+        idx += nconv
+    return out
+
+
+def synthesis_network(P, prefix, ws, img_resolution=256, noise_mode='const', return_features=False):
+    """tat/networks_stylegan2.py:630-645 (SynthesisNetwork.forward)."""
+    cd = channels_dict(img_resolution)
+    block_res = sorted(cd.keys())
+    x = img = None
+    for res, cur_ws in zip(block_res, _split_ws(ws.to(torch.float32), block_res)):
+        in_ch = cd[res // 2] if res > 4 else 0
+        x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode)
+    return (img, x) if return_features else img
+
+
+def encoder_res_block(P, prefix, inp, skip, downsample):
+    """tat/networks_stylegan2_styleunet.py:107-115 (EncoderResBlock.forward)."""
+    if downsample:
+        inp = ops.downsample2d(inp, FIR)
+    out = conv2d_layer(P, f'{prefix}.fromrgb', inp, 1, activation='linear')
+    if skip is not None:
+        out = out + skip
+    out = conv2d_layer(P, f'{prefix}.conv1', out, 3, activation='lrelu')
+    out = conv2d_layer(P, f'{prefix}.conv2', out, 3, activation='lrelu', down=2)
+    return inp, out
+
+
+def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, final_size=4, num_cond_res=64,
+                        noise_mode='const'):
+    """tat/networks_stylegan2_styleunet.py:554-588 (conditional SynthesisNetwork.forward)."""
+    cd = channels_dict(img_resolution)
+    block_res = sorted(cd.keys())
+    block_ws = _split_ws(ws.to(torch.float32), block_res)
+    enc_res = [2 ** i for i in range(int(np.log2(in_size)), int(np.log2(final_size)) - 1, -1)]
+
+    cond_list, cond_out = [], None
+    for i, res in enumerate(enc_res[:-1]):          # same count as the reversed iteration at :569
+        x_in, cond_out = encoder_res_block(P, f'{prefix}.encoder.{i}', x_in, cond_out,
+                                           downsample=(enc_res[:-1][i] < in_size))
+        cond_list.append(cond_out)
+    cond_list = cond_list[::-1]
+
+    x = img = None
+    start = int(np.log2(final_size)) - 1
+    for index, (res, cur_ws) in enumerate(zip(block_res[start:], block_ws[start:])):
+        if 2 ** (index + int(np.log2(final_size))) < num_cond_res:
+            if index == 0:
+                x = conv2d_layer(P, f'{prefix}.fusion.{index}', cond_list[index], 3, activation='linear')
+            else:
+                x = conv2d_layer(P, f'{prefix}.fusion.{index}', torch.cat([x, cond_list[index]], dim=1), 3,
+                                 activation='linear')
+        in_ch = cd[res // 2] if res > 4 else 0
+        x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode)
+    return img
+
+
+def superresolution(P, prefix, rgb, x, ws, force_fp32=True):
+    """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward), fp32 path, noise_mode='none'.
+    conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275)."""
+    assert force_fp32, "the oracle restates the fp32 path only"
+    ws = ws[:, -1:, :].repeat(1, 3, 1)
+    if x.shape[-1] != 128:
+        x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
+        rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
+    x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, 32, noise_mode='none', conv_clamp=256)
+    x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, 256, noise_mode='none', conv_clamp=256)
+    return rgb
