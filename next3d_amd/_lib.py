@@ -1,0 +1,131 @@
+"""ctypes binding of libn3d.so (the C ABI declared in include/n3d.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised — the
+analogue of the reference's TORCH_CHECK -> RuntimeError (torch_utils/ops/bias_act.cpp:39-55).
+The reference's `_init()` (torch_utils/ops/bias_act.py:40-50) JIT-builds a pybind plugin; here
+the library is built ahead of time by `python -m next3d_amd.build` and loaded once.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libn3d.so')
+ABI_VERSION = 1
+
+c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+ACT_IDS = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
+K_BIAS_ACT, K_UPFIRDN2D, K_CONV2D, K_FC, K_RENDER, K_RASTER, K_MISC = range(7)
+FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'misc']
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [('row_scale', c_void_p), ('noise', c_void_p), ('noise_strength', c_void_p), ('bias', c_void_p),
+                ('residual', c_void_p), ('residual_batch_stride', c_int64), ('const_scale', c_float), ('act', c_int),
+                ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+
+
+class Conv2dDesc(ctypes.Structure):
+    _fields_ = [('x', c_void_p), ('wt', c_void_p), ('style', c_void_p), ('y', c_void_p), ('workspace', c_void_p),
+                ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
+                ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
+                ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('epi', Epilogue)]
+
+
+_SIGNATURES = {
+    'n3d_abi_version': (c_int, []),
+    'n3d_last_error': (ctypes.c_char_p, []),
+    'n3d_prof_enable': (c_int, [c_int]),
+    'n3d_prof_reset': (c_int, []),
+    'n3d_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_double),
+                              ctypes.POINTER(c_double)]),
+    'n3d_bias_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float,
+                             c_float, c_void_p]),
+    'n3d_upfirdn2d': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 15 + [c_float, c_int64, c_int64,
+                              ctypes.POINTER(Epilogue), c_void_p]),
+    'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
+    'n3d_fc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
+                       c_float, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/n3d.h declares; tests check every one resolves in the built library."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libn3d.so once.  Raises RuntimeError (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: build it with `python -m next3d_amd.build` '
+                               '(there is no CPU or PyTorch fallback for the n3d ops)')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)           # AttributeError -> missing symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.n3d_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libn3d.so ABI {handle.n3d_abi_version()} != binding ABI {ABI_VERSION}; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('libn3d: ' + lib().n3d_last_error().decode())
+
+
+def stream():
+    """The HIP stream kernels are enqueued on = torch's current stream (as the reference plugins do with
+    at::cuda::getCurrentCUDAStream(), bias_act.cpp:88-94)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != 'cuda':
+            raise RuntimeError('n3d ops run on a HIP device only (got a %s tensor); the CPU restatement lives in '
+                               'oracle/ and is test infrastructure, not a fallback' % t.device.type)
+
+
+def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, residual=None, const_scale=1.0,
+                  act='linear', alpha=None, gain=None, clamp=None):
+    from .torch_utils.ops.bias_act import activation_funcs
+    spec = activation_funcs[act]
+    e = Epilogue()
+    e.row_scale, e.noise, e.noise_strength, e.bias, e.residual = ptr(row_scale), ptr(noise), ptr(noise_strength), ptr(bias), ptr(residual)
+    e.residual_batch_stride = residual.stride(0) if residual is not None else 0
+    e.const_scale = float(const_scale)
+    e.act = ACT_IDS[act]
+    e.alpha = float(spec.def_alpha if alpha is None else alpha)
+    e.gain = float(spec.def_gain if gain is None else gain)
+    e.clamp = float(-1 if clamp is None else clamp)
+    return e
+
+
+def prof_enable(on=True):
+    check(lib().n3d_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    check(lib().n3d_prof_reset())
+
+
+def prof_read():
+    """{family: dict(ms, launches, flops, bytes)} since the last reset (synchronises the recorded events)."""
+    out = {}
+    for fam, name in enumerate(FAMILY_NAMES):
+        ms, n, fl, by = c_double(), c_int64(), c_double(), c_double()
+        check(lib().n3d_prof_read(fam, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+        out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

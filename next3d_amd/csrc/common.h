@@ -1,0 +1,62 @@
+// Shared host/device helpers for libn3d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/n3d.h"
+
+// ---- host-side error + profiling plumbing (runtime.hip)
+int n3d_set_error(const char* fmt, ...);
+struct N3dProfScope {          // brackets the launches of one entry point with events on the launch stream
+    N3dProfScope(int family, hipStream_t s, double flops, double bytes);
+    ~N3dProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
+#define N3D_CHECK(cond, ...)                         \
+    do {                                             \
+        if (!(cond)) return n3d_set_error(__VA_ARGS__); \
+    } while (0)
+
+#define N3D_LAUNCH_CHECK()                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return n3d_set_error("HIP launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device-side: activation + the fused epilogue (n3d_epilogue in n3d.h)
+__device__ __forceinline__ float n3d_act(float x, int act, float alpha) {
+    // forward formulas of bias_act.cu:27-150 / bias_act.py:23-33
+    switch (act) {
+        case N3D_ACT_RELU: return x > 0.f ? x : 0.f;
+        case N3D_ACT_LRELU: return x > 0.f ? x : x * alpha;
+        case N3D_ACT_TANH: return tanhf(x);
+        case N3D_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case N3D_ACT_ELU: return x > 0.f ? x : expf(x) - 1.f;
+        case N3D_ACT_SELU: {
+            const float s = 1.0507009873554804934193349852946f, a = 1.6732632423543772848170429916717f;
+            return x > 0.f ? s * x : s * a * (expf(x) - 1.f);
+        }
+        case N3D_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        case N3D_ACT_SWISH: return x / (1.f + expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue& e, int n, int o, int O, int oy, int ox,
+                                                    int OH, int OW) {
+    float sc = e.const_scale;
+    if (e.row_scale) sc *= e.row_scale[(int64_t)n * O + o];
+    v *= sc;
+    if (e.noise) v += e.noise[(int64_t)oy * OW + ox] * e.noise_strength[0];
+    if (e.bias) v += e.bias[o];
+    v = n3d_act(v, e.act, e.alpha) * e.gain;
+    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
+    if (e.residual) v += e.residual[(int64_t)n * e.residual_batch_stride + ((int64_t)o * OH + oy) * OW + ox];
+    return v;
+}

@@ -1,0 +1,348 @@
+// conv2d for gfx950: fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32) — the one
+// dense contraction of the Next3D generator (~765 GFLOP/frame).  Bound: fp32 MFMA (157 TFLOP/s).
+//
+//   C[o, p] = sum_{tap, i} Wt[tap][i][o] * (style[n,i] * X[n, i, y(p)*S + dy(tap) - P, x(p)*S + dx(tap) - P])
+//
+// One 256-thread workgroup (4 waves) owns BM output channels x (TH x TW = 128) output pixels of one
+// sample.  Per stage of ICB input channels it stages
+//   As[tap][ic][BM]  : weight slab, K-major (the layout n3d_conv2d_prep_weight produces) -> 16-byte global loads,
+//   Bs[ic][PH][PWP]  : the input patch WITH halo, loaded once and re-used by all k*k taps (9x fewer activation
+//                      reads than an im2col GEMM), modulated by style[n,i] on the way in (modulated_conv2d's
+//                      per-sample weights w*s become per-sample activations x*s: the weight slab is shared by
+//                      the whole batch),
+// into LDS, while the next stage's global loads are already in flight in registers.  Every lane then feeds the
+// MFMA with one A and one B float per k-step of 2 channels: lanes 0-31 / 32-63 read two adjacent channel rows,
+// 32 consecutive floats each -> conflict-free ds_read_b32.  fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD,
+// so LDS bandwidth is far from binding; what matters is keeping 4 independent accumulators per wave busy.
+// The epilogue (demodulation, noise, bias, activation, clamp, residual) runs on the accumulators in registers.
+//
+// Replaces F.conv2d / F.conv_transpose2d as called by conv2d_resample (reference
+// torch_utils/ops/conv2d_resample.py:96-136) from modulated_conv2d (training_avatar_texture/networks_stylegan2.py:34-91).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* x; const float* wt; const float* style; float* y; float* partial;
+    int N, I, O, H, W, OH, OW;       // OH/OW: full output dims
+    int GH, GW;                      // per-phase output grid (mode 2: H+1, W+1; else OH, OW)
+    int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
+    int64_t xbs, ybs;
+    n3d_epilogue epi;
+};
+
+// MODE 0: stride 1 pad KS/2 | MODE 1: stride 2 pad 0 | MODE 2: transposed stride 2 (4 polyphase sub-convolutions)
+template <int MT, int NT, int WM, int WN, int TH, int TW, int ICB, int KS, int MODE>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    static_assert(BN == TH * TW, "pixel tile must match the GEMM N tile");
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int S = (MODE == 1) ? 2 : 1;
+    constexpr int P = (MODE == 1) ? 0 : KS / 2;
+    constexpr int PH = (TH - 1) * S + KS;
+    constexpr int PW = (TW - 1) * S + KS;
+    constexpr int PWP = PW + ((PW % 2 == 0) ? 1 : 0) + ((TW < 32) ? 2 : 0);   // odd-ish row pitch spreads rows over banks
+    constexpr int TAPS = KS * KS;
+    constexpr int A_ELEMS = TAPS * ICB * BM;
+    constexpr int B_ELEMS = ICB * PH * PW;
+    constexpr int A_VEC = A_ELEMS / 4;
+    constexpr int A_PER_T = (A_VEC + 255) / 256;
+    constexpr int B_PER_T = (B_ELEMS + 255) / 256;
+
+    __shared__ float As[A_ELEMS];
+    __shared__ float Bs[ICB * PH * PWP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int m0 = blockIdx.y * BM;
+    int z = blockIdx.z;
+    const int ks = z % p.ksplit; z /= p.ksplit;
+    const int phase = z % p.nphase;
+    const int n = z / p.nphase;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // tap table for this block (uniform): weight plane + patch offset of tap t
+    int ntaps = TAPS, pa = 0, pb = 0, nkx = KS;
+    if (MODE == 2) {
+        pa = phase >> 1; pb = phase & 1;
+        const int nky = pa ? 1 : 2;
+        nkx = pb ? 1 : 2;
+        ntaps = nky * nkx;
+    }
+    auto tap_wplane = [&](int t) -> int {
+        if (MODE != 2) return t;
+        const int ti = t / nkx, tj = t % nkx;
+        const int ky = pa ? 1 : 2 * ti, kx = pb ? 1 : 2 * tj;
+        return ky * 3 + kx;
+    };
+    auto tap_boff = [&](int t) -> int {
+        if (MODE != 2) return (t / KS) * PWP + (t % KS);
+        const int ti = t / nkx, tj = t % nkx;
+        const int dy = pa ? 1 : 1 - ti, dx = pb ? 1 : 1 - tj;   // ky=0 -> input row y (dy=1), ky=2 -> row y-1 (dy=0)
+        return dy * PWP + dx;
+    };
+
+    const int ic_begin = ks * p.ic_per_split;
+    const int ic_end = min(p.I, ic_begin + p.ic_per_split);
+    const int nstage = (ic_end - ic_begin + ICB - 1) / ICB;
+
+    const float* xn = p.x + (int64_t)n * p.xbs;
+    const int iy0 = y0 * S - P, ix0 = x0 * S - P;
+    const bool o_vec = (p.O & 3) == 0;
+
+    float4 ra[A_PER_T];
+    float rb[B_PER_T];
+
+    auto load_stage = [&](int st) {
+        const int ic0 = ic_begin + st * ICB;
+        // A: rows (t, ic) of BM contiguous floats
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int v = tid + j * 256;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < A_VEC) {
+                const int row = v / (BM / 4), mv = (v % (BM / 4)) * 4;
+                const int t = row / ICB, ic = row % ICB;
+                const int ci = ic0 + ic, o = m0 + mv;
+                if (t < ntaps && ci < ic_end) {
+                    const float* src = p.wt + ((int64_t)tap_wplane(t) * p.I + ci) * p.O + o;
+                    if (o_vec) {
+                        if (o < p.O) val = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (o + 0 < p.O) val.x = src[0];
+                        if (o + 1 < p.O) val.y = src[1];
+                        if (o + 2 < p.O) val.z = src[2];
+                        if (o + 3 < p.O) val.w = src[3];
+                    }
+                }
+            }
+            ra[j] = val;
+        }
+        // B: patch with halo, modulated
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            float val = 0.f;
+            if (e < B_ELEMS) {
+                const int ic = e / (PH * PW), rem = e % (PH * PW);
+                const int r = rem / PW, q = rem % PW;
+                const int ci = ic0 + ic, iy = iy0 + r, ix = ix0 + q;
+                if (ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    val = xn[((int64_t)ci * p.H + iy) * p.W + ix];
+                    if (p.style) val *= p.style[(int64_t)n * p.I + ci];
+                }
+            }
+            rb[j] = val;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int v = tid + j * 256;
+            if (v < A_VEC) *reinterpret_cast<float4*>(&As[v * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            if (e < B_ELEMS) {
+                const int ic = e / (PH * PW), rem = e % (PH * PW);
+                Bs[(ic * PH + rem / PW) * PWP + rem % PW] = rb[j];
+            }
+        }
+    };
+
+    // per-lane fragment addressing
+    const int half = lane >> 5, l31 = lane & 31;
+    int a_off[MT], b_off[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_off[mt] = (wm * MT + mt) * 32 + l31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pix = (wn * NT + nt) * 32 + l31;
+        b_off[nt] = ((pix / TW) * S) * PWP + (pix % TW) * S;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    if (nstage > 0) {
+        load_stage(0);
+        store_stage();
+    }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_stage(st + 1);
+        for (int t = 0; t < ntaps; ++t) {
+            const float* At = As + (t * ICB + half) * BM;
+            const float* Bt = Bs + half * (PH * PWP) + tap_boff(t);
+#pragma unroll
+            for (int kk = 0; kk < ICB / 2; ++kk) {
+                float a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = At[kk * 2 * BM + a_off[mt]];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = Bt[kk * 2 * (PH * PWP) + b_off[nt]];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (st + 1 < nstage) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pix = (wn * NT + nt) * 32 + l31;
+        const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+        int oy = gy, ox = gx;
+        bool ok = gy < p.GH && gx < p.GW;
+        if (MODE == 2) {
+            oy = 2 * gy + pa; ox = 2 * gx + pb;
+            ok = ok && oy < p.OH && ox < p.OW;
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.O) continue;
+                float v = acc[mt][nt][r];
+                if (p.partial) {
+                    p.partial[(((int64_t)ks * p.N + n) * p.O + o) * ((int64_t)p.OH * p.OW) + (int64_t)oy * p.OW + ox] = v;
+                } else {
+                    v = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
+                    p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.OW + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+// split-K second pass: y = epilogue(sum_ks partial[ks])
+__global__ __launch_bounds__(256) void conv2d_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y,
+                                                                      int ksplit, int N, int O, int OH, int OW, int64_t ybs,
+                                                                      n3d_epilogue epi) {
+    const int64_t plane = (int64_t)OH * OW;
+    const int64_t total = (int64_t)N * O * plane;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += partial[(int64_t)k * total + i];
+        const int64_t pl = i / plane;
+        const int pix = (int)(i % plane);
+        const int n = (int)(pl / O), o = (int)(pl % O);
+        const int oy = pix / OW, ox = pix % OW;
+        v = n3d_apply_epilogue(v, epi, n, o, O, oy, ox, OH, OW);
+        y[(int64_t)n * ybs + ((int64_t)o * OH + oy) * OW + ox] = v;
+    }
+}
+
+// w [O,I,k,k] -> wt [k*k][I][O];  wsq[o,i] = sum_k w^2
+__global__ __launch_bounds__(256) void conv2d_prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                 float* __restrict__ wsq, int O, int I, int KK) {
+    const int64_t total = (int64_t)O * I;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / O), o = (int)(e % O);      // o fastest -> coalesced writes
+        const float* src = w + ((int64_t)o * I + i) * KK;
+        float s = 0.f;
+        for (int t = 0; t < KK; ++t) {
+            const float v = src[t];
+            wt[((int64_t)t * I + i) * O + o] = v;
+            s += v * v;
+        }
+        if (wsq) wsq[(int64_t)o * I + i] = s;
+    }
+}
+
+extern "C" int n3d_conv2d_prep_weight(const float* w, float* wt, float* wsq, int O, int I, int ksize, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(w && wt && O > 0 && I > 0 && (ksize == 1 || ksize == 3), "conv2d_prep_weight: bad arguments");
+    const int64_t total = (int64_t)O * I;
+    const int grid = (int)(cdiv64(total, 256) > 4096 ? 4096 : cdiv64(total, 256));
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 8.0 * total * ksize * ksize);
+    hipLaunchKernelGGL(conv2d_prep_weight_kernel, dim3(grid), dim3(256), 0, stream, w, wt, wsq, O, I, ksize * ksize);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MT, int NT, int WM, int WN, int TH, int TW, int ICB, int KS, int MODE>
+static int launch_conv(ConvParams& p, int ksplit_req, hipStream_t stream) {
+    constexpr int BM = WM * MT * 32;
+    p.tiles_x = cdiv(p.GW, TW);
+    p.tiles_y = cdiv(p.GH, TH);
+    const int max_split = cdiv(p.I, ICB);
+    p.ksplit = ksplit_req < 1 ? 1 : (ksplit_req > max_split ? max_split : ksplit_req);
+    p.ic_per_split = cdiv(cdiv(p.I, p.ksplit), ICB) * ICB;
+    p.ksplit = cdiv(p.I, p.ic_per_split);
+    if (p.ksplit == 1) p.partial = nullptr;
+    const int64_t gz = (int64_t)p.N * p.nphase * p.ksplit;
+    if (gz > 65535) return n3d_set_error("conv2d: grid.z %lld too large", (long long)gz);
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.O, BM), (unsigned)gz);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<MT, NT, WM, WN, TH, TW, ICB, KS, MODE>), grid, dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(d != nullptr, "conv2d: null descriptor");
+    N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0, "conv2d: bad shape");
+    N3D_CHECK(d->ksize == 1 || d->ksize == 3, "conv2d: ksize %d unsupported (1 or 3)", d->ksize);
+    N3D_CHECK(d->mode >= 0 && d->mode <= 2, "conv2d: unknown mode %d", d->mode);
+    N3D_CHECK(d->mode == 0 || d->ksize == 3, "conv2d: strided / transposed modes need ksize 3");
+    N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d: unknown activation %d", d->epi.act);
+    N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d: noise without noise_strength");
+    if (d->N == 0) return 0;
+    N3D_CHECK(d->x && d->wt && d->y, "conv2d: null tensor");
+    N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d: wt must be 16-byte aligned");
+    ConvParams p;
+    p.x = d->x; p.wt = d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.H = d->H; p.W = d->W;
+    p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
+    p.nphase = 1;
+    if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }
+    else if (d->mode == 1) {
+        N3D_CHECK(d->H >= 3 && d->W >= 3, "conv2d: input too small for stride-2 3x3");
+        p.OH = (d->H - 3) / 2 + 1; p.OW = (d->W - 3) / 2 + 1; p.GH = p.OH; p.GW = p.OW;
+    } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
+    N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");
+    const bool wide = p.GW > 16;
+    const double flops = 2.0 * d->N * (double)d->O * d->I * d->ksize * d->ksize *
+                         (d->mode == 2 ? (double)d->H * d->W : (double)p.OH * p.OW);
+    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW +
+                                (double)d->O * d->I * d->ksize * d->ksize);
+    N3dProfScope prof(N3D_K_CONV2D, stream, flops, bytes);
+    int rc;
+    if (d->ksize == 3) {
+        if (d->mode == 0)      rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 0>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 0>(p, d->ksplit, stream);
+        else if (d->mode == 1) rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 1>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 1>(p, d->ksplit, stream);
+        else                   rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 2>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 2>(p, d->ksplit, stream);
+    } else {
+        if (d->O > 64) rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 32, 1, 0>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 32, 1, 0>(p, d->ksplit, stream);
+        else           rc = wide ? launch_conv<1, 1, 1, 4, 4, 32, 32, 1, 0>(p, d->ksplit, stream) : launch_conv<1, 1, 1, 4, 8, 16, 32, 1, 0>(p, d->ksplit, stream);
+    }
+    if (rc) return rc;
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
+        const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
+        hipLaunchKernelGGL(conv2d_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, (const float*)p.partial, p.y,
+                           p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.epi);
+        N3D_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,103 @@
+// upfirdn2d for gfx950: zero-insert upsample -> pad/crop -> 2-D FIR -> decimate, per (n,c) plane, with an
+// optional fused epilogue (noise + bias + activation + clamp + residual) so that the up-sampling
+// StyleGAN2 layer needs one pass over its activation instead of three.
+// HBM-bound (algorithmic bytes = input + output): each workgroup produces a TILE_H x TILE_W output tile of
+// one plane from an LDS-staged input footprint, so every input element is fetched from HBM once per tile
+// and the fh*fw taps are served from LDS; rows are read/written as contiguous 64-lane segments.
+// Replaces upfirdn2d_plugin.upfirdn2d (reference torch_utils/ops/upfirdn2d.cpp:20, upfirdn2d.cu:33-207);
+// index arithmetic follows upfirdn2d.cu:47-67: out[o] = sum_i x[i] * f[fw-1-(i*up+pad0-o*down)] (flip: f[k]).
+#include "common.h"
+
+#define UF_TILE_W 64
+#define UF_TILE_H 8
+#define UF_MAX_TAPS 1024
+#define UF_MAX_FOOT 4608   // floats of LDS input footprint per tile
+
+struct UfParams {
+    const float* x; const float* f; float* y;
+    int N, C, H, W, OH, OW, fh, fw, upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+    int64_t xbs, ybs;
+    int has_epi;
+    n3d_epilogue epi;
+    int tiles_x, tiles_y, foot_w, foot_h;
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+__device__ __forceinline__ int ceil_div(int a, int b) { return -floor_div(-a, b); }
+
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
+    __shared__ float s_f[UF_MAX_TAPS];
+    __shared__ float s_x[UF_MAX_FOOT];
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int ox0 = tx * UF_TILE_W, oy0 = ty * UF_TILE_H;
+
+    // taps, pre-flipped so that the inner loop is a plain correlation over the (virtual) upsampled+padded signal
+    for (int t = threadIdx.x; t < p.fh * p.fw; t += blockDim.x) {
+        const int ky = t / p.fw, kx = t % p.fw;
+        s_f[t] = p.flip ? p.f[t] : p.f[(p.fh - 1 - ky) * p.fw + (p.fw - 1 - kx)];
+    }
+    // input footprint of this tile: rows iy in [iy_lo, iy_lo + foot_h), cols likewise
+    const int ix_lo = ceil_div(ox0 * p.downx - p.padx0, p.upx);
+    const int iy_lo = ceil_div(oy0 * p.downy - p.pady0, p.upy);
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.W;
+    for (int e = threadIdx.x; e < p.foot_h * p.foot_w; e += blockDim.x) {
+        const int r = e / p.foot_w, q = e % p.foot_w;
+        const int iy = iy_lo + r, ix = ix_lo + q;
+        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.W + ix] : 0.f;
+    }
+    __syncthreads();
+
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+    for (int e = threadIdx.x; e < UF_TILE_H * UF_TILE_W; e += blockDim.x) {
+        const int oy = oy0 + e / UF_TILE_W, ox = ox0 + e % UF_TILE_W;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        // padded/upsampled coordinate q = i*up + pad0 ; window [o*down, o*down + f - 1]
+        const int qy0 = oy * p.downy, qx0 = ox * p.downx;
+        const int iy_a = ceil_div(qy0 - p.pady0, p.upy), iy_b = floor_div(qy0 + p.fh - 1 - p.pady0, p.upy);
+        const int ix_a = ceil_div(qx0 - p.padx0, p.upx), ix_b = floor_div(qx0 + p.fw - 1 - p.padx0, p.upx);
+        float v = 0.f;
+        for (int iy = iy_a; iy <= iy_b; ++iy) {
+            const int ky = iy * p.upy + p.pady0 - qy0;
+            const float* frow = s_f + ky * p.fw;
+            const float* xrow = s_x + (iy - iy_lo) * p.foot_w - ix_lo;
+            for (int ix = ix_a; ix <= ix_b; ++ix) v += xrow[ix] * frow[ix * p.upx + p.padx0 - qx0];
+        }
+        v *= p.gain;
+        if (p.has_epi) v = n3d_apply_epilogue(v, p.epi, n, c, p.C, oy, ox, p.OH, p.OW);
+        yp[(int64_t)oy * p.OW + ox] = v;
+    }
+}
+
+extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
+                             int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                             int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && H > 0 && W > 0, "upfirdn2d: bad input shape");
+    N3D_CHECK(fh >= 1 && fw >= 1 && fh * fw <= UF_MAX_TAPS, "upfirdn2d: filter %dx%d unsupported", fh, fw);
+    N3D_CHECK(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "upfirdn2d: up/down must be >= 1");
+    const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx;
+    const int OH = (H * upy + pady0 + pady1 - fh + downy) / downy;
+    N3D_CHECK(OW >= 1 && OH >= 1, "upfirdn2d: output would be empty");   // upfirdn2d.cpp:39
+    if (N == 0) return 0;
+    N3D_CHECK(x && f && y, "upfirdn2d: null tensor");
+    N3D_CHECK(C <= 65535 && N <= 65535, "upfirdn2d: N and C must be <= 65535");
+    UfParams p;
+    p.x = x; p.f = f; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.fh = fh; p.fw = fw;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip;
+    p.gain = gain; p.xbs = xbs; p.ybs = ybs;
+    p.has_epi = epi != nullptr;
+    if (epi) p.epi = *epi;
+    p.tiles_x = cdiv(OW, UF_TILE_W); p.tiles_y = cdiv(OH, UF_TILE_H);
+    // footprint extent: i ranges over ceil((o0*down - pad)/up) .. floor(((o0+T-1)*down + f-1 - pad)/up)
+    p.foot_w = ((UF_TILE_W - 1) * downx + fw - 1) / upx + 2;
+    p.foot_h = ((UF_TILE_H - 1) * downy + fh - 1) / upy + 2;
+    N3D_CHECK(p.foot_w * p.foot_h <= UF_MAX_FOOT, "upfirdn2d: tile footprint %dx%d exceeds LDS budget", p.foot_h, p.foot_w);
+    N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * fh * fw / (upx * upy),
+                      4.0 * N * C * ((double)H * W + (double)OH * OW));
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}

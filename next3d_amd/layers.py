@@ -1,0 +1,93 @@
+"""Fused StyleGAN2 layers on libn3d.so kernels.
+
+A reference SynthesisLayer issues: addmm (affine) -> weight modulate / demodulate (5 elementwise + 1 reduction
+over [N,O,I,3,3]) -> grouped conv -> (upfirdn2d) -> add noise -> bias_act  (reference
+training_avatar_texture/networks_stylegan2.py:311-330, :34-91).  Here the same arithmetic is four launches at most:
+
+    styles = fc(w)                                  n3d_fc
+    dcoef  = rsqrt(fc(styles^2, sum_k W^2) + 1e-8)  n3d_fc   (demodulation factored through W2[o,i] = sum_k w^2)
+    y      = conv(x * styles)                       n3d_conv2d, epilogue: *dcoef, +noise, +bias, lrelu, clamp
+    [up]   y = FIR(y)                               n3d_upfirdn2d with the same epilogue moved behind the filter
+
+i.e. the non-fused formulation of modulated_conv2d (:70-79) — algebraically identical to the grouped-conv branch,
+but one weight tensor is shared by the whole batch, which is what the matrix cores want.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .torch_utils.ops import conv2d_gradfix as cg
+from .torch_utils.ops import upfirdn2d as uf
+
+_SQRT2 = float(np.sqrt(2))
+
+
+def fc(x, weight, bias=None, wgain=1.0, bgain=1.0, act='linear', pre_square=False, post_rsqrt=False):
+    """y = post(act(pre(x) @ weight.T * wgain + bias * bgain)); x [N,I], weight [O,I]."""
+    n, i = x.shape
+    o = weight.shape[0]
+    x = x.contiguous()
+    y = torch.empty([n, o], dtype=torch.float32, device=x.device)
+    from .torch_utils.ops.bias_act import activation_funcs
+    spec = activation_funcs[act]
+    _lib.check(_lib.lib().n3d_fc(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), n, i, o, float(wgain),
+                                 float(bgain), spec.cuda_idx, float(spec.def_alpha), float(spec.def_gain),
+                                 1 if pre_square else 0, 1 if post_rsqrt else 0, _lib.stream()))
+    return y
+
+
+class PreparedConv:
+    """Per-layer constants derived once from the parameters (K-major weights, squared-weight sums)."""
+
+    def __init__(self, P, prefix, modulated, demodulate=True):
+        w = P[f'{prefix}.weight']
+        self.prefix = prefix
+        self.out_channels, self.in_channels, self.ksize = w.shape[0], w.shape[1], w.shape[2]
+        if modulated and demodulate:
+            self.wt, self.wsq = cg.prep_weight(w, want_sq=True)
+        else:
+            self.wt, self.wsq = cg.prep_weight(w), None
+        self.bias = P.get(f'{prefix}.bias')
+        self.weight_gain = 1.0 / np.sqrt(self.in_channels * self.ksize ** 2)
+        if modulated:
+            self.affine_w = P[f'{prefix}.affine.weight']
+            self.affine_b = P[f'{prefix}.affine.bias']
+            self.noise_const = P.get(f'{prefix}.noise_const')
+            self.noise_strength = P.get(f'{prefix}.noise_strength')
+
+
+def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0):
+    """SynthesisLayer.forward (reference networks_stylegan2.py:311-330)."""
+    styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
+    dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
+    noise = L.noise_const if noise_mode == 'const' else None
+    if noise_mode == 'random':
+        raise RuntimeError("noise_mode='random' is a training-time path; inference uses 'const' or 'none'")
+    act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
+               gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
+    if up == 1:
+        return cg.conv_launch(x, L.wt, 3, 0, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act))
+    assert up == 2
+    t = cg.conv_launch(x, L.wt, 3, 2, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef))
+    return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
+
+
+def torgb_layer(L, x, w, conv_clamp=None, residual=None):
+    """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584)."""
+    g = L.weight_gain
+    styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
+    return cg.conv_launch(x, L.wt, 1, 0, style=styles,
+                          epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual))
+
+
+def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None):
+    """Conv2dLayer.forward (reference networks_stylegan2.py:173-183), up=1."""
+    from .torch_utils.ops.bias_act import activation_funcs
+    epi = _lib.make_epilogue(const_scale=L.weight_gain, bias=L.bias, act=activation,
+                             gain=activation_funcs[activation].def_gain * gain,
+                             clamp=None if conv_clamp is None else conv_clamp * gain, residual=residual)
+    if down == 1:
+        return cg.conv_launch(x, L.wt, L.ksize, 0, epilogue=epi, out=out)
+    assert down == 2 and L.ksize == 3
+    x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
+    return cg.conv_launch(x, L.wt, 3, 1, epilogue=epi, out=out)

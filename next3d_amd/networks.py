@@ -1,0 +1,132 @@
+"""The generator's convolutional networks assembled from the fused HIP layers (next3d_amd/layers.py).
+
+Each class prepares its per-layer constants once (`PreparedConv`) from the flat parameter dict and then runs
+forward passes with no further parameter processing.  Structure follows the reference modules:
+  SynthesisNet     training_avatar_texture/networks_stylegan2.py:596-645 (+ SynthesisBlock :492-588, 'skip' arch)
+  StyleUNet        training_avatar_texture/networks_stylegan2_styleunet.py:493-588 (+ EncoderResBlock :97-115)
+  SuperRes8XDC     training_avatar_texture/superresolution.py:264-290
+  MappingNet       training_avatar_texture/networks_stylegan2.py:193-268
+"""
+import numpy as np
+import torch
+
+from . import layers as L
+from . import spec as S
+from .torch_utils.ops import upfirdn2d as uf
+
+
+class _Block:
+    def __init__(self, P, prefix, in_channels, conv_clamp=None):
+        self.in_channels = in_channels
+        self.conv_clamp = conv_clamp
+        self.const = P.get(f'{prefix}.const')
+        self.conv0 = L.PreparedConv(P, f'{prefix}.conv0', modulated=True) if in_channels != 0 else None
+        self.conv1 = L.PreparedConv(P, f'{prefix}.conv1', modulated=True)
+        self.torgb = L.PreparedConv(P, f'{prefix}.torgb', modulated=True, demodulate=False)
+
+    def __call__(self, x, img, ws, fir, noise_mode):
+        """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path)."""
+        k = 0
+        if self.in_channels == 0:
+            x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
+            x = L.synthesis_layer(self.conv1, x, ws[:, k], fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
+        else:
+            x = L.synthesis_layer(self.conv0, x, ws[:, k], fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
+            x = L.synthesis_layer(self.conv1, x, ws[:, k], fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
+        if img is not None:
+            img = uf.upsample2d(img, fir)
+        img = L.torgb_layer(self.torgb, x, ws[:, k], conv_clamp=self.conv_clamp, residual=img)
+        return x, img
+
+
+def _split_ws(ws, block_resolutions):
+    out, idx = [], 0
+    for res in block_resolutions:
+        nconv = 1 if res == 4 else 2
+        out.append(ws.narrow(1, idx, nconv + 1))
+        idx += nconv
+    return out
+
+
+class SynthesisNet:
+    def __init__(self, P, prefix, img_resolution=256):
+        self.cd = S.channels_dict(img_resolution)
+        self.block_res = sorted(self.cd)
+        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2] if r > 4 else 0) for r in self.block_res}
+        self.fir = P[f'{prefix}.b4.resample_filter']
+        self.num_ws = 2 * len(self.block_res)
+
+    def __call__(self, ws, noise_mode='const'):
+        ws = ws.to(torch.float32)
+        x = img = None
+        for res, cur in zip(self.block_res, _split_ws(ws, self.block_res)):
+            x, img = self.blocks[res](x, img, cur.contiguous(), self.fir, noise_mode)
+        return img
+
+
+class _EncoderBlock:
+    def __init__(self, P, prefix, downsample):
+        self.fromrgb = L.PreparedConv(P, f'{prefix}.fromrgb', modulated=False)
+        self.conv1 = L.PreparedConv(P, f'{prefix}.conv1', modulated=False)
+        self.conv2 = L.PreparedConv(P, f'{prefix}.conv2', modulated=False)
+        self.downsample = downsample
+
+    def __call__(self, inp, skip, fir):
+        if self.downsample:
+            inp = uf.downsample2d(inp, fir)
+        out = L.conv2d_layer(self.fromrgb, inp, fir, activation='linear', residual=skip)
+        out = L.conv2d_layer(self.conv1, out, fir, activation='lrelu')
+        out = L.conv2d_layer(self.conv2, out, fir, activation='lrelu', down=2)
+        return inp, out
+
+
+class StyleUNet:
+    def __init__(self, P, prefix, img_resolution=256, in_size=64, final_size=4, num_cond_res=64):
+        self.cd = S.channels_dict(img_resolution)
+        self.block_res = sorted(self.cd)
+        self.final_log2 = int(np.log2(final_size))
+        self.num_cond_res = num_cond_res
+        self.start = self.final_log2 - 1
+        enc_res = [2 ** i for i in range(int(np.log2(in_size)), self.final_log2 - 1, -1)]
+        self.encoder = [_EncoderBlock(P, f'{prefix}.encoder.{i}', downsample=(r < in_size)) for i, r in enumerate(enc_res[:-1])]
+        self.used_res = self.block_res[self.start:]
+        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2]) for r in self.used_res}
+        n_fusion = sum(1 for i in range(len(self.used_res)) if 2 ** (i + self.final_log2) < num_cond_res)
+        self.fusion = [L.PreparedConv(P, f'{prefix}.fusion.{i}', modulated=False) for i in range(n_fusion)]
+        self.fir = P[f'{prefix}.b4.resample_filter']
+
+    def __call__(self, x_in, ws, noise_mode='const'):
+        ws = ws.to(torch.float32)
+        block_ws = _split_ws(ws, self.block_res)[self.start:]
+        conds, cond = [], None
+        for enc in self.encoder:
+            x_in, cond = enc(x_in, cond, self.fir)
+            conds.append(cond)
+        conds = conds[::-1]
+        x = img = None
+        for idx, (res, cur) in enumerate(zip(self.used_res, block_ws)):
+            if idx < len(self.fusion):
+                if idx == 0:
+                    x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
+                else:
+                    x = L.conv2d_layer(self.fusion[idx], torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
+            x, img = self.blocks[res](x, img, cur.contiguous(), self.fir, noise_mode)
+        return img
+
+
+class SuperRes8XDC:
+    def __init__(self, P, prefix):
+        self.block0 = _Block(P, f'{prefix}.block0', 32, conv_clamp=256)
+        self.block1 = _Block(P, f'{prefix}.block1', 256, conv_clamp=256)
+        self.fir = P[f'{prefix}.block0.resample_filter']
+        self.input_resolution = 128
+
+    def __call__(self, rgb, x, ws, resize_fn):
+        """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286)."""
+        ws = ws[:, -1:, :].repeat(1, 3, 1).contiguous()
+        if x.shape[-1] != self.input_resolution:
+            x = resize_fn(x, self.input_resolution)
+            rgb = resize_fn(rgb, self.input_resolution)
+        x, rgb = self.block0(x, rgb, ws, self.fir, 'none')
+        x, rgb = self.block1(x, rgb, ws, self.fir, 'none')
+        return rgb

@@ -1,0 +1,120 @@
+"""conv2d / conv_transpose2d front-ends with the reference's names (torch_utils/ops/conv2d_gradfix.py:37-45),
+executed by the fp32-MFMA implicit-GEMM kernel of libn3d.so (forward only; `enabled` / `no_weight_gradients`
+exist for import compatibility and have no effect at inference)."""
+import contextlib
+
+import torch
+
+from ... import _lib
+
+enabled = False
+weight_gradients_disabled = False
+
+
+@contextlib.contextmanager
+def no_weight_gradients(disable=True):
+    yield
+
+
+def prep_weight(w, want_sq=False):
+    """[O,I,k,k] -> K-major [k*k, I, O] (+ optional per-(o,i) sum of squares for demodulation)."""
+    _lib.require_device(w)
+    o, i, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise RuntimeError(f'conv2d: kernel {kh}x{kw} unsupported (1x1 or 3x3)')
+    w = w.contiguous()
+    wt = torch.empty([kh * kw, i, o], dtype=torch.float32, device=w.device)
+    wsq = torch.empty([o, i], dtype=torch.float32, device=w.device) if want_sq else None
+    _lib.check(_lib.lib().n3d_conv2d_prep_weight(_lib.ptr(w), _lib.ptr(wt), _lib.ptr(wsq), o, i, kh, _lib.stream()))
+    return (wt, wsq) if want_sq else wt
+
+
+def out_shape(h, w, mode):
+    if mode == 0:
+        return h, w
+    if mode == 1:
+        return (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    return 2 * h + 1, 2 * w + 1
+
+
+def pick_ksplit(n, i, o, gh, gw, ksize):
+    """Split the input channels over extra workgroups when the output grid alone cannot fill 256 CUs
+    (low-resolution layers: K = 9*I is deep, the pixel grid is tiny)."""
+    bm = 128 if (ksize == 3 or o > 64) else 32
+    tw, th = (32, 4) if gw > 16 else (16, 8)
+    blocks = -(-gw // tw) * -(-gh // th) * -(-o // bm) * n
+    icb = 8 if ksize == 3 else 32
+    ks = 1
+    while blocks * ks < 256 and (i // (ks * 2)) >= 4 * icb:
+        ks *= 2
+    return ks
+
+
+def conv_launch(x, wt, ksize, mode, out=None, style=None, epilogue=None, ksplit=None):
+    """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights -> y [N,O,OH,OW]."""
+    n, i, h, w = x.shape
+    o = wt.shape[2]
+    assert wt.shape[0] == ksize * ksize and wt.shape[1] == i, (tuple(wt.shape), ksize, i)
+    if x.stride()[1:] != (h * w, w, 1):
+        x = x.contiguous()
+    oh, ow = out_shape(h, w, mode)
+    y = out if out is not None else torch.empty([n, o, oh, ow], dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == (n, o, oh, ow) and y.stride()[1:] == (oh * ow, ow, 1)
+    gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
+    if ksplit is None:
+        ksplit = pick_ksplit(n * (4 if mode == 2 else 1), i, o, gh, gw, ksize)
+    ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    d = _lib.Conv2dDesc()
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)
+    d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
+    d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
+    d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
+    d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
+    _lib.check(_lib.lib().n3d_conv2d(d, _lib.stream()))
+    return y
+
+
+def _grouped(x, weight, groups, ksize, mode, transposed):
+    """groups == batch-folded samples (modulated_conv2d's fused path reshapes x to [1, N*I, H, W])."""
+    n, ci, h, w = x.shape
+    ig = ci // groups
+    outs = []
+    for g in range(groups):
+        if transposed:      # weight [groups*I_g, O_g, k, k] -> per group [O_g, I_g, k, k]
+            wg = weight[g * ig:(g + 1) * ig].transpose(0, 1)
+        else:               # weight [groups*O_g, I_g, k, k]
+            og = weight.shape[0] // groups
+            wg = weight[g * og:(g + 1) * og]
+        outs.append(conv_launch(x[:, g * ig:(g + 1) * ig], prep_weight(wg), ksize, mode))
+    return torch.cat(outs, dim=1)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d subset used by the generator: k in {1,3}; (stride 1, padding k//2) or (stride 2, padding 0)."""
+    _lib.require_device(input, weight)
+    k = weight.shape[2]
+    stride = stride if isinstance(stride, int) else stride[0]
+    pad = padding if isinstance(padding, int) else padding[0]
+    if dilation != 1 or bias is not None:
+        raise RuntimeError('conv2d: dilation / bias are not supported by the n3d kernel')
+    if stride == 1 and pad == k // 2:
+        mode = 0
+    elif stride == 2 and pad == 0 and k == 3:
+        mode = 1
+    else:
+        raise RuntimeError(f'conv2d: stride={stride} padding={pad} kernel={k} is outside the generator-forward path')
+    if groups == 1:
+        return conv_launch(input, prep_weight(weight), k, mode)
+    return _grouped(input, weight, groups, k, mode, transposed=False)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """F.conv_transpose2d subset: 3x3, stride 2, padding 0 (the up-sampling layers, conv2d_resample.py:127)."""
+    _lib.require_device(input, weight)
+    stride = stride if isinstance(stride, int) else stride[0]
+    pad = padding if isinstance(padding, int) else padding[0]
+    if stride != 2 or pad != 0 or weight.shape[2] != 3 or output_padding != 0 or dilation != 1 or bias is not None:
+        raise RuntimeError('conv_transpose2d: only 3x3 / stride 2 / padding 0 is on the generator-forward path')
+    if groups == 1:
+        return conv_launch(input, prep_weight(weight.transpose(0, 1)), 3, 2)
+    return _grouped(input, weight, groups, 3, 2, transposed=True)

@@ -1,0 +1,192 @@
+"""-m gpu parity tests for the operator layer: libn3d.so (through the C ABI) vs the CPU oracle on seeded inputs.
+Tolerances are written per test; fp32 end to end, so they sit at the fp32-roundoff level (north_star: 1e-3 on RGB)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _close(a, b, atol, rtol=1e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f'max err {float(err.max()):.3e} (ref absmax {float(b.abs().max()):.3e})'
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish'])
+@pytest.mark.parametrize('shape,dim', [((3, 5, 7, 9), 1), ((4, 512), 1), ((2, 6, 4, 4), 0), ((1, 3, 17, 5), 3)])
+def test_bias_act(dev, act, shape, dim):
+    from next3d_amd.torch_utils.ops import bias_act
+    x, b = _gen(shape, 1, 3.0), _gen((shape[dim],), 2)
+    for kw in (dict(), dict(gain=0.7, clamp=1.5, alpha=0.3)):
+        y = bias_act.bias_act(x.to(dev), b.to(dev), dim=dim, act=act, **kw)
+        _close(y, O.bias_act(x, b, dim=dim, act=act, **kw), atol=2e-6)
+    y = bias_act.bias_act(x.to(dev), None, act=act)
+    _close(y, O.bias_act(x, None, act=act), atol=2e-6)
+
+
+def test_bias_act_f16_and_errors(dev):
+    from next3d_amd.torch_utils.ops import bias_act
+    x, b = _gen((2, 8, 5, 5), 3).half(), _gen((8,), 4).half()
+    y = bias_act.bias_act(x.to(dev), b.to(dev), act='lrelu', clamp=256)
+    _close(y.float(), O.bias_act(x.float(), b.float(), act='lrelu', clamp=256), atol=2e-3, rtol=2e-3)
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(x.to(dev), _gen((7,), 1).half().to(dev))
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(x, b)                       # CPU tensors: no fallback
+    assert bias_act.bias_act(torch.empty(0, 4, device=dev), None).numel() == 0
+
+
+UF_CASES = [
+    # (shape, up, down, padding, gain)  — the three hot shapes of SURVEY §8(a7) + odd ones
+    ((2, 5, 17, 17), 1, 1, [1, 1, 1, 1], 4.0),
+    ((2, 3, 16, 16), 2, 1, [2, 1, 2, 1], 4.0),
+    ((1, 4, 32, 32), 1, 2, [1, 1, 1, 1], 1.0),
+    ((1, 4, 32, 32), 1, 1, [2, 2, 2, 2], 1.0),
+    ((2, 2, 13, 70), 2, 3, [3, 0, -1, 2], 0.5),
+    ((1, 1, 4, 4), 1, 1, [2, 1, 1, 2], 1.0),
+    ((1, 2, 130, 67), 1, 1, [1, 1, 1, 1], 4.0),
+]
+
+
+@pytest.mark.parametrize('shape,up,down,padding,gain', UF_CASES)
+@pytest.mark.parametrize('flip', [False, True])
+def test_upfirdn2d(dev, shape, up, down, padding, gain, flip):
+    from next3d_amd.torch_utils.ops import upfirdn2d
+    x = _gen(shape, 5)
+    f = O.setup_filter((1, 3, 3, 1)) + 0.01 * torch.arange(16.).reshape(4, 4)     # asymmetric taps
+    y = upfirdn2d.upfirdn2d(x.to(dev), f.to(dev), up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
+    _close(y, O.upfirdn2d(x, f, up=up, down=down, padding=padding, flip_filter=flip, gain=gain), atol=1e-5)
+
+
+def test_upfirdn2d_helpers_and_separable(dev):
+    from next3d_amd.torch_utils.ops import upfirdn2d
+    x = _gen((2, 3, 24, 20), 6)
+    f = O.setup_filter((1, 3, 3, 1))
+    _close(upfirdn2d.upsample2d(x.to(dev), f.to(dev)), O.upsample2d(x, f), atol=1e-5)
+    _close(upfirdn2d.downsample2d(x.to(dev), f.to(dev)), O.downsample2d(x, f), atol=1e-5)
+    f1 = upfirdn2d.setup_filter([1, 2, 4, 6, 9, 6, 4, 2, 1][:8])                      # 8 taps -> separable 1-D
+    assert f1.ndim == 1
+    _close(upfirdn2d.upfirdn2d(x.to(dev), f1.to(dev), up=2, padding=[4, 3, 4, 3], gain=4),
+           O.upfirdn2d(x, f1, up=2, padding=[4, 3, 4, 3], gain=4), atol=1e-5)
+    _close(upfirdn2d.upfirdn2d(x.to(dev), None), x, atol=0)
+    with pytest.raises(RuntimeError):
+        upfirdn2d.upfirdn2d(_gen((1, 1, 2, 2), 1).to(dev), f.to(dev))               # output would be empty
+
+
+def test_fc(dev):
+    from next3d_amd import layers
+    for (n, i, o) in [(4, 512, 512), (3, 1024, 512), (2, 25, 512), (9, 512, 96), (1, 33, 7)]:
+        x, w, b = _gen((n, i), 7), _gen((o, i), 8), _gen((o,), 9)
+        y = layers.fc(x.to(dev), w.to(dev), b.to(dev), wgain=1 / np.sqrt(i))
+        _close(y, O.fully_connected(x, w, b), atol=2e-5)
+        y = layers.fc(x.to(dev), (w / 0.01).to(dev), b.to(dev), wgain=0.01 / np.sqrt(i), bgain=0.01, act='lrelu')
+        _close(y, O.fully_connected(x, w / 0.01, b, activation='lrelu', lr_multiplier=0.01), atol=2e-5)
+    s, w2 = _gen((4, 256), 10), _gen((128, 256), 11).square()
+    d = layers.fc(s.to(dev), w2.to(dev), pre_square=True, post_rsqrt=True)
+    _close(d, (s.square() @ w2.t() + 1e-8).rsqrt(), atol=1e-6, rtol=1e-5)
+
+
+CONV_CASES = [
+    # (N, I, O, H, W, ksize, mode)
+    (2, 16, 128, 32, 32, 3, 0),
+    (1, 24, 160, 20, 37, 3, 0),      # ragged: channel tails, partial tiles
+    (2, 512, 512, 4, 4, 3, 0),       # deep-K small grid (split-K)
+    (1, 64, 128, 16, 16, 3, 0),
+    (2, 32, 256, 33, 33, 3, 1),      # stride 2 after the FIR pre-filter (odd input)
+    (1, 16, 128, 17, 9, 3, 1),
+    (2, 32, 128, 16, 16, 3, 2),      # transposed
+    (1, 512, 512, 4, 4, 3, 2),
+    (1, 8, 128, 5, 40, 3, 2),
+    (2, 128, 32, 64, 64, 1, 0),      # toRGB-like
+    (1, 128, 3, 32, 48, 1, 0),
+    (2, 32, 512, 8, 8, 1, 0),        # fromrgb-like
+    (1, 40, 96, 16, 16, 1, 0),
+]
+
+
+def _conv_ref(x, w, mode):
+    import torch.nn.functional as F
+    if mode == 0:
+        return F.conv2d(x, w, padding=w.shape[2] // 2)
+    if mode == 1:
+        return F.conv2d(x, w, stride=2)
+    return F.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+
+
+@pytest.mark.parametrize('N,I,OC,H,W,k,mode', CONV_CASES)
+def test_conv2d_plain(dev, N, I, OC, H, W, k, mode):
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 12), _gen((OC, I, k, k), 13) / np.sqrt(I * k * k)
+    ref = _conv_ref(x, w, mode)
+    wt = cg.prep_weight(w.to(dev))
+    for ksplit in (1, None, 3):
+        y = cg.conv_launch(x.to(dev), wt, k, mode, ksplit=ksplit)
+        _close(y, ref, atol=2e-5, rtol=1e-4)
+
+
+def test_conv2d_epilogue_and_style(dev):
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    N, I, OC, H, W = 2, 32, 128, 24, 40
+    x, w = _gen((N, I, H, W), 14), _gen((OC, I, 3, 3), 15) / np.sqrt(I * 9)
+    s, d, b = _gen((N, I), 16), _gen((N, OC), 17).abs() + 0.5, _gen((OC,), 18)
+    noise, ns, res = _gen((H, W), 19), torch.tensor(0.3), _gen((N, OC, H, W), 20)
+    import torch.nn.functional as F
+    ref = F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None] * 0.9 + noise * ns
+    ref = O.bias_act(ref, b, act='lrelu', gain=1.3, clamp=2.0) + res
+    t = lambda a: a.to(dev)
+    for ksplit in (1, 4):
+        epi = _lib.make_epilogue(row_scale=t(d), noise=t(noise), noise_strength=t(ns), bias=t(b), residual=t(res),
+                                 const_scale=0.9, act='lrelu', gain=1.3, clamp=2.0)
+        y = cg.conv_launch(t(x), cg.prep_weight(t(w)), 3, 0, style=t(s), epilogue=epi, ksplit=ksplit)
+        _close(y, ref, atol=3e-5, rtol=1e-4)
+
+
+def test_conv2d_resample_branches(dev):
+    """The branch table of conv2d_resample (reference conv2d_resample.py:96-136) incl. the grouped (fused-modconv) form."""
+    from next3d_amd.torch_utils.ops import conv2d_resample as cr
+    f = O.setup_filter((1, 3, 3, 1))
+    x = _gen((2, 16, 20, 20), 21)
+    w3, w1 = _gen((32, 16, 3, 3), 22) / 12, _gen((32, 16, 1, 1), 23) / 4
+    t = lambda a: a.to(dev)
+    for kw in (dict(w=w3, padding=1), dict(w=w3, up=2, padding=1, flip_weight=False), dict(w=w3, down=2, padding=1),
+               dict(w=w1), dict(w=w1, up=2), dict(w=w1, down=2), dict(w=w3, padding=1, flip_weight=False)):
+        w = kw.pop('w')
+        _close(cr.conv2d_resample(t(x), t(w), f=t(f), **kw), O.conv2d_resample(x, w, f=f, **kw), atol=3e-5, rtol=1e-4)
+    xg = x.reshape(1, 32, 20, 20)
+    wg = _gen((2 * 24, 16, 3, 3), 24) / 12
+    for kw in (dict(padding=1), dict(up=2, padding=1, flip_weight=False)):
+        _close(cr.conv2d_resample(t(xg), t(wg), f=t(f), groups=2, **kw), O.conv2d_resample(xg, wg, f=f, groups=2, **kw),
+               atol=3e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('up,res,ic,oc', [(1, 16, 64, 128), (2, 16, 64, 128), (1, 4, 512, 512), (2, 64, 32, 256)])
+def test_synthesis_layer_and_torgb(dev, up, res, ic, oc):
+    from next3d_amd import layers
+    from oracle import networks as ON
+    P = {'L.weight': _gen((oc, ic, 3, 3), 30), 'L.bias': _gen((oc,), 31) * 0.1, 'L.affine.weight': _gen((ic, 512), 32),
+         'L.affine.bias': 1 + 0.1 * _gen((ic,), 33), 'L.noise_const': _gen((res, res), 34), 'L.noise_strength': torch.tensor(0.2),
+         'T.weight': _gen((32, oc, 1, 1), 35), 'T.bias': _gen((32,), 36) * 0.1, 'T.affine.weight': _gen((oc, 512), 37),
+         'T.affine.bias': 1 + 0.1 * _gen((oc,), 38)}
+    Pd = {k: v.to(dev) for k, v in P.items()}
+    fir = O.setup_filter((1, 3, 3, 1))
+    N = 2
+    x, w = _gen((N, ic, res // up, res // up), 39), _gen((N, 512), 40)
+    for clamp in (None, 1.0):
+        ref = ON.synthesis_layer(P, 'L', x, w, up=up, conv_clamp=clamp)
+        y = layers.synthesis_layer(layers.PreparedConv(Pd, 'L', True), x.to(dev), w.to(dev), fir.to(dev), up=up, conv_clamp=clamp)
+        _close(y, ref, atol=1e-4, rtol=1e-4)
+    img = _gen((N, 32, res, res), 41)
+    ref = ON.torgb_layer(P, 'T', ref, w) + img
+    yt = layers.torgb_layer(layers.PreparedConv(Pd, 'T', True, demodulate=False), y, w.to(dev), residual=img.to(dev))
+    _close(yt, ref, atol=2e-4, rtol=1e-4)
