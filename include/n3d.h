@@ -102,6 +102,53 @@ int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 int n3d_fc(const float* x, const float* w, const float* b, float* y, int N, int I, int O, float wgain, float bgain,
            int act, float alpha, float gain, int pre_square, int post_rsqrt, n3d_stream_t stream);
 
+/* ---- tri-plane blend (tat/triplane_next3d.py:171-174): planes = dyn * alpha + static * (1 - alpha), written
+ *      CHANNELS-LAST [N,3,H,W,32] (one texel's 32 channels contiguous) for the renderer's gathers.
+ *      front/side/top [N,32,H,W], stat [N,96,H,W], alpha [N,3,H,W]. */
+int n3d_blend_planes(const float* front, const float* side, const float* top, const float* stat, const float* alpha,
+                     float* planes_cl, int N, int H, int W, n3d_stream_t stream);
+/* NCHW planes [N,3,32,H,W] -> channels-last, for callers holding blended planes in the reference layout. */
+int n3d_planes_to_channels_last(const float* planes, float* planes_cl, int N, int H, int W, n3d_stream_t stream);
+
+/* ---- volume renderer: replaces RaySampler.forward (vr/ray_sampler.py:24-63) + ImportanceRenderer.forward
+ *      (vr/renderer.py:95-147: sample_stratified, sample_from_planes/grid_sampler_2d, OSGDecoder
+ *      tat/triplane_next3d.py:359-371, MipRayMarcher2 vr/ray_marcher.py:27-66, sample_importance, sample_pdf,
+ *      unify_samples).  One wavefront per ray; only feat [N,32,R,R] and depth [N,1,R,R] are written.
+ *      tlin [Sc] = linspace(ray_start, ray_end, Sc); jitter [N,R*R,Sc] and u [N*R*R,Sf] are the uniform
+ *      randoms the reference draws with torch.rand_like / torch.rand (vr/renderer.py:205,252);
+ *      w1 [64,32], w2 [33,64] are the decoder weights ALREADY multiplied by their weight_gain;
+ *      bounds_ws: 2 floats of scratch; wsum [N,R*R] optional (weights.sum(2)). */
+int n3d_render_rays(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
+                    const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
+                    int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream);
+
+/* ---- mesh rasterisation of `views` orthographic views per sample: replaces TriPlaneGenerator.rasterize's
+ *      geometry half (tat/triplane_next3d.py:193-216), Pytorch3dRasterizer.forward (vr/renderer.py:401-440, third-party
+ *      pytorch3d rasterize_meshes) and fill_mouth (vr/renderer.py:583-602, third-party cv2.floodFill).
+ *      verts [N,V,3], lms [N,Lm,3], rot [views,3,3] (angle2matrix), faces [F,3] int32 and face_uv [F,3,3] both with
+ *      the reference's [0,2,1] vertex swap applied, uv_mask [mask_h,mask_w].
+ *      Scratch: tv_ws [N*views*V*3] floats, zbuf_ws [N*views*H*W] uint64.
+ *      Out: grid [N*views,H,W,2] (u,v), alpha [N*views,H,W] (mask*vis, hole-filled when fill != 0, view
+ *      `binarize_view` additionally reduced to {0,1} as the reference's alpha_side), lm2d [N,Lm,2] (front view). */
+int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, const int* faces, const float* face_uv,
+                        const float* uv_mask, int mask_h, int mask_w, float* tv_ws, unsigned long long* zbuf_ws,
+                        float* grid, float* alpha, float* lm2d, int N, int V, int Lm, int F, int views, int H, int W,
+                        float shift_x, float shift_y, float shift_z, float scale, int fill, int binarize_view,
+                        n3d_stream_t stream);
+/* out [N,C,H,W] = grid_sample(textures [N,C,TH,TW], grid[:, view_a]) (+ the same for view_b when view_b >= 0)
+ * — bilinear, zeros, align_corners=False, un-masked as in the reference (tat/triplane_next3d.py:218,225). */
+int n3d_texture_project(const float* textures, const float* grid, float* out, int N, int C, int TH, int TW, int H, int W,
+                        int views, int view_a, int view_b, n3d_stream_t stream);
+/* gen_mouth_mask (tat/triplane_next3d.py:330-344) on the device: lm2d [N,Lm,2] -> bbox [N,4] int32 (y0,y1,x0,x1). */
+int n3d_mouth_bbox(const float* lm2d, int* bbox, int N, int Lm, n3d_stream_t stream);
+/* F.interpolate(mode='bilinear', antialias=True, align_corners=False) = ATen _upsample_bilinear2d_aa
+ * (tat/triplane_next3d.py:152,161; tat/superresolution.py:282-286) with optional per-sample DEVICE boxes
+ * (y0,y1,x0,x1): src_box crops the source, dst_box restricts the written region (dst_square: region is s x s with
+ * s = y1-y0, as the reference's paste at :161).  NULL box = whole tensor. */
+int n3d_resize_aa(const float* src, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW,
+                  int DH, int DW, int dst_square, n3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

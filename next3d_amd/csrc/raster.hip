@@ -1,0 +1,392 @@
+// FLAME-mesh neural-texture rasterisation for gfx950 (compiled with -ffp-contract=off: the face-selection
+// arithmetic mirrors oracle/raster_ref.c operation for operation so pix_to_face is bit-identical).
+//
+//   raster_transform : per view, vertices -> PyTorch3D NDC (y-flip, R, orth shift/scale, proj, +10, x/y negate)
+//   raster_faces     : one thread per (sample*view, face): conservative pixel bbox, strict-inside test, 64-bit
+//                      atomicMin of (z bits << 32 | face) -> lowest z wins, lowest face index on ties
+//   raster_resolve   : per pixel: barycentric uv, vis, bilinear uv_face_mask lookup -> (grid uv, alpha)
+//   fill_holes       : the cv2.floodFill step of fill_mouth on the GPU (one workgroup per 256x256 image, LDS state,
+//                      alternating row/column sweeps until stable) — removes 4*N device->host->device round trips
+//   texture_project  : grid_sample(textures, uv) for front / (side1 + side2) / top planes
+//   mouth_bbox       : landmark -> integer crop box, kept on the device (no host sync, no dynamic shapes)
+//   resize_aa        : antialiased bilinear resize (ATen _upsample_bilinear2d_aa) with per-sample device-side boxes
+//
+// Replaces TriPlaneGenerator.rasterize (reference training_avatar_texture/triplane_next3d.py:190-230),
+// Pytorch3dRasterizer.forward (volumetric_rendering/renderer.py:401-440 -> third-party pytorch3d rasterize_meshes),
+// fill_mouth (renderer.py:583-602 -> third-party cv2.floodFill), gen_mouth_mask (triplane_next3d.py:330-344) and
+// F.interpolate(..., mode='bilinear', antialias=True) (triplane_next3d.py:152,161; superresolution.py:282-286).
+#include "common.h"
+
+#define K_EPS 1e-8f
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2.0f * (float)i + 1.0f) / (float)S; }
+
+// verts [N,V,3]; rot [NV_VIEWS,3,3] (angle2matrix on the host); out tv [N*views, V, 3] in PyTorch3D NDC.
+// lms [N,Lm,3] -> lm2d [N,Lm,2] for view 0 only (the mouth box uses the front view).
+__global__ __launch_bounds__(256) void raster_transform_kernel(const float* __restrict__ verts, const float* __restrict__ lms,
+                                                               const float* __restrict__ rot, float* __restrict__ tv,
+                                                               float* __restrict__ lm2d, int N, int V, int Lm, int views,
+                                                               float sx, float sy, float sz, float scale) {
+    const int64_t total = (int64_t)N * views * V;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const int v = (int)(i % V), view = (int)((i / V) % views), n = (int)(i / ((int64_t)V * views));
+        const float* p = verts + ((int64_t)n * V + v) * 3;
+        const float* R = rot + view * 9;
+        const float x = p[0], y = -p[1], z = p[2];
+        float tx = (x * R[0] + y * R[3] + z * R[6] + sx) * scale;
+        float ty = (x * R[1] + y * R[4] + z * R[7] + sy) * scale;
+        float tz = (x * R[2] + y * R[5] + z * R[8] + sz) * scale;
+        ty = -ty; tz = -tz; tz = tz + 10.f;
+        float* o = tv + i * 3;
+        o[0] = -tx; o[1] = -ty; o[2] = tz;       // Pytorch3dRasterizer.forward negates x,y (renderer.py:403)
+    }
+    const int64_t j = i - total;
+    if (j >= 0 && j < (int64_t)N * Lm) {
+        const float* p = lms + j * 3;
+        const float* R = rot;
+        const float x = p[0], y = -p[1], z = p[2];
+        const float tx = (x * R[0] + y * R[3] + z * R[6] + sx) * scale;
+        const float ty = (x * R[1] + y * R[4] + z * R[7] + sy) * scale;
+        lm2d[j * 2 + 0] = tx; lm2d[j * 2 + 1] = -ty;
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ tv, const int* __restrict__ faces,
+                                                           unsigned long long* __restrict__ zbuf, int NV, int V, int F, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)NV * F) return;
+    const int f = (int)(i % F), nv = (int)(i / F);
+    const float* vn = tv + (int64_t)nv * V * 3;
+    // the reference rasterises faces[..., [0,2,1]] (triplane_next3d.py:207): `faces` is passed already swapped
+    const float* v0 = vn + 3 * (int64_t)faces[3 * f + 0];
+    const float* v1 = vn + 3 * (int64_t)faces[3 * f + 1];
+    const float* v2 = vn + 3 * (int64_t)faces[3 * f + 2];
+    const float x0 = v0[0], y0 = v0[1], z0 = v0[2], x1 = v1[0], y1 = v1[1], z1 = v1[2], x2 = v2[0], y2 = v2[1], z2 = v2[2];
+    const float zmax = fmaxf(z0, fmaxf(z1, z2));
+    const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
+    const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
+    if (zmax < 0.0f || face_area < 0.0f || zero_area) return;      // cull_backfaces=True
+    const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
+    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+    if (!(xmax >= -2.f && xmin <= 2.f && ymax >= -2.f && ymin <= 2.f)) return;   // far off-screen / NaN
+    int xi_lo = (int)floorf((float)(W - 1) - ((xmax + 1.0f) * (float)W - 1.0f) * 0.5f) - 1;
+    int xi_hi = (int)ceilf((float)(W - 1) - ((xmin + 1.0f) * (float)W - 1.0f) * 0.5f) + 1;
+    int yi_lo = (int)floorf((float)(H - 1) - ((ymax + 1.0f) * (float)H - 1.0f) * 0.5f) - 1;
+    int yi_hi = (int)ceilf((float)(H - 1) - ((ymin + 1.0f) * (float)H - 1.0f) * 0.5f) + 1;
+    xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0); xi_hi = min(xi_hi, W - 1); yi_hi = min(yi_hi, H - 1);
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+    for (int yi = yi_lo; yi <= yi_hi; ++yi) {
+        const float yf = pix_to_ndc(H - 1 - yi, H);
+        for (int xi = xi_lo; xi <= xi_hi; ++xi) {
+            const float xf = pix_to_ndc(W - 1 - xi, W);
+            if (xf > xmax || xf < xmin || yf > ymax || yf < ymin) continue;
+            const float w0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+            const float w1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+            const float w2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+            const float pz = w0 * z0 + w1 * z1 + w2 * z2;
+            if (pz < 0.0f) continue;
+            if (!((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f))) continue;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
+            atomicMin(&zbuf[((int64_t)nv * H + yi) * W + xi], key);
+        }
+    }
+}
+
+__device__ __forceinline__ float bilinear_1ch(const float* __restrict__ img, int H, int W, float gx, float gy) {
+    // grid_sampler_2d, bilinear / zeros / align_corners=False, accumulation order nw, ne, sw, se
+    const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    if (!(fx0 > -2.f && fx0 < (float)W + 1.f && fy0 > -2.f && fy0 < (float)H + 1.f)) return 0.f;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+    float acc = 0.f;
+    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc += img[(int64_t)y0 * W + x0] * (wx0 * wy0);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 >= 0 && y0 < H) acc += img[(int64_t)y0 * W + x0 + 1] * (wx1 * wy0);
+    if (x0 >= 0 && x0 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += img[(int64_t)(y0 + 1) * W + x0] * (wx0 * wy1);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += img[(int64_t)(y0 + 1) * W + x0 + 1] * (wx1 * wy1);
+    return acc;
+}
+
+// per pixel: uv = sum_k bary_k * face_uv[f][k], vis; alpha = grid_sample(uv_face_mask, uv) * vis   (renderer.py:425-437,
+// triplane_next3d.py:211-214).  grid [NV,H,W,2], alpha [NV,H,W]
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ tv, const int* __restrict__ faces,
+                                                             const float* __restrict__ face_uv,   // [F,3,3] (vertex order swapped)
+                                                             const unsigned long long* __restrict__ zbuf,
+                                                             const float* __restrict__ uv_mask, int MH, int MW,
+                                                             float* __restrict__ grid, float* __restrict__ alpha, int NV, int V,
+                                                             int F, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)NV * H * W) return;
+    const int xi = (int)(i % W), yi = (int)((i / W) % H), nv = (int)(i / ((int64_t)H * W));
+    const unsigned long long key = zbuf[i];
+    float u = 0.f, v = 0.f, vis = 0.f;
+    if (key != 0xFFFFFFFFFFFFFFFFull) {
+        const int f = (int)(key & 0xFFFFFFFFull);
+        const float* vn = tv + (int64_t)nv * V * 3;
+        const float* v0 = vn + 3 * (int64_t)faces[3 * f + 0];
+        const float* v1 = vn + 3 * (int64_t)faces[3 * f + 1];
+        const float* v2 = vn + 3 * (int64_t)faces[3 * f + 2];
+        const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
+        const float area = edge_fn(v2[0], v2[1], v0[0], v0[1], v1[0], v1[1]) + K_EPS;
+        const float w0 = edge_fn(xf, yf, v1[0], v1[1], v2[0], v2[1]) / area;
+        const float w1 = edge_fn(xf, yf, v2[0], v2[1], v0[0], v0[1]) / area;
+        const float w2 = edge_fn(xf, yf, v0[0], v0[1], v1[0], v1[1]) / area;
+        const float* a = face_uv + (int64_t)f * 9;
+        u = (w0 * a[0] + w1 * a[3]) + w2 * a[6];
+        v = (w0 * a[1] + w1 * a[4]) + w2 * a[7];
+        vis = 1.f;
+    }
+    grid[i * 2 + 0] = u; grid[i * 2 + 1] = v;
+    alpha[i] = bilinear_1ch(uv_mask, MH, MW, u, v) * vis;
+}
+
+// fill_mouth on the device: flood from (0,0) through pixels with seed <= a*255 <= seed + 254 (4-connected), then
+// res = clip(a + ((m*2-1)*-1+1)/2, 0, 1) with m = filled ? 255/127.5-1 : a*255/127.5-1   (renderer.py:583-602)
+#define FH_S 261   // LDS row pitch in bytes (spreads a column of rows over banks)
+__global__ __launch_bounds__(256) void fill_holes_kernel(float* __restrict__ alpha, int H, int W, int binarize_view, int views) {
+    extern __shared__ unsigned char st[];     // bit0 = passable, bit1 = reached
+    const int img = blockIdx.x;
+    float* a = alpha + (int64_t)img * H * W;
+    const int t = threadIdx.x;
+    const float seed = a[0] * 255.f;
+    const float vmin = seed - 0.f, vmax = seed + 254.f;
+    for (int e = t; e < H * W; e += blockDim.x) {
+        const float v = a[e] * 255.f;
+        st[(e / W) * FH_S + (e % W)] = (v >= vmin && v <= vmax) ? 1 : 0;
+    }
+    __syncthreads();
+    if (t == 0) st[0] = 3;     // the seed pixel is always filled
+    __syncthreads();
+    for (int iter = 0; iter < 4096; ++iter) {
+        int changed = 0;
+        if (t < H) {           // row sweeps
+            unsigned char* r = st + t * FH_S;
+            bool prev = (r[0] & 2) != 0;
+            for (int x = 1; x < W; ++x) {
+                unsigned char s = r[x];
+                if (s == 1 && prev) { r[x] = 3; s = 3; changed = 1; }
+                prev = (s & 2) != 0;
+            }
+            prev = (r[W - 1] & 2) != 0;
+            for (int x = W - 2; x >= 0; --x) {
+                unsigned char s = r[x];
+                if (s == 1 && prev) { r[x] = 3; s = 3; changed = 1; }
+                prev = (s & 2) != 0;
+            }
+        }
+        __syncthreads();
+        if (t < W) {           // column sweeps
+            bool prev = (st[t] & 2) != 0;
+            for (int y = 1; y < H; ++y) {
+                unsigned char s = st[y * FH_S + t];
+                if (s == 1 && prev) { st[y * FH_S + t] = 3; s = 3; changed = 1; }
+                prev = (s & 2) != 0;
+            }
+            prev = (st[(H - 1) * FH_S + t] & 2) != 0;
+            for (int y = H - 2; y >= 0; --y) {
+                unsigned char s = st[y * FH_S + t];
+                if (s == 1 && prev) { st[y * FH_S + t] = 3; s = 3; changed = 1; }
+                prev = (s & 2) != 0;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    const bool binarize = (img % views) == binarize_view;     // alpha_side = alpha[1].bool() | alpha[1].bool()
+    for (int e = t; e < H * W; e += blockDim.x) {
+        const float av = a[e];
+        const bool filled = (st[(e / W) * FH_S + (e % W)] & 2) != 0;
+        const float ci = filled ? 255.f : av * 255.f;
+        const float m = ci / 127.5f - 1.f;
+        const float mm = ((m * 2.f - 1.f) * -1.f + 1.f) / 2.f;
+        float r = fminf(fmaxf(av + mm, 0.f), 1.f);
+        if (binarize) r = (r != 0.f) ? 1.f : 0.f;
+        a[e] = r;
+    }
+}
+
+// out_plane[n][c][y][x] = sum over the plane's views of grid_sample(textures[n][c], grid[n*views+view][y][x])
+__global__ __launch_bounds__(256) void texture_project_kernel(const float* __restrict__ tex, const float* __restrict__ grid,
+                                                              float* __restrict__ out, int N, int C, int TH, int TW, int H, int W,
+                                                              int views, int view_a, int view_b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * H * W) return;
+    const int pix = (int)(i % ((int64_t)H * W)), n = (int)(i / ((int64_t)H * W));
+    const float* tn = tex + (int64_t)n * C * TH * TW;
+    float* on = out + (int64_t)n * C * H * W + pix;
+    const float* ga = grid + (((int64_t)n * views + view_a) * H * W + pix) * 2;
+    const float ua = ga[0], va = ga[1];
+    float ub = 0.f, vb = 0.f;
+    if (view_b >= 0) {
+        const float* gb = grid + (((int64_t)n * views + view_b) * H * W + pix) * 2;
+        ub = gb[0]; vb = gb[1];
+    }
+    for (int c = 0; c < C; ++c) {
+        float v = bilinear_1ch(tn + (int64_t)c * TH * TW, TH, TW, ua, va);
+        if (view_b >= 0) v = v + bilinear_1ch(tn + (int64_t)c * TH * TW, TH, TW, ub, vb);
+        on[(int64_t)c * H * W] = v;
+    }
+}
+
+// gen_mouth_mask (triplane_next3d.py:330-344): bbox[n] = (y0, y1, x0, x1)
+__global__ void mouth_bbox_kernel(const float* __restrict__ lm2d, int* __restrict__ bbox, int N, int Lm) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* lm = lm2d + (int64_t)n * Lm * 2;
+    float c0min = INFINITY, c0max = -INFINITY, c1min = INFINITY, c1max = -INFINITY;
+    for (int k = 48; k < 60; ++k) {
+        const float a = lm[k * 2 + 0] * 128.f + 128.f, b = lm[k * 2 + 1] * 128.f + 128.f;
+        c0min = fminf(c0min, a); c0max = fmaxf(c0max, a); c1min = fminf(c1min, b); c1max = fmaxf(c1max, b);
+    }
+    const float l0 = lm[48 * 2 + 0] * 128.f + 128.f, l1 = lm[48 * 2 + 1] * 128.f + 128.f;
+    const float r0 = lm[54 * 2 + 0] * 128.f + 128.f, r1 = lm[54 * 2 + 1] * 128.f + 128.f;
+    const float avg0 = (l0 + r0) * 0.5f, avg1 = (l1 + r1) * 0.5f;
+    const float ext = fmaxf(c0max - c0min, c1max - c1min) * 1.2f;
+    const int res = (int)ext;                    // astype(int): truncation
+    const int h = res >= 0 ? res / 2 : -((-res + 1) / 2);     // python floor division
+    bbox[n * 4 + 0] = (int)((double)avg1 - (double)h);
+    bbox[n * 4 + 1] = (int)((double)avg1 + (double)h);
+    bbox[n * 4 + 2] = (int)((double)avg0 - (double)h);
+    bbox[n * 4 + 3] = (int)((double)avg0 + (double)h);
+}
+
+// antialiased bilinear resize with optional per-sample boxes (y0, y1, x0, x1) on source and/or destination.
+struct ResizeParams {
+    const float* src; float* dst;
+    const int* src_box; const int* dst_box;      // [N,4] device ints or NULL (= full tensor)
+    int N, C, SH, SW, DH, DW;
+    int dst_square;                              // paste mode: destination box is (y0, y0+s, x0, x0+s), s = y1-y0
+};
+
+__device__ __forceinline__ float tri_filter(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+
+__device__ __forceinline__ void aa_range(int i, int in_size, int out_size, int& xmin, int& xsize, float& center, float& invscale,
+                                         float& total) {
+    const float scale = (float)in_size / (float)out_size;
+    const float support = scale >= 1.f ? scale : 1.f;
+    invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * ((float)i + 0.5f);
+    xmin = max((int)(center - support + 0.5f), 0);
+    xsize = min((int)(center + support + 0.5f), in_size) - xmin;
+    total = 0.f;
+    for (int j = 0; j < xsize; ++j) total += tri_filter(((float)(j + xmin) - center + 0.5f) * invscale);
+}
+
+__global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.N * p.C * p.DH * p.DW) return;
+    const int dx = (int)(i % p.DW), dy = (int)((i / p.DW) % p.DH);
+    const int c = (int)((i / ((int64_t)p.DW * p.DH)) % p.C), n = (int)(i / ((int64_t)p.DW * p.DH * p.C));
+    int sy0 = 0, sx0 = 0, sh = p.SH, sw = p.SW, oy0 = 0, ox0 = 0, oh = p.DH, ow = p.DW;
+    if (p.src_box) {
+        const int* b = p.src_box + n * 4;
+        sy0 = b[0]; sx0 = b[2]; sh = b[1] - b[0]; sw = b[3] - b[2];
+    }
+    if (p.dst_box) {
+        const int* b = p.dst_box + n * 4;
+        oy0 = b[0]; ox0 = b[2]; oh = b[1] - b[0]; ow = p.dst_square ? oh : b[3] - b[2];
+    }
+    const int ry = dy - oy0, rx = dx - ox0;
+    if (ry < 0 || ry >= oh || rx < 0 || rx >= ow || sh <= 0 || sw <= 0) return;
+    // clamp the source box to the tensor (python slicing semantics)
+    const int cy0 = max(sy0, 0), cx0 = max(sx0, 0);
+    sh = min(sy0 + sh, p.SH) - cy0; sw = min(sx0 + sw, p.SW) - cx0;
+    if (sh <= 0 || sw <= 0) return;
+    int ymin, ysize, xmin, xsize;
+    float cyc, cxc, yinv, xinv, ytot, xtot;
+    aa_range(ry, sh, oh, ymin, ysize, cyc, yinv, ytot);
+    aa_range(rx, sw, ow, xmin, xsize, cxc, xinv, xtot);
+    const float* s = p.src + ((int64_t)n * p.C + c) * p.SH * p.SW;
+    float acc = 0.f;
+    for (int jy = 0; jy < ysize; ++jy) {
+        const float wy = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
+        const float* row = s + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
+        float h = 0.f;
+        for (int jx = 0; jx < xsize; ++jx) h += row[jx] * (tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot);
+        acc += h * wy;
+    }
+    p.dst[((int64_t)n * p.C + c) * p.DH * p.DW + (int64_t)dy * p.DW + dx] = acc;
+}
+
+extern "C" {
+
+int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, const int* faces, const float* face_uv,
+                        const float* uv_mask, int mask_h, int mask_w, float* tv_ws, unsigned long long* zbuf_ws, float* grid,
+                        float* alpha, float* lm2d, int N, int V, int Lm, int F, int views, int H, int W, float shift_x,
+                        float shift_y, float shift_z, float scale, int fill, int binarize_view, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && V > 0 && F > 0 && views > 0 && H > 0 && W > 0 && Lm >= 0, "rasterize_views: bad shape");
+    N3D_CHECK(!fill || (H <= 256 && W <= 256), "rasterize_views: fill_holes supports images up to 256x256");
+    if (N == 0) return 0;
+    N3D_CHECK(verts && rot && faces && face_uv && uv_mask && tv_ws && zbuf_ws && grid && alpha && (Lm == 0 || (lms && lm2d)),
+              "rasterize_views: null tensor");
+    const int NV = N * views;
+    N3dProfScope prof(N3D_K_RASTER, stream, 0.0, 4.0 * NV * (double)H * W * 6);
+    if (hipMemsetAsync(zbuf_ws, 0xFF, sizeof(unsigned long long) * (size_t)NV * H * W, stream) != hipSuccess)
+        return n3d_set_error("rasterize_views: memset failed");
+    const int64_t nt = (int64_t)NV * V + (int64_t)N * Lm;
+    hipLaunchKernelGGL(raster_transform_kernel, dim3((unsigned)cdiv64(nt, 256)), dim3(256), 0, stream, verts, lms, rot, tv_ws, lm2d, N,
+                       V, Lm, views, shift_x, shift_y, shift_z, scale);
+    N3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)cdiv64((int64_t)NV * F, 256)), dim3(256), 0, stream, (const float*)tv_ws,
+                       faces, zbuf_ws, NV, V, F, H, W);
+    N3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)cdiv64((int64_t)NV * H * W, 256)), dim3(256), 0, stream,
+                       (const float*)tv_ws, faces, face_uv, (const unsigned long long*)zbuf_ws, uv_mask, mask_h, mask_w, grid, alpha,
+                       NV, V, F, H, W);
+    N3D_LAUNCH_CHECK();
+    if (fill) {
+        static bool lds_opt_in = false;
+        if (!lds_opt_in) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
+            if (hipFuncSetAttribute((const void*)fill_holes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * FH_S) != hipSuccess)
+                return n3d_set_error("rasterize_views: cannot reserve %d bytes of LDS", 256 * FH_S);
+            lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(fill_holes_kernel, dim3(NV), dim3(256), (size_t)H * FH_S, stream, alpha, H, W, binarize_view, views);
+        N3D_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int n3d_texture_project(const float* textures, const float* grid, float* out, int N, int C, int TH, int TW, int H, int W,
+                        int views, int view_a, int view_b, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && view_a >= 0 && view_a < views && view_b < views, "texture_project: bad arguments");
+    if (N == 0) return 0;
+    N3D_CHECK(textures && grid && out, "texture_project: null tensor");
+    N3dProfScope prof(N3D_K_RASTER, stream, 8.0 * N * C * (double)H * W, 4.0 * N * C * ((double)H * W + (double)TH * TW));
+    hipLaunchKernelGGL(texture_project_kernel, dim3((unsigned)cdiv64((int64_t)N * H * W, 256)), dim3(256), 0, stream, textures, grid,
+                       out, N, C, TH, TW, H, W, views, view_a, view_b);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_mouth_bbox(const float* lm2d, int* bbox, int N, int Lm, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && Lm >= 60, "mouth_bbox: need >= 60 landmarks");
+    if (N == 0) return 0;
+    N3D_CHECK(lm2d && bbox, "mouth_bbox: null tensor");
+    hipLaunchKernelGGL(mouth_bbox_kernel, dim3(cdiv(N, 64)), dim3(64), 0, stream, lm2d, bbox, N, Lm);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_resize_aa(const float* src, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW, int DH,
+                  int DW, int dst_square, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && SH > 0 && SW > 0 && DH > 0 && DW > 0, "resize_aa: bad shape");
+    if (N == 0) return 0;
+    N3D_CHECK(src && dst, "resize_aa: null tensor");
+    ResizeParams p;
+    p.src = src; p.dst = dst; p.src_box = src_box; p.dst_box = dst_box; p.N = N; p.C = C; p.SH = SH; p.SW = SW; p.DH = DH; p.DW = DW;
+    p.dst_square = dst_square;
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * N * C * ((double)SH * SW + (double)DH * DW));
+    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)cdiv64((int64_t)N * C * DH * DW, 256)), dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+"""TriPlaneGenerator — the B2 (model-level) drop-in boundary.
+
+Same constructor / `mapping` / `synthesis` / `forward` signatures, state-dict names and attributes as the
+reference class (training_avatar_texture/triplane_next3d.py:40-344), so `gen_samples_next3d.py`,
+`gen_videos_next3d.py` and `reenact_avatar_next3d.py` can construct it with `--reload_modules=True`
+(`TriPlaneGenerator(*G.init_args, **G.init_kwargs)` + `misc.copy_params_and_buffers`).  The forward pass
+itself is a different program: every arithmetic step runs in libn3d.so HIP kernels, there are no
+device->host round trips (the reference has 4N+1 per frame: fill_mouth and gen_mouth_mask) and no
+dynamic shapes (the mouth box lives in device memory).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, layers, mesh, networks, spec
+
+_BUFFER_LEAVES = ('noise_const', 'resample_filter', 'w_avg', 'dense_faces', 'faces', 'raw_uvcoords', 'uvcoords', 'uvfaces',
+                  'face_uvcoords')
+RENDERING_VIEWS = [[0, 0, 0], [0, 90, 0], [0, -90, 0], [90, 0, 0]]        # reference triplane_next3d.py:140-145
+
+
+def angle2matrix(angles_deg):
+    """[3] XYZ angles in degrees -> [1,3,3] rotation matrix (reference volumetric_rendering/renderer.py:518-547)."""
+    a = torch.tensor(angles_deg, dtype=torch.float32).reshape(1, 3) * (np.pi) / 180.
+    s, c = torch.sin(a), torch.cos(a)
+    cx, cy, cz = c[:, 0], c[:, 1], c[:, 2]
+    sx, sy, sz = s[:, 0], s[:, 1], s[:, 2]
+    R = torch.stack([cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                     sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                     -sy, cy * sx, cy * cx], dim=0)
+    return torch.reshape(R, (-1, 3, 3))
+
+
+class _Node(torch.nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _attach(root, dotted, tensor, is_buffer):
+    parts = dotted.split('.')
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Node())
+        mod = getattr(mod, p)
+    if is_buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], torch.nn.Parameter(tensor, requires_grad=False))
+
+
+class TriPlaneGenerator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path, sr_num_fp16_res=0,
+                 mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, uv_face_mask=None, **synthesis_kwargs):
+        super().__init__()
+        if (z_dim, c_dim, w_dim, img_resolution, img_channels) != (512, 25, 512, 512, 3):
+            raise RuntimeError('this build implements the next3d_ffhq_512 configuration (z=w=512, c=25, 512x512x3)')
+        if mapping_kwargs.get('num_layers', 2) != 2:
+            raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
+        if synthesis_kwargs.get('channel_base', 32768) != 32768 or synthesis_kwargs.get('channel_max', 512) != 512:
+            raise RuntimeError('channel_base=32768 / channel_max=512 expected')
+        self.init_args = (z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path)
+        self.init_kwargs = dict(sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs,
+                                rendering_kwargs=rendering_kwargs, sr_kwargs=sr_kwargs, **synthesis_kwargs)
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.topology_path = topology_path
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self.load_lms = True
+        self.uv_resolution = 256
+        self.fill_mouth = True
+        self.orth_scale = torch.tensor([[5.0]])
+        self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
+
+        # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
+        mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
+        for name, (shape, kind) in spec.build_spec().items():
+            leaf = name.rsplit('.', 1)[-1]
+            if kind == 'mesh':
+                t = mb[name]
+            elif kind == 'fir':
+                t = spec._fir()
+            elif kind in ('randn',):
+                t = torch.randn(shape)
+            elif kind == 'randn_lr':
+                t = torch.randn(shape) / 0.01
+            elif kind == 'affine_bias':
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            _attach(self, name, t, is_buffer=(leaf in _BUFFER_LEAVES))
+
+        if uv_face_mask is None:      # reference: cv2.imread('data/ffhq/uv_face_eye_mask.png') (triplane_next3d.py:91)
+            uv_face_mask = self._load_uv_mask('data/ffhq/uv_face_eye_mask.png')
+        self.uv_face_mask = torch.nn.functional.interpolate(uv_face_mask.float(), [256, 256])
+        self._prepared = None
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _load_uv_mask(path):
+        if os.path.exists(path):
+            from PIL import Image
+            m = np.asarray(Image.open(path).convert('RGB'), dtype=np.float32)[:, :, 0] / 255.
+            return torch.from_numpy(m)[None, None].contiguous()
+        return mesh.synthetic_uv_face_mask()
+
+    def _apply(self, fn, *a, **k):
+        self._prepared = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prepared = None
+        return super().load_state_dict(*a, **k)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def refresh(self):
+        """Drop derived constants (call after mutating parameters in place)."""
+        self._prepared = None
+
+    def _prep(self):
+        """Derived per-model constants: K-major conv weights, squared-weight sums, scaled decoder weights, mesh tables."""
+        if self._prepared is not None:
+            return self._prepared
+        dev = self.device
+        if dev.type != 'cuda':
+            raise RuntimeError('TriPlaneGenerator runs on a HIP device only: move it with .to("cuda") '
+                               '(no CPU fallback; the CPU restatement is oracle/, test infrastructure)')
+        _lib.lib()
+        P = {k: v.detach() for k, v in self.state_dict().items()}
+        S = type('Prepared', (), {})()
+        S.P = P
+        S.texture = networks.SynthesisNet(P, 'texture_backbone.synthesis')
+        S.static = networks.SynthesisNet(P, 'backbone.synthesis')
+        S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64)
+        S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256)
+        S.sr = networks.SuperRes8XDC(P, 'superresolution')
+        lr = float(self.rendering_kwargs.get('decoder_lr_mul', 1))
+        S.dec_w1 = (P['decoder.net.0.weight'] * (lr / np.sqrt(32))).contiguous()
+        S.dec_b1 = (P['decoder.net.0.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.0.bias']
+        S.dec_w2 = (P['decoder.net.2.weight'] * (lr / np.sqrt(64))).contiguous()
+        S.dec_b2 = (P['decoder.net.2.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.2.bias']
+        S.faces = P['faces'][0][:, [0, 2, 1]].to(torch.int32).contiguous()                 # triplane_next3d.py:207
+        S.face_uv = P['face_uvcoords'][0][:, [0, 2, 1]].contiguous()                       # :208
+        S.rot = torch.cat([angle2matrix(a) for a in RENDERING_VIEWS], 0).to(dev).contiguous()
+        S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
+        S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
+        S.tlin = {}
+        self._prepared = S
+        return S
+
+    # ------------------------------------------------------------------ reference API
+    def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        """reference triplane_next3d.py:111-115 + MappingNetwork.forward (networks_stylegan2.py:233-268)."""
+        S = self._prep()
+        P = S.P
+        if self.rendering_kwargs['c_gen_conditioning_zero']:
+            c = torch.zeros_like(c)
+        c = c[:, :25] * self.rendering_kwargs.get('c_scale', 0)
+        z = z.to(device=self.device, dtype=torch.float32)
+        c = c.to(device=self.device, dtype=torch.float32)
+        pre = 'backbone.mapping'
+        x = _normalize_2nd_moment(z)
+        y = layers.fc(c.contiguous(), P[f'{pre}.embed.weight'], P[f'{pre}.embed.bias'], wgain=1 / np.sqrt(25))
+        x = torch.cat([x, _normalize_2nd_moment(y)], dim=1)
+        for i in range(2):
+            w = P[f'{pre}.fc{i}.weight']
+            x = layers.fc(x, w, P[f'{pre}.fc{i}.bias'], wgain=0.01 / np.sqrt(w.shape[1]), bgain=0.01, act='lrelu')
+        num_ws = 2 * S.texture.num_ws
+        x = x.unsqueeze(1).repeat(1, num_ws, 1)
+        if truncation_psi != 1:
+            w_avg = P[f'{pre}.w_avg']
+            if truncation_cutoff is None:
+                x = w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+    def rasterize(self, v, lms, textures):
+        """reference triplane_next3d.py:190-230 -> ([front, side, top] each [N,32,256,256], alpha [N,3,256,256], bbox [N,4] int32)."""
+        S = self._prep()
+        dev, N, V, Lm, F = v.device, v.shape[0], v.shape[1], lms.shape[1], S.faces.shape[0]
+        views, H, W = len(RENDERING_VIEWS), 256, 256
+        f32 = dict(dtype=torch.float32, device=dev)
+        tv = torch.empty(N * views * V * 3, **f32)
+        zbuf = torch.empty(N * views * H * W, dtype=torch.int64, device=dev)
+        grid = torch.empty(N * views, H, W, 2, **f32)
+        alpha4 = torch.empty(N, views, H, W, **f32)
+        lm2d = torch.empty(N, Lm, 2, **f32)
+        sh = self.orth_shift.reshape(-1).tolist()
+        L = _lib.lib()
+        _lib.check(L.n3d_rasterize_views(_lib.ptr(v.contiguous()), _lib.ptr(lms.contiguous()), _lib.ptr(S.rot), _lib.ptr(S.faces),
+                                         _lib.ptr(S.face_uv), _lib.ptr(S.uv_mask), S.uv_mask.shape[0], S.uv_mask.shape[1],
+                                         _lib.ptr(tv), _lib.ptr(zbuf), _lib.ptr(grid), _lib.ptr(alpha4), _lib.ptr(lm2d), N, V, Lm, F,
+                                         views, H, W, sh[0], sh[1], sh[2], float(self.orth_scale.item()),
+                                         1 if self.fill_mouth else 0, 1, _lib.stream()))
+        planes = []
+        for va, vb in ((0, -1), (1, 2), (3, -1)):
+            out = torch.empty(N, textures.shape[1], H, W, **f32)
+            _lib.check(L.n3d_texture_project(_lib.ptr(textures), _lib.ptr(grid), _lib.ptr(out), N, textures.shape[1],
+                                             textures.shape[2], textures.shape[3], H, W, views, va, vb, _lib.stream()))
+            planes.append(out)
+        bbox = torch.empty(N, 4, dtype=torch.int32, device=dev)
+        _lib.check(L.n3d_mouth_bbox(_lib.ptr(lm2d), _lib.ptr(bbox), N, Lm, _lib.stream()))
+        alpha = alpha4[:, [0, 1, 3]].contiguous()
+        return planes, alpha, bbox
+
+    def _planes(self, ws, v, noise_mode):
+        """Everything up to the blended tri-planes (channels-last [N,3,256,256,32])."""
+        S = self._prep()
+        L = _lib.lib()
+        v = v.to(device=self.device, dtype=torch.float32)
+        if self.load_lms:
+            v, lms = v[:, :5023], v[:, 5023:]
+        else:
+            raise RuntimeError('load_lms=False is not supported: the mouth branch needs the 68 landmarks')
+        N = ws.shape[0]
+        nw = S.texture.num_ws
+        eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
+        textures = S.texture(texture_ws, noise_mode)
+        (front, side, top), alpha, bbox = self.rasterize(v, lms, textures)
+        f32 = dict(dtype=torch.float32, device=ws.device)
+        crop = torch.empty(N, 32, 64, 64, **f32)
+        _lib.check(L.n3d_resize_aa(_lib.ptr(front), _lib.ptr(crop), _lib.ptr(bbox), None, N, 32, 256, 256, 64, 64, 0, _lib.stream()))
+        mouths = S.mouth(crop, eg3d_ws, noise_mode)
+        stitch_in = front.clone()
+        _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
+        stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
+        static = S.static(eg3d_ws, noise_mode)
+        planes = torch.empty(N, 3, 256, 256, 32, **f32)
+        _lib.check(L.n3d_blend_planes(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
+                                      _lib.ptr(planes), N, 256, 256, _lib.stream()))
+        self._debug = dict(textures=textures, front=front, side=side, top=top, alpha=alpha, bbox=bbox, crop=crop, mouths=mouths,
+                           stitch_in=stitch_in, stitch=stitch, static=static) if getattr(self, 'keep_stages', False) else None
+        return planes, eg3d_ws
+
+    def render(self, planes_cl, c, neural_rendering_resolution, depth_jitter=None, importance_u=None):
+        """RaySampler + ImportanceRenderer on channels-last planes -> (feature_image [N,32,R,R], depth_image [N,1,R,R])."""
+        S = self._prep()
+        rk = self.rendering_kwargs
+        dev, N, R = planes_cl.device, planes_cl.shape[0], int(neural_rendering_resolution)
+        Sc, Sf = int(rk['depth_resolution']), int(rk['depth_resolution_importance'])
+        t0, t1 = rk['ray_start'], rk['ray_end']
+        if t0 == 'auto' or t1 == 'auto' or rk.get('disparity_space_sampling', False):
+            raise RuntimeError("ray_start/ray_end='auto' and disparity sampling are not part of the ffhq configuration")
+        if rk.get('white_back', False) or rk.get('density_noise', 0) > 0 or rk.get('clamp_mode', 'softplus') != 'softplus':
+            raise RuntimeError('white_back / density_noise / non-softplus clamp_mode are not part of the ffhq configuration')
+        key = (Sc, float(t0), float(t1))
+        if key not in S.tlin:
+            S.tlin[key] = torch.linspace(t0, t1, Sc).to(dev)
+        c = c.to(device=dev, dtype=torch.float32)
+        cam2world = c[:, :16].contiguous()
+        intrinsics = c[:, 16:25].contiguous()
+        jitter = torch.rand((N, R * R, Sc, 1), device=dev) if depth_jitter is None else depth_jitter.to(dev)
+        u = torch.rand((N * R * R, Sf), device=dev) if importance_u is None else importance_u.to(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        feat = torch.empty(N, 32, R, R, **f32)
+        depth = torch.empty(N, 1, R, R, **f32)
+        _lib.check(_lib.lib().n3d_render_rays(
+            _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter.contiguous()),
+            _lib.ptr(u.contiguous()), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
+            _lib.ptr(depth), None, _lib.ptr(S.bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
+            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
+        return feat, depth
+
+    def synthesis(self, ws, c, v, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
+                  use_cached_backbone=False, depth_jitter=None, importance_u=None, **synthesis_kwargs):
+        """reference triplane_next3d.py:117-188.  Extra keyword inputs `depth_jitter` [N,R²,Sc,1] / `importance_u`
+        [N·R²,Sf] replace the device RNG draws of the renderer (tests feed the oracle's tensors)."""
+        noise_mode = synthesis_kwargs.get('noise_mode', 'random')
+        if noise_mode == 'random':
+            raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        S = self._prep()
+        ws = ws.to(device=self.device, dtype=torch.float32)
+        if use_cached_backbone and getattr(self, '_last_planes', None) is not None:
+            planes, eg3d_ws = self._last_planes
+        else:
+            planes, eg3d_ws = self._planes(ws, v, noise_mode)
+        if cache_backbone:
+            self._last_planes = (planes, eg3d_ws)
+        feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
+        rgb_image = feature_image[:, :3]
+        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa)
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
+
+    def forward(self, z, c, v, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
+                cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, c, v, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+
+
+def _normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def _resize_aa(x, size):
+    """F.interpolate(x, (size,size), mode='bilinear', align_corners=False, antialias=True) on libn3d.so."""
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, size, size, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().n3d_resize_aa(_lib.ptr(x.contiguous()), _lib.ptr(y), None, None, n, c, h, w, size, size, 0, _lib.stream()))
+    return y
