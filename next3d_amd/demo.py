@@ -1,0 +1,51 @@
+"""Synthetic-weights generator + demo inputs shared by bench.py, __graft_entry__.py and the tests.
+
+No pretrained pickle can be downloaded here (reference README.md:40 is a Drive link), so the generator is built with
+seeded synthetic weights of the exact next3d_ffhq_512 architecture; the driving mesh / landmarks are the reference's
+own demo fixture (data/demo/demo.obj, demo_kpt2d.txt) stored as arrays in tests/golden/demo_inputs.npz.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import camera_utils, mesh, spec
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO_NPZ = os.path.join(REPO, 'tests', 'golden', 'demo_inputs.npz')
+
+RENDERING_KWARGS = dict(                      # reference train_next3d.py:313-341 (cfg=ffhq)
+    image_resolution=512, disparity_space_sampling=False, clamp_mode='softplus', c_gen_conditioning_zero=True,
+    c_scale=1.0, superresolution_noise_mode='none', decoder_lr_mul=1.0, sr_antialias=True, depth_resolution=48,
+    depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1, avg_camera_radius=2.7,
+    avg_camera_pivot=[0, 0, 0.2], superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybrid8XDC')
+
+
+def demo_arrays():
+    return np.load(DEMO_NPZ)
+
+
+def build_generator(device, seed=0, rendering_kwargs=None):
+    from .generator import TriPlaneGenerator
+    d = demo_arrays()
+    topo = (d['faces'], d['uvs'], d['uvfaces'])
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2),
+                          rendering_kwargs=dict(rendering_kwargs or RENDERING_KWARGS),
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
+                          uv_face_mask=mesh.synthetic_uv_face_mask(), channel_base=32768, channel_max=512,
+                          fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None)
+    sd = spec.synthetic_state_dict(seed)
+    sd.update(mesh.mesh_buffers(*topo))
+    G.load_state_dict(sd, strict=True)
+    return G.eval().requires_grad_(False).to(device), sd
+
+
+def demo_batch(seeds, yaws=None, pitch=-0.2, device='cpu'):
+    """(z [N,512] f64, c [N,25], c_cond [N,25], v [N,5091,3]) exactly as gen_samples_next3d.py:165-196 builds them."""
+    d = demo_arrays()
+    n = len(seeds)
+    yaws = yaws if yaws is not None else [(0.4, 0.0, -0.4)[i % 3] for i in range(n)]
+    z = torch.from_numpy(np.concatenate([np.random.RandomState(s).randn(1, 512) for s in seeds], 0))
+    cs, cc = zip(*[camera_utils.demo_camera_params(angle_y=y, angle_p=pitch) for y in yaws])
+    v = torch.cat([torch.from_numpy(d['verts']), torch.from_numpy(d['landmarks']).float()], 0).float()[None].repeat(n, 1, 1)
+    return z.to(device), torch.cat(cs, 0).to(device), torch.cat(cc, 0).to(device), v.to(device)
