@@ -70,8 +70,9 @@ int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H,
                   int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                   int64_t x_batch_stride, int64_t y_batch_stride, const n3d_epilogue* epi, n3d_stream_t stream);
 
-/* ---- conv2d weight preparation (done once per model): w [O,I,k,k] -> wt [k*k][I][O] (K-major, the layout
- *      the MFMA kernel streams) and, when wsq != NULL, wsq[o*I+i] = sum_k w[o,i,k]^2 (for demodulation). */
+/* ---- conv2d weight preparation (done once per model): w [O,I,k,k] -> wt [k*k][I][OP] (K-major, the layout
+ *      the MFMA kernel streams; OP = O rounded up to a multiple of 4, zero padded, so rows are 16-byte aligned)
+ *      and, when wsq != NULL, wsq[o*I+i] = sum_k w[o,i,k]^2 (for demodulation). */
 int n3d_conv2d_prep_weight(const float* w, float* wt, float* wsq, int O, int I, int ksize, n3d_stream_t stream);
 
 /* ---- conv2d: the one dense contraction (fp32 MFMA implicit GEMM).  Replaces the ATen conv2d /
@@ -85,7 +86,7 @@ int n3d_conv2d_prep_weight(const float* w, float* wt, float* wsq, int O, int I, 
  *      (ksplit*N*O*OH*OW floats) and a second kernel reduces + applies the epilogue. */
 typedef struct {
     const float* x;      /* [N,I,H,W], batch stride x_batch_stride */
-    const float* wt;     /* prepared weights [k*k][I][O]           */
+    const float* wt;     /* prepared weights [k*k][I][OP]          */
     const float* style;  /* [N,I] or NULL                          */
     float* y;            /* [N,O,OH,OW], batch stride y_batch_stride */
     float* workspace;    /* required when ksplit > 1               */

@@ -118,6 +118,7 @@ def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, re
     e.alpha = float(spec.def_alpha if alpha is None else alpha)
     e.gain = float(spec.def_gain if gain is None else gain)
     e.clamp = float(-1 if clamp is None else clamp)
+    e._keepalive = (row_scale, noise, noise_strength, bias, residual)   # the struct only holds raw pointers
     return e
 
 

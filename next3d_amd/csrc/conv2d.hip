@@ -21,10 +21,13 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __noinline__ float conv_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
 
 struct ConvParams {
     const float* x; const float* wt; const float* style; float* y; float* partial;
-    int N, I, O, H, W, OH, OW;       // OH/OW: full output dims
+    int N, I, O, OP, H, W, OH, OW;   // OH/OW: full output dims; OP = O rounded up to 4 (row pitch of wt)
     int GH, GW;                      // per-phase output grid (mode 2: H+1, W+1; else OH, OW)
     int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
     int64_t xbs, ybs;
@@ -89,69 +92,68 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
     const int nstage = (ic_end - ic_begin + ICB - 1) / ICB;
 
+    // ---- staging state, computed ONCE per thread: the stage loop only bumps two base pointers.
+    // A element v = tid + 256 j  -> As[v*4 .. v*4+3]  <- wt[(plane(t)*I + ic0 + ic)*OP + m0 + mv ..]
+    //   rows with t >= ntaps or m >= OP are never consumed (their accumulator rows are never stored), so they only
+    //   need a SAFE address, not a zero.  B element e = tid + 256 j -> Bs[(ic*PH + r)*PWP + q] <- x[n, ic0+ic, iy0+r, ix0+q]
+    //   (zero outside the image = the convolution's zero padding), times style[n, ic0+ic].
+    __shared__ float s_style[1024];
     const float* xn = p.x + (int64_t)n * p.xbs;
     const int iy0 = y0 * S - P, ix0 = x0 * S - P;
-    const bool o_vec = (p.O & 3) == 0;
+    const int HW = p.H * p.W;
+    for (int i = tid; i < ic_end - ic_begin; i += 256)       // no style = multiply by 1 (keeps the stage loop branch-free)
+        s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
 
-    float4 ra[A_PER_T];
+    int a_goff[A_PER_T], a_ic[A_PER_T];
+#pragma unroll
+    for (int j = 0; j < A_PER_T; ++j) {
+        const int v = tid + j * 256;
+        const int row = v / (BM / 4), mv = (v % (BM / 4)) * 4;
+        const int t = row / ICB, ic = row % ICB;
+        const bool ok = v < A_VEC && t < ntaps && (m0 + mv) < p.OP;
+        a_ic[j] = ok ? ic : ICB;                                   // ICB = "never valid": forces the safe address
+        a_goff[j] = ok ? (tap_wplane(t) * p.I + ic) * p.OP + m0 + mv : 0;
+    }
+    int b_goff[B_PER_T], b_loff[B_PER_T], b_ic[B_PER_T];
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+        const int e = tid + j * 256;
+        const int ic = e / (PH * PW), rem = e % (PH * PW);
+        const int r = rem / PW, q = rem % PW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        const bool ok = e < B_ELEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        b_ic[j] = ok ? ic : ICB;
+        b_goff[j] = ok ? ic * HW + iy * p.W + ix : 0;
+        b_loff[j] = e < B_ELEMS ? (ic * PH + r) * PWP + q : -1;
+    }
+    const float* a_base = p.wt + (int64_t)ic_begin * p.OP;
+    const float* b_base = xn + (int64_t)ic_begin * HW;
+
+    f32x4 ra[A_PER_T];
     float rb[B_PER_T];
 
     auto load_stage = [&](int st) {
-        const int ic0 = ic_begin + st * ICB;
-        // A: rows (t, ic) of BM contiguous floats
+        const int nch = min(ICB, ic_end - ic_begin - st * ICB);     // valid channels of this stage (tail stage: < ICB)
+        const float* ab = a_base + (int64_t)st * ICB * p.OP;
+        const float* bb = b_base + (int64_t)st * ICB * HW;
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j) {
-            const int v = tid + j * 256;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < A_VEC) {
-                const int row = v / (BM / 4), mv = (v % (BM / 4)) * 4;
-                const int t = row / ICB, ic = row % ICB;
-                const int ci = ic0 + ic, o = m0 + mv;
-                if (t < ntaps && ci < ic_end) {
-                    const float* src = p.wt + ((int64_t)tap_wplane(t) * p.I + ci) * p.O + o;
-                    if (o_vec) {
-                        if (o < p.O) val = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (o + 0 < p.O) val.x = src[0];
-                        if (o + 1 < p.O) val.y = src[1];
-                        if (o + 2 < p.O) val.z = src[2];
-                        if (o + 3 < p.O) val.w = src[3];
-                    }
-                }
-            }
-            ra[j] = val;
-        }
-        // B: patch with halo, modulated
+        for (int j = 0; j < A_PER_T; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ab + (a_ic[j] < nch ? a_goff[j] : 0));
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
-            const int e = tid + j * 256;
-            float val = 0.f;
-            if (e < B_ELEMS) {
-                const int ic = e / (PH * PW), rem = e % (PH * PW);
-                const int r = rem / PW, q = rem % PW;
-                const int ci = ic0 + ic, iy = iy0 + r, ix = ix0 + q;
-                if (ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    val = xn[((int64_t)ci * p.H + iy) * p.W + ix];
-                    if (p.style) val *= p.style[(int64_t)n * p.I + ci];
-                }
-            }
-            rb[j] = val;
+            const bool ok = b_ic[j] < nch;
+            const float val = bb[ok ? b_goff[j] : 0] * s_style[st * ICB + (ok ? b_ic[j] : 0)];
+            rb[j] = ok ? val : 0.f;
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j) {
             const int v = tid + j * 256;
-            if (v < A_VEC) *reinterpret_cast<float4*>(&As[v * 4]) = ra[j];
+            if (v < A_VEC) *reinterpret_cast<f32x4*>(&As[v * 4]) = ra[j];
         }
 #pragma unroll
-        for (int j = 0; j < B_PER_T; ++j) {
-            const int e = tid + j * 256;
-            if (e < B_ELEMS) {
-                const int ic = e / (PH * PW), rem = e % (PH * PW);
-                Bs[(ic * PH + rem / PW) * PWP + rem % PW] = rb[j];
-            }
-        }
+        for (int j = 0; j < B_PER_T; ++j)
+            if (b_loff[j] >= 0) Bs[b_loff[j]] = rb[j];
     };
 
     // per-lane fragment addressing
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    __syncthreads();                     // s_style visible
     if (nstage > 0) {
         load_stage(0);
         store_stage();
@@ -205,32 +208,67 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+    const n3d_epilogue& E = p.epi;
+    const int64_t plane = (int64_t)p.OH * p.OW;
+    if (p.partial) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int pix = (wn * NT + nt) * 32 + l31;
+            const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+            int oy = gy, ox = gx;
+            bool ok = gy < p.GH && gx < p.GW;
+            if (MODE == 2) { oy = 2 * gy + pa; ox = 2 * gx + pb; ok = ok && oy < p.OH && ox < p.OW; }
+            if (!ok) continue;
+            float* dst = p.partial + ((int64_t)ks * p.N + n) * p.O * plane + (int64_t)oy * p.OW + ox;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o < p.O) dst[(int64_t)o * plane] = acc[mt][nt][r];
+                }
+        }
+        return;
+    }
+    // per-channel factors first (row scale, bias), then one pass over the pixels
+    float rs[MT][16], bs[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oc = o < p.O ? o : p.O - 1;
+            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+            bs[mt][r] = E.bias ? E.bias[oc] : 0.f;
+        }
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int pix = (wn * NT + nt) * 32 + l31;
         const int gy = y0 + pix / TW, gx = x0 + pix % TW;
         int oy = gy, ox = gx;
         bool ok = gy < p.GH && gx < p.GW;
-        if (MODE == 2) {
-            oy = 2 * gy + pa; ox = 2 * gx + pb;
-            ok = ok && oy < p.OH && ox < p.OW;
-        }
+        if (MODE == 2) { oy = 2 * gy + pa; ox = 2 * gx + pb; ok = ok && oy < p.OH && ox < p.OW; }
         if (!ok) continue;
+        const int64_t po = (int64_t)oy * p.OW + ox;
+        const float nz = E.noise ? E.noise[po] * nstr : 0.f;
+        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (o >= p.O) continue;
-                float v = acc[mt][nt][r];
-                if (p.partial) {
-                    p.partial[(((int64_t)ks * p.N + n) * p.O + o) * ((int64_t)p.OH * p.OW) + (int64_t)oy * p.OW + ox] = v;
-                } else {
-                    v = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
-                    p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.OW + ox] = v;
-                }
+                float v = acc[mt][nt][r] * rs[mt][r] + nz + bs[mt][r];
+                if (lrelu) v = v > 0.f ? v : v * E.alpha;
+                else if (!linear) v = conv_act_generic(v, E.act, E.alpha);
+                v *= E.gain;
+                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+                if (res) v += res[(int64_t)o * plane];
+                dst[(int64_t)o * plane] = v;
             }
-        }
     }
 }
 
@@ -255,17 +293,18 @@ __global__ __launch_bounds__(256) void conv2d_splitk_epilogue_kernel(const float
 // w [O,I,k,k] -> wt [k*k][I][O];  wsq[o,i] = sum_k w^2
 __global__ __launch_bounds__(256) void conv2d_prep_weight_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                                                  float* __restrict__ wsq, int O, int I, int KK) {
-    const int64_t total = (int64_t)O * I;
+    const int OP = (O + 3) & ~3;                           // row pitch: 16-byte rows, zero padded
+    const int64_t total = (int64_t)OP * I;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e / O), o = (int)(e % O);      // o fastest -> coalesced writes
+        const int i = (int)(e / OP), o = (int)(e % OP);    // o fastest -> coalesced writes
         const float* src = w + ((int64_t)o * I + i) * KK;
         float s = 0.f;
         for (int t = 0; t < KK; ++t) {
-            const float v = src[t];
-            wt[((int64_t)t * I + i) * O + o] = v;
+            const float v = o < O ? src[t] : 0.f;
+            wt[((int64_t)t * I + i) * OP + o] = v;
             s += v * v;
         }
-        if (wsq) wsq[(int64_t)o * I + i] = s;
+        if (wsq && o < O) wsq[(int64_t)o * I + i] = s;
     }
 }
 
@@ -312,7 +351,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d: wt must be 16-byte aligned");
     ConvParams p;
     p.x = d->x; p.wt = d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
-    p.N = d->N; p.I = d->I; p.O = d->O; p.H = d->H; p.W = d->W;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP = (d->O + 3) & ~3; p.H = d->H; p.W = d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.nphase = 1;
     if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }
@@ -321,6 +360,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         p.OH = (d->H - 3) / 2 + 1; p.OW = (d->W - 3) / 2 + 1; p.GH = p.OH; p.GW = p.OW;
     } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");
+    N3D_CHECK(d->I <= 1024 * (d->ksplit < 1 ? 1 : d->ksplit), "conv2d: more than 1024 input channels per K-split");
     const bool wide = p.GW > 16;
     const double flops = 2.0 * d->N * (double)d->O * d->I * d->ksize * d->ksize *
                          (d->mode == 2 ? (double)d->H * d->W : (double)p.OH * p.OW);

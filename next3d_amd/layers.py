@@ -66,9 +66,9 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:
-        return cg.conv_launch(x, L.wt, 3, 0, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act))
+        return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act))
     assert up == 2
-    t = cg.conv_launch(x, L.wt, 3, 2, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef))
+    t = cg.conv_launch(x, L.wt, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef))
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 
@@ -76,7 +76,7 @@ def torgb_layer(L, x, w, conv_clamp=None, residual=None):
     """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584)."""
     g = L.weight_gain
     styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
-    return cg.conv_launch(x, L.wt, 1, 0, style=styles,
+    return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=styles,
                           epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual))
 
 
@@ -87,7 +87,7 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
                              gain=activation_funcs[activation].def_gain * gain,
                              clamp=None if conv_clamp is None else conv_clamp * gain, residual=residual)
     if down == 1:
-        return cg.conv_launch(x, L.wt, L.ksize, 0, epilogue=epi, out=out)
+        return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3
     x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
-    return cg.conv_launch(x, L.wt, 3, 1, epilogue=epi, out=out)
+    return cg.conv_launch(x, L.wt, 3, 1, L.out_channels, epilogue=epi, out=out)

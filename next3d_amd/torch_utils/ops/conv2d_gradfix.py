@@ -23,7 +23,7 @@ def prep_weight(w, want_sq=False):
     if kh != kw or kh not in (1, 3):
         raise RuntimeError(f'conv2d: kernel {kh}x{kw} unsupported (1x1 or 3x3)')
     w = w.contiguous()
-    wt = torch.empty([kh * kw, i, o], dtype=torch.float32, device=w.device)
+    wt = torch.empty([kh * kw, i, (o + 3) // 4 * 4], dtype=torch.float32, device=w.device)     # rows padded to 16 bytes
     wsq = torch.empty([o, i], dtype=torch.float32, device=w.device) if want_sq else None
     _lib.check(_lib.lib().n3d_conv2d_prep_weight(_lib.ptr(w), _lib.ptr(wt), _lib.ptr(wsq), o, i, kh, _lib.stream()))
     return (wt, wsq) if want_sq else wt
@@ -50,11 +50,11 @@ def pick_ksplit(n, i, o, gh, gw, ksize):
     return ks
 
 
-def conv_launch(x, wt, ksize, mode, out=None, style=None, epilogue=None, ksplit=None):
-    """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights -> y [N,O,OH,OW]."""
+def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None):
+    """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] -> y [N,out_channels,OH,OW]."""
     n, i, h, w = x.shape
-    o = wt.shape[2]
-    assert wt.shape[0] == ksize * ksize and wt.shape[1] == i, (tuple(wt.shape), ksize, i)
+    o = out_channels
+    assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     if x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
@@ -85,7 +85,7 @@ def _grouped(x, weight, groups, ksize, mode, transposed):
         else:               # weight [groups*O_g, I_g, k, k]
             og = weight.shape[0] // groups
             wg = weight[g * og:(g + 1) * og]
-        outs.append(conv_launch(x[:, g * ig:(g + 1) * ig], prep_weight(wg), ksize, mode))
+        outs.append(conv_launch(x[:, g * ig:(g + 1) * ig], prep_weight(wg), ksize, mode, wg.shape[0]))
     return torch.cat(outs, dim=1)
 
 
@@ -104,7 +104,7 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     else:
         raise RuntimeError(f'conv2d: stride={stride} padding={pad} kernel={k} is outside the generator-forward path')
     if groups == 1:
-        return conv_launch(input, prep_weight(weight), k, mode)
+        return conv_launch(input, prep_weight(weight), k, mode, weight.shape[0])
     return _grouped(input, weight, groups, k, mode, transposed=False)
 
 
@@ -116,5 +116,5 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     if stride != 2 or pad != 0 or weight.shape[2] != 3 or output_padding != 0 or dilation != 1 or bias is not None:
         raise RuntimeError('conv_transpose2d: only 3x3 / stride 2 / padding 0 is on the generator-forward path')
     if groups == 1:
-        return conv_launch(input, prep_weight(weight.transpose(0, 1)), 3, 2)
+        return conv_launch(input, prep_weight(weight.transpose(0, 1)), 3, 2, weight.shape[1])
     return _grouped(input, weight, groups, 3, 2, transposed=True)

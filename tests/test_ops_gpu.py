@@ -130,7 +130,7 @@ def test_conv2d_plain(dev, N, I, OC, H, W, k, mode):
     ref = _conv_ref(x, w, mode)
     wt = cg.prep_weight(w.to(dev))
     for ksplit in (1, None, 3):
-        y = cg.conv_launch(x.to(dev), wt, k, mode, ksplit=ksplit)
+        y = cg.conv_launch(x.to(dev), wt, k, mode, OC, ksplit=ksplit)
         _close(y, ref, atol=2e-5, rtol=1e-4)
 
 
@@ -148,7 +148,7 @@ def test_conv2d_epilogue_and_style(dev):
     for ksplit in (1, 4):
         epi = _lib.make_epilogue(row_scale=t(d), noise=t(noise), noise_strength=t(ns), bias=t(b), residual=t(res),
                                  const_scale=0.9, act='lrelu', gain=1.3, clamp=2.0)
-        y = cg.conv_launch(t(x), cg.prep_weight(t(w)), 3, 0, style=t(s), epilogue=epi, ksplit=ksplit)
+        y = cg.conv_launch(t(x), cg.prep_weight(t(w)), 3, 0, OC, style=t(s), epilogue=epi, ksplit=ksplit)
         _close(y, ref, atol=3e-5, rtol=1e-4)
 
 
