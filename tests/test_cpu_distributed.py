@@ -1,0 +1,57 @@
+"""world_size-2 `gloo` test of the N>1 path: seed/frame sharding + the final frame gather (the only collective)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from next3d_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    seeds = list(range(6))
+    mine = sharding.shard_strided(seeds, rank, world)
+    frames = torch.stack([torch.full((3, 4, 4), s, dtype=torch.uint8) for s in mine])      # "rendered" frame = its seed
+    g = sharding.gather_frames(frames, dst=0)
+    if rank == 0:
+        ordered = sharding.unshard_strided(g, world)
+        out.put(ordered[:, 0, 0, 0].tolist())
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_helpers():
+    assert sharding.shard_block(list(range(10)), 0, 4) == [0, 1, 2] and sharding.shard_block(list(range(10)), 3, 4) == [8, 9]
+    assert sum((sharding.shard_block(list(range(10)), r, 4) for r in range(4)), []) == list(range(10))
+    assert sharding.shard_strided(list(range(7)), 1, 3) == [1, 4]
+    assert sharding.shard_block([], 0, 2) == []
+    t = torch.zeros(2, 3, 4, 4, dtype=torch.uint8)
+    assert sharding.gather_frames(t) is t                      # single process: no collective
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gather_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert q.get() == [0, 1, 2, 3, 4, 5]

@@ -1,0 +1,117 @@
+"""CPU (-m "not gpu") tests: parameter inventory, C-ABI surface, host logic, loud failure without a device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from next3d_amd import build
+    return build.build(verbose=False)
+
+
+def test_spec_matches_reference_state_dict():
+    """next3d_amd.spec reproduces every name/shape the reference constructors register (fixture written by
+    oracle/pin_against_reference.py from the real reference)."""
+    from next3d_amd import spec
+    ref = {}
+    for line in open(os.path.join(GOLDEN, 'ref_state_dict_spec.txt')):
+        name, rest = line.split(' ', 1)
+        shape = tuple(int(v) for v in re.findall(r'\d+', rest.rsplit(')', 1)[0]))
+        ref[name] = shape
+    mine = {k: tuple(v[0]) for k, v in spec.build_spec().items()}
+    assert set(mine) == set(ref), (sorted(set(mine) ^ set(ref))[:10])
+    bad = {k: (mine[k], ref[k]) for k in ref if mine[k] != ref[k]}
+    assert not bad, bad
+    assert len(ref) == 674
+
+
+def test_generator_module_state_dict_names():
+    from next3d_amd import demo, spec
+    d = demo.demo_arrays()
+    from next3d_amd.generator import TriPlaneGenerator
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, (d['faces'], d['uvs'], d['uvfaces']), rendering_kwargs=dict(demo.RENDERING_KWARGS))
+    assert set(G.state_dict()) == set(spec.build_spec())
+    params = {n for n, _ in G.named_parameters()}
+    assert 'backbone.synthesis.b4.conv1.noise_const' not in params and 'backbone.synthesis.b4.conv1.weight' in params
+    assert sum(p.numel() for p in G.parameters()) == 172_815_807
+    with pytest.raises(RuntimeError):                                      # no CPU fallback
+        G.mapping(torch.zeros(1, 512), torch.zeros(1, 25))
+
+
+def test_abi_header_symbols_exported(built_lib):
+    """Every function include/n3d.h declares resolves in libn3d.so and is bound by the ctypes layer."""
+    from next3d_amd import _lib
+    hdr = open(os.path.join(REPO, 'include', 'n3d.h')).read()
+    declared = sorted(set(re.findall(r'\b(n3d_[a-z0-9_]+)\s*\(', hdr)))
+    assert declared == _lib.exported_symbols(), set(declared) ^ set(_lib.exported_symbols())
+    h = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(h, name), name
+    assert h.n3d_abi_version() == _lib.ABI_VERSION
+    nm = subprocess.run(['nm', '-D', '--defined-only', built_lib], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (n3d_[a-z0-9_]+)', nm))
+    assert set(declared) <= exported
+    lib = _lib.lib()
+    assert lib.n3d_last_error() is not None
+
+
+def test_ops_fail_loudly_without_device(built_lib, monkeypatch):
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+    x = torch.zeros(1, 4, 8, 8)
+    for fn in (lambda: bias_act.bias_act(x), lambda: upfirdn2d.upfirdn2d(x, None),
+               lambda: conv2d_resample.conv2d_resample(x, torch.zeros(4, 4, 3, 3), padding=1),
+               lambda: bias_act.bias_act(x, impl='ref')):
+        with pytest.raises(RuntimeError):
+            fn()
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libn3d.so')
+    with pytest.raises(RuntimeError, match='no CPU or PyTorch fallback'):
+        _lib.lib()
+
+
+def test_filters_padding_and_ksplit():
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    from oracle import ops as O
+    assert torch.equal(uf.setup_filter([1, 3, 3, 1]), O.setup_filter((1, 3, 3, 1)))
+    assert uf.setup_filter([1] * 8).ndim == 1 and uf.setup_filter(None).shape == (1, 1)
+    assert uf._parse_padding(2) == (2, 2, 2, 2) and uf._parse_padding([1, 2]) == (1, 1, 2, 2)
+    assert cg.out_shape(16, 16, 2) == (33, 33) and cg.out_shape(33, 33, 1) == (16, 16)
+    assert cg.pick_ksplit(4, 512, 512, 4, 4, 3) == 16 and cg.pick_ksplit(4, 128, 128, 256, 256, 3) == 1
+
+
+def test_camera_and_mesh_helpers():
+    from next3d_amd import camera_utils, demo, mesh
+    g = np.load(os.path.join(GOLDEN, 'case_r32_s24.npz'))
+    c, c_cond = camera_utils.demo_camera_params(angle_y=0.4)
+    assert np.abs(c.numpy() - g['c']).max() <= 1e-6 and np.abs(c_cond.numpy() - g['c_cond']).max() <= 1e-6
+    d = demo.demo_arrays()
+    mb = mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces'])
+    assert mb['face_uvcoords'].shape == (1, 9976, 3, 3) and mb['dense_faces'].shape == (1, 122990, 3)
+    assert float(mb['uvcoords'][..., 2].min()) == 1.0
+    z, cc, _, v = demo.demo_batch([0], yaws=[0.4])
+    assert np.abs(z.numpy() - g['z']).max() == 0 and np.abs(v.numpy() - g['v']).max() == 0
+    m = mesh.synthetic_uv_face_mask()
+    assert m.shape == (1, 1, 256, 256) and float(m.min()) == 0.0 and float(m.max()) == 1.0
+
+
+def test_obj_and_landmark_parsers(tmp_path):
+    from next3d_amd import mesh
+    p = tmp_path / 't.obj'
+    p.write_text('mtllib x\nv 0 0 0\nv 1 0 0.5\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\n')
+    v, f, vt, ft = mesh.parse_obj(str(p))
+    assert v.shape == (3, 3) and f.tolist() == [[0, 1, 2]] and ft.tolist() == [[0, 1, 2]] and vt.shape == (3, 2)
+    assert mesh.parse_obj_vertices(str(p)).shape == (1, 3, 3)
+    q = tmp_path / 'k.txt'
+    q.write_text('\n'.join('0.1 0.2 0.3' for _ in range(68)))
+    assert mesh.parse_landmarks(str(q)).shape == (1, 68, 3)

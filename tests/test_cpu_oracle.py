@@ -1,0 +1,116 @@
+"""CPU (-m "not gpu") tests: the oracle against the golden fixtures produced by the REAL reference
+(oracle/pin_against_reference.py) and against closed-form cases."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from next3d_amd import mesh, spec
+from oracle import cases, generator as ogen, ops as O, raster, renderer
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+RK = dict(c_gen_conditioning_zero=True, c_scale=1.0, depth_resolution=24, depth_resolution_importance=24, ray_start=2.25,
+          ray_end=3.3, box_warp=1)
+
+
+@pytest.fixture(scope='module')
+def state():
+    d = np.load(os.path.join(GOLDEN, 'demo_inputs.npz'))
+    sd = spec.synthetic_state_dict(0)
+    sd.update(mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces']))
+    return sd
+
+
+def test_oracle_reproduces_reference_golden(state):
+    """configs[0] of BASELINE.json (1 seed, R=32, 24+24 samples, fp32 CPU): oracle == reference outputs, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, 'case_r32_s24.npz'))
+    R, Sc, Sf = int(g['R']), int(g['Sc']), int(g['Sf'])
+    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    rk = dict(RK, depth_resolution=Sc, depth_resolution_importance=Sf)
+    ws = ogen.mapping(state, torch.from_numpy(g['z']), torch.from_numpy(g['c_cond']), rk, truncation_psi=float(g['psi']),
+                      truncation_cutoff=int(g['cutoff']))
+    assert np.abs(ws.numpy() - g['ws']).max() == 0
+    out, st = ogen.synthesis(state, ws, torch.from_numpy(g['c']), torch.from_numpy(g['v']), mesh.synthetic_uv_face_mask(), rk,
+                             jitter, u, neural_rendering_resolution=R, return_stages=True)
+    assert np.abs(out['image_raw'].numpy() - g['image_raw']).max() <= 1e-6
+    assert np.abs(out['image_depth'].numpy() - g['image_depth']).max() <= 1e-6
+    assert np.abs(out['image'][..., ::4, ::4].numpy() - g['image_sub4']).max() <= 1e-6
+    assert np.abs(out['image'].mean(dim=(2, 3)).numpy() - g['image_mean']).max() <= 1e-6
+    assert np.array_equal((st['alpha'].numpy() * 255).round().astype(np.uint8), g['alpha'])
+    assert np.array_equal(st['mouth_mask'].numpy(), g['mouth_mask'])
+    assert np.abs(st['textures'][..., ::8, ::8].numpy() - g['textures_sub8']).max() <= 1e-6
+    assert np.abs(st['blended_planes'][..., ::8, ::8].numpy() - g['blended_planes_sub8']).max() <= 1e-6
+
+
+def test_upfirdn2d_against_direct_definition():
+    """upfirdn2d == explicit zero-insert / pad / correlate-with-flipped-filter / decimate, on ragged shapes."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 2, 5, 7, generator=g)
+    f = torch.randn(3, 4, generator=g)
+    up, down, pad = 2, 3, (2, 1, 0, 3)
+    y = O.upfirdn2d(x, f, up=up, down=down, padding=list(pad))
+    z = torch.zeros(1, 2, 5 * up, 7 * up)
+    z[:, :, ::up, ::up] = x
+    z = torch.nn.functional.pad(z, [pad[0], pad[1], pad[2], pad[3]])
+    H, W = z.shape[2] - 3 + 1, z.shape[3] - 4 + 1
+    ref = torch.zeros(1, 2, H, W)
+    ff = f.flip([0, 1])
+    for i in range(H):
+        for j in range(W):
+            ref[:, :, i, j] = (z[:, :, i:i + 3, j:j + 4] * ff).sum(dim=(2, 3))
+    assert torch.allclose(y, ref[:, :, ::down, ::down], atol=1e-5)
+
+
+def test_rasterizer_and_floodfill_closed_form():
+    verts = torch.tensor([[[-0.5, -0.5, 1.0], [0.5, -0.5, 1.0], [0.0, 0.5, 2.0],        # front-facing
+                           [-0.9, -0.9, 0.5], [-0.9, -0.8, 0.5], [-0.8, -0.9, 0.5]]])    # back-facing (culled)
+    faces = torch.tensor([[0, 1, 2], [3, 4, 5]])
+    area = lambda a, b, c: (a[0] - b[0]) * (c[1] - b[1]) - (a[1] - b[1]) * (c[0] - b[0])
+    v = verts[0]
+    front = [i for i, f in enumerate(faces.tolist()) if area(v[f[0]], v[f[1]], v[f[2]]) > 0]
+    p2f, zbuf, bary = raster.rasterize_meshes(verts, faces, image_size=64)
+    hit = p2f[0, :, :, 0] >= 0
+    assert set(p2f[0, :, :, 0][hit].unique().tolist()) == set(front) and len(front) == 1
+    big = 0 in front                                    # exactly one of the two windings survives back-face culling
+    assert abs(int(hit.sum()) - (512 if big else 5)) < (80 if big else 6)      # NDC area 0.5 -> 0.5 * 64*64/4 = 512 px
+    b = bary[0, :, :, 0][hit]
+    assert torch.allclose(b.sum(-1), torch.ones_like(b[:, 0]), atol=1e-5) and bool((b > 0).all())
+    zhit = zbuf[0, :, :, 0][hit]
+    assert float(zhit.min()) >= 0.5 - 1e-6 and float(zhit.max()) <= 2.0 + 1e-6
+    assert bool((p2f[0, :, :, 0][~hit] == -1).all())
+    if big:   # +Y is UP in PyTorch3D NDC: the apex (y=+0.5) lands in the top rows (fewer covered pixels there)
+        rows = hit.any(dim=1).nonzero().flatten()
+        assert hit[rows.min()].sum() < hit[rows.max()].sum()
+    img = np.zeros((8, 8), np.float32)
+    img[2:6, 2:6] = 255.0
+    img[3:5, 3:5] = 0.0                                                     # enclosed hole must NOT be filled
+    raster.floodfill_fixed_range(img, 255.0, 0.0, 254.0)
+    assert img[0, 0] == 255.0 and img[3, 3] == 0.0 and (img[2, 2:6] == 255.0).all()
+    a = torch.zeros(1, 1, 8, 8)
+    a[0, 0, 2:6, 2:6] = 1.0
+    a[0, 0, 3:5, 3:5] = 0.0
+    filled = raster.fill_mouth(a)
+    assert float(filled[0, 0, 3, 3]) == 1.0 and float(filled[0, 0, 0, 0]) == 0.0
+
+
+def test_renderer_properties():
+    """Size-independent properties: weights form a sub-convex combination; importance samples stay inside the coarse range;
+    constant planes give a constant colour."""
+    g = torch.Generator().manual_seed(3)
+    N, R, Sc, Sf = 1, 8, 12, 12
+    P = {'decoder.net.0.weight': torch.randn(64, 32, generator=g), 'decoder.net.0.bias': torch.zeros(64),
+         'decoder.net.2.weight': torch.randn(33, 64, generator=g), 'decoder.net.2.bias': torch.zeros(33)}
+    planes = torch.randn(1, 1, 32, 1, 1, generator=g).expand(N, 3, 32, 16, 16).contiguous()
+    c2w = torch.eye(4)[None].clone()
+    c2w[0, 2, 3] = -2.7
+    K = torch.tensor([[[4.26, 0, 0.5], [0, 4.26, 0.5], [0, 0, 1]]])
+    ray_o, ray_d = renderer.ray_sampler(c2w, K, R)
+    assert torch.allclose(ray_d.norm(dim=-1), torch.ones(N, R * R), atol=1e-6)
+    jitter, u = cases.rng_inputs(N, R, Sc, Sf)
+    opts = dict(depth_resolution=Sc, depth_resolution_importance=Sf, ray_start=2.25, ray_end=3.3, box_warp=1)
+    rgb, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, opts, jitter, u)
+    assert float(wsum.max()) <= 1.0 + 1e-5 and float(wsum.min()) >= 0.0
+    assert float(depth.min()) >= 2.25 and float(depth.max()) <= 3.3 + (3.3 - 2.25) / (Sc - 1)
+    inside = (rgb + 1) / 2 / wsum.clamp_min(1e-6)          # constant colour field -> composite = colour * sum(w)
+    assert float((inside - inside.mean(dim=1, keepdim=True)).abs().max()) < 5e-2
