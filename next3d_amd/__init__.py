@@ -16,7 +16,14 @@ def install_dropin(model=False):
 
     Always aliases `torch_utils.ops.{bias_act,upfirdn2d,conv2d_resample,conv2d_gradfix,fma}`.  With model=True also
     aliases `training_avatar_texture.triplane_next3d` so `--reload_modules=True` constructs this TriPlaneGenerator."""
+    for parent in ('torch_utils', 'torch_utils.ops'):        # keep the reference's own packages when they are importable
+        try:
+            importlib.import_module(parent)
+        except ImportError:
+            sys.modules[parent] = importlib.import_module(f'{__name__}.{parent}')
     for name in _OP_MODULES:
-        sys.modules['torch_utils.ops.' + name] = importlib.import_module(f'{__name__}.torch_utils.ops.{name}')
+        mod = importlib.import_module(f'{__name__}.torch_utils.ops.{name}')
+        sys.modules['torch_utils.ops.' + name] = mod
+        setattr(sys.modules['torch_utils.ops'], name, mod)
     if model:
         sys.modules['training_avatar_texture.triplane_next3d'] = importlib.import_module(f'{__name__}.generator')
