@@ -18,6 +18,8 @@
 //
 // Replaces F.conv2d / F.conv_transpose2d as called by conv2d_resample (reference
 // torch_utils/ops/conv2d_resample.py:96-136) from modulated_conv2d (training_avatar_texture/networks_stylegan2.py:34-91).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,6 +32,7 @@ struct ConvParams {
     int N, I, O, OP, H, W, OH, OW;   // OH/OW: full output dims; OP = O rounded up to 4 (row pitch of wt)
     int GH, GW;                      // per-phase output grid (mode 2: H+1, W+1; else OH, OW)
     int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
+    int dbg;                         // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads
     int64_t xbs, ybs;
     n3d_epilogue epi;
 };
@@ -132,6 +135,9 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
     f32x4 ra[A_PER_T];
     float rb[B_PER_T];
 
+    // load_stage only ISSUES the global loads (raw values stay in registers while the MFMA block runs); the style
+    // modulation / zero padding is applied in store_stage, after the MFMAs — consuming a loaded value any earlier puts an
+    // s_waitcnt vmcnt(0) in front of the MFMA block and serialises the two phases (measured: load + MFMA time added up).
     auto load_stage = [&](int st) {
         const int nch = min(ICB, ic_end - ic_begin - st * ICB);     // valid channels of this stage (tail stage: < ICB)
         const float* ab = a_base + (int64_t)st * ICB * p.OP;
@@ -139,21 +145,21 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ab + (a_ic[j] < nch ? a_goff[j] : 0));
 #pragma unroll
-        for (int j = 0; j < B_PER_T; ++j) {
-            const bool ok = b_ic[j] < nch;
-            const float val = bb[ok ? b_goff[j] : 0] * s_style[st * ICB + (ok ? b_ic[j] : 0)];
-            rb[j] = ok ? val : 0.f;
-        }
+        for (int j = 0; j < B_PER_T; ++j) rb[j] = bb[b_ic[j] < nch ? b_goff[j] : 0];
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](int st) {
+        const int nch = min(ICB, ic_end - ic_begin - st * ICB);
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j) {
             const int v = tid + j * 256;
             if (v < A_VEC) *reinterpret_cast<f32x4*>(&As[v * 4]) = ra[j];
         }
 #pragma unroll
-        for (int j = 0; j < B_PER_T; ++j)
-            if (b_loff[j] >= 0) Bs[b_loff[j]] = rb[j];
+        for (int j = 0; j < B_PER_T; ++j) {
+            const bool ok = b_ic[j] < nch;
+            const float val = rb[j] * s_style[st * ICB + (ok ? b_ic[j] : 0)];
+            if (b_loff[j] >= 0) Bs[b_loff[j]] = ok ? val : 0.f;
+        }
     };
 
     // per-lane fragment addressing
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
     __syncthreads();                     // s_style visible
     if (nstage > 0) {
         load_stage(0);
-        store_stage();
+        store_stage(0);
     }
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
         }
         __syncthreads();
         if (st + 1 < nstage) {
-            store_stage();
+            store_stage(st + 1);
             __syncthreads();
         }
     }
@@ -270,6 +276,222 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
                 dst[(int64_t)o * plane] = v;
             }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed 3x3 stride-2 convolution (the up-sampling layers, conv2d_resample.py:114-131) with all four output
+// phases computed by ONE workgroup from ONE staged input patch.  Output pixel (2y+a, 2x+b) receives
+//   a=0: ky in {0,2} from input rows {y, y-1};  a=1: ky=1 from row y   (same for b / kx / columns),
+// i.e. the nine taps split 4/2/2/1 over the phases.  A workgroup owns 64 output channels x (TH x TW = 128) INPUT-grid
+// positions x 4 phases = 512 output pixels; per k-step of 2 channels a wave issues 9 taps x 2 position tiles = 18 MFMAs
+// from 9 A reads + 8 B reads, so every stage carries the same 144 MFMAs per wave as the stride-1 kernel and the
+// patch / weight slab is staged once for all phases (the per-phase launch left the 1-tap phase with 16 MFMAs per
+// stage: 31-72 TFLOP/s measured vs ~130 for stride 1).
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
+    constexpr int BM = 64, ICB = 16, NT = 2;
+    static_assert(TH * TW == 128, "128 input-grid positions per workgroup");
+    constexpr int PH = TH + 1, PW = TW + 1;
+    constexpr int PWP = PW + ((PW % 2 == 0) ? 1 : 0) + ((TW < 32) ? 2 : 0);
+    constexpr int A_ELEMS = 9 * ICB * BM, B_ELEMS = ICB * PH * PW;
+    constexpr int A_VEC = A_ELEMS / 4;
+    constexpr int A_PER_T = (A_VEC + 255) / 256, B_PER_T = (B_ELEMS + 255) / 256;
+
+    __shared__ float As[A_ELEMS];
+    __shared__ float Bs[ICB * PH * PWP];
+    __shared__ float s_style[1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int m0 = blockIdx.y * BM;
+    const int ks = blockIdx.z % p.ksplit, n = blockIdx.z / p.ksplit;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ic_begin = ks * p.ic_per_split;
+    const int ic_end = min(p.I, ic_begin + p.ic_per_split);
+    const int nstage = (ic_end - ic_begin + ICB - 1) / ICB;
+    const int HW = p.H * p.W;
+    const float* xn = p.x + (int64_t)n * p.xbs;
+
+    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+
+    // Register budget: 128 accumulators + the prefetched stage (47 VGPRs).  Staging addresses are therefore recomputed
+    // from `tid` every stage (constant divisors -> a few VALU ops that run beside the MFMAs) instead of being kept.
+    const float* a_base = p.wt + (int64_t)ic_begin * p.OP;
+    const float* b_base = xn + (int64_t)ic_begin * HW;
+    f32x4 ra[A_PER_T];
+    float rb[B_PER_T];
+    auto load_stage = [&](int st) {
+        const int nch = min(ICB, ic_end - ic_begin - st * ICB);
+        const float* ab = a_base + (int64_t)st * ICB * p.OP;
+        const float* bb = b_base + (int64_t)st * ICB * HW;
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int v = tid + j * 256;
+            const int row = v / (BM / 4), mv = (v % (BM / 4)) * 4;
+            const int t = row / ICB, ic = row % ICB;
+            const bool ok = v < A_VEC && (m0 + mv) < p.OP && ic < nch;
+            ra[j] = *reinterpret_cast<const f32x4*>(ab + (ok ? (t * p.I + ic) * p.OP + m0 + mv : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            const int ic = e / (PH * PW), rem = e % (PH * PW);
+            const int iy = y0 - 1 + rem / PW, ix = x0 - 1 + rem % PW;
+            const bool ok = e < B_ELEMS && ic < nch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            rb[j] = bb[ok ? ic * HW + iy * p.W + ix : 0];          // raw: consumed only in store_stage (see the stride-1 kernel)
+        }
+    };
+    auto store_stage = [&](int st) {
+        const int nch = min(ICB, ic_end - ic_begin - st * ICB);
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int v = tid + j * 256;
+            if (v < A_VEC) *reinterpret_cast<f32x4*>(&As[v * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            const int ic = e / (PH * PW), rem = e % (PH * PW);
+            const int iy = y0 - 1 + rem / PW, ix = x0 - 1 + rem % PW;
+            const bool ok = ic < nch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (e < B_ELEMS) Bs[(ic * PH + rem / PW) * PWP + rem % PW] = ok ? rb[j] * s_style[st * ICB + ic] : 0.f;
+        }
+    };
+
+    // fragment addressing: A rows wm*32 + l31; B position tiles (wn*NT + nt) of 32 positions each
+    const int a_off = wm * 32 + l31;
+    int b_off[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pos = (wn * NT + nt) * 32 + l31;
+        b_off[nt] = (pos / TW) * PWP + (pos % TW);
+    }
+    f32x16 acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][ph][r] = 0.f;
+
+    __syncthreads();
+    if (nstage > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage && !(p.dbg & 4)) load_stage(st + 1);
+        if (!(p.dbg & 2))
+#pragma unroll 2
+        for (int kk = 0; kk < ICB / 2; ++kk) {
+            const float* Ak = As + (2 * kk + half) * BM + a_off;
+            const float* Bk = Bs + (2 * kk + half) * (PH * PWP);
+            float a[9], b[NT][4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a[t] = Ak[t * ICB * BM];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b[nt][d] = Bk[b_off[nt] + (d >> 1) * PWP + (d & 1)];     // d = dy*2 + dx
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+                    const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ky * 3 + kx], b[nt][d], acc[nt][ph], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+    }
+
+    // epilogue
+    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
+    const n3d_epilogue& E = p.epi;
+    const int64_t plane = (int64_t)p.OH * p.OW;
+    float rs[16], bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oc = o < p.O ? o : p.O - 1;
+        rs[r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+        bs[r] = E.bias ? E.bias[oc] : 0.f;
+    }
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+    // Stores: phases (a,0) and (a,1) of one position are horizontally adjacent output pixels (2x, 2x+1): write them as
+    // ONE 8-byte store per lane so a half-wave covers a dense 256-byte row segment (stride-2 dword stores left every
+    // cache line half written: the kernel was store-bound at ~250 GB/s).  Rows have odd pitch (2W+1), so the pair is
+    // only 4-byte aligned; global memory accepts dword-aligned 8-byte stores.
+    struct __attribute__((packed, aligned(4))) pair_t { float v0, v1; };
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pos = (wn * NT + nt) * 32 + l31;
+        const int gy = y0 + pos / TW, gx = x0 + pos % TW;
+        if (gy >= p.GH || gx >= p.GW) continue;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const int oy = 2 * gy + pa, ox = 2 * gx;
+            if (oy >= p.OH) continue;
+            const bool two = ox + 1 < p.OW;
+            const int64_t po = (int64_t)oy * p.OW + ox;
+            if (p.partial) {
+                float* dst = p.partial + ((int64_t)ks * p.N + n) * p.O * plane + po;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o >= p.O) continue;
+                    if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{acc[nt][pa * 2][r], acc[nt][pa * 2 + 1][r]};
+                    else dst[(int64_t)o * plane] = acc[nt][pa * 2][r];
+                }
+                continue;
+            }
+            const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
+            const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
+            float* dst = p.y + (int64_t)n * p.ybs + po;
+            const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.O) continue;
+                float v[2] = {acc[nt][pa * 2][r] * rs[r] + nz0 + bs[r], acc[nt][pa * 2 + 1][r] * rs[r] + nz1 + bs[r]};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (lrelu) v[q] = v[q] > 0.f ? v[q] : v[q] * E.alpha;
+                    else if (!linear) v[q] = conv_act_generic(v[q], E.act, E.alpha);
+                    v[q] *= E.gain;
+                    if (E.clamp >= 0.f) v[q] = fminf(fmaxf(v[q], -E.clamp), E.clamp);
+                    if (res && (q == 0 || two)) v[q] += res[(int64_t)o * plane + q];
+                }
+                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{v[0], v[1]};
+                else dst[(int64_t)o * plane] = v[0];
+            }
+        }
+    }
+}
+
+template <int TH, int TW>
+static int launch_conv_up(ConvParams& p, int ksplit_req, hipStream_t stream) {
+    constexpr int BM = 64, ICB = 16;
+    p.tiles_x = cdiv(p.GW, TW);
+    p.tiles_y = cdiv(p.GH, TH);
+    p.nphase = 1;
+    const int max_split = cdiv(p.I, ICB);
+    p.ksplit = ksplit_req < 1 ? 1 : (ksplit_req > max_split ? max_split : ksplit_req);
+    p.ic_per_split = cdiv(cdiv(p.I, p.ksplit), ICB) * ICB;
+    p.ksplit = cdiv(p.I, p.ic_per_split);
+    if (p.ksplit == 1) p.partial = nullptr;
+    const int64_t gz = (int64_t)p.N * p.ksplit;
+    if (gz > 65535) return n3d_set_error("conv2d: grid.z %lld too large", (long long)gz);
+    dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.O, BM), (unsigned)gz);
+    hipLaunchKernelGGL((conv2d_up_mfma_kernel<TH, TW>), grid, dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
 }
 
 // split-K second pass: y = epilogue(sum_ks partial[ks])
@@ -354,6 +576,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP = (d->O + 3) & ~3; p.H = d->H; p.W = d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.nphase = 1;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }
     else if (d->mode == 1) {
         N3D_CHECK(d->H >= 3 && d->W >= 3, "conv2d: input too small for stride-2 3x3");
@@ -361,6 +584,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");
     N3D_CHECK(d->I <= 1024 * (d->ksplit < 1 ? 1 : d->ksplit), "conv2d: more than 1024 input channels per K-split");
+    N3D_CHECK((int64_t)9 * d->I * ((d->O + 3) & ~3) < (1 << 27), "conv2d: weight tensor too large for 27-bit staging offsets");
     const bool wide = p.GW > 16;
     const double flops = 2.0 * d->N * (double)d->O * d->I * d->ksize * d->ksize *
                          (d->mode == 2 ? (double)d->H * d->W : (double)p.OH * p.OW);
@@ -371,7 +595,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     if (d->ksize == 3) {
         if (d->mode == 0)      rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 0>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 0>(p, d->ksplit, stream);
         else if (d->mode == 1) rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 1>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 1>(p, d->ksplit, stream);
-        else                   rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 8, 3, 2>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 8, 3, 2>(p, d->ksplit, stream);
+        else                   rc = wide ? launch_conv_up<4, 32>(p, d->ksplit, stream) : launch_conv_up<8, 16>(p, d->ksplit, stream);
     } else {
         if (d->O > 64) rc = wide ? launch_conv<2, 2, 2, 2, 4, 32, 32, 1, 0>(p, d->ksplit, stream) : launch_conv<2, 2, 2, 2, 8, 16, 32, 1, 0>(p, d->ksplit, stream);
         else           rc = wide ? launch_conv<1, 1, 1, 4, 4, 32, 32, 1, 0>(p, d->ksplit, stream) : launch_conv<1, 1, 1, 4, 8, 16, 32, 1, 0>(p, d->ksplit, stream);

@@ -71,6 +71,73 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
     }
 }
 
+
+// ---- specialised path: compile-time up/down factors and filter size (the generator only uses the 4x4 [1,3,3,1] filter
+// with (up,down) in {(1,1),(2,1),(1,2)}).  All index arithmetic folds to shifts/constants, every thread produces
+// FT_PER_T outputs at one x (consecutive lanes = consecutive x: conflict-free LDS reads, coalesced 256-byte stores) and
+// the taps live in registers.  HBM-bound: the block reads its input footprint once and writes its outputs once.
+#define FT_W 64
+#define FT_H 16
+#define FT_PER_T (FT_W * FT_H / 256)
+
+template <int UP, int DOWN, int FS>
+__global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
+    constexpr int FOOT_W = ((FT_W - 1) * DOWN + FS - 1) / UP + 2;
+    constexpr int FOOT_H = ((FT_H - 1) * DOWN + FS - 1) / UP + 2;
+    __shared__ float s_x[FOOT_H * FOOT_W];
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int ox0 = tx * FT_W, oy0 = ty * FT_H;
+    float f[FS][FS];                                     // pre-flipped taps (uniform -> scalar registers)
+#pragma unroll
+    for (int ky = 0; ky < FS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < FS; ++kx) f[ky][kx] = p.flip ? p.f[ky * FS + kx] : p.f[(FS - 1 - ky) * FS + (FS - 1 - kx)];
+    const int ix_lo = ceil_div(ox0 * DOWN - p.padx0, UP);
+    const int iy_lo = ceil_div(oy0 * DOWN - p.pady0, UP);
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.W;
+    for (int e = threadIdx.x; e < FOOT_H * FOOT_W; e += 256) {
+        const int r = e / FOOT_W, q = e % FOOT_W;
+        const int iy = iy_lo + r, ix = ix_lo + q;
+        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.W + ix] : 0.f;
+    }
+    __syncthreads();
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+    const int lx = threadIdx.x % FT_W, ly0 = threadIdx.x / FT_W;
+    const int ox = ox0 + lx;
+    const int qx0 = ox * DOWN - p.padx0;                 // upsampled-domain coordinate of tap kx = 0
+    const int kx0 = ((-qx0) % UP + UP) % UP;              // first tap that lands on a real (non-inserted-zero) sample
+#pragma unroll
+    for (int j = 0; j < FT_PER_T; ++j) {
+        const int oy = oy0 + ly0 * FT_PER_T + j;            // consecutive rows per thread: the FS-row windows overlap,
+        const int qy0 = oy * DOWN - p.pady0;                 // so the unrolled loop re-uses LDS reads across j
+        const int ky0 = ((-qy0) % UP + UP) % UP;
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < (FS + UP - 1) / UP; ++a) {
+            const int ky = ky0 + a * UP;
+            if (ky >= FS) continue;
+            const int ry = (qy0 + ky) / UP - iy_lo;       // exact division
+            const float* row = s_x + ry * FOOT_W - ix_lo;
+#pragma unroll
+            for (int b = 0; b < (FS + UP - 1) / UP; ++b) {
+                const int kx = kx0 + b * UP;
+                if (kx >= FS) continue;
+                float w;
+                if (UP == 1) w = f[a][b];
+                else w = f[ky & (FS - 1)][kx & (FS - 1)];
+                v += row[(qx0 + kx) / UP] * w;
+            }
+        }
+        if (oy < p.OH && ox < p.OW) {
+            v *= p.gain;
+            if (p.has_epi) v = n3d_apply_epilogue(v, p.epi, n, c, p.C, oy, ox, p.OH, p.OW);
+            yp[(int64_t)oy * p.OW + ox] = v;
+        }
+    }
+}
+
 extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
                              int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                              int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {
@@ -97,7 +164,16 @@ extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, in
     N3D_CHECK(p.foot_w * p.foot_h <= UF_MAX_FOOT, "upfirdn2d: tile footprint %dx%d exceeds LDS budget", p.foot_h, p.foot_w);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * fh * fw / (upx * upy),
                       4.0 * N * C * ((double)H * W + (double)OH * OW));
-    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
+    const bool fast = fh == 4 && fw == 4 && upx == upy && downx == downy && ((upx == 1 && downx <= 2) || (upx == 2 && downx == 1));
+    if (fast) {
+        p.tiles_x = cdiv(OW, FT_W); p.tiles_y = cdiv(OH, FT_H);
+        dim3 grid(p.tiles_x * p.tiles_y, C, N);
+        if (upx == 1 && downx == 1) hipLaunchKernelGGL((upfirdn2d_fast_kernel<1, 1, 4>), grid, dim3(256), 0, stream, p);
+        else if (upx == 2) hipLaunchKernelGGL((upfirdn2d_fast_kernel<2, 1, 4>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((upfirdn2d_fast_kernel<1, 2, 4>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(upfirdn2d_kernel, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
+    }
     N3D_LAUNCH_CHECK();
     return 0;
 }

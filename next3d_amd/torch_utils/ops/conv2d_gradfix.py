@@ -37,13 +37,13 @@ def out_shape(h, w, mode):
     return 2 * h + 1, 2 * w + 1
 
 
-def pick_ksplit(n, i, o, gh, gw, ksize):
+def pick_ksplit(n, i, o, gh, gw, ksize, mode=0):
     """Split the input channels over extra workgroups when the output grid alone cannot fill 256 CUs
     (low-resolution layers: K = 9*I is deep, the pixel grid is tiny)."""
-    bm = 128 if (ksize == 3 or o > 64) else 32
+    bm = 64 if mode == 2 else (128 if (ksize == 3 or o > 64) else 32)
     tw, th = (32, 4) if gw > 16 else (16, 8)
     blocks = -(-gw // tw) * -(-gh // th) * -(-o // bm) * n
-    icb = 8 if ksize == 3 else 32
+    icb = 16 if mode == 2 else (8 if ksize == 3 else 32)
     ks = 1
     while blocks * ks < 256 and (i // (ks * 2)) >= 4 * icb:
         ks *= 2
@@ -62,7 +62,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride()[1:] == (oh * ow, ow, 1)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
-        ksplit = pick_ksplit(n * (4 if mode == 2 else 1), i, o, gh, gw, ksize)
+        ksplit = pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)
