@@ -97,6 +97,15 @@ typedef struct {
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 
+/* ---- conv2d, split-bf16 ("bf16x3") variant of mode 0 / ksize 3: every fp32 operand is split into hi + lo bf16 halves and
+ *      a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (5.3x the fp32
+ *      MFMA rate, ~2^-16 relative operand error; measured 8e-5 max-abs on the final RGB with every conv emulated this
+ *      way).  Same descriptor as n3d_conv2d except `wt` = the split K-major weights from
+ *      n3d_conv2d_prep_weight_bf16x3: bf16 [k*k][I/16][2 (hi,lo)][2 (k half)][OP64][8], OP64 = O rounded up to 64.
+ *      Requires I % 16 == 0.  Same reference call sites as n3d_conv2d. */
+int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream);
+int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+
 /* ---- fully connected: replaces addmm / matmul+bias_act of FullyConnectedLayer.forward
  *      (tat/networks_stylegan2.py:114-127).  y[n,o] = post(act(sum_i pre(x[n,i]) * w[o,i] * wgain + b[o]*bgain)).
  *      pre_square: use x^2 (demodulation: sum_i s^2 * wsq);  post_rsqrt: y = rsqrt(y + 1e-8). */

@@ -1,0 +1,290 @@
+// conv2d on the bf16 matrix cores with fp32-class accuracy ("bf16x3" operand splitting) for gfx950.
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate, 1/16 of bf16 MFMA.  Every fp32 operand is therefore
+// split into two bf16 halves, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits together), and
+//     a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (the dropped a_lo*b_lo term is <= 2^-16 relative)
+// is evaluated with THREE v_mfma_f32_32x32x16_bf16 per K=16 chunk, accumulating in fp32: 96 MFMA cycles per
+// 32x32x16 block instead of 512 with the fp32 instruction — a 5.3x higher ceiling (833 "fp32-equivalent" TFLOP/s).
+// Each bf16 x bf16 product is exact in fp32, so the only error is the operand truncation: measured 8e-5 max-abs on the
+// final 512x512 RGB when EVERY convolution of the generator is emulated this way on the CPU (tolerance: 1e-3).
+//
+// Structure: same implicit GEMM as conv2d.hip (K-major weights, input patch with halo staged once per stage and reused
+// by all 9 taps, style modulation applied while staging, next stage prefetched into registers during the MFMA block),
+// re-laid-out for K=16 fragments:
+//   weights are split and tiled ONCE at model load (n3d_conv2d_prep_weight_bf16x3):
+//       wt16[tap][I/16][hl][half][OP64][8]   hl: 0 = hi, 1 = lo;  half: channels 0-7 / 8-15 of the chunk
+//     so a workgroup's (tap, hl, half) slab is 64 rows x 16 bytes, copied verbatim into LDS and read back as
+//     conflict-free ds_read_b128 fragments (lane = output channel row, 8 consecutive k per lane);
+//   activations stay fp32 NCHW in HBM; while staging, each work item gathers 8 channels of one patch pixel, applies the
+//     style, splits and packs them into two 16-byte LDS slots  B_{hi,lo}[half][pixel][8]  (lane = pixel, 8 consecutive k).
+// Workgroup = 256 threads = 4 waves; tile = 64 output channels x (8 x 32) pixels; each wave 64 x 64 (2x2 accumulators).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Conv16Params {
+    const float* x; const bf16x8* wt16; const float* style; float* y; float* partial;
+    int N, I, O, OP64, H, W, OH, OW;
+    int tiles_x, tiles_y, ksplit, ic_per_split;
+    int64_t xbs, ybs;
+    n3d_epilogue epi;
+};
+
+__device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+
+// 3x3, stride 1, padding 1
+__global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
+    constexpr int BM = 64, TH = 8, TW = 32, ICB = 16, TAPS = 9;
+    constexpr int PH = TH + 2, PW = TW + 2, PPIX = PH * PW;               // 10 x 34 = 340 patch pixels
+    constexpr int A_ITEMS = TAPS * 2 * 2 * BM;                            // 16-byte slots: [tap][hl][half][row]
+    constexpr int B_ITEMS = 2 * PPIX;                                     // (half, pixel) work items
+    constexpr int A_PER_T = A_ITEMS / 256;                                // 9  (item j of a thread = tap j)
+    constexpr int B_PER_T = (B_ITEMS + 255) / 256;                        // 3
+
+    __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];           // [tap][half][row]
+    __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];                     // [half][pixel]
+    __shared__ float s_style[1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int m0 = blockIdx.y * BM;
+    const int ks = blockIdx.z % p.ksplit, n = blockIdx.z / p.ksplit;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ic_begin = ks * p.ic_per_split;
+    const int ic_end = min(p.I, ic_begin + p.ic_per_split);
+    const int nstage = (ic_end - ic_begin) / ICB;
+    const int KC = p.I / ICB;
+    const int HW = p.H * p.W;
+
+    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+
+    // A staging: thread owns (row, half, hl) for all 9 taps
+    const int a_row = tid & 63, a_q = tid >> 6, a_half = a_q & 1, a_hl = a_q >> 1;
+    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row;
+    const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
+    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row;
+    // B staging: work item e = tid + 256 j -> (half, patch pixel)
+    int b_goff[B_PER_T];
+    bool b_ok[B_PER_T];
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+        const int e = tid + j * 256;
+        const int hf = e / PPIX, pp = e % PPIX;
+        const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
+        b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
+    }
+    const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
+
+    bf16x8 ra[A_PER_T];
+    float rb[B_PER_T][8];
+    auto load_stage = [&](int st) {                       // issue only; consumed in store_stage (after the MFMA block)
+        const bf16x8* as = a_src + st * a_stage_stride;
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) ra[j] = as[j * a_tap_stride];
+        const float* bb = b_base + (int64_t)st * ICB * HW;
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
+    };
+    auto store_stage = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) a_dst[j * 2 * BM] = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            if (e >= B_ITEMS) continue;
+            const int hf = e / PPIX;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
+            bf16x8 hi, lo;
+            split8(v, hi, lo);
+            B_hi[e] = hi;
+            B_lo[e] = lo;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    __syncthreads();
+    if (nstage > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+    const int a_frag = half * BM + l31;                                   // + tap*2*BM + mt*32
+    const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_stage(st + 1);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int boff = (t / 3) * PW + (t % 3);
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[t * 2 * BM + a_frag + mt * 32]; }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[b_frag + nt * PW + boff]; bl[nt] = B_lo[b_frag + nt * PW + boff]; }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+    }
+
+    // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
+    const n3d_epilogue& E = p.epi;
+    const int64_t plane = (int64_t)p.OH * p.OW;
+    float rs[2][16], bs[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oc = o < p.O ? o : p.O - 1;
+            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+            bs[mt][r] = E.bias ? E.bias[oc] : 0.f;
+        }
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int oy = y0 + wn * 2 + nt, ox = x0 + l31;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        const int64_t po = (int64_t)oy * p.OW + ox;
+        if (p.partial) {
+            float* dst = p.partial + ((int64_t)ks * p.N + n) * p.O * plane + po;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o < p.O) dst[(int64_t)o * plane] = acc[mt][nt][r];
+                }
+            continue;
+        }
+        const float nz = E.noise ? E.noise[po] * nstr : 0.f;
+        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.O) continue;
+                float v = acc[mt][nt][r] * rs[mt][r] + nz + bs[mt][r];
+                if (lrelu) v = v > 0.f ? v : v * E.alpha;
+                else if (!linear) v = conv16_act_generic(v, E.act, E.alpha);
+                v *= E.gain;
+                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+                if (res) v += res[(int64_t)o * plane];
+                dst[(int64_t)o * plane] = v;
+            }
+    }
+}
+
+// split-K second pass (same as conv2d.hip's)
+__global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y, int ksplit,
+                                                                      int N, int O, int OH, int OW, int64_t ybs, n3d_epilogue epi) {
+    const int64_t plane = (int64_t)OH * OW, total = (int64_t)N * O * plane;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += partial[(int64_t)k * total + i];
+        const int64_t pl = i / plane;
+        const int pix = (int)(i % plane), n = (int)(pl / O), o = (int)(pl % O);
+        v = n3d_apply_epilogue(v, epi, n, o, O, pix / OW, pix % OW, OH, OW);
+        y[(int64_t)n * ybs + ((int64_t)o * OH + pix / OW) * OW + pix % OW] = v;
+    }
+}
+
+// w [O,I,k,k] fp32 -> wt16[tap][I/16][hl][half][OP64][8] bf16 (hi / lo split, zero padded rows)
+__global__ __launch_bounds__(256) void conv16_prep_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ wt16, int O, int I, int KK,
+                                                                 int OP64) {
+    const int64_t total = (int64_t)KK * I * OP64;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e % OP64);
+        const int i = (int)((e / OP64) % I);
+        const int t = (int)(e / ((int64_t)OP64 * I));
+        const float v = o < O ? w[((int64_t)o * I + i) * KK + t] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int kc = i / 16, hf = (i % 16) / 8, c = i % 8;
+        const int64_t base = ((((int64_t)t * (I / 16) + kc) * 2) * 2 + hf) * OP64 + o;       // hl = 0
+        wt16[base * 8 + c] = hi;
+        wt16[(base + (int64_t)2 * OP64) * 8 + c] = lo;                                        // hl = 1
+    }
+}
+
+extern "C" int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(w && wt16 && O > 0 && I > 0 && ksize == 3, "conv2d_prep_weight_bf16x3: bad arguments (3x3 only)");
+    N3D_CHECK(I % 16 == 0, "conv2d_prep_weight_bf16x3: input channels must be a multiple of 16");
+    const int OP64 = (O + 63) / 64 * 64;
+    const int64_t total = (int64_t)ksize * ksize * I * OP64;
+    const int grid = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(conv16_prep_weight_kernel, dim3(grid), dim3(256), 0, stream, w, (__bf16*)wt16, O, I, ksize * ksize, OP64);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
+    N3D_CHECK(d->ksize == 3 && d->mode == 0, "conv2d_bf16x3: 3x3 stride-1 only");
+    N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
+    N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
+    N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
+    if (d->N == 0) return 0;
+    N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
+    N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
+    Conv16Params p;
+    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = d->H; p.OW = d->W;
+    p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
+    p.tiles_x = cdiv(p.OW, 32); p.tiles_y = cdiv(p.OH, 8);
+    const int max_split = d->I / 16;
+    p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);
+    p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
+    p.ksplit = cdiv(d->I, p.ic_per_split);
+    N3D_CHECK(p.ksplit == 1 || d->workspace != nullptr, "conv2d_bf16x3: ksplit > 1 needs a workspace");
+    N3D_CHECK(p.ic_per_split <= 1024, "conv2d_bf16x3: more than 1024 input channels per K-split");
+    if (p.ksplit == 1) p.partial = nullptr;
+    const int64_t gz = (int64_t)p.N * p.ksplit;
+    N3D_CHECK(gz <= 65535, "conv2d_bf16x3: grid.z too large");
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.OH * p.OW;
+    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D, stream, flops, bytes);
+    hipLaunchKernelGGL(conv2d_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
+        const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
+        hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, (const float*)p.partial, p.y, p.ksplit, p.N, p.O,
+                           p.OH, p.OW, p.ybs, p.epi);
+        N3D_LAUNCH_CHECK();
+    }
+    return 0;
+}

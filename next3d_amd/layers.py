@@ -12,6 +12,8 @@ training_avatar_texture/networks_stylegan2.py:311-330, :34-91).  Here the same a
 i.e. the non-fused formulation of modulated_conv2d (:70-79) — algebraically identical to the grouped-conv branch,
 but one weight tensor is shared by the whole batch, which is what the matrix cores want.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,19 @@ from .torch_utils.ops import conv2d_gradfix as cg
 from .torch_utils.ops import upfirdn2d as uf
 
 _SQRT2 = float(np.sqrt(2))
+
+# Arithmetic used by the 3x3 stride-1 convolutions:
+#   'bf16x3' (default): split-bf16 operands on the bf16 matrix cores, fp32 accumulation (include/n3d.h: n3d_conv2d_bf16x3)
+#   'fp32'            : v_mfma_f32_32x32x2_f32 (bit-equivalent to an fmaf chain)
+# Both meet the 1e-3 RGB tolerance against the reference (1.3e-5 with 'fp32', ~1e-4 with 'bf16x3').
+PRECISION = os.environ.get('N3D_PRECISION', 'bf16x3')
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ('bf16x3', 'fp32'):
+        raise ValueError(mode)
+    PRECISION = mode
 
 
 def fc(x, weight, bias=None, wgain=1.0, bgain=1.0, act='linear', pre_square=False, post_rsqrt=False):
@@ -47,6 +62,7 @@ class PreparedConv:
             self.wt, self.wsq = cg.prep_weight(w, want_sq=True)
         else:
             self.wt, self.wsq = cg.prep_weight(w), None
+        self.wt16 = cg.prep_weight_bf16x3(w) if (self.ksize == 3 and self.in_channels % 16 == 0) else None
         self.bias = P.get(f'{prefix}.bias')
         self.weight_gain = 1.0 / np.sqrt(self.in_channels * self.ksize ** 2)
         if modulated:
@@ -54,6 +70,13 @@ class PreparedConv:
             self.affine_b = P[f'{prefix}.affine.bias']
             self.noise_const = P.get(f'{prefix}.noise_const')
             self.noise_strength = P.get(f'{prefix}.noise_strength')
+
+
+def _conv3x3(L, x, style=None, epilogue=None, out=None):
+    """3x3 stride-1 convolution on the arithmetic selected by PRECISION."""
+    if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 0):
+        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True)
+    return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0):
@@ -66,7 +89,7 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:
-        return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act))
+        return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act))
     assert up == 2
     t = cg.conv_launch(x, L.wt, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef))
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
@@ -86,6 +109,8 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     epi = _lib.make_epilogue(const_scale=L.weight_gain, bias=L.bias, act=activation,
                              gain=activation_funcs[activation].def_gain * gain,
                              clamp=None if conv_clamp is None else conv_clamp * gain, residual=residual)
+    if down == 1 and L.ksize == 3:
+        return _conv3x3(L, x, epilogue=epi, out=out)
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3

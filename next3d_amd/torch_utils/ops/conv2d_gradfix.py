@@ -29,6 +29,23 @@ def prep_weight(w, want_sq=False):
     return (wt, wsq) if want_sq else wt
 
 
+def prep_weight_bf16x3(w):
+    """[O,I,3,3] fp32 -> split-bf16 K-major tiles for the bf16x3 kernel (see include/n3d.h)."""
+    _lib.require_device(w)
+    o, i, kh, kw = w.shape
+    if kh != 3 or kw != 3 or i % 16 != 0:
+        raise RuntimeError('prep_weight_bf16x3: needs a 3x3 kernel and I % 16 == 0')
+    op64 = (o + 63) // 64 * 64
+    wt16 = torch.empty([9, i // 16, 2, 2, op64, 8], dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().n3d_conv2d_prep_weight_bf16x3(_lib.ptr(w.contiguous()), _lib.ptr(wt16), o, i, 3, _lib.stream()))
+    return wt16
+
+
+def bf16x3_eligible(i, h, w, ksize, mode):
+    """Layers the split-bf16 kernel covers: 3x3 stride-1, I % 16 == 0, at least one full 8x32 pixel tile."""
+    return ksize == 3 and mode == 0 and i % 16 == 0 and w >= 32 and h >= 8
+
+
 def out_shape(h, w, mode):
     if mode == 0:
         return h, w
@@ -50,11 +67,23 @@ def pick_ksplit(n, i, o, gh, gw, ksize, mode=0):
     return ks
 
 
-def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None):
-    """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] -> y [N,out_channels,OH,OW]."""
+def pick_ksplit_bf16x3(n, i, o, gh, gw):
+    blocks = -(-gw // 32) * -(-gh // 8) * -(-o // 64) * n
+    ks = 1
+    while blocks * ks < 512 and (i // (ks * 2)) >= 64:
+        ks *= 2
+    return ks
+
+
+def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False):
+    """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
+    bf16x3=True) -> y [N,out_channels,OH,OW]."""
     n, i, h, w = x.shape
     o = out_channels
-    assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
+    if bf16x3:
+        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (9, i // 16, 2, 2, (o + 63) // 64 * 64, 8) and mode == 0 and ksize == 3
+    else:
+        assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     if x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
@@ -62,7 +91,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride()[1:] == (oh * ow, ow, 1)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
-        ksplit = pick_ksplit(n, i, o, gh, gw, ksize, mode)
+        ksplit = pick_ksplit_bf16x3(n, i, o, gh, gw) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)
@@ -70,7 +99,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
-    _lib.check(_lib.lib().n3d_conv2d(d, _lib.stream()))
+    fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
+    _lib.check(fn(d, _lib.stream()))
     return y
 
 

@@ -38,8 +38,11 @@ def _md(a, b):
     return float((torch.as_tensor(a).float().cpu() - torch.as_tensor(b).float().cpu()).abs().max())
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
-def test_forward_matches_reference_golden(G, dev, case):
+def test_forward_matches_reference_golden(G, dev, case, precision):
+    from next3d_amd import layers
+    layers.set_precision(precision)
     d = np.load(os.path.join(GOLDEN, case + '.npz'))
     N, R, Sc, Sf = d['z'].shape[0], int(d['R']), int(d['Sc']), int(d['Sf'])
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
@@ -63,12 +66,13 @@ def test_forward_matches_reference_golden(G, dev, case):
         'image': _md(out['image'][..., ::4, ::4], d['image_sub4']),
         'image_mean': _md(out['image'].mean(dim=(2, 3)), d['image_mean']),
     }
-    print(case, ' '.join(f'{k}={v:.3e}' for k, v in rep.items()))
+    print(case, precision, ' '.join(f'{k}={v:.3e}' for k, v in rep.items()))
     n_alpha_bad = int(((st['alpha'].cpu() * 255).round() != torch.from_numpy(d['alpha'].astype(np.float32))).sum())
     print('alpha pixels differing:', n_alpha_bad)
     assert rep['ws'] <= 1e-4
     assert rep['mouth_mask'] == 0
     assert n_alpha_bad <= 8                       # coverage may flip on razor-edge pixels (fp rounding of the vertex transform)
+    layers.set_precision('bf16x3')
     assert rep['textures'] <= 1e-3 and rep['static_plane'] <= 1e-3
     assert rep['image_raw'] <= 1e-3, rep           # north_star: <= 1e-3 max-abs on rendered RGB
     assert rep['image'] <= 1e-3, rep

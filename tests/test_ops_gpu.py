@@ -190,3 +190,26 @@ def test_synthesis_layer_and_torgb(dev, up, res, ic, oc):
     ref = ON.torgb_layer(P, 'T', ref, w) + img
     yt = layers.torgb_layer(layers.PreparedConv(Pd, 'T', True, demodulate=False), y, w.to(dev), residual=img.to(dev))
     _close(yt, ref, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 19, 45), (2, 512, 512, 32, 32), (1, 128, 64, 64, 96), (1, 16, 3, 8, 32)])
+def test_conv2d_bf16x3(dev, N, I, OC, H, W):
+    """Split-bf16 conv vs the fp32 oracle: operand truncation at 2^-16 relative -> tolerance 1e-4 of the output scale
+    (A = identity-like checks are implicit: weights and inputs are asymmetric random)."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 50), _gen((OC, I, 3, 3), 51) / np.sqrt(I * 9)
+    s, d, b = _gen((N, I), 52), _gen((N, OC), 53).abs() + 0.5, _gen((OC,), 54)
+    ref_plain = F.conv2d(x, w, padding=1)
+    ref_full = O.bias_act(F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None], b, act='lrelu')
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    for ksplit in (1, None, 2):
+        y = cg.conv_launch(t(x), wt16, 3, 0, OC, ksplit=ksplit, bf16x3=True)
+        err = float((y.cpu() - ref_plain).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref_plain.abs().max())), (ksplit, err)
+    ts, td, tb = t(s), t(d), t(b)
+    y = cg.conv_launch(t(x), wt16, 3, 0, OC, style=ts, epilogue=_lib.make_epilogue(row_scale=td, bias=tb, act='lrelu'), bf16x3=True)
+    err = float((y.cpu() - ref_full).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
