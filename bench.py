@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -130,14 +131,20 @@ def main():
         _lib.prof_enable(False)
         prof = _lib.prof_read()
         _lib.prof_reset()
-        conv = prof['conv2d']
-        achieved = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
-        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                    'kernel': 'conv2d_mfma_kernel (all launches of the step)',
-                    'launches_per_step': conv['launches'] / args.steps,
-                    'algorithmic_gflop_per_step': conv['flops'] / args.steps / 1e9,
-                    'avg_launch_ms': conv['ms'] / max(conv['launches'], 1),
+        c16, c32 = prof['conv2d_bf16x3'], prof['conv2d']
+        if c16['ms'] >= c32['ms']:       # dominant kernel family: split-bf16 conv on the bf16 matrix cores
+            dom, name, peak = c16, 'conv2d_bf16x3_kernel + conv2d_up_bf16x3_kernel (all launches of the step)', PEAK_BF16_MFMA_TFLOPS / 3.0
+        else:                            # N3D_PRECISION=fp32: fp32-MFMA conv
+            dom, name, peak = c32, 'conv2d_mfma_kernel (all launches of the step)', PEAK_FP32_MFMA_TFLOPS
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
+        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                    'kernel': name,
+                    'note': 'achieved = algorithmic (fp32-equivalent) conv flops / HIP-event time of the family; for bf16x3 the '
+                            'hardware executes 3 bf16 MFMA flops per algorithmic flop, so peak = 2500/3 TFLOP/s',
+                    'launches_per_step': dom['launches'] / args.steps,
+                    'algorithmic_gflop_per_step': dom['flops'] / args.steps / 1e9,
+                    'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
+                    'all_conv_tflops': (c16['flops'] + c32['flops']) / ((c16['ms'] + c32['ms']) * 1e-3) / 1e12,
                     'family_ms_per_step': {k: round(p['ms'] / args.steps, 4) for k, p in prof.items()}}
 
     cpu = None
@@ -145,11 +152,13 @@ def main():
         cpu = cpu_baseline()
 
     if rank == 0:
+        from next3d_amd import layers
+        precision_dtype = 'bf16x3 (split-bf16 operands, f32 accumulate; f32 elsewhere)' if layers.PRECISION == 'bf16x3' else 'f32'
         frames = args.steps * B * world
         print(json.dumps({
             'metric': 'generator fwd frames/sec at 512² (64³ vol, 96 samples)', 'value': frames / elapsed, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': precision_dtype, 'data': 'synthetic',
             'config': {'workload': f'BASELINE.json configs[1]: batch={B} seeds per GPU, 512² output, 64² neural render, '
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,

@@ -18,6 +18,8 @@
 //   activations stay fp32 NCHW in HBM; while staging, each work item gathers 8 channels of one patch pixel, applies the
 //     style, splits and packs them into two 16-byte LDS slots  B_{hi,lo}[half][pixel][8]  (lane = pixel, 8 consecutive k).
 // Workgroup = 256 threads = 4 waves; tile = 64 output channels x (8 x 32) pixels; each wave 64 x 64 (2x2 accumulators).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,6 +30,7 @@ struct Conv16Params {
     const float* x; const bf16x8* wt16; const float* style; float* y; float* partial;
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, ksplit, ic_per_split;
+    int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
     int64_t xbs, ybs;
     n3d_epilogue epi;
 };
@@ -127,12 +130,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     __syncthreads();
+    if (p.dbg & 16) {          // experiment: de-phase the two co-resident workgroups of a CU (odd hardware wave slot waits)
+        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID[3:0] = wave slot
+        if (hwid & 1) { for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16); }
+    }
     if (nstage > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
     const int a_frag = half * BM + l31;                                   // + tap*2*BM + mt*32
     const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
     for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage) load_stage(st + 1);
+        if (st + 1 < nstage && !(p.dbg & 4)) load_stage(st + 1);
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int boff = (t / 3) * PW + (t % 3);
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
     }
 
     // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
+    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     const n3d_epilogue& E = p.epi;
     const int64_t plane = (int64_t)p.OH * p.OW;
     float rs[2][16], bs[2][16];
@@ -201,6 +210,175 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
                 if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
                 if (res) v += res[(int64_t)o * plane];
                 dst[(int64_t)o * plane] = v;
+            }
+    }
+}
+
+
+// Transposed 3x3 stride-2 (the up-sampling layers) on the split-bf16 path: all four output phases from one staged patch,
+// exactly as conv2d_up_mfma_kernel in conv2d.hip (tap (ky,kx) feeds phase (ky==1, kx==1) from patch offset
+// (ky==2 ? 0 : 1, kx==2 ? 0 : 1)).  Workgroup = 64 output channels x (4 x 32) input-grid positions x 4 phases; each wave
+// owns one row of 32 positions: acc[2 row-tiles][4 phases].  Per K=16 chunk: 8 B-fragment reads (4 offsets x hi/lo) are
+// shared by all 9 taps, 36 A-fragment reads, 54 MFMAs.
+__global__ __launch_bounds__(256, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) {
+    constexpr int BM = 64, TH = 4, TW = 32, ICB = 16, TAPS = 9;
+    constexpr int PH = TH + 1, PW = TW + 1, PPIX = PH * PW;               // 5 x 33 = 165 patch pixels (halo: top / left)
+    constexpr int A_PER_T = TAPS * 2 * 2 * BM / 256;                      // 9
+    constexpr int B_ITEMS = 2 * PPIX;
+    constexpr int B_PER_T = (B_ITEMS + 255) / 256;                        // 2
+
+    __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];
+    __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];
+    __shared__ float s_style[1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+    const int m0 = blockIdx.y * BM;
+    const int ks = blockIdx.z % p.ksplit, n = blockIdx.z / p.ksplit;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ic_begin = ks * p.ic_per_split;
+    const int ic_end = min(p.I, ic_begin + p.ic_per_split);
+    const int nstage = (ic_end - ic_begin) / ICB;
+    const int KC = p.I / ICB;
+    const int HW = p.H * p.W;
+    const int GH = p.H + 1, GW = p.W + 1;
+
+    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+
+    const int a_row = tid & 63, a_q = tid >> 6, a_half = a_q & 1, a_hl = a_q >> 1;
+    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row;
+    const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
+    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row;
+    int b_goff[B_PER_T];
+    bool b_ok[B_PER_T];
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+        const int e = tid + j * 256;
+        const int hf = e / PPIX, pp = e % PPIX;
+        const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
+        b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
+    }
+    const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
+
+    bf16x8 ra[A_PER_T];
+    float rb[B_PER_T][8];
+    auto load_stage = [&](int st) {
+        const bf16x8* as = a_src + st * a_stage_stride;
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) ra[j] = as[j * a_tap_stride];
+        const float* bb = b_base + (int64_t)st * ICB * HW;
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
+    };
+    auto store_stage = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) a_dst[j * 2 * BM] = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PER_T; ++j) {
+            const int e = tid + j * 256;
+            if (e >= B_ITEMS) continue;
+            const int hf = e / PPIX;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
+            bf16x8 hi, lo;
+            split8(v, hi, lo);
+            B_hi[e] = hi;
+            B_lo[e] = lo;
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][ph][r] = 0.f;
+
+    __syncthreads();
+    if (nstage > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+    const int a_frag = half * BM + l31;
+    const int b_frag = half * PPIX + wn * PW + l31;                       // position (row wn, col l31); + dy*PW + dx
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_stage(st + 1);
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { bh[d] = B_hi[b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[b_frag + (d >> 1) * PW + (d & 1)]; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int t = ky * 3 + kx;
+                const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+                const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const bf16x8 ah = A_hi[t * 2 * BM + a_frag + mt * 32], al = A_lo[t * 2 * BM + a_frag + mt * 32];
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[d], acc[mt][ph], 0, 0, 0);
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[d], acc[mt][ph], 0, 0, 0);
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[d], acc[mt][ph], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+        if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+    }
+
+    // epilogue: phases (a,0),(a,1) of one position are adjacent output pixels -> one 8-byte store per lane
+    const n3d_epilogue& E = p.epi;
+    const int64_t plane = (int64_t)p.OH * p.OW;
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+    struct __attribute__((packed, aligned(4))) pair_t { float v0, v1; };
+    const int gy = y0 + wn, gx = x0 + l31;
+    if (gy >= GH || gx >= GW) return;
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+        const int oy = 2 * gy + pa, ox = 2 * gx;
+        if (oy >= p.OH) continue;
+        const bool two = ox + 1 < p.OW;
+        const int64_t po = (int64_t)oy * p.OW + ox;
+        if (p.partial) {
+            float* dst = p.partial + ((int64_t)ks * p.N + n) * p.O * plane + po;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (o >= p.O) continue;
+                    if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{acc[mt][pa * 2][r], acc[mt][pa * 2 + 1][r]};
+                    else dst[(int64_t)o * plane] = acc[mt][pa * 2][r];
+                }
+            continue;
+        }
+        const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
+        const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
+        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (o >= p.O) continue;
+                const float rs = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + o] : 1.f);
+                const float bs = E.bias ? E.bias[o] : 0.f;
+                float v[2] = {acc[mt][pa * 2][r] * rs + nz0 + bs, acc[mt][pa * 2 + 1][r] * rs + nz1 + bs};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (lrelu) v[q] = v[q] > 0.f ? v[q] : v[q] * E.alpha;
+                    else if (!linear) v[q] = conv16_act_generic(v[q], E.act, E.alpha);
+                    v[q] *= E.gain;
+                    if (E.clamp >= 0.f) v[q] = fminf(fmaxf(v[q], -E.clamp), E.clamp);
+                    if (res && (q == 0 || two)) v[q] += res[(int64_t)o * plane + q];
+                }
+                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{v[0], v[1]};
+                else dst[(int64_t)o * plane] = v[0];
             }
     }
 }
@@ -253,7 +431,7 @@ extern "C" int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, 
 extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
-    N3D_CHECK(d->ksize == 3 && d->mode == 0, "conv2d_bf16x3: 3x3 stride-1 only");
+    N3D_CHECK(d->ksize == 3 && (d->mode == 0 || d->mode == 2), "conv2d_bf16x3: 3x3 stride-1 or transposed stride-2 only");
     N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
     N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
     N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
@@ -262,9 +440,12 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     Conv16Params p;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
-    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = d->H; p.OW = d->W;
+    const bool up = d->mode == 2;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
+    p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
-    p.tiles_x = cdiv(p.OW, 32); p.tiles_y = cdiv(p.OH, 8);
+    p.tiles_x = up ? cdiv(d->W + 1, 32) : cdiv(p.OW, 32); p.tiles_y = up ? cdiv(d->H + 1, 4) : cdiv(p.OH, 8);
     const int max_split = d->I / 16;
     p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);
     p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
@@ -274,10 +455,11 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     if (p.ksplit == 1) p.partial = nullptr;
     const int64_t gz = (int64_t)p.N * p.ksplit;
     N3D_CHECK(gz <= 65535, "conv2d_bf16x3: grid.z too large");
-    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.OH * p.OW;
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (up ? (double)d->H * d->W : (double)p.OH * p.OW);
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
-    N3dProfScope prof(N3D_K_CONV2D, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv2d_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;

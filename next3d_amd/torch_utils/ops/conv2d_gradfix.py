@@ -42,8 +42,9 @@ def prep_weight_bf16x3(w):
 
 
 def bf16x3_eligible(i, h, w, ksize, mode):
-    """Layers the split-bf16 kernel covers: 3x3 stride-1, I % 16 == 0, at least one full 8x32 pixel tile."""
-    return ksize == 3 and mode == 0 and i % 16 == 0 and w >= 32 and h >= 8
+    """Layers the split-bf16 kernels cover: 3x3 stride-1 or transposed stride-2, I % 16 == 0, at least one full
+    32-wide pixel tile (smaller layers are launch/latency-bound and stay on the fp32 split-K path)."""
+    return ksize == 3 and mode in (0, 2) and i % 16 == 0 and w >= 32 and h >= (8 if mode == 0 else 4)
 
 
 def out_shape(h, w, mode):
@@ -67,8 +68,8 @@ def pick_ksplit(n, i, o, gh, gw, ksize, mode=0):
     return ks
 
 
-def pick_ksplit_bf16x3(n, i, o, gh, gw):
-    blocks = -(-gw // 32) * -(-gh // 8) * -(-o // 64) * n
+def pick_ksplit_bf16x3(n, i, o, gh, gw, mode=0):
+    blocks = -(-gw // 32) * -(-gh // (4 if mode == 2 else 8)) * -(-o // 64) * n
     ks = 1
     while blocks * ks < 512 and (i // (ks * 2)) >= 64:
         ks *= 2
@@ -81,7 +82,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     n, i, h, w = x.shape
     o = out_channels
     if bf16x3:
-        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (9, i // 16, 2, 2, (o + 63) // 64 * 64, 8) and mode == 0 and ksize == 3
+        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (9, i // 16, 2, 2, (o + 63) // 64 * 64, 8) and mode in (0, 2) and ksize == 3
     else:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     if x.stride()[1:] != (h * w, w, 1):
@@ -91,7 +92,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride()[1:] == (oh * ow, ow, 1)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
-        ksplit = pick_ksplit_bf16x3(n, i, o, gh, gw) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
+        ksplit = pick_ksplit_bf16x3(n, i, o, gh, gw, mode) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)

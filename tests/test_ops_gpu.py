@@ -213,3 +213,20 @@ def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     y = cg.conv_launch(t(x), wt16, 3, 0, OC, style=ts, epilogue=_lib.make_epilogue(row_scale=td, bias=tb, act='lrelu'), bf16x3=True)
     err = float((y.cpu() - ref_full).abs().max())
     assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
+
+
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 7, 45), (1, 512, 256, 64, 64), (1, 16, 64, 4, 33)])
+def test_conv2d_up_bf16x3(dev, N, I, OC, H, W):
+    """Split-bf16 transposed stride-2 conv vs F.conv_transpose2d."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 60), _gen((OC, I, 3, 3), 61) / np.sqrt(I * 9)
+    s, d = _gen((N, I), 62), _gen((N, OC), 63).abs() + 0.5
+    ref = F.conv_transpose2d(x * s[:, :, None, None], w.transpose(0, 1), stride=2) * d[:, :, None, None]
+    t = lambda a: a.to(dev)
+    wt16, ts, td = cg.prep_weight_bf16x3(t(w)), t(s), t(d)
+    for ksplit in (1, None, 2):
+        y = cg.conv_launch(t(x), wt16, 3, 2, OC, style=ts, epilogue=_lib.make_epilogue(row_scale=td), ksplit=ksplit, bf16x3=True)
+        err = float((y.cpu() - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ksplit, err)

@@ -48,17 +48,21 @@ for (I, O, H, W, k, mode, cnt) in LAYERS:
     fl = 2.0 * N * O * I * k * k * (H * W if mode == 2 else oh * ow)
     tot_ms += ms * cnt; tot_fl += fl * cnt
     print(f'conv I={I:4d} O={O:4d} {H:3d}x{W:3d} k={k} mode={mode} x{cnt}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  ksplit={cg.pick_ksplit(N, I, O, (H + 1 if mode == 2 else oh), (W + 1 if mode == 2 else ow), k, mode)}')
-print('--- bf16x3 (split-bf16) 3x3 stride-1')
+print('--- bf16x3 (split-bf16)')
+tot16_ms = tot16_fl = 0
 for (I, O, H, W, k, mode, cnt) in LAYERS:
     if not cg.bf16x3_eligible(I, H, W, k, mode):
         continue
     x = torch.randn(N, I, H, W, device=dev); w = torch.randn(O, I, k, k, device=dev); s = torch.randn(N, I, device=dev)
     wt16 = cg.prep_weight_bf16x3(w)
-    y = torch.empty(N, O, H, W, device=dev)
+    oh, ow = cg.out_shape(H, W, mode)
+    y = torch.empty(N, O, oh, ow, device=dev)
     epi = _lib.make_epilogue(act='lrelu')
-    ms = timeit(lambda: cg.conv_launch(x, wt16, 3, 0, O, out=y, style=s, epilogue=epi, bf16x3=True))
+    ms = timeit(lambda: cg.conv_launch(x, wt16, 3, mode, O, out=y, style=s, epilogue=epi, bf16x3=True))
     fl = 2.0 * N * O * I * 9 * H * W
-    print(f'bf16x3 I={I:4d} O={O:4d} {H:3d}x{W:3d} x{cnt}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s(fp32-equiv)  ksplit={cg.pick_ksplit_bf16x3(N, I, O, H, W)}')
+    tot16_ms += ms * cnt; tot16_fl += fl * cnt
+    print(f'bf16x3 I={I:4d} O={O:4d} {H:3d}x{W:3d} mode={mode} x{cnt}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s(fp32-equiv)')
+print(f'bf16x3-eligible total: {tot16_ms:.2f} ms, {tot16_fl / tot16_ms / 1e9:.1f} TFLOP/s fp32-equiv')
 print(f'conv total (weighted by per-frame count): {tot_ms:.2f} ms, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s')
 
 f = uf.setup_filter([1, 3, 3, 1]).to(dev)
