@@ -46,14 +46,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     }
 }
 
-// 3x3, stride 1, padding 1
-__global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
-    constexpr int BM = 64, TH = 8, TW = 32, ICB = 16, TAPS = 9;
-    constexpr int PH = TH + 2, PW = TW + 2, PPIX = PH * PW;               // 10 x 34 = 340 patch pixels
+// 3x3, stride 1, padding 1.  NW waves per workgroup, each owning 2 pixel rows: tile = 64 channels x (2 NW x 32) pixels.
+// NW = 8 (512 threads, one workgroup per CU) halves the weight-slab traffic and the per-thread staging work per MFMA.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
+    constexpr int NT_ = 64 * NW;                                          // threads
+    constexpr int BM = 64, TH = 2 * NW, TW = 32, ICB = 16, TAPS = 9;
+    constexpr int PH = TH + 2, PW = TW + 2, PPIX = PH * PW;               // NW=4: 10 x 34 = 340 patch pixels
     constexpr int A_ITEMS = TAPS * 2 * 2 * BM;                            // 16-byte slots: [tap][hl][half][row]
     constexpr int B_ITEMS = 2 * PPIX;                                     // (half, pixel) work items
-    constexpr int A_PER_T = A_ITEMS / 256;                                // 9  (item j of a thread = tap j)
-    constexpr int B_PER_T = (B_ITEMS + 255) / 256;                        // 3
+    constexpr int TAP_STEP = NT_ / 256;                                   // thread's j-th A item = tap (tid/256 + TAP_STEP*j)
+    constexpr int A_PER_T = (TAPS + TAP_STEP - 1) / TAP_STEP;             // 9 (NW=4) / 5 (NW=8)
+    constexpr int B_PER_T = (B_ITEMS + NT_ - 1) / NT_;
 
     __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];           // [tap][half][row]
     __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];                     // [half][pixel]
@@ -71,19 +75,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
     const int KC = p.I / ICB;
     const int HW = p.H * p.W;
 
-    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
 
     // A staging: thread owns (row, half, hl) for all 9 taps
-    const int a_row = tid & 63, a_q = tid >> 6, a_half = a_q & 1, a_hl = a_q >> 1;
-    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row;
+    const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
     const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
-    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row;
+    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
+    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row + a_t0 * 2 * BM;
     // B staging: work item e = tid + 256 j -> (half, patch pixel)
     int b_goff[B_PER_T];
     bool b_ok[B_PER_T];
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
-        const int e = tid + j * 256;
+        const int e = tid + j * NT_;
         const int hf = e / PPIX, pp = e % PPIX;
         const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
         b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
     auto load_stage = [&](int st) {                       // issue only; consumed in store_stage (after the MFMA block)
         const bf16x8* as = a_src + st * a_stage_stride;
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j) ra[j] = as[j * a_tap_stride];
+        for (int j = 0; j < A_PER_T; ++j)
+            if (a_t0 + TAP_STEP * j < TAPS) ra[j] = as[j * TAP_STEP * a_tap_stride];
         const float* bb = b_base + (int64_t)st * ICB * HW;
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j)
@@ -105,10 +110,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
     };
     auto store_stage = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j) a_dst[j * 2 * BM] = ra[j];
+        for (int j = 0; j < A_PER_T; ++j)
+            if (a_t0 + TAP_STEP * j < TAPS) a_dst[j * TAP_STEP * 2 * BM] = ra[j];
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
-            const int e = tid + j * 256;
+            const int e = tid + j * NT_;
             if (e >= B_ITEMS) continue;
             const int hf = e / PPIX;
             float v[8];
@@ -220,12 +226,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
 // (ky==2 ? 0 : 1, kx==2 ? 0 : 1)).  Workgroup = 64 output channels x (4 x 32) input-grid positions x 4 phases; each wave
 // owns one row of 32 positions: acc[2 row-tiles][4 phases].  Per K=16 chunk: 8 B-fragment reads (4 offsets x hi/lo) are
 // shared by all 9 taps, 36 A-fragment reads, 54 MFMAs.
-__global__ __launch_bounds__(256, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) {
-    constexpr int BM = 64, TH = 4, TW = 32, ICB = 16, TAPS = 9;
-    constexpr int PH = TH + 1, PW = TW + 1, PPIX = PH * PW;               // 5 x 33 = 165 patch pixels (halo: top / left)
-    constexpr int A_PER_T = TAPS * 2 * 2 * BM / 256;                      // 9
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) {
+    constexpr int NT_ = 64 * NW;
+    constexpr int BM = 64, TH = NW, TW = 32, ICB = 16, TAPS = 9;
+    constexpr int PH = TH + 1, PW = TW + 1, PPIX = PH * PW;               // NW=4: 5 x 33 = 165 patch pixels (halo: top / left)
+    constexpr int TAP_STEP = NT_ / 256;
+    constexpr int A_PER_T = (TAPS + TAP_STEP - 1) / TAP_STEP;
     constexpr int B_ITEMS = 2 * PPIX;
-    constexpr int B_PER_T = (B_ITEMS + 255) / 256;                        // 2
+    constexpr int B_PER_T = (B_ITEMS + NT_ - 1) / NT_;
 
     __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];
     __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];
@@ -244,17 +253,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_bf16x3_kernel(Conv16Params p
     const int HW = p.H * p.W;
     const int GH = p.H + 1, GW = p.W + 1;
 
-    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
 
-    const int a_row = tid & 63, a_q = tid >> 6, a_half = a_q & 1, a_hl = a_q >> 1;
-    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row;
+    const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
     const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
-    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row;
+    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
+    bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row + a_t0 * 2 * BM;
     int b_goff[B_PER_T];
     bool b_ok[B_PER_T];
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
-        const int e = tid + j * 256;
+        const int e = tid + j * NT_;
         const int hf = e / PPIX, pp = e % PPIX;
         const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
         b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_bf16x3_kernel(Conv16Params p
     auto load_stage = [&](int st) {
         const bf16x8* as = a_src + st * a_stage_stride;
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j) ra[j] = as[j * a_tap_stride];
+        for (int j = 0; j < A_PER_T; ++j)
+            if (a_t0 + TAP_STEP * j < TAPS) ra[j] = as[j * TAP_STEP * a_tap_stride];
         const float* bb = b_base + (int64_t)st * ICB * HW;
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j)
@@ -276,10 +286,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_bf16x3_kernel(Conv16Params p
     };
     auto store_stage = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j) a_dst[j * 2 * BM] = ra[j];
+        for (int j = 0; j < A_PER_T; ++j)
+            if (a_t0 + TAP_STEP * j < TAPS) a_dst[j * TAP_STEP * 2 * BM] = ra[j];
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
-            const int e = tid + j * 256;
+            const int e = tid + j * NT_;
             if (e >= B_ITEMS) continue;
             const int hf = e / PPIX;
             float v[8];
@@ -445,7 +456,13 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
-    p.tiles_x = up ? cdiv(d->W + 1, 32) : cdiv(p.OW, 32); p.tiles_y = up ? cdiv(d->H + 1, 4) : cdiv(p.OH, 8);
+    // 8-wave workgroups when the image is tall enough to fill them and the grid still covers the chip
+    const int gh = up ? d->H + 1 : p.OH, gw = up ? d->W + 1 : p.OW;
+    const int th4 = up ? 4 : 8;
+    const int64_t blocks8 = (int64_t)cdiv(gw, 32) * cdiv(gh, 2 * th4) * cdiv(d->O, 64) * d->N;
+    const bool big = gh >= 2 * th4 && blocks8 >= 256;
+    const int th = big ? 2 * th4 : th4;
+    p.tiles_x = cdiv(gw, 32); p.tiles_y = cdiv(gh, th);
     const int max_split = d->I / 16;
     p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);
     p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
@@ -458,8 +475,11 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (up ? (double)d->H * d->W : (double)p.OH * p.OW);
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv2d_bf16x3_kernel, dim3(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz), dim3(256), 0, stream, p);
+    const dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz);
+    if (up && big) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
+    else if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<4>, grid, dim3(256), 0, stream, p);
+    else if (big) hipLaunchKernelGGL(conv2d_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv2d_bf16x3_kernel<4>, grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
