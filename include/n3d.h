@@ -52,12 +52,14 @@ int n3d_bias_act(const void* x, const void* b, void* y, int64_t numel, int size_
  *   v = v * row_scale[n*O + o] * const_scale;  v += noise[oy*OW+ox] * (*noise_strength);  v += bias[o];
  *   v = act(v) * gain;  clamp;  v += residual[n, o, oy, ox]                                            */
 typedef struct {
-    const float* row_scale;       /* [N,O] or NULL  (demodulation coefficients, tat/networks_stylegan2.py:72-79) */
+    const float* row_scale;       /* [N,O] (row pitch row_scale_stride; 0 = O) or NULL — demodulation coefficients,
+                                     tat/networks_stylegan2.py:72-79                                              */
     const float* noise;           /* [OH,OW] or NULL (noise_const, :320-321)                                     */
     const float* noise_strength;  /* device scalar, required when noise != NULL                                  */
     const float* bias;            /* [O] or NULL                                                                 */
     const float* residual;        /* [N,O,OH,OW] (batch stride residual_batch_stride) or NULL                    */
     int64_t residual_batch_stride;
+    int64_t row_scale_stride;     /* floats between consecutive samples of row_scale (0 = densely packed [N,O])   */
     float const_scale;            /* e.g. Conv2dLayer.weight_gain (tat/networks_stylegan2.py:174)                */
     int act;                      /* N3D_ACT_*                                                                   */
     float alpha, gain, clamp;     /* clamp < 0: none                                                             */
@@ -93,6 +95,7 @@ typedef struct {
     int N, I, O, H, W;
     int ksize, mode, ksplit;
     int64_t x_batch_stride, y_batch_stride;
+    int64_t style_stride; /* floats between consecutive samples of `style` (0 = densely packed [N,I]) */
     n3d_epilogue epi;
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
@@ -111,6 +114,23 @@ int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
  *      pre_square: use x^2 (demodulation: sum_i s^2 * wsq);  post_rsqrt: y = rsqrt(y + 1e-8). */
 int n3d_fc(const float* x, const float* w, const float* b, float* y, int N, int I, int O, float wgain, float bgain,
            int act, float alpha, float gain, int pre_square, int post_rsqrt, n3d_stream_t stream);
+
+/* ---- batched fully connected: every style affine (and every demodulation coefficient) of one network in ONE launch.
+ *      jobs: DEVICE array of n3d_fc_job; rows: DEVICE int32[total_rows][2] = (job index, output row within the job).
+ *      For job j and sample n:  y_base[y_off + n*y_stride + o] = post(act(sum_i pre(x_base[x_off + n*x_stride + i]) *
+ *      w[o*I + i] * wgain + b[o]*bgain)).  Same reference code as n3d_fc. */
+typedef struct {
+    const float* w;       /* [O,I] */
+    const float* b;       /* [O] or NULL */
+    int64_t x_off, x_stride, y_off, y_stride;
+    int I, O;
+    float wgain, bgain;
+    int act;              /* N3D_ACT_* */
+    float alpha, gain;
+    int pre_square, post_rsqrt;
+} n3d_fc_job;
+int n3d_fc_multi(const n3d_fc_job* jobs, const int* rows, int total_rows, const float* x_base, float* y_base, int N,
+                 n3d_stream_t stream);
 
 /* ---- tri-plane blend (tat/triplane_next3d.py:171-174): planes = dyn * alpha + static * (1 - alpha), written
  *      CHANNELS-LAST [N,3,H,W,32] (one texel's 32 channels contiguous) for the renderer's gathers.

@@ -23,7 +23,8 @@ FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'mi
 
 class Epilogue(ctypes.Structure):
     _fields_ = [('row_scale', c_void_p), ('noise', c_void_p), ('noise_strength', c_void_p), ('bias', c_void_p),
-                ('residual', c_void_p), ('residual_batch_stride', c_int64), ('const_scale', c_float), ('act', c_int),
+                ('residual', c_void_p), ('residual_batch_stride', c_int64), ('row_scale_stride', c_int64),
+                ('const_scale', c_float), ('act', c_int),
                 ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
 
 
@@ -31,7 +32,13 @@ class Conv2dDesc(ctypes.Structure):
     _fields_ = [('x', c_void_p), ('wt', c_void_p), ('style', c_void_p), ('y', c_void_p), ('workspace', c_void_p),
                 ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
-                ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('epi', Epilogue)]
+                ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64), ('epi', Epilogue)]
+
+
+class FcJob(ctypes.Structure):
+    _fields_ = [('w', c_void_p), ('b', c_void_p), ('x_off', c_int64), ('x_stride', c_int64), ('y_off', c_int64),
+                ('y_stride', c_int64), ('I', c_int), ('O', c_int), ('wgain', c_float), ('bgain', c_float), ('act', c_int),
+                ('alpha', c_float), ('gain', c_float), ('pre_square', c_int), ('post_rsqrt', c_int)]
 
 
 _SIGNATURES = {
@@ -57,6 +64,7 @@ _SIGNATURES = {
     'n3d_texture_project': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
     'n3d_mouth_bbox': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'n3d_resize_aa': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
+    'n3d_fc_multi': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'n3d_fc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
                        c_float, c_int, c_int, c_void_p]),
 }
@@ -115,6 +123,7 @@ def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, re
     e = Epilogue()
     e.row_scale, e.noise, e.noise_strength, e.bias, e.residual = ptr(row_scale), ptr(noise), ptr(noise_strength), ptr(bias), ptr(residual)
     e.residual_batch_stride = residual.stride(0) if residual is not None else 0
+    e.row_scale_stride = row_scale.stride(0) if row_scale is not None else 0
     e.const_scale = float(const_scale)
     e.act = ACT_IDS[act]
     e.alpha = float(spec.def_alpha if alpha is None else alpha)

@@ -51,7 +51,7 @@ __device__ __forceinline__ float n3d_act(float x, int act, float alpha) {
 __device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue& e, int n, int o, int O, int oy, int ox,
                                                     int OH, int OW) {
     float sc = e.const_scale;
-    if (e.row_scale) sc *= e.row_scale[(int64_t)n * O + o];
+    if (e.row_scale) sc *= e.row_scale[(int64_t)n * (e.row_scale_stride ? e.row_scale_stride : O) + o];
     v *= sc;
     if (e.noise) v += e.noise[(int64_t)oy * OW + ox] * e.noise_strength[0];
     if (e.bias) v += e.bias[o];

@@ -33,7 +33,7 @@ struct ConvParams {
     int GH, GW;                      // per-phase output grid (mode 2: H+1, W+1; else OH, OW)
     int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
     int dbg;                         // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads
-    int64_t xbs, ybs;
+    int64_t xbs, ybs, style_stride;
     n3d_epilogue epi;
 };
 
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
     const int iy0 = y0 * S - P, ix0 = x0 * S - P;
     const int HW = p.H * p.W;
     for (int i = tid; i < ic_end - ic_begin; i += 256)       // no style = multiply by 1 (keeps the stage loop branch-free)
-        s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+        s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + ic_begin + i] : 1.f;
 
     int a_goff[A_PER_T], a_ic[A_PER_T];
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
         for (int r = 0; r < 16; ++r) {
             const int o = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int oc = o < p.O ? o : p.O - 1;
-            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + oc] : 1.f);
             bs[mt][r] = E.bias ? E.bias[oc] : 0.f;
         }
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
     const int HW = p.H * p.W;
     const float* xn = p.x + (int64_t)n * p.xbs;
 
-    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+    for (int i = tid; i < ic_end - ic_begin; i += 256) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + ic_begin + i] : 1.f;
 
     // Register budget: 128 accumulators + the prefetched stage (47 VGPRs).  Staging addresses are therefore recomputed
     // from `tid` every stage (constant divisors -> a few VALU ops that run beside the MFMAs) instead of being kept.
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
     for (int r = 0; r < 16; ++r) {
         const int o = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int oc = o < p.O ? o : p.O - 1;
-        rs[r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+        rs[r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + oc] : 1.f);
         bs[r] = E.bias ? E.bias[oc] : 0.f;
     }
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
@@ -575,6 +575,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     p.x = d->x; p.wt = d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP = (d->O + 3) & ~3; p.H = d->H; p.W = d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
+    p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.nphase = 1;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }

@@ -31,7 +31,7 @@ struct Conv16Params {
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, ksplit, ic_per_split;
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
-    int64_t xbs, ybs;
+    int64_t xbs, ybs, style_stride;
     n3d_epilogue epi;
 };
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     const int KC = p.I / ICB;
     const int HW = p.H * p.W;
 
-    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + ic_begin + i] : 1.f;
 
     // A staging: thread owns (row, half, hl) for all 9 taps
     const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
         for (int r = 0; r < 16; ++r) {
             const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int oc = o < p.O ? o : p.O - 1;
-            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + oc] : 1.f);
+            rs[mt][r] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + oc] : 1.f);
             bs[mt][r] = E.bias ? E.bias[oc] : 0.f;
         }
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     const int HW = p.H * p.W;
     const int GH = p.H + 1, GW = p.W + 1;
 
-    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.I + ic_begin + i] : 1.f;
+    for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + ic_begin + i] : 1.f;
 
     const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
     const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
             for (int r = 0; r < 16; ++r) {
                 const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (o >= p.O) continue;
-                const float rs = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * p.O + o] : 1.f);
+                const float rs = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
                 const float bs = E.bias ? E.bias[o] : 0.f;
                 float v[2] = {acc[mt][pa * 2][r] * rs + nz0 + bs, acc[mt][pa * 2 + 1][r] * rs + nz1 + bs};
 #pragma unroll
@@ -456,6 +456,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
+    p.style_stride = d->style_stride ? d->style_stride : d->I;
     // 8-wave workgroups when the image is tall enough to fill them and the grid still covers the chip
     const int gh = up ? d->H + 1 : p.OH, gw = up ? d->W + 1 : p.OW;
     const int th4 = up ? 4 : 8;

@@ -79,10 +79,86 @@ def _conv3x3(L, x, style=None, epilogue=None, out=None):
     return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
 
 
-def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0):
-    """SynthesisLayer.forward (reference networks_stylegan2.py:311-330)."""
-    styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
-    dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
+class StyleBank:
+    """Every style affine and demodulation coefficient of one network in TWO launches (n3d_fc_multi) instead of two per
+    layer: entries = [(PreparedConv, ws slot, 'conv' | 'torgb')] in any order; `compute(ws)` returns, per entry, strided
+    views (styles [N,I], dcoef [N,O] or None) into two packed buffers."""
+
+    def __init__(self, entries, device):
+        self.entries = entries
+        jobs_s, jobs_d, rows_s, rows_d = [], [], [], []
+        self.cols, self.dcols = [], []
+        ci = co = 0
+        for L, slot, kind in entries:
+            g = L.weight_gain if kind == 'torgb' else 1.0
+            j = _lib.FcJob()
+            j.w, j.b = _lib.ptr(L.affine_w), _lib.ptr(L.affine_b)
+            j.x_off, j.x_stride, j.y_off, j.y_stride = slot * 512, 0, ci, 0           # strides patched per call
+            j.I, j.O, j.wgain, j.bgain = 512, L.in_channels, g / np.sqrt(512), g
+            j.act, j.alpha, j.gain, j.pre_square, j.post_rsqrt = 1, 0.0, 1.0, 0, 0
+            rows_s += [(len(jobs_s), o) for o in range(L.in_channels)]
+            jobs_s.append(j)
+            self.cols.append(ci)
+            if kind == 'conv':
+                d = _lib.FcJob()
+                d.w, d.b = _lib.ptr(L.wsq), None
+                d.x_off, d.x_stride, d.y_off, d.y_stride = ci, 0, co, 0
+                d.I, d.O, d.wgain, d.bgain = L.in_channels, L.out_channels, 1.0, 1.0
+                d.act, d.alpha, d.gain, d.pre_square, d.post_rsqrt = 1, 0.0, 1.0, 1, 1
+                rows_d += [(len(jobs_d), o) for o in range(L.out_channels)]
+                jobs_d.append(d)
+                self.dcols.append(co)
+                co += L.out_channels
+            else:
+                self.dcols.append(None)
+            ci += L.in_channels
+        self.total_i, self.total_o = ci, co
+        self._jobs_s, self._jobs_d = jobs_s, jobs_d
+        self.rows_s = torch.tensor(rows_s, dtype=torch.int32, device=device).contiguous()
+        self.rows_d = torch.tensor(rows_d, dtype=torch.int32, device=device).contiguous() if rows_d else None
+        self.device = device
+        self._dev_jobs = {}
+
+    def _jobs_on_device(self, ws_stride):
+        """Job tables in device memory for a given ws batch stride (cached)."""
+        if ws_stride not in self._dev_jobs:
+            import ctypes
+            def pack(jobs, xs, ys):
+                arr = (_lib.FcJob * len(jobs))()
+                for i, j in enumerate(jobs):
+                    ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(j), ctypes.sizeof(_lib.FcJob))
+                    arr[i].x_stride, arr[i].y_stride = xs, ys
+                raw = bytes(arr)
+                return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            js = pack(self._jobs_s, ws_stride, self.total_i)
+            jd = pack(self._jobs_d, self.total_i, self.total_o) if self._jobs_d else None
+            self._dev_jobs[ws_stride] = (js, jd)
+        return self._dev_jobs[ws_stride]
+
+    def compute(self, ws):
+        """ws [N, num_ws, 512] float32 with unit inner strides (any batch stride)."""
+        assert ws.dtype == torch.float32 and ws.stride(2) == 1 and ws.stride(1) == 512 and ws.shape[2] == 512
+        n = ws.shape[0]
+        js, jd = self._jobs_on_device(ws.stride(0))
+        styles = torch.empty([n, self.total_i], dtype=torch.float32, device=ws.device)
+        L_ = _lib.lib()
+        _lib.check(L_.n3d_fc_multi(_lib.ptr(js), _lib.ptr(self.rows_s), self.rows_s.shape[0], _lib.ptr(ws), _lib.ptr(styles), n, _lib.stream()))
+        dcoef = None
+        if jd is not None:
+            dcoef = torch.empty([n, self.total_o], dtype=torch.float32, device=ws.device)
+            _lib.check(L_.n3d_fc_multi(_lib.ptr(jd), _lib.ptr(self.rows_d), self.rows_d.shape[0], _lib.ptr(styles), _lib.ptr(dcoef), n, _lib.stream()))
+        out = {}
+        for (Lc, slot, kind), c0, d0 in zip(self.entries, self.cols, self.dcols):
+            out[Lc.prefix] = (styles[:, c0:c0 + Lc.in_channels], None if d0 is None else dcoef[:, d0:d0 + Lc.out_channels])
+        return out
+
+
+def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None):
+    """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
+    StyleBank; otherwise they are computed here from the latent `w`."""
+    if styles is None:
+        styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
+        dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
     noise = L.noise_const if noise_mode == 'const' else None
     if noise_mode == 'random':
         raise RuntimeError("noise_mode='random' is a training-time path; inference uses 'const' or 'none'")
@@ -98,10 +174,11 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 
-def torgb_layer(L, x, w, conv_clamp=None, residual=None):
+def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None):
     """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584)."""
     g = L.weight_gain
-    styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
+    if styles is None:
+        styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
     return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=styles,
                           epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual))
 

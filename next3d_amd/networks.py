@@ -24,28 +24,42 @@ class _Block:
         self.conv1 = L.PreparedConv(P, f'{prefix}.conv1', modulated=True)
         self.torgb = L.PreparedConv(P, f'{prefix}.torgb', modulated=True, demodulate=False)
 
-    def __call__(self, x, img, ws, fir, noise_mode):
-        """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path)."""
-        k = 0
+    def entries(self, first_slot):
+        """(layer, ws slot, kind) triples for a StyleBank; `first_slot` = ws index of this block's first conv."""
+        out, k = [], first_slot
+        if self.conv0 is not None:
+            out.append((self.conv0, k, 'conv')); k += 1
+        out.append((self.conv1, k, 'conv')); k += 1
+        out.append((self.torgb, k, 'torgb'))
+        return out
+
+    def __call__(self, x, img, bank, n, fir, noise_mode):
+        """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path); `bank` = StyleBank.compute(ws) result."""
+        sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
-            x = self.const.unsqueeze(0).expand(ws.shape[0], -1, -1, -1)
-            x = L.synthesis_layer(self.conv1, x, ws[:, k], fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
+            x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
+            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
-            x = L.synthesis_layer(self.conv0, x, ws[:, k], fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
-            x = L.synthesis_layer(self.conv1, x, ws[:, k], fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp); k += 1
+            x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv0))
+            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         if img is not None:
             img = uf.upsample2d(img, fir)
-        img = L.torgb_layer(self.torgb, x, ws[:, k], conv_clamp=self.conv_clamp, residual=img)
+        img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
         return x, img
 
 
-def _split_ws(ws, block_resolutions):
-    out, idx = [], 0
+def _first_slots(block_resolutions):
+    """ws index of each block's first conv: b4 has one conv, the others two (networks_stylegan2.py:632-640)."""
+    out, idx = {}, 0
     for res in block_resolutions:
-        nconv = 1 if res == 4 else 2
-        out.append(ws.narrow(1, idx, nconv + 1))
-        idx += nconv
+        out[res] = idx
+        idx += 1 if res == 4 else 2
     return out
+
+
+def _ws3(ws):
+    ws = ws.to(torch.float32)
+    return ws if (ws.stride(2) == 1 and ws.stride(1) == ws.shape[2]) else ws.contiguous()
 
 
 class SynthesisNet:
@@ -55,12 +69,15 @@ class SynthesisNet:
         self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2] if r > 4 else 0) for r in self.block_res}
         self.fir = P[f'{prefix}.b4.resample_filter']
         self.num_ws = 2 * len(self.block_res)
+        slots = _first_slots(self.block_res)
+        self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.block_res), []), self.fir.device)
 
     def __call__(self, ws, noise_mode='const'):
-        ws = ws.to(torch.float32)
+        ws = _ws3(ws)
+        bank = self.bank.compute(ws)
         x = img = None
-        for res, cur in zip(self.block_res, _split_ws(ws, self.block_res)):
-            x, img = self.blocks[res](x, img, cur.contiguous(), self.fir, noise_mode)
+        for res in self.block_res:
+            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode)
         return img
 
 
@@ -94,23 +111,25 @@ class StyleUNet:
         n_fusion = sum(1 for i in range(len(self.used_res)) if 2 ** (i + self.final_log2) < num_cond_res)
         self.fusion = [L.PreparedConv(P, f'{prefix}.fusion.{i}', modulated=False) for i in range(n_fusion)]
         self.fir = P[f'{prefix}.b4.resample_filter']
+        slots = _first_slots(self.block_res)
+        self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.used_res), []), self.fir.device)
 
     def __call__(self, x_in, ws, noise_mode='const'):
-        ws = ws.to(torch.float32)
-        block_ws = _split_ws(ws, self.block_res)[self.start:]
+        ws = _ws3(ws)
+        bank = self.bank.compute(ws)
         conds, cond = [], None
         for enc in self.encoder:
             x_in, cond = enc(x_in, cond, self.fir)
             conds.append(cond)
         conds = conds[::-1]
         x = img = None
-        for idx, (res, cur) in enumerate(zip(self.used_res, block_ws)):
+        for idx, res in enumerate(self.used_res):
             if idx < len(self.fusion):
                 if idx == 0:
                     x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
                 else:
                     x = L.conv2d_layer(self.fusion[idx], torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
-            x, img = self.blocks[res](x, img, cur.contiguous(), self.fir, noise_mode)
+            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode)
         return img
 
 
@@ -120,13 +139,20 @@ class SuperRes8XDC:
         self.block1 = _Block(P, f'{prefix}.block1', 256, conv_clamp=256)
         self.fir = P[f'{prefix}.block0.resample_filter']
         self.input_resolution = 128
+        self._banks = {}
 
     def __call__(self, rgb, x, ws, resize_fn):
-        """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286)."""
-        ws = ws[:, -1:, :].repeat(1, 3, 1).contiguous()
+        """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286).  Every layer is driven by the
+        LAST latent of `ws` (`ws[:, -1:].repeat(1, 3, 1)`, :280): all StyleBank jobs read that one slot."""
+        ws = _ws3(ws)
+        last = ws.shape[1] - 1
+        if last not in self._banks:
+            ent = [(l, last, k) for blk in (self.block0, self.block1) for (l, _, k) in blk.entries(0)]
+            self._banks[last] = L.StyleBank(ent, self.fir.device)
+        bank = self._banks[last].compute(ws)
         if x.shape[-1] != self.input_resolution:
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
-        x, rgb = self.block0(x, rgb, ws, self.fir, 'none')
-        x, rgb = self.block1(x, rgb, ws, self.fir, 'none')
+        x, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, 'none')
+        x, rgb = self.block1(x, rgb, bank, ws.shape[0], self.fir, 'none')
         return rgb

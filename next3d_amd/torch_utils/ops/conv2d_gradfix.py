@@ -99,6 +99,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
+    d.style_stride = style.stride(0) if style is not None else 0
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
