@@ -59,8 +59,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     constexpr int A_PER_T = (TAPS + TAP_STEP - 1) / TAP_STEP;             // 9 (NW=4) / 5 (NW=8)
     constexpr int B_PER_T = (B_ITEMS + NT_ - 1) / NT_;
 
-    __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];           // [tap][half][row]
-    __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];                     // [half][pixel]
+    // NW == 8: LDS is double-buffered (2 x 76 KB) and the eight waves run a ping-pong schedule — waves 0-3 convert + store
+    // stage s+1 and issue the loads of stage s+2 BEFORE their MFMA block, waves 4-7 AFTER it — so on every SIMD (waves w and
+    // w+4 share one) the bf16 matrix pipe is fed by one wave while the other does the VALU/LDS staging work; one barrier per
+    // stage.  NW == 4 (small images): single buffer, two barriers per stage, two workgroups per CU.
+    constexpr int NBUF = (NW == 8) ? 2 : 1;
+    constexpr int A_SZ = TAPS * 2 * BM, B_SZ = 2 * PPIX;
+    __shared__ bf16x8 A_hi[NBUF * A_SZ], A_lo[NBUF * A_SZ];               // [buf][tap][half][row]
+    __shared__ bf16x8 B_hi[NBUF * B_SZ], B_lo[NBUF * B_SZ];               // [buf][half][pixel]
     __shared__ float s_style[1024];
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -109,9 +115,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
     };
     auto store_stage = [&](int st) {
+        const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j)
-            if (a_t0 + TAP_STEP * j < TAPS) a_dst[j * TAP_STEP * 2 * BM] = ra[j];
+            if (a_t0 + TAP_STEP * j < TAPS) a_dst[bo_a + j * TAP_STEP * 2 * BM] = ra[j];
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
             const int e = tid + j * NT_;
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
             bf16x8 hi, lo;
             split8(v, hi, lo);
-            B_hi[e] = hi;
-            B_lo[e] = lo;
+            B_hi[bo_b + e] = hi;
+            B_lo[bo_b + e] = lo;
         }
     };
 
@@ -144,17 +151,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     __syncthreads();
     const int a_frag = half * BM + l31;                                   // + tap*2*BM + mt*32
     const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
-    for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage && !(p.dbg & 4)) load_stage(st + 1);
-        if (!(p.dbg & 2))
+    auto mfma_block = [&](int st) {
+        const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int boff = (t / 3) * PW + (t % 3);
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[t * 2 * BM + a_frag + mt * 32]; }
+            for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[b_frag + nt * PW + boff]; bl[nt] = B_lo[b_frag + nt * PW + boff]; }
+            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[bo_b + b_frag + nt * PW + boff]; bl[nt] = B_lo[bo_b + b_frag + nt * PW + boff]; }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -164,8 +170,30 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+    };
+    if (NBUF == 2) {
+        // registers hold the raw data of stage st+1 at the top of iteration st
+        if (nstage > 1) load_stage(1);
+        const bool stage_first = wn < NW / 2;
+        for (int st = 0; st < nstage; ++st) {
+            if (stage_first) {
+                if (st + 1 < nstage) store_stage(st + 1);
+                if (st + 2 < nstage) load_stage(st + 2);
+                mfma_block(st);
+            } else {
+                mfma_block(st);
+                if (st + 1 < nstage) store_stage(st + 1);
+                if (st + 2 < nstage) load_stage(st + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int st = 0; st < nstage; ++st) {
+            if (st + 1 < nstage && !(p.dbg & 4)) load_stage(st + 1);
+            if (!(p.dbg & 2)) mfma_block(st);
+            __syncthreads();
+            if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+        }
     }
 
     // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
@@ -236,8 +264,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     constexpr int B_ITEMS = 2 * PPIX;
     constexpr int B_PER_T = (B_ITEMS + NT_ - 1) / NT_;
 
-    __shared__ bf16x8 A_hi[TAPS * 2 * BM], A_lo[TAPS * 2 * BM];
-    __shared__ bf16x8 B_hi[2 * PPIX], B_lo[2 * PPIX];
+    constexpr int NBUF = (NW == 8) ? 2 : 1;                               // NW == 8: double buffer + ping-pong (see above)
+    constexpr int A_SZ = TAPS * 2 * BM, B_SZ = 2 * PPIX;
+    __shared__ bf16x8 A_hi[NBUF * A_SZ], A_lo[NBUF * A_SZ];
+    __shared__ bf16x8 B_hi[NBUF * B_SZ], B_lo[NBUF * B_SZ];
     __shared__ float s_style[1024];
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -285,9 +315,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
             for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
     };
     auto store_stage = [&](int st) {
+        const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j)
-            if (a_t0 + TAP_STEP * j < TAPS) a_dst[j * TAP_STEP * 2 * BM] = ra[j];
+            if (a_t0 + TAP_STEP * j < TAPS) a_dst[bo_a + j * TAP_STEP * 2 * BM] = ra[j];
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
             const int e = tid + j * NT_;
@@ -298,8 +329,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
             for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
             bf16x8 hi, lo;
             split8(v, hi, lo);
-            B_hi[e] = hi;
-            B_lo[e] = lo;
+            B_hi[bo_b + e] = hi;
+            B_lo[bo_b + e] = lo;
         }
     };
 
@@ -316,11 +347,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     __syncthreads();
     const int a_frag = half * BM + l31;
     const int b_frag = half * PPIX + wn * PW + l31;                       // position (row wn, col l31); + dy*PW + dx
-    for (int st = 0; st < nstage; ++st) {
-        if (st + 1 < nstage) load_stage(st + 1);
+    auto mfma_block = [&](int st) {
+        const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
         bf16x8 bh[4], bl[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { bh[d] = B_hi[b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[b_frag + (d >> 1) * PW + (d & 1)]; }
+        for (int d = 0; d < 4; ++d) { bh[d] = B_hi[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -330,14 +361,35 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                 const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x8 ah = A_hi[t * 2 * BM + a_frag + mt * 32], al = A_lo[t * 2 * BM + a_frag + mt * 32];
+                    const bf16x8 ah = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32], al = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32];
                     acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[d], acc[mt][ph], 0, 0, 0);
                     acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[d], acc[mt][ph], 0, 0, 0);
                     acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[d], acc[mt][ph], 0, 0, 0);
                 }
             }
-        __syncthreads();
-        if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+    };
+    if (NBUF == 2) {
+        if (nstage > 1) load_stage(1);
+        const bool stage_first = wn < NW / 2;
+        for (int st = 0; st < nstage; ++st) {
+            if (stage_first) {
+                if (st + 1 < nstage) store_stage(st + 1);
+                if (st + 2 < nstage) load_stage(st + 2);
+                mfma_block(st);
+            } else {
+                mfma_block(st);
+                if (st + 1 < nstage) store_stage(st + 1);
+                if (st + 2 < nstage) load_stage(st + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int st = 0; st < nstage; ++st) {
+            if (st + 1 < nstage) load_stage(st + 1);
+            mfma_block(st);
+            __syncthreads();
+            if (st + 1 < nstage) { store_stage(st + 1); __syncthreads(); }
+        }
     }
 
     // epilogue: phases (a,0),(a,1) of one position are adjacent output pixels -> one 8-byte store per lane
