@@ -29,7 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Conv16Params {
     const float* x; const bf16x8* wt16; const float* style; float* y; float* partial;
     int N, I, O, OP64, H, W, OH, OW;
-    int tiles_x, tiles_y, ksplit, ic_per_split;
+    int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
     int64_t xbs, ybs, style_stride;
     n3d_epilogue epi;
@@ -71,9 +71,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-    const int m0 = blockIdx.y * BM;
-    const int ks = blockIdx.z % p.ksplit, n = blockIdx.z / p.ksplit;
+    // 1-D grid, XCD-aware: hardware block b runs on XCD b % 8 — remap so that each XCD owns a contiguous range of LOGICAL
+    // ids, ordered M-tile fastest: the O/64 workgroups that read the same input patch run back-to-back on ONE XCD and share
+    // it through that XCD's L2 instead of fetching it O/64 times from HBM / Infinity Cache.
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mt_i = lb % p.tiles_m; lb /= p.tiles_m;
+    const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
+    const int tx = tile_i % p.tiles_x, ty = tile_i / p.tiles_x;
+    const int m0 = mt_i * BM;
+    const int ks = lb % p.ksplit, n = lb / p.ksplit;
     const int y0 = ty * TH, x0 = tx * TW;
     const int ic_begin = ks * p.ic_per_split;
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
@@ -143,16 +153,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     __syncthreads();
-    if (p.dbg & 16) {          // experiment: de-phase the two co-resident workgroups of a CU (odd hardware wave slot waits)
-        const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID[3:0] = wave slot
-        if (hwid & 1) { for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16); }
-    }
     if (nstage > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
     const int a_frag = half * BM + l31;                                   // + tap*2*BM + mt*32
     const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
+        __builtin_amdgcn_s_setprio(1);      // role-split schedule: favour the wave that is feeding the matrix pipe
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int boff = (t / 3) * PW + (t % 3);
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     if (NBUF == 2) {
         // registers hold the raw data of stage st+1 at the top of iteration st
@@ -177,13 +185,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
         const bool stage_first = wn < NW / 2;
         for (int st = 0; st < nstage; ++st) {
             if (stage_first) {
-                if (st + 1 < nstage) store_stage(st + 1);
-                if (st + 2 < nstage) load_stage(st + 2);
-                mfma_block(st);
+                if (st + 1 < nstage && !(p.dbg & 8)) store_stage(st + 1);
+                if (st + 2 < nstage && !(p.dbg & 4)) load_stage(st + 2);
+                if (!(p.dbg & 2)) mfma_block(st);
             } else {
-                mfma_block(st);
-                if (st + 1 < nstage) store_stage(st + 1);
-                if (st + 2 < nstage) load_stage(st + 2);
+                if (!(p.dbg & 2)) mfma_block(st);
+                if (st + 1 < nstage && !(p.dbg & 8)) store_stage(st + 1);
+                if (st + 2 < nstage && !(p.dbg & 4)) load_stage(st + 2);
             }
             __syncthreads();
         }
@@ -272,9 +280,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-    const int m0 = blockIdx.y * BM;
-    const int ks = blockIdx.z % p.ksplit, n = blockIdx.z / p.ksplit;
+    // 1-D grid, XCD-aware: hardware block b runs on XCD b % 8 — remap so that each XCD owns a contiguous range of LOGICAL
+    // ids, ordered M-tile fastest: the O/64 workgroups that read the same input patch run back-to-back on ONE XCD and share
+    // it through that XCD's L2 instead of fetching it O/64 times from HBM / Infinity Cache.
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mt_i = lb % p.tiles_m; lb /= p.tiles_m;
+    const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
+    const int tx = tile_i % p.tiles_x, ty = tile_i / p.tiles_x;
+    const int m0 = mt_i * BM;
+    const int ks = lb % p.ksplit, n = lb / p.ksplit;
     const int y0 = ty * TH, x0 = tx * TW;
     const int ic_begin = ks * p.ic_per_split;
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     const int b_frag = half * PPIX + wn * PW + l31;                       // position (row wn, col l31); + dy*PW + dx
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
+        __builtin_amdgcn_s_setprio(1);
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) { bh[d] = B_hi[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; }
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                     acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[d], acc[mt][ph], 0, 0, 0);
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
     };
     if (NBUF == 2) {
         if (nstage > 1) load_stage(1);
@@ -523,12 +543,13 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(p.ksplit == 1 || d->workspace != nullptr, "conv2d_bf16x3: ksplit > 1 needs a workspace");
     N3D_CHECK(p.ic_per_split <= 1024, "conv2d_bf16x3: more than 1024 input channels per K-split");
     if (p.ksplit == 1) p.partial = nullptr;
-    const int64_t gz = (int64_t)p.N * p.ksplit;
-    N3D_CHECK(gz <= 65535, "conv2d_bf16x3: grid.z too large");
+    p.tiles_m = cdiv(p.O, 64);
+    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
+    N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (up ? (double)d->H * d->W : (double)p.OH * p.OW);
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    const dim3 grid(p.tiles_x * p.tiles_y, cdiv(p.O, 64), (unsigned)gz);
+    const dim3 grid((unsigned)nblk);
     if (up && big) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
     else if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<4>, grid, dim3(256), 0, stream, p);
     else if (big) hipLaunchKernelGGL(conv2d_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
