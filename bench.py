@@ -96,7 +96,8 @@ def main():
     def step():
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
         img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)['image']
-        frames = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8)      # gen_samples_next3d.py:201 (NCHW kept)
+        frames = torch.empty(img.shape, dtype=torch.uint8, device=dev)       # gen_samples_next3d.py:201 (NCHW kept)
+        _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img), _lib.ptr(frames), img.numel(), _lib.stream()))
         if world > 1:
             dist.gather(frames, gathered, dst=0)
         return frames

@@ -132,6 +132,21 @@ typedef struct {
 int n3d_fc_multi(const n3d_fc_job* jobs, const int* rows, int total_rows, const float* x_base, float* y_base, int N,
                  n3d_stream_t stream);
 
+/* ---- small element-wise pieces of the path.
+ *      n3d_normalize_2nd_moment: y[r,:] = x[r,:] * rsqrt(mean(x[r,:]^2) + eps)  (tat/networks_stylegan2.py:27-29); y rows
+ *        have pitch y_stride so two calls can fill the halves of the mapping network's concatenated input (:239-246).
+ *      n3d_truncate_ws: broadcast w [N,D] to ws [N,num_ws,D] and lerp the first `cutoff` latents towards w_avg with
+ *        psi (MappingNetwork.forward :255-267; w_avg NULL or psi == 1 => plain broadcast).
+ *      n3d_fma: y = a*b + c over a [NC,P] with b, c addressed as [nc*stride_nc + p*stride_p] (0 strides broadcast)
+ *        (torch_utils/ops/fma.py:17-28 — only the non-fused modulated-conv branch uses it).
+ *      n3d_to_uint8: (x*127.5+128).clamp(0,255) -> uint8 (gen_samples_next3d.py:201), layout preserved. */
+int n3d_normalize_2nd_moment(const float* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream);
+int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int num_ws, int D, int cutoff, float psi,
+                    n3d_stream_t stream);
+int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p,
+            int64_t c_nc, int64_t c_p, n3d_stream_t stream);
+int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t stream);
+
 /* ---- tri-plane blend (tat/triplane_next3d.py:171-174): planes = dyn * alpha + static * (1 - alpha), written
  *      CHANNELS-LAST [N,3,H,W,32] (one texel's 32 channels contiguous) for the renderer's gathers.
  *      front/side/top [N,32,H,W], stat [N,96,H,W], alpha [N,3,H,W]. */

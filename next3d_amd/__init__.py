@@ -7,7 +7,7 @@
 import importlib
 import sys
 
-_OP_MODULES = ('bias_act', 'upfirdn2d', 'conv2d_resample', 'conv2d_gradfix', 'fma')
+_OP_MODULES = ('bias_act', 'upfirdn2d', 'conv2d_resample', 'conv2d_gradfix', 'fma', 'filtered_lrelu')
 
 
 def install_dropin(model=False):

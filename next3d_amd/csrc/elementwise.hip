@@ -1,0 +1,108 @@
+// Small element-wise kernels of the generator forward path (HBM-bound or launch-bound; 16-byte accesses where aligned).
+//   normalize_2nd_moment : x * rsqrt(mean(x^2, dim=1) + eps)            (training_avatar_texture/networks_stylegan2.py:27-29)
+//   truncate_ws          : w_avg + psi * (ws - w_avg) on the first `cutoff` latents, broadcast of one w to num_ws
+//                          (MappingNetwork.forward :255-267)
+//   fma                  : a * b + c with NCHW / per-(n,c) / per-pixel broadcasting     (torch_utils/ops/fma.py:17-28)
+//   to_uint8             : (img * 127.5 + 128).clamp(0, 255) -> uint8              (gen_samples_next3d.py:201)
+#include "common.h"
+
+// one wave per row
+__global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int D,
+                                                                   int64_t y_stride, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + (int64_t)r * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float k = rsqrtf(s / (float)D + eps);
+    float* yr = y + (int64_t)r * y_stride;
+    for (int i = lane; i < D; i += 64) yr[i] = xr[i] * k;
+}
+
+// ws[n, j, :] = j < cutoff ? lerp(w_avg, w[n], psi) : w[n]
+__global__ __launch_bounds__(256) void truncate_ws_kernel(const float* __restrict__ w, const float* __restrict__ w_avg, float* __restrict__ ws,
+                                                          int N, int num_ws, int D, int cutoff, float psi) {
+    const int64_t total = (int64_t)N * num_ws * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D), j = (int)((i / D) % num_ws), n = (int)(i / ((int64_t)D * num_ws));
+        const float v = w[(int64_t)n * D + d];
+        ws[i] = (j < cutoff && w_avg) ? w_avg[d] + psi * (v - w_avg[d]) : v;
+    }
+}
+
+// y[n,c,p] = a[n,c,p] * b[(n*C + c) * bs_nc + p * bs_p] + c[...] ; strides 0 broadcast
+__global__ __launch_bounds__(256) void fma_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                  float* __restrict__ y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p, int64_t c_nc,
+                                                  int64_t c_p) {
+    const int64_t total = NC * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nc = i / P, pp = i % P;
+        y[i] = a[i] * b[nc * b_nc + pp * b_p] + c[nc * c_nc + pp * c_p];
+    }
+}
+
+__global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        uchar4 o;
+        o.x = (unsigned char)fminf(fmaxf(v.x * 127.5f + 128.f, 0.f), 255.f);
+        o.y = (unsigned char)fminf(fmaxf(v.y * 127.5f + 128.f, 0.f), 255.f);
+        o.z = (unsigned char)fminf(fmaxf(v.z * 127.5f + 128.f, 0.f), 255.f);
+        o.w = (unsigned char)fminf(fmaxf(v.w * 127.5f + 128.f, 0.f), 255.f);
+        reinterpret_cast<uchar4*>(y)[i] = o;
+    }
+}
+
+static inline int grid_for(int64_t n) { const int64_t g = cdiv64(n, 256); return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+extern "C" {
+
+int n3d_normalize_2nd_moment(const float* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(rows >= 0 && D > 0 && y_stride >= D, "normalize_2nd_moment: bad shape");
+    if (rows == 0) return 0;
+    N3D_CHECK(x && y, "normalize_2nd_moment: null tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 3.0 * rows * D, 8.0 * rows * D);
+    hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, D, y_stride, eps);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int num_ws, int D, int cutoff, float psi, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && num_ws > 0 && D > 0, "truncate_ws: bad shape");
+    if (N == 0) return 0;
+    N3D_CHECK(w && ws, "truncate_ws: null tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 2.0 * N * num_ws * D, 4.0 * N * D * (num_ws + 1));
+    hipLaunchKernelGGL(truncate_ws_kernel, dim3(grid_for((int64_t)N * num_ws * D)), dim3(256), 0, stream, w, w_avg, ws, N, num_ws, D, cutoff, psi);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p, int64_t c_nc,
+            int64_t c_p, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(NC >= 0 && P >= 0, "fma: bad shape");
+    if (NC * P == 0) return 0;
+    N3D_CHECK(a && b && c && y, "fma: null tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 2.0 * NC * P, 8.0 * NC * P);
+    hipLaunchKernelGGL(fma_kernel, dim3(grid_for(NC * P)), dim3(256), 0, stream, a, b, c, y, NC, P, b_nc, b_p, c_nc, c_p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(numel >= 0 && numel % 4 == 0, "to_uint8: numel must be a multiple of 4");
+    if (numel == 0) return 0;
+    N3D_CHECK(x && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 3) == 0, "to_uint8: null or misaligned tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 2.0 * numel, 5.0 * numel);
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, stream, x, y, numel / 4);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
 // FT_PER_T outputs at one x (consecutive lanes = consecutive x: conflict-free LDS reads, coalesced 256-byte stores) and
 // the taps live in registers.  HBM-bound: the block reads its input footprint once and writes its outputs once.
 #define FT_W 64
-#define FT_H 16
+#define FT_H 32
 #define FT_PER_T (FT_W * FT_H / 256)
 
 template <int UP, int DOWN, int FS>

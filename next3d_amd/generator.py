@@ -164,21 +164,22 @@ class TriPlaneGenerator(torch.nn.Module):
         z = z.to(device=self.device, dtype=torch.float32)
         c = c.to(device=self.device, dtype=torch.float32)
         pre = 'backbone.mapping'
-        x = _normalize_2nd_moment(z)
+        n = z.shape[0]
+        L = _lib.lib()
+        x = torch.empty(n, 1024, dtype=torch.float32, device=self.device)          # cat([norm(z), norm(embed(c))], 1)
+        _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(z.contiguous()), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
         y = layers.fc(c.contiguous(), P[f'{pre}.embed.weight'], P[f'{pre}.embed.bias'], wgain=1 / np.sqrt(25))
-        x = torch.cat([x, _normalize_2nd_moment(y)], dim=1)
+        _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(y), _lib.c_void_p(x.data_ptr() + 512 * 4), n, 512, 1024, 1e-8, _lib.stream()))
         for i in range(2):
             w = P[f'{pre}.fc{i}.weight']
             x = layers.fc(x, w, P[f'{pre}.fc{i}.bias'], wgain=0.01 / np.sqrt(w.shape[1]), bgain=0.01, act='lrelu')
         num_ws = 2 * S.texture.num_ws
-        x = x.unsqueeze(1).repeat(1, num_ws, 1)
-        if truncation_psi != 1:
-            w_avg = P[f'{pre}.w_avg']
-            if truncation_cutoff is None:
-                x = w_avg.lerp(x, truncation_psi)
-            else:
-                x[:, :truncation_cutoff] = w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+        ws = torch.empty(n, num_ws, 512, dtype=torch.float32, device=self.device)
+        trunc = truncation_psi != 1
+        cutoff = num_ws if truncation_cutoff is None else min(int(truncation_cutoff), num_ws)
+        _lib.check(L.n3d_truncate_ws(_lib.ptr(x), _lib.ptr(P[f'{pre}.w_avg']) if trunc else None, _lib.ptr(ws), n, num_ws, 512,
+                                     cutoff if trunc else 0, float(truncation_psi), _lib.stream()))
+        return ws
 
     def rasterize(self, v, lms, textures):
         """reference triplane_next3d.py:190-230 -> ([front, side, top] each [N,32,256,256], alpha [N,3,256,256], bbox [N,4] int32)."""
@@ -296,10 +297,6 @@ class TriPlaneGenerator(torch.nn.Module):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
         return self.synthesis(ws, c, v, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
                               cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
-
-
-def _normalize_2nd_moment(x, dim=1, eps=1e-8):
-    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
 def _resize_aa(x, size):

@@ -230,3 +230,23 @@ def test_conv2d_up_bf16x3(dev, N, I, OC, H, W):
         y = cg.conv_launch(t(x), wt16, 3, 2, OC, style=ts, epilogue=_lib.make_epilogue(row_scale=td), ksplit=ksplit, bf16x3=True)
         err = float((y.cpu() - ref).abs().max())
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ksplit, err)
+
+
+def test_filtered_lrelu_fma_and_small_kernels(dev):
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import filtered_lrelu, fma, upfirdn2d
+    x, b = _gen((2, 6, 18, 18), 70), _gen((6,), 71)
+    for fu_t, fd_t, up, down, pad in (([1, 3, 3, 1], [1, 3, 3, 1], 2, 2, [2, 1, 2, 1]), ([1, 2, 1], None, 1, 1, 1),
+                                      (list(range(1, 13)), list(range(1, 13)), 2, 2, 10)):
+        fu = upfirdn2d.setup_filter(fu_t)
+        fd = upfirdn2d.setup_filter(fd_t) if fd_t is not None else None
+        ref = O.filtered_lrelu(x, fu, fd, b, up=up, down=down, padding=pad, gain=1.7, slope=0.1, clamp=0.8)
+        y = filtered_lrelu.filtered_lrelu(x.to(dev), fu.to(dev), None if fd is None else fd.to(dev), b.to(dev), up=up, down=down,
+                                          padding=pad, gain=1.7, slope=0.1, clamp=0.8)
+        _close(y, ref, atol=2e-5, rtol=1e-4)
+    a, bb, cc = _gen((2, 5, 7, 9), 72), _gen((2, 5, 1, 1), 73), _gen((7, 9), 74)
+    _close(fma.fma(a.to(dev), bb.to(dev), cc.to(dev)), torch.addcmul(cc, a, bb), atol=1e-6)
+    img = _gen((2, 3, 8, 8), 75) * 2
+    out = torch.empty(img.shape, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img.to(dev)), _lib.ptr(out), img.numel(), _lib.stream()))
+    assert torch.equal(out.cpu(), (img * 127.5 + 128).clamp(0, 255).to(torch.uint8))
