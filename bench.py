@@ -138,7 +138,12 @@ def main():
         else:                            # N3D_PRECISION=fp32: fp32-MFMA conv
             dom, name, peak = c32, 'conv2d_mfma_kernel (all launches of the step)', PEAK_FP32_MFMA_TFLOPS
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+        traffic = None           # HBM bytes per launch of the roofline kernel: PMC passes cannot run inside bench.py, so the
+        tpath = os.path.join(REPO, 'profiles', 'r01_traffic_pmc.json')       # committed rocprofv3 --pmc result is attached
+        if dom is c16 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))['traffic_bytes_per_launch_fetch_x2']
+        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                     'kernel': name,
                     'note': 'achieved = algorithmic (fp32-equivalent) conv flops / HIP-event time of the family; for bf16x3 the '
                             'hardware executes 3 bf16 MFMA flops per algorithmic flop, so peak = 2500/3 TFLOP/s',
