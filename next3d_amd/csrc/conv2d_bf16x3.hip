@@ -159,15 +159,22 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
-        __builtin_amdgcn_s_setprio(1);      // role-split schedule: favour the wave that is feeding the matrix pipe
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);      // role-split schedule: favour the wave that is feeding the matrix pipe
+        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int boff = (t / 3) * PW + (t % 3);
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            if (p.dbg & 32) {      // ablation: no LDS fragment reads (operands stay whatever the first tap loaded)
+                if (t == 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ah[q] = A_hi[a_frag + q * 32]; al[q] = A_lo[a_frag + q * 32]; bh[q] = B_hi[b_frag + q * PW]; bl[q] = B_lo[b_frag + q * PW]; }
+                }
+            } else {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[bo_b + b_frag + nt * PW + boff]; bl[nt] = B_lo[bo_b + b_frag + nt * PW + boff]; }
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                 }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
     };
     if (NBUF == 2) {
         // registers hold the raw data of stage st+1 at the top of iteration st
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     const int b_frag = half * PPIX + wn * PW + l31;                       // position (row wn, col l31); + dy*PW + dx
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
-        __builtin_amdgcn_s_setprio(1);
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) { bh[d] = B_hi[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; }
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                     acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[d], acc[mt][ph], 0, 0, 0);
                 }
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
     };
     if (NBUF == 2) {
         if (nstage > 1) load_stage(1);

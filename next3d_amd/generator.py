@@ -73,6 +73,7 @@ class TriPlaneGenerator(torch.nn.Module):
         self.fill_mouth = True
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
+        self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -149,6 +150,7 @@ class TriPlaneGenerator(torch.nn.Module):
         S.rot = torch.cat([angle2matrix(a) for a in RENDERING_VIEWS], 0).to(dev).contiguous()
         S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
         S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
+        S.side_stream = torch.cuda.Stream(device=dev)
         S.tlin = {}
         self._prepared = S
         return S
@@ -222,6 +224,15 @@ class TriPlaneGenerator(torch.nn.Module):
         N = ws.shape[0]
         nw = S.texture.num_ws
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
+        # The static tri-plane backbone depends only on the latents: run it on a second HIP stream so its low-resolution
+        # layers (a handful of workgroups each) overlap the texture -> raster -> mouth -> blending chain.
+        cur = torch.cuda.current_stream()
+        if self.overlap_static:
+            side = S.side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                static = S.static(eg3d_ws, noise_mode)
+            static.record_stream(cur)
         textures = S.texture(texture_ws, noise_mode)
         (front, side, top), alpha, bbox = self.rasterize(v, lms, textures)
         f32 = dict(dtype=torch.float32, device=ws.device)
@@ -231,7 +242,10 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch_in = front.clone()
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
-        static = S.static(eg3d_ws, noise_mode)
+        if self.overlap_static:
+            cur.wait_stream(S.side_stream)
+        else:
+            static = S.static(eg3d_ws, noise_mode)
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
         _lib.check(L.n3d_blend_planes(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
                                       _lib.ptr(planes), N, 256, 256, _lib.stream()))
