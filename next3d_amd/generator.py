@@ -151,6 +151,7 @@ class TriPlaneGenerator(torch.nn.Module):
         S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
         S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
         S.side_stream = torch.cuda.Stream(device=dev)
+        S.alpha_views = torch.tensor([0, 1, 3], dtype=torch.int64, device=dev)
         S.tlin = {}
         self._prepared = S
         return S
@@ -209,7 +210,7 @@ class TriPlaneGenerator(torch.nn.Module):
             planes.append(out)
         bbox = torch.empty(N, 4, dtype=torch.int32, device=dev)
         _lib.check(L.n3d_mouth_bbox(_lib.ptr(lm2d), _lib.ptr(bbox), N, Lm, _lib.stream()))
-        alpha = alpha4[:, [0, 1, 3]].contiguous()
+        alpha = alpha4.index_select(1, S.alpha_views)          # views 0 (front), 1 (side; view 2's alpha is unused, :226), 3 (top)
         return planes, alpha, bbox
 
     def _planes(self, ws, v, noise_mode):
