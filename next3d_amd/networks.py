@@ -33,7 +33,7 @@ class _Block:
         out.append((self.torgb, k, 'torgb'))
         return out
 
-    def __call__(self, x, img, bank, n, fir, noise_mode):
+    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None):
         """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path); `bank` = StyleBank.compute(ws) result."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
@@ -42,10 +42,35 @@ class _Block:
         else:
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv0))
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
-        if img is not None:
-            img = uf.upsample2d(img, fir)
-        img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
+        # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
+        # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.
+        if img_stream is None:
+            if img is not None:
+                img = uf.upsample2d(img, fir)
+            img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
+        else:
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(img_stream):
+                img_stream.wait_event(ev)
+                if img is not None:
+                    img = uf.upsample2d(img, fir)
+                img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
         return x, img
+
+
+_IMG_STREAMS = {}
+
+
+def _img_stream(device):
+    """Side stream for the skip-image branch of the network running on the CURRENT stream (one per (device, stream)), or
+    None unless N3D_OVERLAP_IMG=1 (measured: no gain on MI355X — the large convolutions already fill the chip — so opt-in)."""
+    import os
+    if os.environ.get('N3D_OVERLAP_IMG', '0') == '0':
+        return None
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _IMG_STREAMS:
+        _IMG_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _IMG_STREAMS[key]
 
 
 def _first_slots(block_resolutions):
@@ -75,9 +100,16 @@ class SynthesisNet:
     def __call__(self, ws, noise_mode='const'):
         ws = _ws3(ws)
         bank = self.bank.compute(ws)
+        side = _img_stream(ws.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
         x = img = None
+        keep = []                      # feature maps read by the side stream stay referenced until the join
         for res in self.block_res:
-            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode)
+            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side)
+            keep.append(x)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return img
 
 
@@ -122,14 +154,21 @@ class StyleUNet:
             x_in, cond = enc(x_in, cond, self.fir)
             conds.append(cond)
         conds = conds[::-1]
+        side = _img_stream(ws.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
         x = img = None
+        keep = []
         for idx, res in enumerate(self.used_res):
             if idx < len(self.fusion):
                 if idx == 0:
                     x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
                 else:
                     x = L.conv2d_layer(self.fusion[idx], torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
-            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode)
+            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side)
+            keep.append(x)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return img
 
 
@@ -153,6 +192,11 @@ class SuperRes8XDC:
         if x.shape[-1] != self.input_resolution:
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
-        x, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, 'none')
-        x, rgb = self.block1(x, rgb, bank, ws.shape[0], self.fir, 'none')
+        side = _img_stream(ws.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, 'none', side)
+        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, 'none', side)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return rgb
