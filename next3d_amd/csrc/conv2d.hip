@@ -33,7 +33,7 @@ struct ConvParams {
     int GH, GW;                      // per-phase output grid (mode 2: H+1, W+1; else OH, OW)
     int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
     int dbg;                         // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads
-    int64_t xbs, ybs, style_stride;
+    int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
     n3d_epilogue epi;
 };
 
@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
         if (!ok) continue;
         const int64_t po = (int64_t)oy * p.OW + ox;
         const float nz = E.noise ? E.noise[po] * nstr : 0.f;
-        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const int64_t yplane = (int64_t)p.OH * p.yrs;
+        float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
                 v *= E.gain;
                 if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
                 if (res) v += res[(int64_t)o * plane];
-                dst[(int64_t)o * plane] = v;
+                dst[(int64_t)o * yplane] = v;
             }
     }
 }
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
             }
             const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
             const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
-            float* dst = p.y + (int64_t)n * p.ybs + po;
+            const int64_t yplane = (int64_t)p.OH * p.yrs;
+            float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
             const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
                     if (E.clamp >= 0.f) v[q] = fminf(fmaxf(v[q], -E.clamp), E.clamp);
                     if (res && (q == 0 || two)) v[q] += res[(int64_t)o * plane + q];
                 }
-                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{v[0], v[1]};
-                else dst[(int64_t)o * plane] = v[0];
+                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * yplane) = pair_t{v[0], v[1]};
+                else dst[(int64_t)o * yplane] = v[0];
             }
         }
     }
@@ -497,7 +499,7 @@ static int launch_conv_up(ConvParams& p, int ksplit_req, hipStream_t stream) {
 // split-K second pass: y = epilogue(sum_ks partial[ks])
 __global__ __launch_bounds__(256) void conv2d_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y,
                                                                       int ksplit, int N, int O, int OH, int OW, int64_t ybs,
-                                                                      n3d_epilogue epi) {
+                                                                      int64_t yrs, n3d_epilogue epi) {
     const int64_t plane = (int64_t)OH * OW;
     const int64_t total = (int64_t)N * O * plane;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256) void conv2d_splitk_epilogue_kernel(const float
         const int n = (int)(pl / O), o = (int)(pl % O);
         const int oy = pix / OW, ox = pix % OW;
         v = n3d_apply_epilogue(v, epi, n, o, O, oy, ox, OH, OW);
-        y[(int64_t)n * ybs + ((int64_t)o * OH + oy) * OW + ox] = v;
+        y[(int64_t)n * ybs + ((int64_t)o * OH + oy) * yrs + ox] = v;
     }
 }
 
@@ -583,6 +585,8 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         N3D_CHECK(d->H >= 3 && d->W >= 3, "conv2d: input too small for stride-2 3x3");
         p.OH = (d->H - 3) / 2 + 1; p.OW = (d->W - 3) / 2 + 1; p.GH = p.OH; p.GW = p.OW;
     } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
+    p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
+    N3D_CHECK(p.yrs >= p.OW, "conv2d: y_row_stride smaller than the output width");
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");
     N3D_CHECK(d->I <= 1024 * (d->ksplit < 1 ? 1 : d->ksplit), "conv2d: more than 1024 input channels per K-split");
     N3D_CHECK((int64_t)9 * d->I * ((d->O + 3) & ~3) < (1 << 27), "conv2d: weight tensor too large for 27-bit staging offsets");
@@ -606,7 +610,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
         const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
         hipLaunchKernelGGL(conv2d_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, (const float*)p.partial, p.y,
-                           p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.epi);
+                           p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi);
         N3D_LAUNCH_CHECK();
     }
     return 0;

@@ -31,7 +31,7 @@ struct Conv16Params {
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
-    int64_t xbs, ybs, style_stride;
+    int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
     n3d_epilogue epi;
 };
 
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             continue;
         }
         const float nz = E.noise ? E.noise[po] * nstr : 0.f;
-        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const int64_t yplane = (int64_t)p.OH * p.yrs;
+        float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
                 v *= E.gain;
                 if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
                 if (res) v += res[(int64_t)o * plane];
-                dst[(int64_t)o * plane] = v;
+                dst[(int64_t)o * yplane] = v;
             }
     }
 }
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
         }
         const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
         const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
-        float* dst = p.y + (int64_t)n * p.ybs + po;
+        const int64_t yplane = (int64_t)p.OH * p.yrs;
+        float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -467,15 +469,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                     if (E.clamp >= 0.f) v[q] = fminf(fmaxf(v[q], -E.clamp), E.clamp);
                     if (res && (q == 0 || two)) v[q] += res[(int64_t)o * plane + q];
                 }
-                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * plane) = pair_t{v[0], v[1]};
-                else dst[(int64_t)o * plane] = v[0];
+                if (two) *reinterpret_cast<pair_t*>(dst + (int64_t)o * yplane) = pair_t{v[0], v[1]};
+                else dst[(int64_t)o * yplane] = v[0];
             }
     }
 }
 
 // split-K second pass (same as conv2d.hip's)
 __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y, int ksplit,
-                                                                      int N, int O, int OH, int OW, int64_t ybs, n3d_epilogue epi) {
+                                                                      int N, int O, int OH, int OW, int64_t ybs, int64_t yrs, n3d_epilogue epi) {
     const int64_t plane = (int64_t)OH * OW, total = (int64_t)N * O * plane;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float
         const int64_t pl = i / plane;
         const int pix = (int)(i % plane), n = (int)(pl / O), o = (int)(pl % O);
         v = n3d_apply_epilogue(v, epi, n, o, O, pix / OW, pix % OW, OH, OW);
-        y[(int64_t)n * ybs + ((int64_t)o * OH + pix / OW) * OW + pix % OW] = v;
+        y[(int64_t)n * ybs + ((int64_t)o * OH + pix / OW) * yrs + pix % OW] = v;
     }
 }
 
@@ -536,6 +538,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
+    p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
+    N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     // 8-wave workgroups when the image is tall enough to fill them and the grid still covers the chip
     const int gh = up ? d->H + 1 : p.OH, gw = up ? d->W + 1 : p.OW;
     const int th4 = up ? 4 : 8;
@@ -566,7 +570,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
         const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
         const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
         hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, (const float*)p.partial, p.y, p.ksplit, p.N, p.O,
-                           p.OH, p.OW, p.ybs, p.epi);
+                           p.OH, p.OW, p.ybs, p.yrs, p.epi);
         N3D_LAUNCH_CHECK();
     }
     return 0;

@@ -17,7 +17,7 @@ struct UfParams {
     const float* x; const float* f; float* y;
     int N, C, H, W, OH, OW, fh, fw, upx, upy, downx, downy, padx0, pady0, flip;
     float gain;
-    int64_t xbs, ybs;
+    int64_t xbs, ybs, xrs;                    // xrs: input row pitch in floats (plane pitch = H * xrs)
     int has_epi;
     n3d_epilogue epi;
     int tiles_x, tiles_y, foot_w, foot_h;
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
     // input footprint of this tile: rows iy in [iy_lo, iy_lo + foot_h), cols likewise
     const int ix_lo = ceil_div(ox0 * p.downx - p.padx0, p.upx);
     const int iy_lo = ceil_div(oy0 * p.downy - p.pady0, p.upy);
-    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.W;
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.xrs;
     for (int e = threadIdx.x; e < p.foot_h * p.foot_w; e += blockDim.x) {
         const int r = e / p.foot_w, q = e % p.foot_w;
         const int iy = iy_lo + r, ix = ix_lo + q;
-        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.W + ix] : 0.f;
+        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.xrs + ix] : 0.f;
     }
     __syncthreads();
 
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
         for (int kx = 0; kx < FS; ++kx) f[ky][kx] = p.flip ? p.f[ky * FS + kx] : p.f[(FS - 1 - ky) * FS + (FS - 1 - kx)];
     const int ix_lo = ceil_div(ox0 * DOWN - p.padx0, UP);
     const int iy_lo = ceil_div(oy0 * DOWN - p.pady0, UP);
-    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.W;
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.xrs;
     for (int e = threadIdx.x; e < FOOT_H * FOOT_W; e += 256) {
         const int r = e / FOOT_W, q = e % FOOT_W;
         const int iy = iy_lo + r, ix = ix_lo + q;
-        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.W + ix] : 0.f;
+        s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.xrs + ix] : 0.f;
     }
     __syncthreads();
     float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
@@ -138,11 +138,103 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
     }
 }
 
-extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
-                             int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
-                             int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {
+// ---- 16-byte path for the FIR that follows a transposed convolution (up = down = 1, 4x4 taps, pad 1): the input rows
+// have a pitch that is a multiple of 4 floats and the output width is a multiple of 4, so the footprint is fetched with
+// aligned global_load_dwordx4 -> ds_write_b128, every thread produces a 4-wide x RPT-high patch from ds_read_b128 rows
+// (7 input floats per row for 4 outputs) and stores float4s.  Input columns beyond W (the pitch padding) are never used:
+// they are replaced by zeros with a select, so uninitialised padding cannot leak NaNs.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TW>
+__global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
+    constexpr int TH = 32, CG = TW / 4, RG = 256 / CG, RPT = TH / RG, FW4 = (TW + 8) / 4, FH = TH + 3;
+    __shared__ f32x4 s_x[FH * FW4];
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    float f[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) f[ky][kx] = p.flip ? p.f[ky * 4 + kx] : p.f[(3 - ky) * 4 + (3 - kx)];
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c * p.H * p.xrs;
+    const int iy_lo = oy0 - p.pady0;
+    for (int e = threadIdx.x; e < FH * FW4; e += 256) {
+        const int r = e / FW4, q = e % FW4;
+        const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;          // LDS column 0 = input column ox0 - 4 (padx0 == 1)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < p.H && col >= 0 && col < p.W) {
+            v = *reinterpret_cast<const f32x4*>(xp + (int64_t)iy * p.xrs + col);
+            if (col + 1 >= p.W) v.y = 0.f;
+            if (col + 2 >= p.W) v.z = 0.f;
+            if (col + 3 >= p.W) v.w = 0.f;
+        }
+        s_x[e] = v;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
+    const int ox = ox0 + 4 * cg;
+    float acc[RPT][4];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RPT + 3; ++rr) {
+        const f32x4* row = s_x + (rg * RPT + rr) * FW4 + cg;
+        const f32x4 a = row[0], b = row[1], d = row[2];
+        const float in[7] = {a.w, b.x, b.y, b.z, b.w, d.x, d.y};      // input columns ox-1 .. ox+5
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int ky = rr - j;
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) acc[j][i] += in[i + kx] * f[ky][kx];
+        }
+    }
+    if (ox >= p.OW) return;
+    const n3d_epilogue& E = p.epi;
+    float sc = 1.f, bias = 0.f, nstr = 0.f;
+    if (p.has_epi) {
+        sc = E.const_scale;
+        if (E.row_scale) sc *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + c];
+        if (E.bias) bias = E.bias[c];
+        if (E.noise) nstr = E.noise_strength[0];
+    }
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int oy = oy0 + rg * RPT + j;
+        if (oy >= p.OH) continue;
+        const int64_t po = (int64_t)oy * p.OW + ox;
+        f32x4 v = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        v *= p.gain;
+        if (p.has_epi) {
+            v *= sc;
+            if (E.noise) v += *reinterpret_cast<const f32x4*>(E.noise + po) * nstr;
+            v += bias;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = (E.act == N3D_ACT_LRELU) ? (v[i] > 0.f ? v[i] : v[i] * E.alpha) : n3d_act(v[i], E.act, E.alpha);
+                t *= E.gain;
+                if (E.clamp >= 0.f) t = fminf(fmaxf(t, -E.clamp), E.clamp);
+                v[i] = t;
+            }
+            if (E.residual) v += *reinterpret_cast<const f32x4*>(E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)c * p.OH * p.OW + po);
+        }
+        *reinterpret_cast<f32x4*>(yp + po) = v;
+    }
+}
+
+static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t xrs, int fh, int fw, int upx,
+                          int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                          int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(N >= 0 && C > 0 && H > 0 && W > 0, "upfirdn2d: bad input shape");
+    N3D_CHECK(xrs >= W, "upfirdn2d: input row pitch smaller than the width");
     N3D_CHECK(fh >= 1 && fw >= 1 && fh * fw <= UF_MAX_TAPS, "upfirdn2d: filter %dx%d unsupported", fh, fw);
     N3D_CHECK(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "upfirdn2d: up/down must be >= 1");
     const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx;
@@ -154,7 +246,7 @@ extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, in
     UfParams p;
     p.x = x; p.f = f; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.fh = fh; p.fw = fw;
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip;
-    p.gain = gain; p.xbs = xbs; p.ybs = ybs;
+    p.gain = gain; p.xbs = xbs; p.ybs = ybs; p.xrs = xrs;
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, UF_TILE_W); p.tiles_y = cdiv(OH, UF_TILE_H);
@@ -165,7 +257,18 @@ extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, in
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * fh * fw / (upx * upy),
                       4.0 * N * C * ((double)H * W + (double)OH * OW));
     const bool fast = fh == 4 && fw == 4 && upx == upy && downx == downy && ((upx == 1 && downx <= 2) || (upx == 2 && downx == 1));
-    if (fast) {
+    const bool aligned = ((xrs | xbs | ybs | OW) & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+                         (!epi || ((!epi->noise || ((uintptr_t)epi->noise & 15) == 0) &&
+                                   (!epi->residual || (((uintptr_t)epi->residual & 15) == 0 && (epi->residual_batch_stride & 3) == 0))));
+    if (fast && upx == 1 && downx == 1 && padx0 == 1 && aligned) {
+        if (OW >= 128) {
+            p.tiles_x = cdiv(OW, 128); p.tiles_y = cdiv(OH, 32);
+            hipLaunchKernelGGL(fir4_vec_kernel<128>, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
+        } else {
+            p.tiles_x = cdiv(OW, 64); p.tiles_y = cdiv(OH, 32);
+            hipLaunchKernelGGL(fir4_vec_kernel<64>, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
+        }
+    } else if (fast) {
         p.tiles_x = cdiv(OW, FT_W); p.tiles_y = cdiv(OH, FT_H);
         dim3 grid(p.tiles_x * p.tiles_y, C, N);
         if (upx == 1 && downx == 1) hipLaunchKernelGGL((upfirdn2d_fast_kernel<1, 1, 4>), grid, dim3(256), 0, stream, p);
@@ -176,4 +279,19 @@ extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, in
     }
     N3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
+                             int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                             int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream) {
+    return upfirdn2d_impl(x, f, y, N, C, H, W, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, xbs, ybs,
+                          epi, stream);
+}
+
+extern "C" int n3d_upfirdn2d_pitched(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t x_row_stride,
+                                     int fh, int fw, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
+                                     int pady1, int flip, float gain, int64_t xbs, int64_t ybs, const n3d_epilogue* epi,
+                                     n3d_stream_t stream) {
+    return upfirdn2d_impl(x, f, y, N, C, H, W, x_row_stride ? x_row_stride : W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0,
+                          pady1, flip, gain, xbs, ybs, epi, stream);
 }

@@ -76,9 +76,11 @@ def pick_ksplit_bf16x3(n, i, o, gh, gw, mode=0):
     return ks
 
 
-def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False):
+def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
-    bf16x3=True) -> y [N,out_channels,OH,OW]."""
+    bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
+    padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
+    `out` may itself be such a view."""
     n, i, h, w = x.shape
     o = out_channels
     if bf16x3:
@@ -88,8 +90,13 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     if x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
-    y = out if out is not None else torch.empty([n, o, oh, ow], dtype=torch.float32, device=x.device)
-    assert tuple(y.shape) == (n, o, oh, ow) and y.stride()[1:] == (oh * ow, ow, 1)
+    if out is not None:
+        y = out
+    elif row_pitch:
+        y = torch.empty([n, o, oh, (ow + 3) // 4 * 4], dtype=torch.float32, device=x.device)[..., :ow]
+    else:
+        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
         ksplit = pick_ksplit_bf16x3(n, i, o, gh, gw, mode) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
@@ -100,6 +107,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
     d.style_stride = style.stride(0) if style is not None else 0
+    d.y_row_stride = y.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))

@@ -64,9 +64,9 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None):
     if ow < 1 or oh < 1:
         raise RuntimeError('upfirdn2d: output would be empty')
     y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().n3d_upfirdn2d(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y), n, c, h, w, fh, fw, upx, upy, downx, downy,
-                                        px0, px1, py0, py1, 1 if flip_filter else 0, float(gain), x.stride(0), y.stride(0),
-                                        epilogue, _lib.stream()))
+    _lib.check(_lib.lib().n3d_upfirdn2d_pitched(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y), n, c, h, w, x.stride(2), fh, fw, upx, upy,
+                                                downx, downy, px0, px1, py0, py1, 1 if flip_filter else 0, float(gain),
+                                                x.stride(0), y.stride(0), epilogue, _lib.stream()))
     return y
 
 
@@ -83,7 +83,8 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
     assert f.dtype == torch.float32 and f.ndim in [1, 2]
-    x = x if x.stride()[1:] == (x.shape[2] * x.shape[3], x.shape[3], 1) else x.contiguous()
+    # dense planes, or rows with a pitch (a [..., :W] view of a wider buffer: conv_launch(..., row_pitch=True))
+    x = x if (x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)) else x.contiguous()
     if f.ndim == 2:
         return _launch(x, f.contiguous(), up, down, padding, flip_filter, gain, _epilogue)
     # separable: horizontal pass then vertical pass, gain split as sqrt per pass (upfirdn2d.py:240-244)

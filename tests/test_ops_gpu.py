@@ -232,6 +232,48 @@ def test_conv2d_up_bf16x3(dev, N, I, OC, H, W):
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ksplit, err)
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 17, 17), (1, 2, 129, 257), (1, 2, 65, 65), (2, 1, 33, 129)])
+@pytest.mark.parametrize('flip', [False, True])
+def test_upfirdn2d_pitched_rows(dev, shape, flip):
+    """The FIR after a transposed conv reads an odd-width input through rows padded to 16 bytes (aligned float4 path):
+    same result as the dense input, with and without the fused epilogue, and NaNs in the pitch padding must not leak."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import upfirdn2d
+    n, c, h, w = shape
+    x = _gen(shape, 70)
+    f = O.setup_filter((1, 3, 3, 1)) + 0.01 * torch.arange(16.).reshape(4, 4)
+    buf = torch.full((n, c, h, (w + 3) // 4 * 4), float('nan'), device=dev)
+    xv = buf[..., :w]
+    xv.copy_(x.to(dev))
+    ref = O.upfirdn2d(x, f, padding=[1, 1, 1, 1], flip_filter=flip, gain=4)
+    y = upfirdn2d.upfirdn2d(xv, f.to(dev), padding=[1, 1, 1, 1], flip_filter=flip, gain=4)
+    assert y.shape == ref.shape and y.is_contiguous()
+    _close(y, ref, atol=1e-5)
+    noise, b, res = _gen(ref.shape[2:], 71), _gen((c,), 72), _gen(ref.shape, 73)
+    ns = torch.tensor([0.3])
+    epi = _lib.make_epilogue(noise=noise.to(dev), noise_strength=ns.to(dev), bias=b.to(dev), act='lrelu', gain=np.sqrt(2), clamp=1.5,
+                             residual=res.to(dev))
+    y = upfirdn2d.upfirdn2d(xv, f.to(dev), padding=[1, 1, 1, 1], flip_filter=flip, gain=4, _epilogue=epi)
+    ref2 = O.bias_act(ref + noise * ns, b, act='lrelu', gain=np.sqrt(2), clamp=1.5) + res
+    _close(y, ref2, atol=1e-5)
+
+
+@pytest.mark.parametrize('bf16x3', [False, True])
+@pytest.mark.parametrize('mode,N,I,OC,H,W', [(2, 2, 32, 70, 16, 32), (2, 1, 64, 64, 33, 45), (0, 1, 32, 40, 9, 37), (1, 1, 16, 8, 21, 35)])
+def test_conv2d_row_pitch(dev, bf16x3, mode, N, I, OC, H, W):
+    """conv_launch(row_pitch=True): the padded-row output view holds exactly the dense result (all kernels, split-K too)."""
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    if bf16x3 and not cg.bf16x3_eligible(I, H, W, 3, mode):
+        pytest.skip('shape not on the bf16x3 path')
+    x, w = _gen((N, I, H, W), 80).to(dev), (_gen((OC, I, 3, 3), 81) / np.sqrt(I * 9)).to(dev)
+    wt = cg.prep_weight_bf16x3(w) if bf16x3 else cg.prep_weight(w)
+    for ksplit in (1, 2):
+        dense = cg.conv_launch(x, wt, 3, mode, OC, ksplit=ksplit, bf16x3=bf16x3)
+        pitched = cg.conv_launch(x, wt, 3, mode, OC, ksplit=ksplit, bf16x3=bf16x3, row_pitch=True)
+        assert pitched.shape == dense.shape and pitched.stride(2) % 4 == 0 and pitched.stride(1) == pitched.shape[2] * pitched.stride(2)
+        assert torch.equal(pitched, dense), (mode, ksplit)
+
+
 def test_filtered_lrelu_fma_and_small_kernels(dev):
     from next3d_amd import _lib
     from next3d_amd.torch_utils.ops import filtered_lrelu, fma, upfirdn2d
