@@ -116,6 +116,9 @@ int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
  *      Requires I % 16 == 0.  Same reference call sites as n3d_conv2d. */
 int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream);
 int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+/* Number of workgroups n3d_conv2d_bf16x3 launches for this shape at ksplit = 1 (its tile plan): the host picks a split-K
+ * factor from it so that small layers still cover the 256 CUs. */
+int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);
 
 /* ---- fully connected: replaces addmm / matmul+bias_act of FullyConnectedLayer.forward
  *      (tat/networks_stylegan2.py:114-127).  y[n,o] = post(act(sum_i pre(x[n,i]) * w[o,i] * wgain + b[o]*bgain)).

@@ -30,6 +30,7 @@ struct Conv16Params {
     const float* x; const bf16x8* wt16; const float* style; float* y; float* partial;
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
+    int tw, th;   // transposed kernel: tile = th rows x tw columns of input-grid positions, flattened over the waves' lanes
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
     int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
     n3d_epilogue epi;
@@ -48,11 +49,15 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 
 // 3x3, stride 1, padding 1.  NW waves per workgroup, each owning 2 pixel rows: tile = 64 channels x (2 NW x 32) pixels.
 // NW = 8 (512 threads, one workgroup per CU) halves the weight-slab traffic and the per-thread staging work per MFMA.
-template <int NW>
+template <int NW, bool FLAT>
 __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
     constexpr int NT_ = 64 * NW;                                          // threads
     constexpr int BM = 64, TH = 2 * NW, TW = 32, ICB = 16, TAPS = 9;
-    constexpr int PH = TH + 2, PW = TW + 2, PPIX = PH * PW;               // NW=4: 10 x 34 = 340 patch pixels
+    constexpr int PH = TH + 2, PW_C = TW + 2, PPIX = PH * PW_C;           // NW=4: 10 x 34 = 340 patch pixels
+    // FLAT (images narrower than 32): the tile is th x tw = p.th x p.tw pixels flattened row-major over the 64 NW MFMA
+    // columns (position q -> row q / tw, col q % tw), so a 16x16 or 8x8 image still fills the 32-wide N tiles; the patch
+    // is (th+2) x (tw+2) <= PPIX (host plan) with a run-time row pitch.
+    const int PW = FLAT ? p.tw + 2 : PW_C;
     constexpr int A_ITEMS = TAPS * 2 * 2 * BM;                            // 16-byte slots: [tap][hl][half][row]
     constexpr int B_ITEMS = 2 * PPIX;                                     // (half, pixel) work items
     constexpr int TAP_STEP = NT_ / 256;                                   // thread's j-th A item = tap (tid/256 + TAP_STEP*j)
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     const int tx = tile_i % p.tiles_x, ty = tile_i / p.tiles_x;
     const int m0 = mt_i * BM;
     const int ks = lb % p.ksplit, n = lb / p.ksplit;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = FLAT ? ty * p.th : ty * TH, x0 = FLAT ? 0 : tx * TW;
+    const int prows = FLAT ? p.th + 2 : PH;
     const int ic_begin = ks * p.ic_per_split;
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
     const int nstage = (ic_end - ic_begin) / ICB;
@@ -105,8 +111,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     for (int j = 0; j < B_PER_T; ++j) {
         const int e = tid + j * NT_;
         const int hf = e / PPIX, pp = e % PPIX;
-        const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
-        b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int pr = pp / PW;
+        const int iy = y0 - 1 + pr, ix = x0 - 1 + pp % PW;
+        b_ok[j] = e < B_ITEMS && pr < prows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
     }
     const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
@@ -156,7 +163,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     if (nstage > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
     const int a_frag = half * BM + l31;                                   // + tap*2*BM + mt*32
-    const int b_frag = half * PPIX + (wn * 2) * PW + l31;                 // + nt*PW + ky*PW + kx
+    int q_row[2], q_col[2];                                               // this lane's pixel in each of its two N tiles
+    bool q_act[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        if (FLAT) {
+            const int q = (wn * 2 + nt) * 32 + l31;
+            q_act[nt] = q < p.th * p.tw;
+            q_row[nt] = q_act[nt] ? q / p.tw : 0; q_col[nt] = q_act[nt] ? q % p.tw : 0;
+        } else { q_act[nt] = true; q_row[nt] = wn * 2 + nt; q_col[nt] = l31; }
+    }
+    const int b_frag0 = half * PPIX + q_row[0] * PW + q_col[0];           // + ky*PW + kx
+    const int b_frag1 = half * PPIX + q_row[1] * PW + q_col[1];
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);      // role-split schedule: favour the wave that is feeding the matrix pipe
@@ -167,13 +185,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             if (p.dbg & 32) {      // ablation: no LDS fragment reads (operands stay whatever the first tap loaded)
                 if (t == 0) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) { ah[q] = A_hi[a_frag + q * 32]; al[q] = A_lo[a_frag + q * 32]; bh[q] = B_hi[b_frag + q * PW]; bl[q] = B_lo[b_frag + q * PW]; }
+                    for (int q = 0; q < 2; ++q) { ah[q] = A_hi[a_frag + q * 32]; al[q] = A_lo[a_frag + q * 32]; bh[q] = B_hi[q ? b_frag1 : b_frag0]; bl[q] = B_lo[q ? b_frag1 : b_frag0]; }
                 }
             } else {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[bo_b + b_frag + nt * PW + boff]; bl[nt] = B_lo[bo_b + b_frag + nt * PW + boff]; }
+            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[bo_b + (nt ? b_frag1 : b_frag0) + boff]; bl[nt] = B_lo[bo_b + (nt ? b_frag1 : b_frag0) + boff]; }
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -229,8 +247,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int oy = y0 + wn * 2 + nt, ox = x0 + l31;
-        if (oy >= p.OH || ox >= p.OW) continue;
+        const int oy = y0 + q_row[nt], ox = x0 + q_col[nt];
+        if (!q_act[nt] || oy >= p.OH || ox >= p.OW) continue;
         const int64_t po = (int64_t)oy * p.OW + ox;
         if (p.partial) {
             float* dst = p.partial + ((int64_t)ks * p.N + n) * p.O * plane + po;
@@ -267,14 +285,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
 
 // Transposed 3x3 stride-2 (the up-sampling layers) on the split-bf16 path: all four output phases from one staged patch,
 // exactly as conv2d_up_mfma_kernel in conv2d.hip (tap (ky,kx) feeds phase (ky==1, kx==1) from patch offset
-// (ky==2 ? 0 : 1, kx==2 ? 0 : 1)).  Workgroup = 64 output channels x (4 x 32) input-grid positions x 4 phases; each wave
-// owns one row of 32 positions: acc[2 row-tiles][4 phases].  Per K=16 chunk: 8 B-fragment reads (4 offsets x hi/lo) are
+// (ky==2 ? 0 : 1, kx==2 ? 0 : 1)).  Workgroup = 64 output channels x (th x tw <= 32*NW) input-grid positions x 4 phases.  The
+// MFMA N dimension is 32 independent positions, so the tile's positions are FLATTENED row-major over the waves' lanes
+// (position q = wave*32 + lane -> row q / tw, col q % tw): the grid is (H+1) x (W+1), and a 33-wide tile covers W = 32 in
+// one piece (a fixed 32-wide tile would need a second, 97 %-empty tile for the last column).  acc[2 row-tiles][4 phases].  Per K=16 chunk: 8 B-fragment reads (4 offsets x hi/lo) are
 // shared by all 9 taps, 36 A-fragment reads, 54 MFMAs.
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) {
     constexpr int NT_ = 64 * NW;
-    constexpr int BM = 64, TH = NW, TW = 32, ICB = 16, TAPS = 9;
-    constexpr int PH = TH + 1, PW = TW + 1, PPIX = PH * PW;               // NW=4: 5 x 33 = 165 patch pixels (halo: top / left)
+    constexpr int BM = 64, ICB = 16, TAPS = 9;
+    constexpr int PPIX = (NW + 1) * 33;                                   // patch capacity: (th+1) x (tw+1) <= PPIX (host plan)
     constexpr int TAP_STEP = NT_ / 256;
     constexpr int A_PER_T = (TAPS + TAP_STEP - 1) / TAP_STEP;
     constexpr int B_ITEMS = 2 * PPIX;
@@ -301,7 +321,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     const int tx = tile_i % p.tiles_x, ty = tile_i / p.tiles_x;
     const int m0 = mt_i * BM;
     const int ks = lb % p.ksplit, n = lb / p.ksplit;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = ty * p.th, x0 = tx * p.tw;
+    const int PW = p.tw + 1, prows = p.th + 1;
     const int ic_begin = ks * p.ic_per_split;
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
     const int nstage = (ic_end - ic_begin) / ICB;
@@ -321,8 +342,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     for (int j = 0; j < B_PER_T; ++j) {
         const int e = tid + j * NT_;
         const int hf = e / PPIX, pp = e % PPIX;
-        const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
-        b_ok[j] = e < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int pr = pp / PW;
+        const int iy = y0 - 1 + pr, ix = x0 - 1 + pp % PW;
+        b_ok[j] = e < B_ITEMS && pr < prows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
     }
     const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
@@ -372,7 +394,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     if (nstage > 0) { load_stage(0); store_stage(0); }
     __syncthreads();
     const int a_frag = half * BM + l31;
-    const int b_frag = half * PPIX + wn * PW + l31;                       // position (row wn, col l31); + dy*PW + dx
+    const int q_pos = wn * 32 + l31;                                      // flattened tile position of this lane
+    const bool q_act = q_pos < p.th * p.tw;
+    const int q_row = q_act ? q_pos / p.tw : 0, q_col = q_act ? q_pos % p.tw : 0;
+    const int b_frag = half * PPIX + q_row * PW + q_col;                  // + dy*PW + dx
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);
@@ -426,8 +451,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
     struct __attribute__((packed, aligned(4))) pair_t { float v0, v1; };
-    const int gy = y0 + wn, gx = x0 + l31;
-    if (gy >= GH || gx >= GW) return;
+    const int gy = y0 + q_row, gx = x0 + q_col;
+    if (!q_act || gy >= GH || gx >= GW) return;
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
         const int oy = 2 * gy + pa, ox = 2 * gx;
@@ -520,6 +545,52 @@ extern "C" int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, 
     return 0;
 }
 
+// Tile plan shared by the launch and by n3d_conv2d_bf16x3_blocks (the host's split-K heuristic).  Stride-1: 8-wave
+// workgroups when the grid still covers the chip with them, else 4-wave.  Transposed mode: balanced (th x tw) tiles of at most 32*NW
+// flattened positions, tw <= 33, th <= 32 (patch (th+1) x (tw+1) <= (NW+1)*33 entries of LDS).
+static void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th) {
+    if (gw > 66) {                     // wide images: 32-aligned tile columns (the 33rd-column remainder is a few percent)
+        *tw = 32; *th = nw;
+        *tiles_x = cdiv(gw, 32); *tiles_y = cdiv(gh, nw);
+        return;
+    }
+    *tiles_x = cdiv(gw, 33);
+    *tw = cdiv(gw, *tiles_x);
+    int th_max = (32 * nw) / *tw;
+    if (th_max > 32) th_max = 32;
+    while ((th_max + 1) * (*tw + 1) > (nw + 1) * 33) --th_max;
+    *tiles_y = cdiv(gh, th_max);
+    *th = cdiv(gh, *tiles_y);
+}
+
+static void conv16_plan(int N, int O, int H, int W, int mode, bool* big, int* tiles_x, int* tiles_y, int* tw, int* th) {
+    const int tiles_m = cdiv(O, 64);
+    if (mode == 2) {                   // always the 8-wave kernel (measured 1.5x the 4-wave one even at 0.6 workgroups per CU)
+        conv16_up_tiles(H + 1, W + 1, 8, tiles_x, tiles_y, tw, th);
+        *big = true;
+        return;
+    }
+    if (W < 32) {                      // narrow image: flattened 4-wave tiles (256 positions), th rows of the full width
+        int th_max = 256 / W;
+        if (th_max > 32) th_max = 32;
+        while ((th_max + 2) * (W + 2) > 340) --th_max;
+        *big = false; *tw = W; *tiles_x = 1;
+        *tiles_y = cdiv(H, th_max); *th = cdiv(H, *tiles_y);
+        return;
+    }
+    const int64_t blocks8 = (int64_t)cdiv(W, 32) * cdiv(H, 16) * tiles_m * N;
+    *big = H >= 16 && blocks8 >= 256;
+    *tw = 32; *th = *big ? 16 : 8;
+    *tiles_x = cdiv(W, 32); *tiles_y = cdiv(H, *th);
+}
+
+extern "C" int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode) {
+    bool big; int tx, ty, tw, th;
+    conv16_plan(N, O, H, W, mode, &big, &tx, &ty, &tw, &th);
+    const int64_t b = (int64_t)tx * ty * cdiv(O, 64) * N;
+    return b > 0x7fffffff ? 0x7fffffff : (int)b;
+}
+
 extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
@@ -540,13 +611,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
-    // 8-wave workgroups when the image is tall enough to fill them and the grid still covers the chip
-    const int gh = up ? d->H + 1 : p.OH, gw = up ? d->W + 1 : p.OW;
-    const int th4 = up ? 4 : 8;
-    const int64_t blocks8 = (int64_t)cdiv(gw, 32) * cdiv(gh, 2 * th4) * cdiv(d->O, 64) * d->N;
-    const bool big = gh >= 2 * th4 && blocks8 >= 256;
-    const int th = big ? 2 * th4 : th4;
-    p.tiles_x = cdiv(gw, 32); p.tiles_y = cdiv(gh, th);
+    bool big;
+    conv16_plan(d->N, d->O, d->H, d->W, d->mode, &big, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
     const int max_split = d->I / 16;
     p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);
     p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
@@ -561,10 +627,10 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     const dim3 grid((unsigned)nblk);
-    if (up && big) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
-    else if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<4>, grid, dim3(256), 0, stream, p);
-    else if (big) hipLaunchKernelGGL(conv2d_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(conv2d_bf16x3_kernel<4>, grid, dim3(256), 0, stream, p);
+    if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
+    else if (big) hipLaunchKernelGGL((conv2d_bf16x3_kernel<8, false>), grid, dim3(512), 0, stream, p);
+    else if (d->W < 32) hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, false>), grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;

@@ -42,9 +42,9 @@ def prep_weight_bf16x3(w):
 
 
 def bf16x3_eligible(i, h, w, ksize, mode):
-    """Layers the split-bf16 kernels cover: 3x3 stride-1 or transposed stride-2, I % 16 == 0, at least one full
-    32-wide pixel tile (smaller layers are launch/latency-bound and stay on the fp32 split-K path)."""
-    return ksize == 3 and mode in (0, 2) and i % 16 == 0 and w >= 32 and h >= (8 if mode == 0 else 4)
+    """Layers the split-bf16 kernels cover: 3x3, I % 16 == 0, stride-1 or transposed stride-2, from 4x4 up (images
+    narrower than a 32-pixel MFMA tile are flattened row-major over the tile's columns)."""
+    return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
 def out_shape(h, w, mode):
@@ -68,10 +68,14 @@ def pick_ksplit(n, i, o, gh, gw, ksize, mode=0):
     return ks
 
 
-def pick_ksplit_bf16x3(n, i, o, gh, gw, mode=0):
-    blocks = -(-gw // 32) * -(-gh // (4 if mode == 2 else 8)) * -(-o // 64) * n
+def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
+    """Split-K factor for the split-bf16 kernels from the library's own tile plan (n3d_conv2d_bf16x3_blocks)."""
+    blocks = _lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode)
+    # transposed: 8-wave workgroups, one per CU -> split only until ~2/3 of the CUs have one (measured: 160 blocks are
+    # faster unsplit); stride-1: smaller 4-wave workgroups, several per CU
+    want = 160 if mode == 2 else 512
     ks = 1
-    while blocks * ks < 512 and (i // (ks * 2)) >= 64:
+    while blocks * ks < want and (i // (ks * 2)) >= 64:
         ks *= 2
     return ks
 
@@ -99,7 +103,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
-        ksplit = pick_ksplit_bf16x3(n, i, o, gh, gw, mode) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
+        ksplit = pick_ksplit_bf16x3(n, i, o, h, w, mode) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)

@@ -192,7 +192,9 @@ def test_synthesis_layer_and_torgb(dev, up, res, ic, oc):
     _close(yt, ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 19, 45), (2, 512, 512, 32, 32), (1, 128, 64, 64, 96), (1, 16, 3, 8, 32)])
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 19, 45), (2, 512, 512, 32, 32), (1, 128, 64, 64, 96), (1, 16, 3, 8, 32),
+                                       (4, 512, 512, 16, 16), (2, 128, 70, 8, 8), (4, 64, 64, 4, 4), (1, 32, 40, 37, 20), (1, 16, 8, 70, 5),
+                                       (1, 32, 64, 9, 31)])
 def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     """Split-bf16 conv vs the fp32 oracle: operand truncation at 2^-16 relative -> tolerance 1e-4 of the output scale
     (A = identity-like checks are implicit: weights and inputs are asymmetric random)."""
@@ -215,7 +217,9 @@ def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
 
 
-@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 7, 45), (1, 512, 256, 64, 64), (1, 16, 64, 4, 33)])
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 7, 45), (1, 512, 256, 64, 64), (1, 16, 64, 4, 33),
+                                       (4, 512, 512, 16, 16), (2, 128, 70, 8, 8), (1, 32, 64, 9, 13), (4, 64, 256, 66, 34),
+                                       (1, 16, 64, 40, 3), (1, 16, 8, 1, 1)])
 def test_conv2d_up_bf16x3(dev, N, I, OC, H, W):
     """Split-bf16 transposed stride-2 conv vs F.conv_transpose2d."""
     import torch.nn.functional as F
