@@ -63,6 +63,11 @@ typedef struct {
     float const_scale;            /* e.g. Conv2dLayer.weight_gain (tat/networks_stylegan2.py:174)                */
     int act;                      /* N3D_ACT_*                                                                   */
     float alpha, gain, clamp;     /* clamp < 0: none                                                             */
+    const float* residual_up_filter; /* NULL, or 16 taps [4][4]: `residual` is then the LOW-resolution image
+                                        [N,O,OH/2,OW/2] and is upsampled x2 on the fly exactly like
+                                        upfirdn2d.upsample2d(residual, f) (up=2, padding (2,1,2,1), gain 4, no flip):
+                                        the skip-image path img = upsample2d(img) + toRGB(x) of SynthesisBlock.forward
+                                        (tat/networks_stylegan2.py:580-584) without materialising the upsampled image */
 } n3d_epilogue;
 
 /* ---- upfirdn2d: replaces upfirdn2d_plugin.upfirdn2d (torch_utils/ops/upfirdn2d.cpp:20, kernels

@@ -48,6 +48,32 @@ __device__ __forceinline__ float n3d_act(float x, int act, float alpha) {
     }
 }
 
+// x2 upsampling of a low-resolution residual on the fly (n3d_epilogue.residual_up_filter): upfirdn2d with up=2, padding
+// (2,1,2,1), 4x4 taps, gain 4 (upfirdn2d.py:upsample2d).  Output o takes the inputs iA = floor((o-1)/2) and iA+1 with
+// taps kA = 1 - 2 iA + o and kA - 2 (index arithmetic of upfirdn2d.cu:47-67 with up=2, pad0=2, down=1).
+struct n3d_up2_taps {
+    int off[4];      // offsets into the low-res plane (0 where the tap is outside the image)
+    float w[4];      // tap weights, gain included (0 outside)
+};
+__device__ __forceinline__ n3d_up2_taps n3d_up2_setup(const float* __restrict__ f, int oy, int ox, int LH, int LW) {
+    n3d_up2_taps t;
+    const int iyA = (oy - 1) >> 1, ixA = (ox - 1) >> 1;
+    const int kyA = 1 - 2 * iyA + oy, kxA = 1 - 2 * ixA + ox;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int iy = iyA + a, ix = ixA + b;
+            const bool ok = iy >= 0 && iy < LH && ix >= 0 && ix < LW;
+            t.off[a * 2 + b] = ok ? iy * LW + ix : 0;
+            t.w[a * 2 + b] = ok ? 4.f * f[(kyA - 2 * a) * 4 + (kxA - 2 * b)] : 0.f;
+        }
+    return t;
+}
+__device__ __forceinline__ float n3d_up2_apply(const n3d_up2_taps& t, const float* __restrict__ plane) {
+    return ((plane[t.off[0]] * t.w[0] + plane[t.off[1]] * t.w[1]) + plane[t.off[2]] * t.w[2]) + plane[t.off[3]] * t.w[3];
+}
+
 __device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue& e, int n, int o, int O, int oy, int ox,
                                                     int OH, int OW) {
     float sc = e.const_scale;
@@ -57,6 +83,14 @@ __device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue&
     if (e.bias) v += e.bias[o];
     v = n3d_act(v, e.act, e.alpha) * e.gain;
     if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
-    if (e.residual) v += e.residual[(int64_t)n * e.residual_batch_stride + ((int64_t)o * OH + oy) * OW + ox];
+    if (e.residual) {
+        if (e.residual_up_filter) {
+            const int LH = OH >> 1, LW = OW >> 1;
+            const n3d_up2_taps t = n3d_up2_setup(e.residual_up_filter, oy, ox, LH, LW);
+            v += n3d_up2_apply(t, e.residual + (int64_t)n * e.residual_batch_stride + (int64_t)o * LH * LW);
+        } else {
+            v += e.residual[(int64_t)n * e.residual_batch_stride + ((int64_t)o * OH + oy) * OW + ox];
+        }
+    }
     return v;
 }

@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
         const float nz = E.noise ? E.noise[po] * nstr : 0.f;
         const int64_t yplane = (int64_t)p.OH * p.yrs;
         float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
-        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
+        const bool res_up = E.residual && E.residual_up_filter;
+        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + (res_up ? 0 : po) : nullptr;
+        n3d_up2_taps up2;
+        const int64_t lplane = (int64_t)(p.OH >> 1) * (p.OW >> 1);
+        if (res_up) up2 = n3d_up2_setup(E.residual_up_filter, oy, ox, p.OH >> 1, p.OW >> 1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
                 else if (!linear) v = conv_act_generic(v, E.act, E.alpha);
                 v *= E.gain;
                 if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
-                if (res) v += res[(int64_t)o * plane];
+                if (res_up) v += n3d_up2_apply(up2, res + (int64_t)o * lplane);
+                else if (res) v += res[(int64_t)o * plane];
                 dst[(int64_t)o * yplane] = v;
             }
     }
@@ -587,6 +592,8 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d: y_row_stride smaller than the output width");
+    N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->mode != 2 && p.OH % 2 == 0 && p.OW % 2 == 0),
+              "conv2d: residual_up_filter needs a residual, an even output size and a non-transposed mode");
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");
     N3D_CHECK(d->I <= 1024 * (d->ksplit < 1 ? 1 : d->ksplit), "conv2d: more than 1024 input channels per K-split");
     N3D_CHECK((int64_t)9 * d->I * ((d->O + 3) & ~3) < (1 << 27), "conv2d: weight tensor too large for 27-bit staging offsets");

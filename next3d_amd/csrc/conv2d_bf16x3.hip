@@ -36,6 +36,8 @@ struct Conv16Params {
     n3d_epilogue epi;
 };
 
+int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
+
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void conv16_prep_weight_kernel(const float* __
 
 extern "C" int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    N3D_CHECK(w && wt16 && O > 0 && I > 0 && ksize == 3, "conv2d_prep_weight_bf16x3: bad arguments (3x3 only)");
+    N3D_CHECK(w && wt16 && O > 0 && I > 0 && (ksize == 3 || ksize == 1), "conv2d_prep_weight_bf16x3: bad arguments (3x3 / 1x1 only)");
     N3D_CHECK(I % 16 == 0, "conv2d_prep_weight_bf16x3: input channels must be a multiple of 16");
     const int OP64 = (O + 63) / 64 * 64;
     const int64_t total = (int64_t)ksize * ksize * I * OP64;
@@ -594,13 +596,15 @@ extern "C" int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode) {
 extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
-    N3D_CHECK(d->ksize == 3 && (d->mode == 0 || d->mode == 2), "conv2d_bf16x3: 3x3 stride-1 or transposed stride-2 only");
+    N3D_CHECK((d->ksize == 3 && (d->mode == 0 || d->mode == 2)) || (d->ksize == 1 && d->mode == 0),
+              "conv2d_bf16x3: 3x3 stride-1 / transposed stride-2 or 1x1 stride-1 only");
     N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
     N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
     N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
     if (d->N == 0) return 0;
     N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
+    if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     Conv16Params p;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     const bool up = d->mode == 2;
@@ -611,6 +615,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    N3D_CHECK(!d->epi.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
     bool big;
     conv16_plan(d->N, d->O, d->H, d->W, d->mode, &big, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
     const int max_split = d->I / 16;

@@ -240,6 +240,7 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
     const int OW = (W * upx + padx0 + padx1 - fw + downx) / downx;
     const int OH = (H * upy + pady0 + pady1 - fh + downy) / downy;
     N3D_CHECK(OW >= 1 && OH >= 1, "upfirdn2d: output would be empty");   // upfirdn2d.cpp:39
+    N3D_CHECK(!epi || !epi->residual_up_filter || (epi->residual && OH % 2 == 0 && OW % 2 == 0), "upfirdn2d: residual_up_filter needs a residual and an even output size");
     if (N == 0) return 0;
     N3D_CHECK(x && f && y, "upfirdn2d: null tensor");
     N3D_CHECK(C <= 65535 && N <= 65535, "upfirdn2d: N and C must be <= 65535");
@@ -258,7 +259,7 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
                       4.0 * N * C * ((double)H * W + (double)OH * OW));
     const bool fast = fh == 4 && fw == 4 && upx == upy && downx == downy && ((upx == 1 && downx <= 2) || (upx == 2 && downx == 1));
     const bool aligned = ((xrs | xbs | ybs | OW) & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
-                         (!epi || ((!epi->noise || ((uintptr_t)epi->noise & 15) == 0) &&
+                         (!epi || (!epi->residual_up_filter && (!epi->noise || ((uintptr_t)epi->noise & 15) == 0) &&
                                    (!epi->residual || (((uintptr_t)epi->residual & 15) == 0 && (epi->residual_batch_stride & 3) == 0))));
     if (fast && upx == 1 && downx == 1 && padx0 == 1 && aligned) {
         if (OW >= 128) {

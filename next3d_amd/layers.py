@@ -62,7 +62,8 @@ class PreparedConv:
             self.wt, self.wsq = cg.prep_weight(w, want_sq=True)
         else:
             self.wt, self.wsq = cg.prep_weight(w), None
-        self.wt16 = cg.prep_weight_bf16x3(w) if (self.ksize == 3 and self.in_channels % 16 == 0) else None
+        self.wt16 = cg.prep_weight_bf16x3(w) if ((self.ksize == 3 and self.in_channels % 16 == 0) or
+                                                 (self.ksize == 1 and self.in_channels % 32 == 0)) else None
         self.bias = P.get(f'{prefix}.bias')
         self.weight_gain = 1.0 / np.sqrt(self.in_channels * self.ksize ** 2)
         if modulated:
@@ -175,13 +176,22 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 
-def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None):
-    """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584)."""
+def _conv1x1(L, x, style=None, epilogue=None, out=None):
+    """1x1 stride-1 convolution on the arithmetic selected by PRECISION."""
+    if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0):
+        return cg.conv_launch(x, L.wt16, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True)
+    return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
+
+
+def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None):
+    """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584).  With
+    `residual_up_filter`, `residual` is the PREVIOUS block's half-resolution image and upsample2d (:582) is evaluated
+    inside the convolution's epilogue."""
     g = L.weight_gain
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
-    return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=styles,
-                          epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual))
+    return _conv1x1(L, x, style=styles, epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual,
+                                                                    residual_up_filter=residual_up_filter))
 
 
 def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None):
@@ -192,6 +202,8 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
                              clamp=None if conv_clamp is None else conv_clamp * gain, residual=residual)
     if down == 1 and L.ksize == 3:
         return _conv3x3(L, x, epilogue=epi, out=out)
+    if down == 1 and L.ksize == 1:
+        return _conv1x1(L, x, epilogue=epi, out=out)
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3

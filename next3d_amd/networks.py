@@ -45,9 +45,12 @@ class _Block:
         # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
         # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.
         if img_stream is None:
-            if img is not None:
+            # upsample2d(img) is evaluated inside the toRGB epilogue (4 taps of the half-resolution image per pixel)
+            up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
+            if img is not None and up is None:
                 img = uf.upsample2d(img, fir)
-            img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
+            img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0],
+                                residual_up_filter=up)
         else:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(img_stream):

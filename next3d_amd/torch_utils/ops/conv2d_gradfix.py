@@ -30,20 +30,22 @@ def prep_weight(w, want_sq=False):
 
 
 def prep_weight_bf16x3(w):
-    """[O,I,3,3] fp32 -> split-bf16 K-major tiles for the bf16x3 kernel (see include/n3d.h)."""
+    """[O,I,k,k] fp32 (k = 3 or 1) -> split-bf16 K-major tiles for the bf16x3 kernels (see include/n3d.h)."""
     _lib.require_device(w)
     o, i, kh, kw = w.shape
-    if kh != 3 or kw != 3 or i % 16 != 0:
-        raise RuntimeError('prep_weight_bf16x3: needs a 3x3 kernel and I % 16 == 0')
+    if kh != kw or kh not in (1, 3) or i % 16 != 0:
+        raise RuntimeError('prep_weight_bf16x3: needs a 3x3 or 1x1 kernel and I % 16 == 0')
     op64 = (o + 63) // 64 * 64
-    wt16 = torch.empty([9, i // 16, 2, 2, op64, 8], dtype=torch.bfloat16, device=w.device)
-    _lib.check(_lib.lib().n3d_conv2d_prep_weight_bf16x3(_lib.ptr(w.contiguous()), _lib.ptr(wt16), o, i, 3, _lib.stream()))
+    wt16 = torch.empty([kh * kh, i // 16, 2, 2, op64, 8], dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().n3d_conv2d_prep_weight_bf16x3(_lib.ptr(w.contiguous()), _lib.ptr(wt16), o, i, kh, _lib.stream()))
     return wt16
 
 
 def bf16x3_eligible(i, h, w, ksize, mode):
     """Layers the split-bf16 kernels cover: 3x3, I % 16 == 0, stride-1 or transposed stride-2, from 4x4 up (images
     narrower than a 32-pixel MFMA tile are flattened row-major over the tile's columns)."""
+    if ksize == 1:          # 1x1 (toRGB / fromRGB / fusion): activations streamed straight into the MFMA fragments
+        return mode == 0 and i % 32 == 0 and i <= 1024
     return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
@@ -88,7 +90,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     n, i, h, w = x.shape
     o = out_channels
     if bf16x3:
-        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (9, i // 16, 2, 2, (o + 63) // 64 * 64, 8) and mode in (0, 2) and ksize == 3
+        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (ksize * ksize, i // 16, 2, 2, (o + 63) // 64 * 64, 8)
+        assert (ksize == 3 and mode in (0, 2)) or (ksize == 1 and mode == 0)
     else:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     if x.stride()[1:] != (h * w, w, 1):
@@ -103,7 +106,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
-        ksplit = pick_ksplit_bf16x3(n, i, o, h, w, mode) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
+        ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)

@@ -278,6 +278,39 @@ def test_conv2d_row_pitch(dev, bf16x3, mode, N, I, OC, H, W):
         assert torch.equal(pitched, dense), (mode, ksplit)
 
 
+@pytest.mark.parametrize('bf16x3', [False, True])
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 128, 96, 32, 32), (1, 32, 512, 16, 16), (2, 512, 3, 8, 8), (1, 64, 40, 6, 10), (1, 256, 130, 20, 12),
+                                       (4, 512, 96, 4, 4), (1, 128, 32, 64, 48)])
+def test_conv1x1_and_fused_skip_upsample(dev, bf16x3, N, I, OC, H, W):
+    """1x1 conv (toRGB / fromRGB): fp32-MFMA and split-bf16 kernels vs F.conv2d, with style, bias, clamp, a dense residual,
+    and the fused skip path  img = upsample2d(img_lowres) + toRGB(x)  (n3d_epilogue.residual_up_filter)."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 90), _gen((OC, I, 1, 1), 91) / np.sqrt(I)
+    st, b = _gen((N, I), 92), _gen((OC,), 93)
+    res, low = _gen((N, OC, H, W), 94), _gen((N, OC, H // 2, W // 2), 95)
+    f = O.setup_filter((1, 3, 3, 1)) + 0.01 * torch.arange(16.).reshape(4, 4)       # asymmetric taps: catches index flips
+    t = lambda a: a.to(dev)
+    wt = cg.prep_weight_bf16x3(t(w)) if bf16x3 else cg.prep_weight(t(w))
+    tol = lambda ref: (1e-4 if bf16x3 else 2e-5) * max(1.0, float(ref.abs().max()))
+    core = F.conv2d(x * st[:, :, None, None], w)
+    y = cg.conv_launch(t(x), wt, 1, 0, OC, style=t(st), bf16x3=bf16x3)
+    assert float((y.cpu() - core).abs().max()) <= tol(core)
+    ref = O.bias_act(core, b, clamp=0.7) + res
+    tb, tres, tlow, tf = t(b), t(res), t(low), t(f)
+    y = cg.conv_launch(t(x), wt, 1, 0, OC, style=t(st), epilogue=_lib.make_epilogue(bias=tb, clamp=0.7, residual=tres), bf16x3=bf16x3)
+    assert float((y.cpu() - ref).abs().max()) <= tol(ref)
+    ref = O.bias_act(core, b, clamp=0.7) + O.upsample2d(low, f)
+    y = cg.conv_launch(t(x), wt, 1, 0, OC, style=t(st), bf16x3=bf16x3,
+                       epilogue=_lib.make_epilogue(bias=tb, clamp=0.7, residual=tlow, residual_up_filter=tf))
+    assert float((y.cpu() - ref).abs().max()) <= tol(ref)
+    if not bf16x3:          # the split-K epilogue kernel takes the same fused path
+        y = cg.conv_launch(t(x), wt, 1, 0, OC, style=t(st), ksplit=2,
+                           epilogue=_lib.make_epilogue(bias=tb, clamp=0.7, residual=tlow, residual_up_filter=tf))
+        assert float((y.cpu() - ref).abs().max()) <= tol(ref)
+
+
 def test_filtered_lrelu_fma_and_small_kernels(dev):
     from next3d_amd import _lib
     from next3d_amd.torch_utils.ops import filtered_lrelu, fma, upfirdn2d
