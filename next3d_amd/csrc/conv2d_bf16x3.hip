@@ -37,6 +37,7 @@ struct Conv16Params {
 };
 
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
+int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
 
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
 
@@ -586,7 +587,21 @@ static void conv16_plan(int N, int O, int H, int W, int mode, bool* big, int* ti
     *tiles_x = cdiv(W, 32); *tiles_y = cdiv(H, *th);
 }
 
+int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
+                                  const n3d_epilogue& epi, hipStream_t stream) {
+    const int64_t total = (int64_t)N * O * OH * OW;
+    const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
+    hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode) {
+    if (mode == 1) {
+        const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+        const int64_t b = (int64_t)cdiv(OW, 32) * cdiv(OH, 16) * cdiv(O, 64) * N;
+        return b > 0x7fffffff ? 0x7fffffff : (int)b;
+    }
     bool big; int tx, ty, tw, th;
     conv16_plan(N, O, H, W, mode, &big, &tx, &ty, &tw, &th);
     const int64_t b = (int64_t)tx * ty * cdiv(O, 64) * N;
@@ -596,8 +611,8 @@ extern "C" int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode) {
 extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
-    N3D_CHECK((d->ksize == 3 && (d->mode == 0 || d->mode == 2)) || (d->ksize == 1 && d->mode == 0),
-              "conv2d_bf16x3: 3x3 stride-1 / transposed stride-2 or 1x1 stride-1 only");
+    N3D_CHECK((d->ksize == 3 && d->mode >= 0 && d->mode <= 2) || (d->ksize == 1 && d->mode == 0),
+              "conv2d_bf16x3: 3x3 (stride 1, stride 2, transposed stride 2) or 1x1 stride-1 only");
     N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
     N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
     N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
@@ -605,6 +620,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
+    if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     Conv16Params p;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     const bool up = d->mode == 2;

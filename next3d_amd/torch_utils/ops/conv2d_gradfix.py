@@ -46,6 +46,8 @@ def bf16x3_eligible(i, h, w, ksize, mode):
     narrower than a 32-pixel MFMA tile are flattened row-major over the tile's columns)."""
     if ksize == 1:          # 1x1 (toRGB / fromRGB / fusion): activations streamed straight into the MFMA fragments
         return mode == 0 and i % 32 == 0 and i <= 1024
+    if mode == 1:           # stride 2: polyphase kernel, 16 x 32 output tiles (smaller outputs stay on the fp32 split-K path)
+        return ksize == 3 and i % 16 == 0 and (w - 3) // 2 + 1 >= 32 and (h - 3) // 2 + 1 >= 16
     return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
@@ -75,7 +77,7 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
     blocks = _lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode)
     # transposed: 8-wave workgroups, one per CU -> split only until ~2/3 of the CUs have one (measured: 160 blocks are
     # faster unsplit); stride-1: smaller 4-wave workgroups, several per CU
-    want = 160 if mode == 2 else 512
+    want = 512 if mode == 0 else 160       # modes 1 / 2: 8-wave workgroups, one per CU
     ks = 1
     while blocks * ks < want and (i // (ks * 2)) >= 64:
         ks *= 2
@@ -91,7 +93,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     o = out_channels
     if bf16x3:
         assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (ksize * ksize, i // 16, 2, 2, (o + 63) // 64 * 64, 8)
-        assert (ksize == 3 and mode in (0, 2)) or (ksize == 1 and mode == 0)
+        assert (ksize == 3 and mode in (0, 1, 2)) or (ksize == 1 and mode == 0)
     else:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     if x.stride()[1:] != (h * w, w, 1):

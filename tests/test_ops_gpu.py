@@ -278,6 +278,31 @@ def test_conv2d_row_pitch(dev, bf16x3, mode, N, I, OC, H, W):
         assert torch.equal(pitched, dense), (mode, ksplit)
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 65, 65), (1, 128, 70, 129, 131), (1, 16, 64, 35, 67), (1, 32, 8, 9, 9), (2, 32, 64, 4, 70),
+                                       (1, 256, 256, 66, 64)])
+def test_conv2d_stride2_bf16x3(dev, N, I, OC, H, W):
+    """Split-bf16 polyphase stride-2 conv vs F.conv2d(stride=2), plain / split-K / fused epilogue with residual."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 100), _gen((OC, I, 3, 3), 101) / np.sqrt(I * 9)
+    b = _gen((OC,), 102)
+    ref = F.conv2d(x, w, stride=2)
+    res = _gen(tuple(ref.shape), 103)
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    for ksplit in (1, None, 2):
+        y = cg.conv_launch(t(x), wt16, 3, 1, OC, ksplit=ksplit, bf16x3=True)
+        assert y.shape == ref.shape
+        err = float((y.cpu() - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ksplit, err)
+    ref2 = O.bias_act(ref * 0.5, b, act='lrelu') + res
+    tb, tres = t(b), t(res)
+    y = cg.conv_launch(t(x), wt16, 3, 1, OC, epilogue=_lib.make_epilogue(const_scale=0.5, bias=tb, act='lrelu', residual=tres), bf16x3=True)
+    err = float((y.cpu() - ref2).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref2.abs().max())), err
+
+
 @pytest.mark.parametrize('bf16x3', [False, True])
 @pytest.mark.parametrize('N,I,OC,H,W', [(2, 128, 96, 32, 32), (1, 32, 512, 16, 16), (2, 512, 3, 8, 8), (1, 64, 40, 6, 10), (1, 256, 130, 20, 12),
                                        (4, 512, 96, 4, 4), (1, 128, 32, 64, 48)])
