@@ -169,6 +169,113 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
         }
 }
 
+// ---- few-pixel layers (<= 64 x 64): the K loop above is a serial chain of I/32 load -> MFMA steps, ~2 us each, on a
+// handful of workgroups.  Here the 8 waves of a workgroup split the INPUT CHANNELS of one 32-pixel tile instead: every wave
+// issues all loads of its I/8 slice at once (activations by buffer loads, its weight fragments straight from the L2-resident
+// prepared tiles — no LDS staging, no barrier in the loop), and the eight partial accumulators are summed through LDS in a
+// fixed order; wave w then applies the epilogue to rows r = w (mod 8) of the 32 MT x 32 tile.
+template <int MT>
+__global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params p) {
+    constexpr int BM = 32 * MT;
+    constexpr int GS = MT <= 2 ? 4 : 2;                                   // 16-channel chunks in flight per wave
+    __shared__ float red[8 * MT * 16 * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    int lb = blockIdx.x;
+    const int mt_i = lb % p.tiles_m; lb /= p.tiles_m;
+    const int tp = lb % p.tiles_p, n = lb / p.tiles_p;
+    const int m0 = mt_i * BM;
+    const int px = tp * 32 + l31;
+    const bool px_ok = px < p.HW;
+    const int nchunk = p.I / 128;                                         // chunks per wave (I % 128 == 0)
+    const int c_begin = wn * nchunk;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * p.HW * 4, 0x00020000);
+    const int x_voff = ((px_ok ? px : 0) + half * 8 * p.HW) * 4;
+    const float* sty = p.style ? p.style + (int64_t)n * p.style_stride : nullptr;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    for (int g0 = 0; g0 < nchunk; g0 += GS) {
+        float raw[GS][8];
+        bf16x8 ah[GS][MT], al[GS][MT];
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            if (g0 + g >= nchunk) continue;
+            const int c = c_begin + g0 + g;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch)
+                raw[g][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, (c * 16 + ch) * p.HW * 4, 0));
+            const bf16x8* a = p.wt16 + ((int64_t)c * 4 + half) * p.OP64 + m0 + l31;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool ok = m0 + mt * 32 + l31 < p.OP64;
+                ah[g][mt] = a[ok ? mt * 32 : 0];
+                al[g][mt] = a[(ok ? mt * 32 : 0) + 2 * p.OP64];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            if (g0 + g >= nchunk) continue;
+            const int c = c_begin + g0 + g;
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const float v = raw[g][ch] * (sty ? sty[c * 16 + half * 8 + ch] : 1.f);
+                const __bf16 h = (__bf16)v;
+                bh[ch] = h;
+                bl[ch] = (__bf16)(v - (float)h);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g][mt], bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g][mt], bl, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g][mt], bh, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    // rows of weights beyond OP64 were read from row 0: they only feed output channels >= O, which are never stored
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wn * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    if (!px_ok) return;
+
+    const n3d_epilogue& E = p.epi;
+    const int oy = px / p.W, ox = px % p.W;
+    const float nz = E.noise ? E.noise[px] * E.noise_strength[0] : 0.f;
+    const int64_t yplane = (int64_t)p.H * p.yrs;
+    float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
+    const bool res_up = E.residual && E.residual_up_filter;
+    const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + (res_up ? 0 : px) : nullptr;
+    const int64_t lplane = (int64_t)(p.H >> 1) * (p.W >> 1);
+    n3d_up2_taps up2;
+    if (res_up) up2 = n3d_up2_setup(E.residual_up_filter, oy, ox, p.H >> 1, p.W >> 1);
+    const float* rsp = E.row_scale ? E.row_scale + (int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) : nullptr;
+#pragma unroll
+    for (int q = 0; q < MT * 2; ++q) {                                    // this wave's rows: item = q*8 + wn -> (mt, r)
+        const int item = q * 8 + wn, mt = item >> 4, r = item & 15;
+        const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o >= p.O) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[((w * MT + mt) * 16 + r) * 64 + lane];
+        v = v * (E.const_scale * (rsp ? rsp[o] : 1.f)) + nz + (E.bias ? E.bias[o] : 0.f);
+        v = conv1_act_generic(v, E.act, E.alpha) * E.gain;
+        if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+        if (res_up) v += n3d_up2_apply(up2, res + (int64_t)o * lplane);
+        else if (res) v += res[(int64_t)o * p.HW];
+        dst[(int64_t)o * yplane] = v;
+    }
+}
+
 // called by n3d_conv2d_bf16x3 for ksize == 1 (descriptor already validated for the common fields)
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->mode == 0, "conv2d_bf16x3: 1x1 supports stride 1 only");
@@ -183,6 +290,24 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->H % 2 == 0 && d->W % 2 == 0),
               "conv2d_bf16x3: residual_up_filter needs a residual and an even output size");
+    const double flops = 2.0 * d->N * (double)d->O * d->I * p.HW;
+    const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.HW + (double)d->O * d->I);
+    if (p.HW <= 4096 && d->I % 128 == 0) {          // few pixels, long K: waves split the input channels (see above)
+        int mt = cdiv(d->O, 32);
+        if (mt > 4) mt = 4;
+        p.tiles_p = cdiv(p.HW, 32);
+        p.tiles_m = cdiv(d->O, 32 * mt);
+        N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+        const dim3 grid((unsigned)(p.tiles_p * p.tiles_m * d->N));
+        switch (mt) {
+            case 1: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<1>, grid, dim3(512), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<2>, grid, dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<3>, grid, dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<4>, grid, dim3(512), 0, stream, p); break;
+        }
+        N3D_LAUNCH_CHECK();
+        return 0;
+    }
     p.tiles_p = cdiv(p.HW, 256);
     // output-channel tile: everything in one workgroup up to 128 channels (x is then read exactly once); few-pixel layers
     // take 32-channel tiles instead so that more than a handful of CUs work on them (x re-reads hit L2)
@@ -192,8 +317,6 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.tiles_m = cdiv(d->O, 32 * mt);
     const int64_t nblk = (int64_t)p.tiles_p * p.tiles_m * d->N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
-    const double flops = 2.0 * d->N * (double)d->O * d->I * p.HW;
-    const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.HW + (double)d->O * d->I);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     const dim3 grid((unsigned)nblk);
     switch (mt) {
