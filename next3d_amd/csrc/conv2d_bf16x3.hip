@@ -503,17 +503,34 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     }
 }
 
-// split-K second pass (same as conv2d.hip's)
+// split-K second pass: sum the partial tiles and apply the epilogue.  VEC: 4 consecutive pixels of one row per thread
+// (OW % 4 == 0, aligned pointers): 16-byte loads/stores and one index decomposition per 4 outputs.
+template <bool VEC>
 __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y, int ksplit,
                                                                       int N, int O, int OH, int OW, int64_t ybs, int64_t yrs, n3d_epilogue epi) {
     const int64_t plane = (int64_t)OH * OW, total = (int64_t)N * O * plane;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int k = 0; k < ksplit; ++k) v += partial[(int64_t)k * total + i];
+    constexpr int V = VEC ? 4 : 1;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total; i += (int64_t)gridDim.x * blockDim.x * V) {
+        float v[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = 0.f;
+        for (int k = 0; k < ksplit; ++k) {
+            if (VEC) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(partial + (int64_t)k * total + i);
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[q] += t[q];
+            } else {
+                v[0] += partial[(int64_t)k * total + i];
+            }
+        }
         const int64_t pl = i / plane;
         const int pix = (int)(i % plane), n = (int)(pl / O), o = (int)(pl % O);
-        v = n3d_apply_epilogue(v, epi, n, o, O, pix / OW, pix % OW, OH, OW);
-        y[(int64_t)n * ybs + ((int64_t)o * OH + pix / OW) * yrs + pix % OW] = v;
+        const int oy = pix / OW, ox = pix % OW;
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = n3d_apply_epilogue(v[q], epi, n, o, O, oy, ox + q, OH, OW);
+        float* dst = y + (int64_t)n * ybs + ((int64_t)o * OH + oy) * yrs + ox;
+        if (VEC) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        else dst[0] = v[0];
     }
 }
 
@@ -590,8 +607,11 @@ static void conv16_plan(int N, int O, int H, int W, int mode, bool* big, int* ti
 int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
                                   const n3d_epilogue& epi, hipStream_t stream) {
     const int64_t total = (int64_t)N * O * OH * OW;
-    const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
-    hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
+    const bool vec = (OW & 3) == 0 && ((ybs | yrs) & 3) == 0 && (((uintptr_t)partial | (uintptr_t)y) & 15) == 0;
+    const int64_t items = vec ? total / 4 : total;
+    const int grid = (int)(cdiv64(items, 256) > 4096 ? 4096 : cdiv64(items, 256));
+    if (vec) hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<true>, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
+    else hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<false>, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
     N3D_LAUNCH_CHECK();
     return 0;
 }
@@ -653,12 +673,6 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     else if (d->W < 32) hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, false>), grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
-    if (p.ksplit > 1) {
-        const int64_t total = (int64_t)p.N * p.O * p.OH * p.OW;
-        const int grid = (int)(cdiv64(total, 256) > 2048 ? 2048 : cdiv64(total, 256));
-        hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3(grid), dim3(256), 0, stream, (const float*)p.partial, p.y, p.ksplit, p.N, p.O,
-                           p.OH, p.OW, p.ybs, p.yrs, p.epi);
-        N3D_LAUNCH_CHECK();
-    }
+    if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi, stream);
     return 0;
 }

@@ -42,29 +42,42 @@ struct RenderParams {
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-// bilinear, zeros padding, align_corners=False; accumulates w * texel[0..31] into f
-__device__ __forceinline__ void gather_plane(const float* __restrict__ plane, int PH, int PW, float gx, float gy, float (&f)[RN_C]) {
+// bilinear, zeros padding, align_corners=False: the 4 taps of one plane as (texel pointer, weight); taps outside the plane
+// get weight 0 and point at texel (0,0) (always loadable), so the gather below is branch-free
+__device__ __forceinline__ void plane_taps(const float* __restrict__ plane, int PH, int PW, float gx, float gy,
+                                           const float4* (&tp)[4], float (&tw)[4]) {
     const float ix = ((gx + 1.f) * (float)PW - 1.f) * 0.5f;
     const float iy = ((gy + 1.f) * (float)PH - 1.f) * 0.5f;
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     // guard against NaN/inf/huge coordinates before the int conversion
-    if (!(fx0 > -2.f && fx0 < (float)PW + 1.f && fy0 > -2.f && fy0 < (float)PH + 1.f)) return;
-    const int x0 = (int)fx0, y0 = (int)fy0;
+    const bool sane = fx0 > -2.f && fx0 < (float)PW + 1.f && fy0 > -2.f && fy0 < (float)PH + 1.f;
+    const int x0 = sane ? (int)fx0 : -4, y0 = sane ? (int)fy0 : -4;
     const float wx1 = ix - fx0, wy1 = iy - fy0;
     const float wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
     const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};   // nw, ne, sw, se
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-        if (xx < 0 || xx >= PW || yy < 0 || yy >= PH) continue;
-        const float4* t = reinterpret_cast<const float4*>(plane + ((int64_t)yy * PW + xx) * RN_C);
-        const float w = wgt[k];
+        const bool ok = xx >= 0 && xx < PW && yy >= 0 && yy < PH;
+        tp[k] = reinterpret_cast<const float4*>(plane + (ok ? ((int64_t)yy * PW + xx) * RN_C : 0));
+        tw[k] = ok ? wgt[k] : 0.f;
+    }
+}
+
+// f += sum_k tw[k] * texel_k[0..31]: all 32 16-byte loads of the plane's four taps are issued before the first use
+__device__ __forceinline__ void gather4(const float4* const (&tp)[4], const float (&tw)[4], float (&f)[RN_C]) {
+    float4 v[4][RN_C / 4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < RN_C / 4; ++q) v[k][q] = tp[k][q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int q = 0; q < RN_C / 4; ++q) {
-            const float4 v = t[q];
-            f[4 * q + 0] += w * v.x; f[4 * q + 1] += w * v.y; f[4 * q + 2] += w * v.z; f[4 * q + 3] += w * v.w;
+            f[4 * q + 0] += tw[k] * v[k][q].x; f[4 * q + 1] += tw[k] * v[k][q].y;
+            f[4 * q + 2] += tw[k] * v[k][q].z; f[4 * q + 3] += tw[k] * v[k][q].w;
         }
-    }
 }
 
 // decode one sample: features at `pt` -> (rgb[32] in out[1..32], sigma in out[0])
@@ -75,9 +88,13 @@ __device__ __forceinline__ void decode_point(const RenderParams& p, int n, float
     float f[RN_C];
 #pragma unroll
     for (int c = 0; c < RN_C; ++c) f[c] = 0.f;
-    gather_plane(base, p.PH, p.PW, cx, cy, f);            // plane 0: (x, y)
-    gather_plane(base + ps, p.PH, p.PW, cx, cz, f);       // plane 1: (x, z)
-    gather_plane(base + 2 * ps, p.PH, p.PW, cz, cy, f);   // plane 2: (z, y)   (renderer.py:42-44)
+    const float4* tp[3][4];
+    float tw[3][4];
+    plane_taps(base, p.PH, p.PW, cx, cy, tp[0], tw[0]);            // plane 0: (x, y)
+    plane_taps(base + ps, p.PH, p.PW, cx, cz, tp[1], tw[1]);       // plane 1: (x, z)
+    plane_taps(base + 2 * ps, p.PH, p.PW, cz, cy, tp[2], tw[2]);   // plane 2: (z, y)   (renderer.py:42-44)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) gather4(tp[pl], tw[pl], f);
 #pragma unroll
     for (int c = 0; c < RN_C; ++c) f[c] = f[c] / 3.f;      // mean over the three planes (triplane_next3d.py:361)
 #pragma unroll
