@@ -40,7 +40,11 @@ struct RenderParams {
     float depth_delta, coord_scale;
 };
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// softplus / sigmoid on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): the libm
+// log1pf(expf(x)) pair is ~100 VALU instructions and was 40 % of this VALU-bound kernel's instruction stream.  For very
+// negative x, log(1 + e^x) loses the e^x tail below 2^-24 — an absolute error < 6e-8 on a quantity of order 1.
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.f + __expf(-x)); }
 
 // bilinear, zeros padding, align_corners=False: the 4 taps of one plane as (texel pointer, weight); taps outside the plane
 // get weight 0 and point at texel (0,0) (always loadable), so the gather below is branch-free
@@ -96,7 +100,7 @@ __device__ __forceinline__ void decode_point(const RenderParams& p, int n, float
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) gather4(tp[pl], tw[pl], f);
 #pragma unroll
-    for (int c = 0; c < RN_C; ++c) f[c] = f[c] / 3.f;      // mean over the three planes (triplane_next3d.py:361)
+    for (int c = 0; c < RN_C; ++c) f[c] = f[c] * (1.f / 3.f);      // mean over the three planes (triplane_next3d.py:361)
 #pragma unroll
     for (int k = 0; k <= RN_C; ++k) out[k] = p.b2[k];
     for (int j = 0; j < RN_HID; ++j) {      // hidden unit j: uniform weight addresses -> scalar loads
@@ -108,7 +112,7 @@ __device__ __forceinline__ void decode_point(const RenderParams& p, int n, float
         for (int k = 0; k <= RN_C; ++k) out[k] += p.w2[k * RN_HID + j] * h;
     }
 #pragma unroll
-    for (int k = 1; k <= RN_C; ++k) out[k] = (1.f / (1.f + expf(-out[k]))) * (1.f + 2.f * 0.001f) - 0.001f;
+    for (int k = 1; k <= RN_C; ++k) out[k] = sigmoid_f(out[k]) * (1.f + 2.f * 0.001f) - 0.001f;
 }
 
 // LDS layout per ray (one wave per block): all arrays sized for M = Sc + Sf samples
