@@ -177,7 +177,9 @@ int n3d_planes_to_channels_last(const float* planes, float* planes_cl, int N, in
  *      unify_samples).  One wavefront per ray; only feat [N,32,R,R] and depth [N,1,R,R] are written.
  *      tlin [Sc] = linspace(ray_start, ray_end, Sc); jitter [N,R*R,Sc] and u [N*R*R,Sf] are the uniform
  *      randoms the reference draws with torch.rand_like / torch.rand (vr/renderer.py:205,252);
- *      w1 [64,32], w2 [33,64] are the decoder weights ALREADY multiplied by their weight_gain;
+ *      w1 [64,32] and w2t [64,34] are the decoder weights ALREADY multiplied by their weight_gain; w2t is the second
+ *      layer TRANSPOSED (hidden-unit major) with each row padded by one zero (so a unit's 33 outgoing weights are
+ *      contiguous, 8-byte aligned pairs);
  *      bounds_ws: 2 floats of scratch; wsum [N,R*R] optional (weights.sum(2)). */
 int n3d_render_rays(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
                     const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,

@@ -21,6 +21,8 @@
 #define RN_C 32        // plane channels
 #define RN_HID 64
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct RenderParams {
     const float* planes;      // [N,3,PH,PW,32] channels-last
     const float* cam2world;   // [N,16]
@@ -30,7 +32,7 @@ struct RenderParams {
     const float* u;           // [N*R*R,Sf]
     const float* w1;          // [64,32] pre-scaled by 1/sqrt(32)
     const float* b1;          // [64]
-    const float* w2;          // [33,64] pre-scaled by 1/sqrt(64)
+    const float* w2;          // [64,34] = (W2 / sqrt(64))^T, rows padded with one zero: hidden unit j's 33 outgoing weights are contiguous
     const float* b2;          // [33]
     const float* bounds;      // [2] global min / max of the coarse depths (ray_marcher.py:54)
     float* feat;              // [N,32,R,R]
@@ -69,19 +71,21 @@ __device__ __forceinline__ void plane_taps(const float* __restrict__ plane, int 
 }
 
 // f += sum_k tw[k] * texel_k[0..31]: all 32 16-byte loads of the plane's four taps are issued before the first use
-__device__ __forceinline__ void gather4(const float4* const (&tp)[4], const float (&tw)[4], float (&f)[RN_C]) {
+__device__ __forceinline__ void gather4(const float4* const (&tp)[4], const float (&tw)[4], f32x2 (&f)[RN_C / 2]) {
     float4 v[4][RN_C / 4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int q = 0; q < RN_C / 4; ++q) v[k][q] = tp[k][q];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 w2 = f32x2{tw[k], tw[k]};
 #pragma unroll
         for (int q = 0; q < RN_C / 4; ++q) {
-            f[4 * q + 0] += tw[k] * v[k][q].x; f[4 * q + 1] += tw[k] * v[k][q].y;
-            f[4 * q + 2] += tw[k] * v[k][q].z; f[4 * q + 3] += tw[k] * v[k][q].w;
+            f[2 * q] = __builtin_elementwise_fma(w2, f32x2{v[k][q].x, v[k][q].y}, f[2 * q]);
+            f[2 * q + 1] = __builtin_elementwise_fma(w2, f32x2{v[k][q].z, v[k][q].w}, f[2 * q + 1]);
         }
+    }
 }
 
 // decode one sample: features at `pt` -> (rgb[32] in out[1..32], sigma in out[0])
@@ -89,28 +93,38 @@ __device__ __forceinline__ void decode_point(const RenderParams& p, int n, float
     const float cx = p.coord_scale * px, cy = p.coord_scale * py, cz = p.coord_scale * pz;
     const float* base = p.planes + (int64_t)n * 3 * p.PH * p.PW * RN_C;
     const int64_t ps = (int64_t)p.PH * p.PW * RN_C;
-    float f[RN_C];
+    f32x2 f2[RN_C / 2];
 #pragma unroll
-    for (int c = 0; c < RN_C; ++c) f[c] = 0.f;
+    for (int c = 0; c < RN_C / 2; ++c) f2[c] = f32x2{0.f, 0.f};
     const float4* tp[3][4];
     float tw[3][4];
     plane_taps(base, p.PH, p.PW, cx, cy, tp[0], tw[0]);            // plane 0: (x, y)
     plane_taps(base + ps, p.PH, p.PW, cx, cz, tp[1], tw[1]);       // plane 1: (x, z)
     plane_taps(base + 2 * ps, p.PH, p.PW, cz, cy, tp[2], tw[2]);   // plane 2: (z, y)   (renderer.py:42-44)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) gather4(tp[pl], tw[pl], f);
+    for (int pl = 0; pl < 3; ++pl) gather4(tp[pl], tw[pl], f2);
 #pragma unroll
-    for (int c = 0; c < RN_C; ++c) f[c] = f[c] * (1.f / 3.f);      // mean over the three planes (triplane_next3d.py:361)
+    for (int c = 0; c < RN_C / 2; ++c) f2[c] = f2[c] * (1.f / 3.f);   // mean over the three planes (triplane_next3d.py:361)
+    // 32 -> 64 softplus -> 33 MLP on packed fp32 FMAs (v_pk_fma_f32: two lanes of math per VALU slot; the vector unit's fp32
+    // peak assumes them).  Weights are wave-uniform -> scalar loads; the 33 outputs are 17 (even, odd) pairs.
+    f32x2 o2[17];
 #pragma unroll
-    for (int k = 0; k <= RN_C; ++k) out[k] = p.b2[k];
+    for (int k = 0; k < 16; ++k) o2[k] = f32x2{p.b2[2 * k], p.b2[2 * k + 1]};
+    o2[16] = f32x2{p.b2[32], 0.f};
     for (int j = 0; j < RN_HID; ++j) {      // hidden unit j: uniform weight addresses -> scalar loads
-        float h = p.b1[j];
+        const f32x2* w1r = reinterpret_cast<const f32x2*>(p.w1 + j * RN_C);
+        f32x2 h2 = f32x2{p.b1[j], 0.f};
 #pragma unroll
-        for (int c = 0; c < RN_C; ++c) h += p.w1[j * RN_C + c] * f[c];
-        h = softplus_f(h);
+        for (int c = 0; c < RN_C / 2; ++c) h2 = __builtin_elementwise_fma(w1r[c], f2[c], h2);
+        const float h = softplus_f(h2.x + h2.y);
+        const f32x2 hh = f32x2{h, h};
+        const f32x2* w2r = reinterpret_cast<const f32x2*>(p.w2 + j * 34);
 #pragma unroll
-        for (int k = 0; k <= RN_C; ++k) out[k] += p.w2[k * RN_HID + j] * h;
+        for (int k = 0; k < 17; ++k) o2[k] = __builtin_elementwise_fma(w2r[k], hh, o2[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { out[2 * k] = o2[k].x; out[2 * k + 1] = o2[k].y; }
+    out[32] = o2[16].x;
 #pragma unroll
     for (int k = 1; k <= RN_C; ++k) out[k] = sigmoid_f(out[k]) * (1.f + 2.f * 0.001f) - 0.001f;
 }

@@ -143,7 +143,8 @@ class TriPlaneGenerator(torch.nn.Module):
         lr = float(self.rendering_kwargs.get('decoder_lr_mul', 1))
         S.dec_w1 = (P['decoder.net.0.weight'] * (lr / np.sqrt(32))).contiguous()
         S.dec_b1 = (P['decoder.net.0.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.0.bias']
-        S.dec_w2 = (P['decoder.net.2.weight'] * (lr / np.sqrt(64))).contiguous()
+        w2 = P['decoder.net.2.weight'] * (lr / np.sqrt(64))                     # [33, 64]
+        S.dec_w2 = torch.cat([w2.t(), torch.zeros(64, 1, device=w2.device)], dim=1).contiguous()   # [64, 34]: n3d_render_rays' w2t
         S.dec_b2 = (P['decoder.net.2.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.2.bias']
         S.faces = P['faces'][0][:, [0, 2, 1]].to(torch.int32).contiguous()                 # triplane_next3d.py:207
         S.face_uv = P['face_uvcoords'][0][:, [0, 2, 1]].contiguous()                       # :208
