@@ -181,28 +181,28 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     auto mfma_block = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);      // role-split schedule: favour the wave that is feeding the matrix pipe
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        // fragments of tap t+1 are fetched (second register set) before the MFMAs of tap t are issued: the LDS latency
+        // hides behind 12 MFMAs instead of draining the matrix pipe at every tap
+        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto fetch = [&](int t, int s) {
+            const int boff = (t / 3) * PW + (t % 3);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { ah[s][mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[s][mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) { bh[s][nt] = B_hi[bo_b + (nt ? b_frag1 : b_frag0) + boff]; bl[s][nt] = B_lo[bo_b + (nt ? b_frag1 : b_frag0) + boff]; }
+        };
+        fetch(0, 0);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            const int boff = (t / 3) * PW + (t % 3);
-            if (p.dbg & 32) {      // ablation: no LDS fragment reads (operands stay whatever the first tap loaded)
-                if (t == 0) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) { ah[q] = A_hi[a_frag + q * 32]; al[q] = A_lo[a_frag + q * 32]; bh[q] = B_hi[q ? b_frag1 : b_frag0]; bl[q] = B_lo[q ? b_frag1 : b_frag0]; }
-                }
-            } else {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[bo_b + (nt ? b_frag1 : b_frag0) + boff]; bl[nt] = B_lo[bo_b + (nt ? b_frag1 : b_frag0) + boff]; }
-            }
+            const int s = t & 1;
+            if (t + 1 < TAPS) fetch(t + 1, s ^ 1);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[s][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
                 }
         }
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
@@ -407,21 +407,26 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) { bh[d] = B_hi[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[bo_b + b_frag + (d >> 1) * PW + (d & 1)]; }
+        // A fragments of tap t+1 are fetched into a second register set before the MFMAs of tap t are issued
+        bf16x8 ah[2][2], al[2][2];
+        auto fetch_a = [&](int t, int s) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int mt = 0; mt < 2; ++mt) { ah[s][mt] = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32]; al[s][mt] = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32]; }
+        };
+        fetch_a(0, 0);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int t = ky * 3 + kx;
-                const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
-                const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+        for (int t = 0; t < TAPS; ++t) {
+            const int ky = t / 3, kx = t % 3, s = t & 1;
+            const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+            const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+            if (t + 1 < TAPS) fetch_a(t + 1, s ^ 1);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x8 ah = A_hi[bo_a + t * 2 * BM + a_frag + mt * 32], al = A_lo[bo_a + t * 2 * BM + a_frag + mt * 32];
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[d], acc[mt][ph], 0, 0, 0);
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[d], acc[mt][ph], 0, 0, 0);
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[d], acc[mt][ph], 0, 0, 0);
-                }
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
+                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[d], acc[mt][ph], 0, 0, 0);
+                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
             }
+        }
         if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
     };
     if (NBUF == 2) {
