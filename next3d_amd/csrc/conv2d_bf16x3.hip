@@ -434,13 +434,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
         const bool stage_first = wn < NW / 2;
         for (int st = 0; st < nstage; ++st) {
             if (stage_first) {
-                if (st + 1 < nstage) store_stage(st + 1);
-                if (st + 2 < nstage) load_stage(st + 2);
-                mfma_block(st);
+                if (st + 1 < nstage && !(p.dbg & 8)) store_stage(st + 1);
+                if (st + 2 < nstage && !(p.dbg & 4)) load_stage(st + 2);
+                if (!(p.dbg & 2)) mfma_block(st);
             } else {
-                mfma_block(st);
-                if (st + 1 < nstage) store_stage(st + 1);
-                if (st + 2 < nstage) load_stage(st + 2);
+                if (!(p.dbg & 2)) mfma_block(st);
+                if (st + 1 < nstage && !(p.dbg & 8)) store_stage(st + 1);
+                if (st + 2 < nstage && !(p.dbg & 4)) load_stage(st + 2);
             }
             __syncthreads();
         }
@@ -454,11 +454,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     }
 
     // epilogue: phases (a,0),(a,1) of one position are adjacent output pixels -> one 8-byte store per lane
+    if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     const n3d_epilogue& E = p.epi;
     const int64_t plane = (int64_t)p.OH * p.OW;
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
     struct __attribute__((packed, aligned(4))) pair_t { float v0, v1; };
+    // per-channel factors through LDS (the K loop is over: s_style is free): with 128 accumulators live there are no
+    // registers to hoist their global loads out of the store loop, which made it a chain of dependent load -> store steps
+    float* s_rs = s_style, *s_bs = s_style + BM;
+    if (tid < BM) {
+        const int o = min(m0 + tid, p.O - 1);
+        s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
+        s_bs[tid] = E.bias ? E.bias[o] : 0.f;
+    }
+    __syncthreads();
     const int gy = y0 + q_row, gx = x0 + q_col;
     if (!q_act || gy >= GH || gx >= GW) return;
 #pragma unroll
@@ -491,8 +501,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
             for (int r = 0; r < 16; ++r) {
                 const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (o >= p.O) continue;
-                const float rs = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
-                const float bs = E.bias ? E.bias[o] : 0.f;
+                const float rs = s_rs[o - m0], bs = s_bs[o - m0];
                 float v[2] = {acc[mt][pa * 2][r] * rs + nz0 + bs, acc[mt][pa * 2 + 1][r] * rs + nz1 + bs};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
