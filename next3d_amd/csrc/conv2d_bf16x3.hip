@@ -471,6 +471,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     __syncthreads();
     const int gy = y0 + q_row, gx = x0 + q_col;
     if (!q_act || gy >= GH || gx >= GW) return;
+    const bool simple = !p.partial && linear && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f && m0 + BM <= p.O;
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
         const int oy = 2 * gy + pa, ox = 2 * gx;
@@ -490,10 +491,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                 }
             continue;
         }
-        const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
-        const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
         const int64_t yplane = (int64_t)p.OH * p.yrs;
         float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
+        if (simple) {               // the up-sampling layers: y = acc * demodulation, everything else happens in the FIR pass
+            float* d0 = dst + (int64_t)(m0 + 4 * half) * yplane;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
+                    const float rs = s_rs[ol + 4 * half];
+                    if (two) *reinterpret_cast<pair_t*>(d0 + (int64_t)ol * yplane) = pair_t{acc[mt][pa * 2][r] * rs, acc[mt][pa * 2 + 1][r] * rs};
+                    else d0[(int64_t)ol * yplane] = acc[mt][pa * 2][r] * rs;
+                }
+            continue;
+        }
+        const float nz0 = E.noise ? E.noise[po] * nstr : 0.f;
+        const float nz1 = (E.noise && two) ? E.noise[po + 1] * nstr : 0.f;
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)

@@ -9,7 +9,7 @@ N = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 dev = torch.device('cuda')
 x = torch.randn(N, I, H, W, device=dev); w = torch.randn(O, I, 3, 3, device=dev); s = torch.randn(N, I, device=dev)
 wt16 = cg.prep_weight_bf16x3(w)
-epi = _lib.make_epilogue(act='lrelu')
+epi = _lib.make_epilogue(act="lrelu") if mode != 2 else _lib.make_epilogue(row_scale=torch.rand(N, O, device=dev) + 0.5)
 gf = 2.0 * N * I * O * 9 * H * W / 1e9
 print(f'I{I} O{O} {H}x{W} mode{mode} N{N}: blocks={_lib.lib().n3d_conv2d_bf16x3_blocks(N, O, H, W, mode)} auto ksplit={cg.pick_ksplit_bf16x3(N, I, O, H, W, mode)}')
 for ks in (1, 2, 4, 8):
