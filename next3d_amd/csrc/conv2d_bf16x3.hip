@@ -248,6 +248,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
         }
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+    const bool simple = !p.partial && (linear || (lrelu && E.alpha >= 0.f && E.alpha <= 1.f)) && !E.residual && m0 + BM <= p.O;
+    const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int oy = y0 + q_row[nt], ox = x0 + q_col[nt];
@@ -267,6 +269,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
         const float nz = E.noise ? E.noise[po] * nstr : 0.f;
         const int64_t yplane = (int64_t)p.OH * p.yrs;
         float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
+        if (simple) {       // the common layer epilogue as straight-line code: leaky ReLU = max(v, alpha v) (linear: alpha 1),
+            float* d0 = dst + (int64_t)(m0 + 4 * half) * yplane;          // no clamp = clamp at +inf, full channel tile, no residual
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mt][nt][r] * rs[mt][r] + nz + bs[mt][r];
+                    v = fmaxf(v, v * alpha_eff) * E.gain;
+                    d0[(int64_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * yplane] = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                }
+            continue;
+        }
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
