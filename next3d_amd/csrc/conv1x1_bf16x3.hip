@@ -41,6 +41,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     constexpr int A_PER_T = (A_ITEMS + NTHR - 1) / NTHR;
     __shared__ bf16x8 A_s[2 * A_ITEMS];
     __shared__ float s_style[1024];
+    __shared__ float s_rs[BM], s_bs[BM];                                  // per-channel epilogue factors (no dependent global loads in the store loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -57,6 +58,12 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     const int nsteps = p.I / (16 * KC);
 
     for (int i = tid; i < p.I; i += NTHR) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + i] : 1.f;
+    if (tid < BM) {
+        const n3d_epilogue& E = p.epi;
+        const int o = min(m0 + tid, p.O - 1);
+        s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
+        s_bs[tid] = E.bias ? E.bias[o] : 0.f;
+    }
 
     // weights: thread's j-th slot e = tid + 512 j -> (kc, hl, half, row)
     const bf16x8* a_src[A_PER_T];
@@ -151,14 +158,28 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     const int64_t lplane = (int64_t)(p.H >> 1) * (p.W >> 1);
     n3d_up2_taps up2;
     if (res_up) up2 = n3d_up2_setup(E.residual_up_filter, oy, ox, p.H >> 1, p.W >> 1);
-    const float* rsp = E.row_scale ? E.row_scale + (int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) : nullptr;
+    if ((linear || (lrelu && E.alpha >= 0.f && E.alpha <= 1.f)) && !E.residual && m0 + BM <= p.O) {
+        // the common epilogue as straight-line code: leaky ReLU = max(v, alpha v) (linear: alpha 1), no clamp = clamp at +inf
+        const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
+        float* d0 = dst + (int64_t)(m0 + 4 * half) * yplane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[mt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half];
+                v = fmaxf(v, v * alpha_eff) * E.gain;
+                d0[(int64_t)ol * yplane] = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (o >= p.O) continue;
-            float v = acc[mt][r] * (E.const_scale * (rsp ? rsp[o] : 1.f)) + nz + (E.bias ? E.bias[o] : 0.f);
+            float v = acc[mt][r] * s_rs[o - m0] + nz + s_bs[o - m0];
             if (lrelu) v = v > 0.f ? v : v * E.alpha;
             else if (!linear) v = conv1_act_generic(v, E.act, E.alpha);
             v *= E.gain;

@@ -203,7 +203,16 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
     const int64_t plane = (int64_t)p.OH * p.OW;
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
-    const float* rsp = E.row_scale ? E.row_scale + (int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) : nullptr;
+    // per-channel factors through LDS (the K loop is over: s_style is free) -> no dependent global loads in the store loop
+    float* s_rs = s_style, *s_bs = s_style + BM;
+    if (tid < BM) {
+        const int o = min(m0 + tid, p.O - 1);
+        s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
+        s_bs[tid] = E.bias ? E.bias[o] : 0.f;
+    }
+    __syncthreads();
+    const bool simple = !p.partial && (linear || (lrelu && E.alpha >= 0.f && E.alpha <= 1.f)) && !E.residual && m0 + BM <= p.O;
+    const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int oy = y0 + wn * 2 + nt, ox = x0 + l31;
@@ -223,6 +232,19 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
         const float nz = E.noise ? E.noise[po] * nstr : 0.f;
         const int64_t yplane = (int64_t)p.OH * p.yrs;
         float* dst = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox;
+        if (simple) {       // straight-line common case: leaky ReLU = max(v, alpha v) (linear: alpha 1), no clamp = clamp at +inf
+            float* d0 = dst + (int64_t)(m0 + 4 * half) * yplane;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[mt][nt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half];
+                    v = fmaxf(v, v * alpha_eff) * E.gain;
+                    d0[(int64_t)ol * yplane] = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                }
+            continue;
+        }
         const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
             for (int r = 0; r < 16; ++r) {
                 const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (o >= p.O) continue;
-                float v = acc[mt][nt][r] * (E.const_scale * (rsp ? rsp[o] : 1.f)) + nz + (E.bias ? E.bias[o] : 0.f);
+                float v = acc[mt][nt][r] * s_rs[o - m0] + nz + s_bs[o - m0];
                 if (lrelu) v = v > 0.f ? v : v * E.alpha;
                 else if (!linear) v = convs2_act_generic(v, E.act, E.alpha);
                 v *= E.gain;
