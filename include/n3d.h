@@ -37,7 +37,8 @@ const char* n3d_last_error(void);
  * kernel launches with HIP events recorded ON THE LAUNCH STREAM and books its algorithmic flops / bytes.
  * n3d_prof_read synchronises the recorded events and returns the totals for one family since the last reset. */
 enum { N3D_K_BIAS_ACT = 0, N3D_K_UPFIRDN2D = 1, N3D_K_CONV2D = 2, N3D_K_FC = 3, N3D_K_RENDER = 4, N3D_K_RASTER = 5,
-       N3D_K_MISC = 6, N3D_K_CONV2D_BF16X3 = 7, N3D_K_COUNT = 8 };
+       N3D_K_MISC = 6, N3D_K_CONV2D_BF16X3 = 7 /* 3x3 split-bf16 kernels: MFMA-bound */,
+       N3D_K_CONV1X1_BF16X3 = 8 /* 1x1 split-bf16 kernels: HBM-bound */, N3D_K_COUNT = 9 };
 int n3d_prof_enable(int on);
 int n3d_prof_reset(void);
 int n3d_prof_read(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);

@@ -318,7 +318,7 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
         if (mt > 4) mt = 4;
         p.tiles_p = cdiv(p.HW, 32);
         p.tiles_m = cdiv(d->O, 32 * mt);
-        N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+        N3dProfScope prof(N3D_K_CONV1X1_BF16X3, stream, flops, bytes);
         const dim3 grid((unsigned)(p.tiles_p * p.tiles_m * d->N));
         switch (mt) {
             case 1: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<1>, grid, dim3(512), 0, stream, p); break;
@@ -338,7 +338,7 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.tiles_m = cdiv(d->O, 32 * mt);
     const int64_t nblk = (int64_t)p.tiles_p * p.tiles_m * d->N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
-    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    N3dProfScope prof(N3D_K_CONV1X1_BF16X3, stream, flops, bytes);
     const dim3 grid((unsigned)nblk);
     switch (mt) {
         case 1: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<1>, grid, dim3(512), 0, stream, p); break;
