@@ -74,6 +74,7 @@ class TriPlaneGenerator(torch.nn.Module):
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
         self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
+        self.overlap_raster = os.environ.get('N3D_OVERLAP_RASTER', '0') != '0'       # mesh rasterisation on a third stream (measured: -1 %, opt-in)
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -152,6 +153,7 @@ class TriPlaneGenerator(torch.nn.Module):
         S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
         S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
         S.side_stream = torch.cuda.Stream(device=dev)
+        S.raster_stream = torch.cuda.Stream(device=dev)
         S.alpha_views = torch.tensor([0, 1, 3], dtype=torch.int64, device=dev)
         S.tlin = {}
         self._prepared = S
@@ -185,8 +187,10 @@ class TriPlaneGenerator(torch.nn.Module):
                                      cutoff if trunc else 0, float(truncation_psi), _lib.stream()))
         return ws
 
-    def rasterize(self, v, lms, textures):
-        """reference triplane_next3d.py:190-230 -> ([front, side, top] each [N,32,256,256], alpha [N,3,256,256], bbox [N,4] int32)."""
+    def raster_geometry(self, v, lms):
+        """The texture-independent half of `rasterize` (reference triplane_next3d.py:190-222): z-buffer the four orthographic
+        views of the mesh -> (uv sampling grid [N*4,256,256,2], alpha [N,3,256,256], mouth box [N,4] int32).  It depends only
+        on the vertices, so `_planes` issues it on the side stream, under the texture backbone's convolutions."""
         S = self._prep()
         dev, N, V, Lm, F = v.device, v.shape[0], v.shape[1], lms.shape[1], S.faces.shape[0]
         views, H, W = len(RENDERING_VIEWS), 256, 256
@@ -203,16 +207,27 @@ class TriPlaneGenerator(torch.nn.Module):
                                          _lib.ptr(tv), _lib.ptr(zbuf), _lib.ptr(grid), _lib.ptr(alpha4), _lib.ptr(lm2d), N, V, Lm, F,
                                          views, H, W, sh[0], sh[1], sh[2], float(self.orth_scale.item()),
                                          1 if self.fill_mouth else 0, 1, _lib.stream()))
-        planes = []
-        for va, vb in ((0, -1), (1, 2), (3, -1)):
-            out = torch.empty(N, textures.shape[1], H, W, **f32)
-            _lib.check(L.n3d_texture_project(_lib.ptr(textures), _lib.ptr(grid), _lib.ptr(out), N, textures.shape[1],
-                                             textures.shape[2], textures.shape[3], H, W, views, va, vb, _lib.stream()))
-            planes.append(out)
         bbox = torch.empty(N, 4, dtype=torch.int32, device=dev)
         _lib.check(L.n3d_mouth_bbox(_lib.ptr(lm2d), _lib.ptr(bbox), N, Lm, _lib.stream()))
         alpha = alpha4.index_select(1, S.alpha_views)          # views 0 (front), 1 (side; view 2's alpha is unused, :226), 3 (top)
-        return planes, alpha, bbox
+        return grid, alpha, bbox
+
+    def project_textures(self, textures, grid):
+        """reference triplane_next3d.py:223-230: sample the neural texture through the rasterised uv grids -> [front, side, top]."""
+        N, views, H, W = textures.shape[0], len(RENDERING_VIEWS), 256, 256
+        L = _lib.lib()
+        planes = []
+        for va, vb in ((0, -1), (1, 2), (3, -1)):
+            out = torch.empty(N, textures.shape[1], H, W, dtype=torch.float32, device=textures.device)
+            _lib.check(L.n3d_texture_project(_lib.ptr(textures), _lib.ptr(grid), _lib.ptr(out), N, textures.shape[1],
+                                             textures.shape[2], textures.shape[3], H, W, views, va, vb, _lib.stream()))
+            planes.append(out)
+        return planes
+
+    def rasterize(self, v, lms, textures):
+        """reference triplane_next3d.py:190-230 -> ([front, side, top] each [N,32,256,256], alpha [N,3,256,256], bbox [N,4] int32)."""
+        grid, alpha, bbox = self.raster_geometry(v, lms)
+        return self.project_textures(textures, grid), alpha, bbox
 
     def _planes(self, ws, v, noise_mode):
         """Everything up to the blended tri-planes (channels-last [N,3,256,256,32])."""
@@ -228,15 +243,31 @@ class TriPlaneGenerator(torch.nn.Module):
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
         # The static tri-plane backbone depends only on the latents: run it on a second HIP stream so its low-resolution
         # layers (a handful of workgroups each) overlap the texture -> raster -> mouth -> blending chain.
+        # The mesh rasterisation depends only on the vertices and can run on a third stream under the texture backbone
+        # (N3D_OVERLAP_RASTER=1); measured 1-3 % slower than in line (the chip is already full), so it is off by default.
         cur = torch.cuda.current_stream()
         if self.overlap_static:
-            side = S.side_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            side_s = S.side_stream
+            side_s.wait_stream(cur)
+            if self.overlap_raster:
+                S.raster_stream.wait_stream(cur)
+                with torch.cuda.stream(S.raster_stream):
+                    grid, alpha, bbox = self.raster_geometry(v, lms)
+                    raster_done = S.raster_stream.record_event()
+            with torch.cuda.stream(side_s):
                 static = S.static(eg3d_ws, noise_mode)
             static.record_stream(cur)
-        textures = S.texture(texture_ws, noise_mode)
-        (front, side, top), alpha, bbox = self.rasterize(v, lms, textures)
+            textures = S.texture(texture_ws, noise_mode)
+            if self.overlap_raster:
+                for t in (grid, alpha, bbox):
+                    t.record_stream(cur)
+                cur.wait_event(raster_done)
+            else:
+                grid, alpha, bbox = self.raster_geometry(v, lms)
+        else:
+            textures = S.texture(texture_ws, noise_mode)
+            grid, alpha, bbox = self.raster_geometry(v, lms)
+        front, side, top = self.project_textures(textures, grid)
         f32 = dict(dtype=torch.float32, device=ws.device)
         crop = torch.empty(N, 32, 64, 64, **f32)
         _lib.check(L.n3d_resize_aa(_lib.ptr(front), _lib.ptr(crop), _lib.ptr(bbox), None, N, 32, 256, 256, 64, 64, 0, _lib.stream()))

@@ -17,7 +17,7 @@ def per_kernel(db, counter):
     return agg
 
 
-fam = ('conv2d_bf16x3_kernel', 'conv2d_up_bf16x3_kernel', 'conv2d_s2_bf16x3_kernel', 'conv1x1_bf16x3')
+fam = ('conv2d_bf16x3_kernel', 'conv2d_up_bf16x3_kernel', 'conv2d_s2_bf16x3_kernel')     # bench.py's roofline family (3x3)
 f, w = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
 sel = lambda d: {k: v for k, v in d.items() if any(s in k for s in fam)}
 f, w = sel(f), sel(w)
