@@ -117,9 +117,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
         const int pr = pp / PW;
         const int iy = y0 - 1 + pr, ix = x0 - 1 + pp % PW;
         b_ok[j] = e < B_ITEMS && pr < prows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
+        // byte offset inside the sample; pixels outside the image get an offset beyond the buffer: the load returns 0
+        b_goff[j] = b_ok[j] ? (hf * 8 * HW + iy * p.W + ix) * 4 : (int)0x80000000;
     }
-    const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
+    // buffer loads: one descriptor per sample (SGPRs) + a 32-bit lane offset + the channel offset in an SGPR — no 64-bit
+    // per-lane address arithmetic, and the zero padding of the halo comes from the hardware range check
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * HW * 4, 0x00020000);
 
     bf16x8 ra[A_PER_T];
     float rb[B_PER_T][8];
@@ -128,11 +131,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j)
             if (a_t0 + TAP_STEP * j < TAPS) ra[j] = as[j * TAP_STEP * a_tap_stride];
-        const float* bb = b_base + (int64_t)st * ICB * HW;
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
+            for (int c = 0; c < 8; ++c)
+                rb[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_goff[j], (ic_begin + st * ICB + c) * HW * 4, 0));
     };
     auto store_stage = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
             const int hf = e / PPIX;
             float v[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
+            for (int c = 0; c < 8; ++c) v[c] = rb[j][c] * s_style[st * ICB + hf * 8 + c];
             bf16x8 hi, lo;
             split8(v, hi, lo);
             B_hi[bo_b + e] = hi;
@@ -362,9 +365,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
         const int pr = pp / PW;
         const int iy = y0 - 1 + pr, ix = x0 - 1 + pp % PW;
         b_ok[j] = e < B_ITEMS && pr < prows && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        b_goff[j] = b_ok[j] ? hf * 8 * HW + iy * p.W + ix : 0;
+        b_goff[j] = b_ok[j] ? (hf * 8 * HW + iy * p.W + ix) * 4 : (int)0x80000000;     // byte offset; outside the image: beyond the buffer -> 0
     }
-    const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * HW * 4, 0x00020000);
 
     bf16x8 ra[A_PER_T];
     float rb[B_PER_T][8];
@@ -373,11 +376,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
 #pragma unroll
         for (int j = 0; j < A_PER_T; ++j)
             if (a_t0 + TAP_STEP * j < TAPS) ra[j] = as[j * TAP_STEP * a_tap_stride];
-        const float* bb = b_base + (int64_t)st * ICB * HW;
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb[j][c] = bb[b_goff[j] + (b_ok[j] ? c * HW : 0)];
+            for (int c = 0; c < 8; ++c)
+                rb[j][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_goff[j], (ic_begin + st * ICB + c) * HW * 4, 0));
     };
     auto store_stage = [&](int st) {
         const int bo_a = (NBUF == 2 && (st & 1)) ? A_SZ : 0, bo_b = (NBUF == 2 && (st & 1)) ? B_SZ : 0;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
             const int hf = e / PPIX;
             float v[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = b_ok[j] ? rb[j][c] * s_style[st * ICB + hf * 8 + c] : 0.f;
+            for (int c = 0; c < 8; ++c) v[c] = rb[j][c] * s_style[st * ICB + hf * 8 + c];
             bf16x8 hi, lo;
             split8(v, hi, lo);
             B_hi[bo_b + e] = hi;
@@ -694,6 +697,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     N3D_CHECK(!d->epi.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
+    N3D_CHECK((int64_t)d->I * d->H * d->W * 4 < (1ll << 31), "conv2d_bf16x3: one sample's input exceeds 2 GiB (32-bit buffer offsets)");
     bool big;
     conv16_plan(d->N, d->O, d->H, d->W, d->mode, &big, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
     const int max_split = d->I / 16;

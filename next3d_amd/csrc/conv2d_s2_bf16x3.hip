@@ -85,9 +85,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
         const int hf = e / PPIX, pp = e % PPIX;
         b_iy[j] = e < B_ITEMS ? 2 * (y0 + pp / PW) : p.H;                 // rows/cols at or beyond H/W are never loaded
         b_ix[j] = 2 * (x0 + pp % PW);
-        b_goff[j] = hf * 8 * HW + b_iy[j] * p.W + b_ix[j];
+        b_goff[j] = (hf * 8 * HW + b_iy[j] * p.W + b_ix[j]) * 4;          // byte offset of the phase-(0,0) pixel inside the sample
     }
-    const float* b_base = p.x + (int64_t)n * p.xbs + (int64_t)ic_begin * HW;
+    // buffer loads: descriptor per sample (SGPRs) + 32-bit lane offset + (channel, phase) offset in an SGPR
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * HW * 4, 0x00020000);
 
     bf16x8 ra[2];
     float rb[B_PER_T][8];
@@ -105,12 +106,13 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
                 ra[jj] = as[(ky * 3 + kx) * a_tap_stride];
             }
         }
-        const float* bb = b_base + (int64_t)c * ICB * HW + py * p.W + px;
 #pragma unroll
         for (int j = 0; j < B_PER_T; ++j) {
             rb_ok[j] = b_iy[j] + py < p.H && b_ix[j] + px < p.W;
+            const int voff = rb_ok[j] ? b_goff[j] : (int)0x80000000;          // beyond the buffer: the load returns 0
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) rb[j][ch] = rb_ok[j] ? bb[b_goff[j] + ch * HW] : 0.f;
+            for (int ch = 0; ch < 8; ++ch)
+                rb[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, (((ic_begin + c * ICB + ch) * p.H + py) * p.W + px) * 4, 0));
         }
     };
     auto store_stage = [&](int st) {
@@ -279,6 +281,7 @@ int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     N3D_CHECK(!d->epi.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
+    N3D_CHECK((int64_t)d->I * d->H * d->W * 4 < (1ll << 31), "conv2d_bf16x3: one sample's input exceeds 2 GiB (32-bit buffer offsets)");
     p.tiles_x = cdiv(p.OW, 32); p.tiles_y = cdiv(p.OH, 16); p.tiles_m = cdiv(p.O, 64);
     const int max_split = d->I / 16;
     p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);

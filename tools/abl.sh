@@ -1,2 +1,3 @@
-timeout 600 python -m pytest tests/test_generator_gpu.py -m gpu -x -q 2>&1 | tail -2
-for i in 1 2; do for f in 0 1; do echo "raster_side=$f"; N3D_OVERLAP_RASTER=$f timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"])"; done; done
+timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "bf16x3 or synthesis or stride2" 2>&1 | tail -2
+for i in 1 2; do
+for L in gpurun_ab_prev.so next3d_amd/libn3d.so; do echo $L; N3D_LIB=$PWD/$L timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"], d[\"roofline\"][\"family_ms_per_step\"])"; done; done
