@@ -187,6 +187,14 @@ int n3d_render_rays(const float* planes_cl, const float* cam2world, const float*
                     const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
                     int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream);
 
+/* ---- point queries (shape extraction): replaces ImportanceRenderer.run_model (vr/renderer.py:149-155: sample_from_planes +
+ *      OSGDecoder) as called by TriPlaneGenerator.sample / sample_mixed (tat/triplane_next3d.py:232-322).
+ *      coords [N,M,3] world coordinates -> rgb [N,M,32], sigma [N,M,1]; coord_scale = 2 / box_warp; decoder weights as in
+ *      n3d_render_rays (w1 [64,32], w2t [64,34], pre-scaled).  The reference's view directions are unused by the decoder. */
+int n3d_sample_points(const float* planes_cl, const float* coords, const float* w1, const float* b1, const float* w2t,
+                      const float* b2, float* rgb, float* sigma, int N, int64_t M, int PH, int PW, float coord_scale,
+                      n3d_stream_t stream);
+
 /* ---- mesh rasterisation of `views` orthographic views per sample: replaces TriPlaneGenerator.rasterize's
  *      geometry half (tat/triplane_next3d.py:193-216), Pytorch3dRasterizer.forward (vr/renderer.py:401-440, third-party
  *      pytorch3d rasterize_meshes) and fill_mouth (vr/renderer.py:583-602, third-party cv2.floodFill).

@@ -404,3 +404,37 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
     N3D_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- point queries: tri-plane features + decoder at arbitrary 3-D points (shape extraction).  One lane per point, the
+// same gather + MLP code as the renderer.  Replaces ImportanceRenderer.run_model (reference vr/renderer.py:149-155) as
+// called by TriPlaneGenerator.sample / sample_mixed (tat/triplane_next3d.py:232-322).
+__global__ __launch_bounds__(256) void sample_points_kernel(RenderParams p, const float* __restrict__ coords, float* __restrict__ rgb,
+                                                            float* __restrict__ sigma, int64_t M) {
+    const int n = blockIdx.y;
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* c = coords + ((int64_t)n * M + m) * 3;
+    float out[RN_C + 1];
+    decode_point(p, n, c[0], c[1], c[2], out);
+    sigma[(int64_t)n * M + m] = out[0];
+    float4* dst = reinterpret_cast<float4*>(rgb + ((int64_t)n * M + m) * RN_C);
+#pragma unroll
+    for (int q = 0; q < RN_C / 4; ++q) dst[q] = make_float4(out[1 + 4 * q], out[2 + 4 * q], out[3 + 4 * q], out[4 + 4 * q]);
+}
+
+extern "C" int n3d_sample_points(const float* planes_cl, const float* coords, const float* w1, const float* b1, const float* w2t,
+                                 const float* b2, float* rgb, float* sigma, int N, int64_t M, int PH, int PW, float coord_scale,
+                                 n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && M >= 0 && N <= 65535 && cdiv64(M, 256) < (1ll << 31), "sample_points: bad sizes");
+    if (N == 0 || M == 0) return 0;
+    N3D_CHECK(planes_cl && coords && w1 && b1 && w2t && b2 && rgb && sigma, "sample_points: null tensor");
+    N3D_CHECK((((uintptr_t)planes_cl | (uintptr_t)rgb) & 15) == 0, "sample_points: planes / rgb must be 16-byte aligned");
+    RenderParams p = {};
+    p.planes = planes_cl; p.w1 = w1; p.b1 = b1; p.w2 = w2t; p.b2 = b2; p.N = N; p.PH = PH; p.PW = PW; p.coord_scale = coord_scale;
+    const double pts = (double)N * (double)M;
+    N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)), pts * (12.0 * RN_C * 4.0 + 4.0 * (RN_C + 4)));
+    hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)cdiv64(M, 256), N), dim3(256), 0, stream, p, coords, rgb, sigma, M);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}

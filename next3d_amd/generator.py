@@ -339,6 +339,39 @@ class TriPlaneGenerator(torch.nn.Module):
         sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
+    def sample_mixed(self, coordinates, directions, ws, v, truncation_psi=1, truncation_cutoff=None, update_emas=False,
+                     cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        """reference triplane_next3d.py:278-322: RGB features and density at arbitrary 3-D points (shape extraction,
+        gen_samples_next3d.py:208-246) -> {'rgb' [N,M,32], 'sigma' [N,M,1]}.  `directions` is accepted and ignored exactly as
+        OSGDecoder ignores it (:359).  The reference rebuilds all planes for every chunk of points; `cache_backbone` /
+        `use_cached_backbone` (same flags as `synthesis`) keep them across calls."""
+        noise_mode = synthesis_kwargs.get('noise_mode', 'random')
+        if noise_mode == 'random':
+            raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
+        S = self._prep()
+        ws = ws.to(device=self.device, dtype=torch.float32)
+        if use_cached_backbone and getattr(self, '_last_planes', None) is not None:
+            planes, _ = self._last_planes
+        else:
+            planes, eg3d_ws = self._planes(ws, v, noise_mode)
+            if cache_backbone:
+                self._last_planes = (planes, eg3d_ws)
+        coords = coordinates.to(device=self.device, dtype=torch.float32).contiguous()
+        N, M = coords.shape[0], coords.shape[1]
+        if N != planes.shape[0] or coords.shape[2] != 3:
+            raise RuntimeError(f'sample: coordinates must be [N={planes.shape[0]}, M, 3], got {tuple(coords.shape)}')
+        rgb = torch.empty(N, M, 32, dtype=torch.float32, device=self.device)
+        sigma = torch.empty(N, M, 1, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().n3d_sample_points(_lib.ptr(planes), _lib.ptr(coords), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2),
+                                                _lib.ptr(S.dec_b2), _lib.ptr(rgb), _lib.ptr(sigma), N, M, planes.shape[2], planes.shape[3],
+                                                2.0 / float(self.rendering_kwargs['box_warp']), _lib.stream()))
+        return {'rgb': rgb, 'sigma': sigma}
+
+    def sample(self, coordinates, directions, z, c, v, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        """reference triplane_next3d.py:232-276: `mapping` + `sample_mixed`."""
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.sample_mixed(coordinates, directions, ws, v, update_emas=update_emas, **synthesis_kwargs)
+
     def forward(self, z, c, v, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
                 cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)

@@ -53,17 +53,13 @@ def rasterize(P, v, lms, textures, uv_face_mask):
     return [rend[0], side, rend[3]], [alphas[0], alpha_side, alphas[3]], lm2ds
 
 
-def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_rendering_resolution=64,
-              noise_mode='const', return_stages=False):
-    """triplane_next3d.py:117-188 (synthesis).  `jitter`/`u`: see oracle/renderer.py."""
-    st = {}
+def blended_planes(P, ws, v, uv_face_mask, noise_mode='const', st=None):
+    """triplane_next3d.py:119-174 (synthesis) == :236-276 (sample) == :282-322 (sample_mixed): everything up to the
+    blended tri-planes [N,3,32,256,256].  Returns (planes, eg3d_ws); `st` (a dict) collects the stage tensors."""
+    st = {} if st is None else st
     v, lms = v[:, :5023], v[:, 5023:]
     N = ws.shape[0]
     eg3d_ws, texture_ws = ws[:, :NUM_WS_HALF], ws[:, NUM_WS_HALF:]
-    cam2world = c[:, :16].view(-1, 4, 4)
-    intrinsics = c[:, 16:25].view(-1, 3, 3)
-    R = neural_rendering_resolution
-    ray_o, ray_d = renderer.ray_sampler(cam2world, intrinsics, R)
 
     textures = networks.synthesis_network(P, 'texture_backbone.synthesis', texture_ws, noise_mode=noise_mode)
     st['textures'] = textures
@@ -100,6 +96,34 @@ def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_ren
     dyn = torch.cat((stitch, rend[1], rend[2]), 1).view(*static.shape)
     planes = dyn * alpha + static * (1 - alpha)
     st['blended_planes'] = planes
+    return planes, eg3d_ws
+
+
+def run_model(P, planes, coordinates, rendering_kwargs):
+    """vr/renderer.py:149-155 (ImportanceRenderer.run_model): tri-plane features + decoder at arbitrary points
+    (density_noise is 0 at inference) -> {'rgb' [N,M,32], 'sigma' [N,M,1]}."""
+    feats = renderer.sample_from_planes(planes, coordinates, rendering_kwargs['box_warp'])
+    rgb, sigma = renderer.osg_decoder(P, 'decoder', feats)
+    return {'rgb': rgb, 'sigma': sigma}
+
+
+def sample_mixed(P, coordinates, ws, v, uv_face_mask, rendering_kwargs, noise_mode='const'):
+    """triplane_next3d.py:278-322 (sample_mixed; `sample` :232-276 is the same after `mapping`).  The view directions the
+    reference passes are unused by OSGDecoder (:359)."""
+    planes, _ = blended_planes(P, ws, v, uv_face_mask, noise_mode)
+    return run_model(P, planes, coordinates, rendering_kwargs)
+
+
+def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_rendering_resolution=64,
+              noise_mode='const', return_stages=False):
+    """triplane_next3d.py:117-188 (synthesis).  `jitter`/`u`: see oracle/renderer.py."""
+    st = {}
+    N = ws.shape[0]
+    cam2world = c[:, :16].view(-1, 4, 4)
+    intrinsics = c[:, 16:25].view(-1, 3, 3)
+    R = neural_rendering_resolution
+    ray_o, ray_d = renderer.ray_sampler(cam2world, intrinsics, R)
+    planes, eg3d_ws = blended_planes(P, ws, v, uv_face_mask, noise_mode, st)
 
     feat, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, rendering_kwargs,
                                                      jitter, u)

@@ -152,6 +152,13 @@ def main():
             'image_depth': md(out_ref['image_depth'], out_or['image_depth']),
             'image': md(out_ref['image'], out_or['image']),
         }
+        # point queries (G.sample_mixed, triplane_next3d.py:278): the shape-extraction entry point, same planes + decoder
+        gq = torch.Generator().manual_seed(777)
+        coords = torch.rand(N, 4096, 3, generator=gq) * 1.1 - 0.55          # a little outside the box on purpose (zero padding)
+        smp_ref = G.sample_mixed(coords, torch.zeros_like(coords), ws_ref, v, noise_mode='const')
+        smp_or = ogen.run_model(sd, st['blended_planes'], coords, rk)
+        rep['sample_rgb'] = md(smp_ref['rgb'], smp_or['rgb'])
+        rep['sample_sigma'] = md(smp_ref['sigma'], smp_or['sigma'])
         print(f'[{cname}] reference {t_ref:.1f}s oracle {t_or:.1f}s  max-abs(ref-oracle): ' +
               ' '.join(f'{k}={v:.2e}' for k, v in rep.items()))
         ok = all(v <= 1e-4 for v in rep.values())
@@ -170,6 +177,7 @@ def main():
             rendering_stitch_sub8=sub(stages['rendering_stitch'], 8), static_plane_sub8=sub(stages['static_plane'], 8),
             blended_planes_sub8=sub(planes, 8), alpha=(st['alpha'].numpy() * 255).round().astype(np.uint8),
             mouth_mask=st['mouth_mask'].numpy(),
+            sample_coords=coords.numpy(), sample_rgb=smp_ref['rgb'].numpy(), sample_sigma=smp_ref['sigma'].numpy(),
             stage_absmean=np.array([float(stages[k].abs().mean()) for k in
                                     ('textures', 'mouths_plane', 'rendering_stitch', 'static_plane')]),
         )

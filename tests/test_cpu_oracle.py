@@ -38,6 +38,10 @@ def test_oracle_reproduces_reference_golden(state):
     assert np.abs(out['image'][..., ::4, ::4].numpy() - g['image_sub4']).max() <= 1e-6
     assert np.abs(out['image'].mean(dim=(2, 3)).numpy() - g['image_mean']).max() <= 1e-6
     assert np.array_equal((st['alpha'].numpy() * 255).round().astype(np.uint8), g['alpha'])
+    # point queries (G.sample_mixed, triplane_next3d.py:278) on the same planes
+    smp = ogen.run_model(state, st['blended_planes'], torch.from_numpy(g['sample_coords']), rk)
+    assert np.abs(smp['rgb'].numpy() - g['sample_rgb']).max() <= 1e-6
+    assert np.abs(smp['sigma'].numpy() - g['sample_sigma']).max() <= 1e-6
     assert np.array_equal(st['mouth_mask'].numpy(), g['mouth_mask'])
     assert np.abs(st['textures'][..., ::8, ::8].numpy() - g['textures_sub8']).max() <= 1e-6
     assert np.abs(st['blended_planes'][..., ::8, ::8].numpy() - g['blended_planes_sub8']).max() <= 1e-6

@@ -77,3 +77,28 @@ def test_forward_matches_reference_golden(G, dev, case, precision):
     assert rep['image_raw'] <= 1e-3, rep           # north_star: <= 1e-3 max-abs on rendered RGB
     assert rep['image'] <= 1e-3, rep
     assert rep['image_depth'] <= 1e-3, rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+def test_sample_mixed_matches_reference_golden(G, dev, case):
+    """G.sample / G.sample_mixed (shape-extraction point queries, triplane_next3d.py:232-322) against the reference's own
+    outputs; the planes are cached on the first call and re-used by the second (the reference rebuilds them per chunk)."""
+    d = np.load(os.path.join(GOLDEN, case + '.npz'))
+    ws = G.mapping(torch.from_numpy(d['z']).to(dev), torch.from_numpy(d['c_cond']).to(dev), truncation_psi=float(d['psi']),
+                   truncation_cutoff=int(d['cutoff']))
+    coords = torch.from_numpy(d['sample_coords']).to(dev)
+    v = torch.from_numpy(d['v']).to(dev)
+    out = G.sample_mixed(coords, torch.zeros_like(coords), ws, v, noise_mode='const', cache_backbone=True)
+    e_rgb, e_sig = _md(out['rgb'], d['sample_rgb']), _md(out['sigma'], d['sample_sigma'])
+    print(case, 'sample_mixed rgb', e_rgb, 'sigma', e_sig, 'sigma range', float(d['sample_sigma'].min()), float(d['sample_sigma'].max()))
+    assert out['rgb'].shape == d['sample_rgb'].shape and out['sigma'].shape == d['sample_sigma'].shape
+    assert e_rgb <= 1e-3 and e_sig <= 1e-3 * max(1.0, float(np.abs(d['sample_sigma']).max()))
+    half = coords.shape[1] // 2
+    out2 = G.sample_mixed(coords[:, half:].contiguous(), None, ws, v, noise_mode='const', use_cached_backbone=True)
+    assert torch.equal(out2['rgb'], out['rgb'][:, half:]) and torch.equal(out2['sigma'], out['sigma'][:, half:])
+    out3 = G.sample(coords, None, torch.from_numpy(d['z']).to(dev), torch.from_numpy(d['c_cond']).to(dev), v,
+                    truncation_psi=float(d['psi']), truncation_cutoff=int(d['cutoff']), noise_mode='const')
+    assert _md(out3['rgb'], d['sample_rgb']) <= 1e-3
+    with pytest.raises(RuntimeError):
+        G.sample_mixed(coords[:, :, :2], None, ws, v, noise_mode='const')
