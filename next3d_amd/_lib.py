@@ -95,6 +95,8 @@ def lib():
                                '(there is no CPU or PyTorch fallback for the n3d ops)')
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get('N3D_LIB') and not hasattr(handle, name):
+                continue                         # A/B runs against an older build (N3D_LIB) may lack newer entry points
             fn = getattr(handle, name)           # AttributeError -> missing symbol
             fn.restype, fn.argtypes = res, args
         if handle.n3d_abi_version() != ABI_VERSION:

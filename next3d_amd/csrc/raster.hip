@@ -15,6 +15,8 @@
 // Pytorch3dRasterizer.forward (volumetric_rendering/renderer.py:401-440 -> third-party pytorch3d rasterize_meshes),
 // fill_mouth (renderer.py:583-602 -> third-party cv2.floodFill), gen_mouth_mask (triplane_next3d.py:330-344) and
 // F.interpolate(..., mode='bilinear', antialias=True) (triplane_next3d.py:152,161; superresolution.py:282-286).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define K_EPS 1e-8f
@@ -311,6 +313,11 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
     p.dst[((int64_t)n * p.C + c) * p.DH * p.DW + (int64_t)dy * p.DW + dx] = acc;
 }
 
+__global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long* __restrict__ zbuf, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) zbuf[i] = 0xFFFFFFFFFFFFFFFFull;
+}
+
 extern "C" {
 
 int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, const int* faces, const float* face_uv,
@@ -325,8 +332,10 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
               "rasterize_views: null tensor");
     const int NV = N * views;
     N3dProfScope prof(N3D_K_RASTER, stream, 0.0, 4.0 * NV * (double)H * W * 6);
-    if (hipMemsetAsync(zbuf_ws, 0xFF, sizeof(unsigned long long) * (size_t)NV * H * W, stream) != hipSuccess)
-        return n3d_set_error("rasterize_views: memset failed");
+    // z-buffer clear as an ordinary kernel on the launch stream
+    hipLaunchKernelGGL(raster_clear_kernel, dim3((unsigned)cdiv64((int64_t)NV * H * W, 256)), dim3(256), 0, stream, zbuf_ws,
+                       (int64_t)NV * H * W);
+    N3D_LAUNCH_CHECK();
     const int64_t nt = (int64_t)NV * V + (int64_t)N * Lm;
     hipLaunchKernelGGL(raster_transform_kernel, dim3((unsigned)cdiv64(nt, 256)), dim3(256), 0, stream, verts, lms, rot, tv_ws, lm2d, N,
                        V, Lm, views, shift_x, shift_y, shift_z, scale);

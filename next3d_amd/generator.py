@@ -74,7 +74,6 @@ class TriPlaneGenerator(torch.nn.Module):
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
         self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
-        self.overlap_raster = os.environ.get('N3D_OVERLAP_RASTER', '0') != '0'       # mesh rasterisation on a third stream (measured: -1 %, opt-in)
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -153,7 +152,6 @@ class TriPlaneGenerator(torch.nn.Module):
         S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
         S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
         S.side_stream = torch.cuda.Stream(device=dev)
-        S.raster_stream = torch.cuda.Stream(device=dev)
         S.alpha_views = torch.tensor([0, 1, 3], dtype=torch.int64, device=dev)
         S.tlin = {}
         self._prepared = S
@@ -173,7 +171,8 @@ class TriPlaneGenerator(torch.nn.Module):
         n = z.shape[0]
         L = _lib.lib()
         x = torch.empty(n, 1024, dtype=torch.float32, device=self.device)          # cat([norm(z), norm(embed(c))], 1)
-        _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(z.contiguous()), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
+        z = z.contiguous()              # (never pass a temporary to _lib.ptr: it is freed before the launch and its block can be re-used)
+        _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(z), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
         y = layers.fc(c.contiguous(), P[f'{pre}.embed.weight'], P[f'{pre}.embed.bias'], wgain=1 / np.sqrt(25))
         _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(y), _lib.c_void_p(x.data_ptr() + 512 * 4), n, 512, 1024, 1e-8, _lib.stream()))
         for i in range(2):
@@ -202,7 +201,10 @@ class TriPlaneGenerator(torch.nn.Module):
         lm2d = torch.empty(N, Lm, 2, **f32)
         sh = self.orth_shift.reshape(-1).tolist()
         L = _lib.lib()
-        _lib.check(L.n3d_rasterize_views(_lib.ptr(v.contiguous()), _lib.ptr(lms.contiguous()), _lib.ptr(S.rot), _lib.ptr(S.faces),
+        # contiguous copies must stay referenced until the launch: a temporary passed straight to _lib.ptr() is freed at once and
+        # the NEXT temporary (the landmarks) may be carved out of the same block, overwriting the vertices before the kernel runs
+        v, lms = v.contiguous(), lms.contiguous()
+        _lib.check(L.n3d_rasterize_views(_lib.ptr(v), _lib.ptr(lms), _lib.ptr(S.rot), _lib.ptr(S.faces),
                                          _lib.ptr(S.face_uv), _lib.ptr(S.uv_mask), S.uv_mask.shape[0], S.uv_mask.shape[1],
                                          _lib.ptr(tv), _lib.ptr(zbuf), _lib.ptr(grid), _lib.ptr(alpha4), _lib.ptr(lm2d), N, V, Lm, F,
                                          views, H, W, sh[0], sh[1], sh[2], float(self.orth_scale.item()),
@@ -229,8 +231,10 @@ class TriPlaneGenerator(torch.nn.Module):
         grid, alpha, bbox = self.raster_geometry(v, lms)
         return self.project_textures(textures, grid), alpha, bbox
 
-    def _planes(self, ws, v, noise_mode):
-        """Everything up to the blended tri-planes (channels-last [N,3,256,256,32])."""
+    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False):
+        """Everything up to the blended tri-planes (channels-last [N,3,256,256,32]).  `cache_identity` keeps the two
+        latent-only results (neural texture, static tri-planes); `use_cached_identity` re-uses them for a new mesh `v` (the
+        reenactment loop, reenact_avatar_next3d.py:139-160: one identity, one mesh per frame)."""
         S = self._prep()
         L = _lib.lib()
         v = v.to(device=self.device, dtype=torch.float32)
@@ -241,32 +245,26 @@ class TriPlaneGenerator(torch.nn.Module):
         N = ws.shape[0]
         nw = S.texture.num_ws
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
-        # The static tri-plane backbone depends only on the latents: run it on a second HIP stream so its low-resolution
-        # layers (a handful of workgroups each) overlap the texture -> raster -> mouth -> blending chain.
-        # The mesh rasterisation depends only on the vertices and can run on a third stream under the texture backbone
-        # (N3D_OVERLAP_RASTER=1); measured 1-3 % slower than in line (the chip is already full), so it is off by default.
+        # The mesh rasterisation depends only on the vertices and runs FIRST, alone: its z-buffer is built with 64-bit
+        # atomicMin, and on this stack those atomics were observed to get lost (whole faces missing, different ones every run)
+        # whenever the 8-wave split-bf16 convolution kernels of ANOTHER stream are resident at the same time — so no other
+        # stream may be active while it runs (tools/dbg_race2.py reproduces it).
+        grid, alpha, bbox = self.raster_geometry(v, lms)
+        # The static tri-plane backbone depends only on the latents: it runs on a second HIP stream so that its low-resolution
+        # layers (a handful of workgroups each) overlap the texture -> mouth -> blending chain.
         cur = torch.cuda.current_stream()
-        if self.overlap_static:
-            side_s = S.side_stream
-            side_s.wait_stream(cur)
-            if self.overlap_raster:
-                S.raster_stream.wait_stream(cur)
-                with torch.cuda.stream(S.raster_stream):
-                    grid, alpha, bbox = self.raster_geometry(v, lms)
-                    raster_done = S.raster_stream.record_event()
-            with torch.cuda.stream(side_s):
+        ident = getattr(self, '_identity_cache', None) if use_cached_identity else None
+        static = None
+        if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
+            textures, static = ident
+        elif self.overlap_static:
+            S.side_stream.wait_stream(cur)          # ... after the rasterisation
+            with torch.cuda.stream(S.side_stream):
                 static = S.static(eg3d_ws, noise_mode)
             static.record_stream(cur)
             textures = S.texture(texture_ws, noise_mode)
-            if self.overlap_raster:
-                for t in (grid, alpha, bbox):
-                    t.record_stream(cur)
-                cur.wait_event(raster_done)
-            else:
-                grid, alpha, bbox = self.raster_geometry(v, lms)
         else:
             textures = S.texture(texture_ws, noise_mode)
-            grid, alpha, bbox = self.raster_geometry(v, lms)
         front, side, top = self.project_textures(textures, grid)
         f32 = dict(dtype=torch.float32, device=ws.device)
         crop = torch.empty(N, 32, 64, 64, **f32)
@@ -275,14 +273,16 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch_in = front.clone()
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
-        if self.overlap_static:
+        if ident is None and self.overlap_static:
             cur.wait_stream(S.side_stream)
-        else:
+        elif static is None:
             static = S.static(eg3d_ws, noise_mode)
+        if cache_identity:
+            self._identity_cache = (textures, static)
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
         _lib.check(L.n3d_blend_planes(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
                                       _lib.ptr(planes), N, 256, 256, _lib.stream()))
-        self._debug = dict(textures=textures, front=front, side=side, top=top, alpha=alpha, bbox=bbox, crop=crop, mouths=mouths,
+        self._debug = dict(textures=textures, front=front, side=side, top=top, alpha=alpha, bbox=bbox, grid=grid, crop=crop, mouths=mouths,
                            stitch_in=stitch_in, stitch=stitch, static=static) if getattr(self, 'keep_stages', False) else None
         return planes, eg3d_ws
 
@@ -303,22 +303,26 @@ class TriPlaneGenerator(torch.nn.Module):
         c = c.to(device=dev, dtype=torch.float32)
         cam2world = c[:, :16].contiguous()
         intrinsics = c[:, 16:25].contiguous()
-        jitter = torch.rand((N, R * R, Sc, 1), device=dev) if depth_jitter is None else depth_jitter.to(dev)
-        u = torch.rand((N * R * R, Sf), device=dev) if importance_u is None else importance_u.to(dev)
+        jitter = (torch.rand((N, R * R, Sc, 1), device=dev) if depth_jitter is None else depth_jitter.to(dev)).contiguous()
+        u = (torch.rand((N * R * R, Sf), device=dev) if importance_u is None else importance_u.to(dev)).contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         feat = torch.empty(N, 32, R, R, **f32)
         depth = torch.empty(N, 1, R, R, **f32)
         _lib.check(_lib.lib().n3d_render_rays(
-            _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter.contiguous()),
-            _lib.ptr(u.contiguous()), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
+            _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter),
+            _lib.ptr(u), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
             _lib.ptr(depth), None, _lib.ptr(S.bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
             float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
         return feat, depth
 
     def synthesis(self, ws, c, v, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
-                  use_cached_backbone=False, depth_jitter=None, importance_u=None, **synthesis_kwargs):
+                  use_cached_backbone=False, depth_jitter=None, importance_u=None, cache_identity=False,
+                  use_cached_identity=False, **synthesis_kwargs):
         """reference triplane_next3d.py:117-188.  Extra keyword inputs `depth_jitter` [N,R²,Sc,1] / `importance_u`
-        [N·R²,Sf] replace the device RNG draws of the renderer (tests feed the oracle's tensors)."""
+        [N·R²,Sf] replace the device RNG draws of the renderer (tests feed the oracle's tensors).  `cache_backbone` /
+        `use_cached_backbone` (reference signature; semantics of upstream training/triplane.py:67-72) keep the blended planes
+        across calls (camera orbits); `cache_identity` / `use_cached_identity` keep only the latent-dependent networks
+        (texture + static backbone) so that a new mesh per frame re-runs just raster -> mouth -> blending."""
         noise_mode = synthesis_kwargs.get('noise_mode', 'random')
         if noise_mode == 'random':
             raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
@@ -331,7 +335,7 @@ class TriPlaneGenerator(torch.nn.Module):
         if use_cached_backbone and getattr(self, '_last_planes', None) is not None:
             planes, eg3d_ws = self._last_planes
         else:
-            planes, eg3d_ws = self._planes(ws, v, noise_mode)
+            planes, eg3d_ws = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity)
         if cache_backbone:
             self._last_planes = (planes, eg3d_ws)
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
@@ -383,5 +387,6 @@ def _resize_aa(x, size):
     """F.interpolate(x, (size,size), mode='bilinear', align_corners=False, antialias=True) on libn3d.so."""
     n, c, h, w = x.shape
     y = torch.empty(n, c, size, size, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().n3d_resize_aa(_lib.ptr(x.contiguous()), _lib.ptr(y), None, None, n, c, h, w, size, size, 0, _lib.stream()))
+    x = x.contiguous()
+    _lib.check(_lib.lib().n3d_resize_aa(_lib.ptr(x), _lib.ptr(y), None, None, n, c, h, w, size, size, 0, _lib.stream()))
     return y

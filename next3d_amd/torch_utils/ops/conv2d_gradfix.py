@@ -37,7 +37,8 @@ def prep_weight_bf16x3(w):
         raise RuntimeError('prep_weight_bf16x3: needs a 3x3 or 1x1 kernel and I % 16 == 0')
     op64 = (o + 63) // 64 * 64
     wt16 = torch.empty([kh * kh, i // 16, 2, 2, op64, 8], dtype=torch.bfloat16, device=w.device)
-    _lib.check(_lib.lib().n3d_conv2d_prep_weight_bf16x3(_lib.ptr(w.contiguous()), _lib.ptr(wt16), o, i, kh, _lib.stream()))
+    w = w.contiguous()
+    _lib.check(_lib.lib().n3d_conv2d_prep_weight_bf16x3(_lib.ptr(w), _lib.ptr(wt16), o, i, kh, _lib.stream()))
     return wt16
 
 
