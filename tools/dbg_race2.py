@@ -47,4 +47,8 @@ for it in range(12):
     names = ['tv', 'zbuf', 'grid', 'alpha', 'lm2d']
     diff = {n: int((a != b).sum()) for n, a, b in zip(names, r, ref)}
     badn += int(any(diff.values()))
+    if any(diff.values()):
+        import time; time.sleep(0.05); torch.cuda.synchronize()
+        late = int((r[1] != ref[1]).sum())
+        print('  zbuf mismatches right after sync:', diff['zbuf'], ' 50 ms later:', late)
 print(kind, 'corrupted', badn, 'of 12')
