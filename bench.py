@@ -121,6 +121,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the inputs do not change between steps, so pipelined steps must return identical frames: a cheap guard against stream
+    # races in exactly the configuration that was timed (tests/test_generator_gpu.py has the per-stage version)
+    fa = step().clone(); fb = step().clone(); fc = step()
+    torch.cuda.synchronize()
+    reproducible = bool(torch.equal(fa, fb) and torch.equal(fb, fc))
+
     roofline = None
     if not args.no_roofline:
         # same K steps again with per-launch HIP events on the launch stream (kept out of the timed region above so
@@ -177,7 +183,9 @@ def main():
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,
                        'gather': 'RCCL gather of uint8 frames to rank 0' if world > 1 else 'none'},
-            'roofline': roofline, 'cpu_baseline': cpu}))
+            'frames_bitwise_reproducible': reproducible, 'roofline': roofline, 'cpu_baseline': cpu}))
+        if not reproducible:
+            print('bench.py: pipelined steps returned different frames', file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
 
