@@ -115,3 +115,32 @@ def test_obj_and_landmark_parsers(tmp_path):
     q = tmp_path / 'k.txt'
     q.write_text('\n'.join('0.1 0.2 0.3' for _ in range(68)))
     assert mesh.parse_landmarks(str(q)).shape == (1, 68, 3)
+
+
+def test_packed_mesh_sequence_roundtrip(tmp_path):
+    """next3d_amd.meshio: .obj/_kpt2d.txt frames -> packed file -> batches identical to the per-frame text parse."""
+    from next3d_amd import mesh, meshio
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'demo_inputs.npz'))
+    objs, kpts = [], []
+    for t in range(5):
+        o, k = tmp_path / f'f{t}.obj', tmp_path / f'f{t}_kpt2d.txt'
+        with open(o, 'w') as fh:
+            fh.write('# test\n')
+            for x, y, z in d['verts'] + 0.001 * t:
+                fh.write(f'v {x:.8f} {y:.8f} {z:.8f}\n')
+            fh.write('f 1 2 3\n')
+        np.savetxt(k, d['landmarks'] - 0.002 * t)
+        objs.append(str(o)); kpts.append(str(k))
+    out = str(tmp_path / 'seq.n3dmesh')
+    arr = meshio.pack_sequence(objs, kpts, out)
+    seq = meshio.MeshSequence(out)
+    assert len(seq) == 5 and (seq.V, seq.L) == (5023, 68) and arr.shape == (5, 5091, 3)
+    ref = [torch.cat([mesh.parse_obj_vertices(o), mesh.parse_landmarks(k)], 1)[0] for o, k in zip(objs, kpts)]
+    got = list(seq.batches(2, 'cpu'))
+    assert [g.shape[0] for g in got] == [2, 2, 1]
+    assert torch.equal(torch.cat(got, 0), torch.stack(ref, 0))
+    assert [g.shape[0] for g in seq.batches(2, 'cpu', drop_last=True)] == [2, 2]
+    with open(out, 'r+b') as fh:
+        fh.write(b'XXXXXXXX')
+    with pytest.raises(ValueError):
+        meshio.MeshSequence(out)

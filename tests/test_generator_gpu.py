@@ -146,3 +146,18 @@ def test_pipelined_steps_are_bitwise_reproducible(G, dev):
     for o in outs[1:]:
         for k in ('image', 'image_raw', 'image_depth'):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.gpu
+def test_packed_mesh_sequence_streams_to_device(dev, tmp_path):
+    """meshio.MeshSequence.batches: pinned double-buffered uploads on a copy stream return the packed frames unchanged."""
+    from next3d_amd import meshio
+    d = np.load(os.path.join(GOLDEN, 'demo_inputs.npz'))
+    frames = np.stack([np.concatenate([d['verts'] + 0.001 * t, d['landmarks'] - 0.002 * t], 0) for t in range(7)], 0).astype('<f4')
+    path = str(tmp_path / 'seq.n3dmesh')
+    with open(path, 'wb') as fh:
+        fh.write(meshio.HEADER.pack(meshio.MAGIC, 7, 5023, 68, 0)); fh.write(frames.tobytes())
+    seq = meshio.MeshSequence(path)
+    got = [b.clone() for b in seq.batches(3, dev)]
+    assert [g.shape[0] for g in got] == [3, 3, 1] and all(g.is_cuda for g in got)
+    assert torch.equal(torch.cat(got, 0).cpu(), torch.from_numpy(frames))
