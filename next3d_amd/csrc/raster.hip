@@ -113,6 +113,31 @@ __device__ __forceinline__ float bilinear_1ch(const float* __restrict__ img, int
     return acc;
 }
 
+struct BilinearTaps { int off[4]; float w[4]; bool ok[4]; };
+__device__ __forceinline__ BilinearTaps bilinear_setup(int H, int W, float gx, float gy) {
+    BilinearTaps t;
+    const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const bool sane = fx0 > -2.f && fx0 < (float)W + 1.f && fy0 > -2.f && fy0 < (float)H + 1.f;
+    const int x0 = sane ? (int)fx0 : -4, y0 = sane ? (int)fy0 : -4;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+    const float ww[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        t.ok[k] = xx >= 0 && xx < W && yy >= 0 && yy < H;
+        t.off[k] = t.ok[k] ? yy * W + xx : 0;
+        t.w[k] = ww[k];
+    }
+    return t;
+}
+__device__ __forceinline__ float bilinear_apply(const BilinearTaps& t, const float* __restrict__ img) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (t.ok[k]) acc += img[t.off[k]] * t.w[k];
+    return acc;
+}
+
 // per pixel: uv = sum_k bary_k * face_uv[f][k], vis; alpha = grid_sample(uv_face_mask, uv) * vis   (renderer.py:425-437,
 // triplane_next3d.py:211-214).  grid [NV,H,W,2], alpha [NV,H,W]
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ tv, const int* __restrict__ faces,
@@ -287,9 +312,12 @@ __global__ __launch_bounds__(256) void texture_project_kernel(const float* __res
         const float* gb = grid + (((int64_t)n * views + view_b) * H * W + pix) * 2;
         ub = gb[0]; vb = gb[1];
     }
+    // tap offsets and weights once per pixel (bilinear_1ch's arithmetic, same accumulation order nw, ne, sw, se)
+    BilinearTaps ta = bilinear_setup(TH, TW, ua, va), tb = bilinear_setup(TH, TW, ub, vb);
     for (int c = 0; c < C; ++c) {
-        float v = bilinear_1ch(tn + (int64_t)c * TH * TW, TH, TW, ua, va);
-        if (view_b >= 0) v = v + bilinear_1ch(tn + (int64_t)c * TH * TW, TH, TW, ub, vb);
+        const float* tc = tn + (int64_t)c * TH * TW;
+        float v = bilinear_apply(ta, tc);
+        if (view_b >= 0) v = v + bilinear_apply(tb, tc);
         on[(int64_t)c * H * W] = v;
     }
 }
@@ -364,12 +392,27 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
     aa_range(rx, sw, ow, xmin, xsize, cxc, xinv, xtot);
     const float* s = p.src + ((int64_t)n * p.C + c) * p.SH * p.SW;
     float acc = 0.f;
-    for (int jy = 0; jy < ysize; ++jy) {
-        const float wy = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
-        const float* row = s + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
-        float h = 0.f;
-        for (int jx = 0; jx < xsize; ++jx) h += row[jx] * (tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot);
-        acc += h * wy;
+    constexpr int MAXT = 16;
+    if (xsize <= MAXT) {            // the horizontal weights do not depend on the row: compute (and divide) them once
+        float wx[MAXT];
+#pragma unroll
+        for (int jx = 0; jx < MAXT; ++jx) wx[jx] = jx < xsize ? tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot : 0.f;
+        for (int jy = 0; jy < ysize; ++jy) {
+            const float wy = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
+            const float* row = s + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
+            float h = 0.f;
+#pragma unroll
+            for (int jx = 0; jx < MAXT; ++jx) if (jx < xsize) h += row[jx] * wx[jx];
+            acc += h * wy;
+        }
+    } else {
+        for (int jy = 0; jy < ysize; ++jy) {
+            const float wy = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
+            const float* row = s + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
+            float h = 0.f;
+            for (int jx = 0; jx < xsize; ++jx) h += row[jx] * (tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot);
+            acc += h * wy;
+        }
     }
     p.dst[((int64_t)n * p.C + c) * p.DH * p.DW + (int64_t)dy * p.DW + dx] = acc;
 }
