@@ -92,18 +92,24 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     jitter = torch.rand((B, R * R, Sc, 1), device=dev, generator=g)
     u = torch.rand((B * R * R, Sf), device=dev, generator=g)
-    gathered = [torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    from next3d_amd.sharding import AsyncFrameGather
+    # asynchronous gather: this step's frames travel over xGMI while the next step computes (sharding.AsyncFrameGather)
+    gatherer = AsyncFrameGather(torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev), dst=0)
+
+    def drain():
+        gatherer.drain()
 
     def step():
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
         img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)['image']
         frames = torch.empty(img.shape, dtype=torch.uint8, device=dev)       # gen_samples_next3d.py:201 (NCHW kept)
         _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img), _lib.ptr(frames), img.numel(), _lib.stream()))
-        if world > 1:
-            dist.gather(frames, gathered, dst=0)
+        gatherer.submit(frames)
         return frames
 
     def sync():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -32,6 +32,32 @@ def gather_frames(frames, dst=0, group=None):
     return torch.cat(out, 0) if rank == dst else None
 
 
+class AsyncFrameGather:
+    """The per-step frame gather of a video / benchmark loop, off the critical path: `submit(frames)` starts an asynchronous
+    gather to `dst` (RCCL runs it on its own stream while the next step computes) after waiting for the previous one, so the
+    receive buffers on `dst` are never the target of two collectives at once; `drain()` waits for the last one.
+    `received` (on dst, after drain / the next submit) = list of the ranks' frame batches of the most recent completed step."""
+
+    def __init__(self, like, dst=0, group=None):
+        self.dst, self.group = dst, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.received = [torch.empty_like(like) for _ in range(self.world)] if (self.world > 1 and self.rank == dst) else None
+        self._pending = None
+
+    def submit(self, frames):
+        if self.world == 1:
+            return
+        self.drain()
+        work = dist.gather(frames, self.received, dst=self.dst, group=self.group, async_op=True)
+        self._pending = (work, frames)                     # `frames` stays referenced until the collective is done
+
+    def drain(self):
+        if self._pending is not None:
+            self._pending[0].wait()
+            self._pending = None
+
+
 def unshard_strided(gathered, world):
     """Invert shard_strided on a gathered [world*B, ...] tensor: frame k = gathered[(k % world) * B + k // world]."""
     b = gathered.shape[0] // world

@@ -30,6 +30,18 @@ def _worker(rank, world, port, out):
         out.put(ordered[:, 0, 0, 0].tolist())
     else:
         assert g is None
+    # the benchmark / video loop pattern: one asynchronous gather per step, overlapped with the next step
+    ag = sharding.AsyncFrameGather(frames, dst=0)
+    seen = []
+    for step in range(4):
+        ag.submit(frames + 10 * step)
+        if rank == 0 and step > 0:
+            pass                                            # (the previous step's frames are complete after this submit's drain)
+    ag.drain()
+    if rank == 0:
+        assert [int(t[0, 0, 0, 0]) for t in ag.received] == [30 + r for r in range(world)]
+    else:
+        assert ag.received is None
     dist.barrier()
     dist.destroy_process_group()
 

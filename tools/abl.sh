@@ -1,1 +1,3 @@
-for d in 0 1 2 14 15; do echo "dbg=$d"; N3D_CONV_DBG=$d python tools/dbg_race.py mode0_big,flat4 2>&1 | tail -4; done
+timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "conv1x1" 2>&1 | tail -1
+for i in 1 2; do
+for L in gpurun_ab_prev.so next3d_amd/libn3d.so; do echo $L; N3D_LIB=$PWD/$L timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"], d[\"roofline\"][\"family_ms_per_step\"][\"conv1x1_bf16x3\"])"; done; done
