@@ -157,11 +157,15 @@ def main():
         else:                            # N3D_PRECISION=fp32: fp32-MFMA conv
             dom, name, peak = c32, 'conv2d_mfma_kernel (all launches of the step)', PEAK_FP32_MFMA_TFLOPS
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-        traffic = None           # HBM bytes per launch of the roofline kernel: PMC passes cannot run inside bench.py, so the
+        traffic = traffic_x2 = None   # HBM bytes per launch of the roofline family: PMC passes cannot run inside bench.py, so the
         tpath = os.path.join(REPO, 'profiles', 'r01_traffic_pmc.json')       # committed rocprofv3 --pmc result is attached
         if dom is c16 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))['traffic_bytes_per_launch_fetch_x2']
+            tj = json.load(open(tpath))
+            # raw FETCH_SIZE + WRITE_SIZE; the guide's gfx950 x2 correction applies to 16-byte-per-lane reads only (here: the
+            # weight slabs, which mostly hit L2), the activation patches are read 4 bytes per lane -> raw is the estimate, x2 the bound
+            traffic, traffic_x2 = tj['traffic_bytes_per_launch_raw'], tj['traffic_bytes_per_launch_fetch_x2']
         roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                    'traffic_fetch_x2_upper_bound': traffic_x2,
                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                     'kernel': name,
                     'note': 'achieved = algorithmic (fp32-equivalent) conv flops / HIP-event time of the family; for bf16x3 the '
