@@ -94,13 +94,16 @@ def main():
     u = torch.rand((B * R * R, Sf), device=dev, generator=g)
 
     from next3d_amd.sharding import AsyncFrameGather
-    # asynchronous gather: this step's frames travel over xGMI while the next step computes (sharding.AsyncFrameGather)
+    # asynchronous (host never blocks) gather of the finished frames, one per step (sharding.AsyncFrameGather)
     gatherer = AsyncFrameGather(torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev), dst=0)
 
     def drain():
         gatherer.drain()
 
     def step():
+        # the previous step's gather is joined BEFORE this step's kernels are enqueued: the rasteriser must not overlap another
+        # stream's kernels, and an RCCL gather kernel is exactly that
+        gatherer.drain()
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
         img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)['image']
         frames = torch.empty(img.shape, dtype=torch.uint8, device=dev)       # gen_samples_next3d.py:201 (NCHW kept)
