@@ -43,3 +43,39 @@ int probe_math_run(void* out, int T, void* stream) {
     return (int)hipGetLastError();
 }
 }
+extern "C" {
+// gather probe: out[t] = sum of 9 dependent gathers data[3*idx[3f+k] + c] (the rasteriser's access pattern)
+__global__ void probe_gather(const float* __restrict__ data, const int* __restrict__ idx, float* __restrict__ out, int F, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int f = t % F;
+    float acc = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const float* v = data + 3 * (long)idx[3 * f + k];
+        acc += v[0] * 1.f + v[1] * 2.f + v[2] * 3.f;
+    }
+    out[t] = acc;
+}
+int probe_gather_run(const void* data, const void* idx, void* out, int F, int T, void* stream) {
+    hipLaunchKernelGGL(probe_gather, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)data, (const int*)idx, (float*)out, F, T);
+    return (int)hipGetLastError();
+}
+}
+extern "C" {
+// many non-returning 64-bit atomicMin per thread (the rasteriser's pattern: one per covered pixel, then the thread exits)
+__global__ void probe_many(unsigned long long* z64, int M, int T, int per) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    unsigned int s = (unsigned)t * 2654435761u + 12345u;
+    for (int i = 0; i < per; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const int slot = (int)((s >> 8) % (unsigned)M);
+        const unsigned long long key = ((unsigned long long)(s >> 4) << 32) | (unsigned)t;
+        atomicMin(&z64[slot], key);
+    }
+}
+int probe_many_run(void* z64, int M, int T, int per, void* stream) {
+    hipLaunchKernelGGL(probe_many, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)z64, M, T, per);
+    return (int)hipGetLastError();
+}
+}

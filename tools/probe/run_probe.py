@@ -45,3 +45,45 @@ for mode in ('alone', 'with_conv'):
         torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
         bad += int((out != refm).sum())
     print('math probe', mode, 'elements differing (20 runs):', bad)
+
+P.probe_gather_run.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+V, F, T3 = 5023 * 8, 9976, 9976 * 8
+g = torch.Generator(device=dev).manual_seed(3)
+data = torch.randn(V * 3, device=dev, generator=g); idx = torch.randint(0, V, (F * 3,), device=dev, generator=g, dtype=torch.int32)
+outg = torch.empty(T3, device=dev)
+P.probe_gather_run(data.data_ptr(), idx.data_ptr(), outg.data_ptr(), F, T3, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+refg = outg.clone()
+for mode in ('alone', 'with_conv'):
+    bad = 0
+    for it in range(30):
+        if mode == 'with_conv':
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    cg.conv_launch(x, wt, 3, 0, 256, bf16x3=True)
+        outg.fill_(-1.0)
+        data2 = data.clone()                     # freshly written source, like the transformed vertices
+        P.probe_gather_run(data2.data_ptr(), idx.data_ptr(), outg.data_ptr(), F, T3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        bad += int((outg != refg).sum())
+    print('gather probe', mode, 'elements differing (30 runs):', bad)
+
+P.probe_many_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+M2, T4, PER = 8 * 65536, 8 * 9976, 40
+zz = torch.empty(M2, dtype=torch.int64, device=dev)
+def many():
+    zz.fill_(-1)
+    P.probe_many_run(zz.data_ptr(), M2, T4, PER, torch.cuda.current_stream().cuda_stream)
+many(); torch.cuda.synchronize(); refz = zz.clone()
+for mode in ('alone', 'with_conv'):
+    bad = 0
+    for it in range(30):
+        if mode == 'with_conv':
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    cg.conv_launch(x, wt, 3, 0, 256, bf16x3=True)
+        many()
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        bad += int((zz != refz).sum())
+    print('many-atomics probe', mode, 'slots differing (30 runs):', bad)
