@@ -144,3 +144,26 @@ def test_packed_mesh_sequence_roundtrip(tmp_path):
         fh.write(b'XXXXXXXX')
     with pytest.raises(ValueError):
         meshio.MeshSequence(out)
+
+
+def test_abi_struct_layouts_match_ctypes(tmp_path):
+    """n3d_epilogue / n3d_conv2d_desc / n3d_fc_job as gcc lays them out from include/n3d.h == the ctypes mirrors in
+    next3d_amd/_lib.py (size and every field offset): a silent mismatch would hand the kernels garbage pointers."""
+    import ctypes as C
+    from next3d_amd import _lib
+    structs = {'n3d_epilogue': _lib.Epilogue, 'n3d_conv2d_desc': _lib.Conv2dDesc, 'n3d_fc_job': _lib.FcJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "n3d.h")}"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / 'layout.c', tmp_path / 'layout'
+    src.write_text('\n'.join(lines))
+    subprocess.run(['gcc', '-std=c11', str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out.strip().splitlines()}
+    for cname, cls in structs.items():
+        assert got[(cname, 'size')] == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
