@@ -199,7 +199,9 @@ def main():
             'frames_bitwise_reproducible': reproducible, 'roofline': roofline, 'cpu_baseline': cpu}))
         if not reproducible:
             print('bench.py: pipelined steps returned different frames', file=sys.stderr)
+    drain()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
