@@ -33,7 +33,7 @@ class _Block:
         out.append((self.torgb, k, 'torgb'))
         return out
 
-    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None):
+    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None):
         """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path); `bank` = StyleBank.compute(ws) result."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
@@ -41,7 +41,7 @@ class _Block:
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv0))
-            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
+            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
         # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.
         if img_stream is None:
@@ -116,6 +116,9 @@ class SynthesisNet:
         return img
 
 
+_CAT_COPY = False          # True: concatenate by copy (torch.cat) instead of writing both halves in place — A/B and tests
+
+
 class _EncoderBlock:
     def __init__(self, P, prefix, downsample):
         self.fromrgb = L.PreparedConv(P, f'{prefix}.fromrgb', modulated=False)
@@ -123,12 +126,12 @@ class _EncoderBlock:
         self.conv2 = L.PreparedConv(P, f'{prefix}.conv2', modulated=False)
         self.downsample = downsample
 
-    def __call__(self, inp, skip, fir):
+    def __call__(self, inp, skip, fir, out_buf=None):
         if self.downsample:
             inp = uf.downsample2d(inp, fir)
         out = L.conv2d_layer(self.fromrgb, inp, fir, activation='linear', residual=skip)
         out = L.conv2d_layer(self.conv1, out, fir, activation='lrelu')
-        out = L.conv2d_layer(self.conv2, out, fir, activation='lrelu', down=2)
+        out = L.conv2d_layer(self.conv2, out, fir, activation='lrelu', down=2, out=out_buf)
         return inp, out
 
 
@@ -152,11 +155,25 @@ class StyleUNet:
     def __call__(self, x_in, ws, noise_mode='const'):
         ws = _ws3(ws)
         bank = self.bank.compute(ws)
-        conds, cond = [], None
-        for enc in self.encoder:
-            x_in, cond = enc(x_in, cond, self.fir)
-            conds.append(cond)
-        conds = conds[::-1]
+        # The decoder concatenates its feature map with the encoder's condition before every fusion conv (reference
+        # networks_stylegan2_styleunet.py:565-567: torch.cat([x, conds[idx]], 1)).  Both halves are WRITTEN IN PLACE into one
+        # buffer by the convolutions that produce them (channel-slice views: the kernels take a batch stride), so no
+        # concatenation pass over 2 x (x + cond) bytes runs.
+        n, n_enc = x_in.shape[0], len(self.encoder)
+        cat = {}                                                   # fusion index -> [N, Cx + Cc, H, W]
+        conds, cond = [None] * n_enc, None
+        h = x_in.shape[2]
+        for i, enc in enumerate(self.encoder):
+            idx = n_enc - 1 - i                                    # position of this encoder block's output in conds[::-1]
+            hin = h // 2 if enc.downsample else h
+            out_buf = None
+            if 1 <= idx < len(self.fusion) and not _CAT_COPY:
+                cx, cc = self.cd[self.used_res[idx - 1]], enc.conv2.out_channels
+                cat[idx] = torch.empty(n, cx + cc, hin // 2, hin // 2, dtype=torch.float32, device=x_in.device)
+                out_buf = cat[idx][:, cx:]
+            x_in, cond = enc(x_in, cond, self.fir, out_buf)
+            conds[idx] = cond
+            h = hin
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -167,8 +184,12 @@ class StyleUNet:
                 if idx == 0:
                     x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
                 else:
-                    x = L.conv2d_layer(self.fusion[idx], torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
-            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side)
+                    x = L.conv2d_layer(self.fusion[idx], cat[idx] if idx in cat else torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
+            nxt = cat.get(idx + 1)
+            x_out = nxt[:, :self.cd[res]] if (nxt is not None and nxt.shape[2] == res) else None
+            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_out=x_out)
+            if nxt is not None and x_out is None:                 # shapes did not line up: fall back to a copy
+                nxt[:, :self.cd[res]].copy_(x)
             keep.append(x)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

@@ -1,3 +1,8 @@
-timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "conv1x1" 2>&1 | tail -1
-for i in 1 2; do
-for L in gpurun_ab_prev.so next3d_amd/libn3d.so; do echo $L; N3D_LIB=$PWD/$L timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d[\"value\"], d[\"roofline\"][\"family_ms_per_step\"][\"conv1x1_bf16x3\"])"; done; done
+timeout 500 python -m pytest tests/test_networks_gpu.py tests/test_generator_gpu.py -m gpu -x -q 2>&1 | tail -1
+python - <<'PY'
+import json, subprocess, sys, os
+for mode in ('copy', 'inplace', 'copy', 'inplace'):
+    code = "import next3d_amd.networks as n; n._CAT_COPY = %s; import runpy, sys; sys.argv=['bench.py','--no-cpu-baseline','--no-roofline']; runpy.run_path('bench.py', run_name='__main__')" % (mode == 'copy')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    print(mode, json.loads(out)['value'])
+PY
