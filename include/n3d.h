@@ -77,12 +77,15 @@ typedef struct {
 int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
                   int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                   int64_t x_batch_stride, int64_t y_batch_stride, const n3d_epilogue* epi, n3d_stream_t stream);
-/* Same, with an explicit input row pitch (floats, >= W; plane pitch = H * x_row_stride): rows that start 16-byte aligned
- * (pitch % 4 == 0) are fetched with aligned 16-byte loads. */
-int n3d_upfirdn2d_pitched(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t x_row_stride, int fh,
-                          int fw, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
-                          float gain, int64_t x_batch_stride, int64_t y_batch_stride, const n3d_epilogue* epi,
-                          n3d_stream_t stream);
+/* Same, with explicit row pitches (floats; plane pitch = rows * pitch): x_row_stride >= W for the input, y_row_stride >= OW
+ * (0 = OW) for the output.  Rows that start 16-byte aligned (pitch % 4 == 0) are fetched / stored with aligned 16-byte
+ * accesses; a pitched output takes no per-pixel epilogue inputs (noise / residual).  The odd-width images of the model —
+ * the (2W+1)-wide transposed-conv output in front of the up FIR, the (W+1)-wide FIR output in front of the stride-2 conv —
+ * travel this way. */
+int n3d_upfirdn2d_pitched(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t x_row_stride,
+                          int64_t y_row_stride, int fh, int fw, int upx, int upy, int downx, int downy, int padx0, int padx1,
+                          int pady0, int pady1, int flip, float gain, int64_t x_batch_stride, int64_t y_batch_stride,
+                          const n3d_epilogue* epi, n3d_stream_t stream);
 
 /* ---- conv2d weight preparation (done once per model): w [O,I,k,k] -> wt [k*k][I][OP] (K-major, the layout
  *      the MFMA kernel streams; OP = O rounded up to a multiple of 4, zero padded, so rows are 16-byte aligned)
@@ -108,6 +111,8 @@ typedef struct {
     int ksize, mode, ksplit;
     int64_t x_batch_stride, y_batch_stride;
     int64_t style_stride; /* floats between consecutive samples of `style` (0 = densely packed [N,I]) */
+    int64_t x_row_stride; /* floats between consecutive INPUT rows (0 = W).  Only the split-bf16 stride-2 kernel (mode 1) takes a
+                             pitched input (the FIR output in front of it); every other kernel requires 0 / W */
     int64_t y_row_stride; /* floats between consecutive output rows (0 = OW).  A multiple of 4 >= OW gives the odd-width
                              (2W+1) transposed-conv output 16-byte-aligned rows for the FIR that follows */
     n3d_epilogue epi;

@@ -33,7 +33,7 @@ class Conv2dDesc(ctypes.Structure):
                 ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
-                ('y_row_stride', c_int64), ('epi', Epilogue)]
+                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue)]
 
 
 class FcJob(ctypes.Structure):
@@ -53,7 +53,7 @@ _SIGNATURES = {
                              c_float, c_void_p]),
     'n3d_upfirdn2d': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 15 + [c_float, c_int64, c_int64,
                               ctypes.POINTER(Epilogue), c_void_p]),
-    'n3d_upfirdn2d_pitched': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_int64] + [c_int] * 11 +
+    'n3d_upfirdn2d_pitched': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_int64, c_int64] + [c_int] * 11 +
                               [c_float, c_int64, c_int64, ctypes.POINTER(Epilogue), c_void_p]),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),

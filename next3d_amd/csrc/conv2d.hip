@@ -592,6 +592,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     } else { p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1; p.GH = d->H + 1; p.GW = d->W + 1; p.nphase = 4; }
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d: y_row_stride smaller than the output width");
+    N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W, "conv2d: the fp32 kernels take dense input rows");
     N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->mode != 2 && p.OH % 2 == 0 && p.OW % 2 == 0),
               "conv2d: residual_up_filter needs a residual, an even output size and a non-transposed mode");
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");

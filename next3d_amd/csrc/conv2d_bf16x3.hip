@@ -684,6 +684,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     if (d->N == 0) return 0;
     N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
+    N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     Conv16Params p;

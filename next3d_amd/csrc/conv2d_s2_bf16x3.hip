@@ -25,6 +25,7 @@ struct ConvS2Params {
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
     int64_t xbs, ybs, style_stride, yrs;
+    int xrs;                                  // input row pitch in floats (>= W; the FIR in front writes 16-byte-aligned rows)
     n3d_epilogue epi;
 };
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
     const int ic_end = min(p.I, ic_begin + p.ic_per_split);
     const int nstage = (ic_end - ic_begin) / ICB * 4;                     // stage = (chunk, phase): st -> chunk st >> 2, phase st & 3
     const int KC = p.I / ICB;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.xrs;               // plane pitch
 
     for (int i = tid; i < ic_end - ic_begin; i += NT_) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + ic_begin + i] : 1.f;
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
         const int hf = e / PPIX, pp = e % PPIX;
         b_iy[j] = e < B_ITEMS ? 2 * (y0 + pp / PW) : p.H;                 // rows/cols at or beyond H/W are never loaded
         b_ix[j] = 2 * (x0 + pp % PW);
-        b_goff[j] = (hf * 8 * HW + b_iy[j] * p.W + b_ix[j]) * 4;          // byte offset of the phase-(0,0) pixel inside the sample
+        b_goff[j] = (hf * 8 * HW + b_iy[j] * p.xrs + b_ix[j]) * 4;          // byte offset of the phase-(0,0) pixel inside the sample
     }
     // buffer loads: descriptor per sample (SGPRs) + 32-bit lane offset + (channel, phase) offset in an SGPR
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * HW * 4, 0x00020000);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_bf16x3_kernel(ConvS2Params p
             const int voff = rb_ok[j] ? b_goff[j] : (int)0x80000000;          // beyond the buffer: the load returns 0
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch)
-                rb[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, (((ic_begin + c * ICB + ch) * p.H + py) * p.W + px) * 4, 0));
+                rb[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, (((ic_begin + c * ICB + ch) * p.H + py) * p.xrs + px) * 4, 0));
         }
     };
     auto store_stage = [&](int st) {
@@ -279,9 +280,11 @@ int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
+    p.xrs = d->x_row_stride ? (int)d->x_row_stride : d->W;
+    N3D_CHECK(p.xrs >= d->W, "conv2d_bf16x3: x_row_stride smaller than the input width");
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     N3D_CHECK(!d->epi.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
-    N3D_CHECK((int64_t)d->I * d->H * d->W * 4 < (1ll << 31), "conv2d_bf16x3: one sample's input exceeds 2 GiB (32-bit buffer offsets)");
+    N3D_CHECK((int64_t)d->I * d->H * (d->x_row_stride ? d->x_row_stride : d->W) * 4 < (1ll << 31), "conv2d_bf16x3: one sample's input exceeds 2 GiB (32-bit buffer offsets)");
     p.tiles_x = cdiv(p.OW, 32); p.tiles_y = cdiv(p.OH, 16); p.tiles_m = cdiv(p.O, 64);
     const int max_split = d->I / 16;
     p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);

@@ -17,7 +17,7 @@ struct UfParams {
     const float* x; const float* f; float* y;
     int N, C, H, W, OH, OW, fh, fw, upx, upy, downx, downy, padx0, pady0, flip;
     float gain;
-    int64_t xbs, ybs, xrs;                    // xrs: input row pitch in floats (plane pitch = H * xrs)
+    int64_t xbs, ybs, xrs, yrs;               // xrs / yrs: input / output row pitch in floats (plane pitch = rows * pitch)
     int has_epi;
     n3d_epilogue epi;
     int tiles_x, tiles_y, foot_w, foot_h;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
     }
     __syncthreads();
 
-    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.yrs;
     for (int e = threadIdx.x; e < UF_TILE_H * UF_TILE_W; e += blockDim.x) {
         const int oy = oy0 + e / UF_TILE_W, ox = ox0 + e % UF_TILE_W;
         if (oy >= p.OH || ox >= p.OW) continue;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfParams p) {
         }
         v *= p.gain;
         if (p.has_epi) v = n3d_apply_epilogue(v, p.epi, n, c, p.C, oy, ox, p.OH, p.OW);
-        yp[(int64_t)oy * p.OW + ox] = v;
+        yp[(int64_t)oy * p.yrs + ox] = v;
     }
 }
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
         s_x[e] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xp[(int64_t)iy * p.xrs + ix] : 0.f;
     }
     __syncthreads();
-    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.yrs;
     const int lx = threadIdx.x % FT_W, ly0 = threadIdx.x / FT_W;
     const int ox = ox0 + lx;
     const int qx0 = ox * DOWN - p.padx0;                 // upsampled-domain coordinate of tap kx = 0
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
         if (oy < p.OH && ox < p.OW) {
             v *= p.gain;
             if (p.has_epi) v = n3d_apply_epilogue(v, p.epi, n, c, p.C, oy, ox, p.OH, p.OW);
-            yp[(int64_t)oy * p.OW + ox] = v;
+            yp[(int64_t)oy * p.yrs + ox] = v;
         }
     }
 }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_fast_kernel(UfParams p) {
 // they are replaced by zeros with a select, so uninitialised padding cannot leak NaNs.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TW>
+template <int TW, int PADX0>
 __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
     constexpr int TH = 32, CG = TW / 4, RG = 256 / CG, RPT = TH / RG, FW4 = (TW + 8) / 4, FH = TH + 3;
     __shared__ f32x4 s_x[FH * FW4];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
     const int iy_lo = oy0 - p.pady0;
     for (int e = threadIdx.x; e < FH * FW4; e += 256) {
         const int r = e / FW4, q = e % FW4;
-        const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;          // LDS column 0 = input column ox0 - 4 (padx0 == 1)
+        const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;          // LDS column 0 = input column ox0 - 4
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (iy >= 0 && iy < p.H && col >= 0 && col < p.W) {
             v = *reinterpret_cast<const f32x4*>(xp + (int64_t)iy * p.xrs + col);
@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
     for (int rr = 0; rr < RPT + 3; ++rr) {
         const f32x4* row = s_x + (rg * RPT + rr) * FW4 + cg;
         const f32x4 a = row[0], b = row[1], d = row[2];
-        const float in[7] = {a.w, b.x, b.y, b.z, b.w, d.x, d.y};      // input columns ox-1 .. ox+5
+        // input columns ox - PADX0 .. ox - PADX0 + 6
+        const float in[7] = {PADX0 == 1 ? a.w : a.z, PADX0 == 1 ? b.x : a.w, PADX0 == 1 ? b.y : b.x, PADX0 == 1 ? b.z : b.y,
+                             PADX0 == 1 ? b.w : b.z, PADX0 == 1 ? d.x : b.w, PADX0 == 1 ? d.y : d.x};
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int ky = rr - j;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
         if (E.bias) bias = E.bias[c];
         if (E.noise) nstr = E.noise_strength[0];
     }
-    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.OW;
+    float* yp = p.y + (int64_t)n * p.ybs + (int64_t)c * p.OH * p.yrs;     // (the pitch padding, if any, receives taps of zero padding)
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         const int oy = oy0 + rg * RPT + j;
@@ -225,11 +227,11 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
             }
             if (E.residual) v += *reinterpret_cast<const f32x4*>(E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)c * p.OH * p.OW + po);
         }
-        *reinterpret_cast<f32x4*>(yp + po) = v;
+        *reinterpret_cast<f32x4*>(yp + (int64_t)oy * p.yrs + ox) = v;
     }
 }
 
-static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t xrs, int fh, int fw, int upx,
+static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t xrs, int64_t yrs, int fh, int fw, int upx,
                           int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                           int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -247,7 +249,9 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
     UfParams p;
     p.x = x; p.f = f; p.y = y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.fh = fh; p.fw = fw;
     p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0; p.flip = flip;
-    p.gain = gain; p.xbs = xbs; p.ybs = ybs; p.xrs = xrs;
+    p.gain = gain; p.xbs = xbs; p.ybs = ybs; p.xrs = xrs; p.yrs = yrs ? yrs : OW;
+    N3D_CHECK(p.yrs >= OW, "upfirdn2d: output row pitch smaller than the output width");
+    N3D_CHECK(p.yrs == OW || !epi || (!epi->noise && !epi->residual), "upfirdn2d: a pitched output cannot take per-pixel epilogue inputs");
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, UF_TILE_W); p.tiles_y = cdiv(OH, UF_TILE_H);
@@ -258,17 +262,17 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * fh * fw / (upx * upy),
                       4.0 * N * C * ((double)H * W + (double)OH * OW));
     const bool fast = fh == 4 && fw == 4 && upx == upy && downx == downy && ((upx == 1 && downx <= 2) || (upx == 2 && downx == 1));
-    const bool aligned = ((xrs | xbs | ybs | OW) & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+    const bool aligned = ((xrs | xbs | ybs | p.yrs) & 3) == 0 && ((OW & 3) == 0 || !epi) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
                          (!epi || (!epi->residual_up_filter && (!epi->noise || ((uintptr_t)epi->noise & 15) == 0) &&
                                    (!epi->residual || (((uintptr_t)epi->residual & 15) == 0 && (epi->residual_batch_stride & 3) == 0))));
-    if (fast && upx == 1 && downx == 1 && padx0 == 1 && aligned) {
-        if (OW >= 128) {
-            p.tiles_x = cdiv(OW, 128); p.tiles_y = cdiv(OH, 32);
-            hipLaunchKernelGGL(fir4_vec_kernel<128>, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
-        } else {
-            p.tiles_x = cdiv(OW, 64); p.tiles_y = cdiv(OH, 32);
-            hipLaunchKernelGGL(fir4_vec_kernel<64>, dim3(p.tiles_x * p.tiles_y, C, N), dim3(256), 0, stream, p);
-        }
+    if (fast && upx == 1 && downx == 1 && (padx0 == 1 || padx0 == 2) && aligned) {
+        const int tw = OW >= 128 ? 128 : 64;
+        p.tiles_x = cdiv(OW, tw); p.tiles_y = cdiv(OH, 32);
+        const dim3 grid(p.tiles_x * p.tiles_y, C, N);
+        if (tw == 128 && padx0 == 1) hipLaunchKernelGGL((fir4_vec_kernel<128, 1>), grid, dim3(256), 0, stream, p);
+        else if (tw == 128) hipLaunchKernelGGL((fir4_vec_kernel<128, 2>), grid, dim3(256), 0, stream, p);
+        else if (padx0 == 1) hipLaunchKernelGGL((fir4_vec_kernel<64, 1>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((fir4_vec_kernel<64, 2>), grid, dim3(256), 0, stream, p);
     } else if (fast) {
         p.tiles_x = cdiv(OW, FT_W); p.tiles_y = cdiv(OH, FT_H);
         dim3 grid(p.tiles_x * p.tiles_y, C, N);
@@ -285,14 +289,14 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
 extern "C" int n3d_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw, int upx,
                              int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                              int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream) {
-    return upfirdn2d_impl(x, f, y, N, C, H, W, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, xbs, ybs,
+    return upfirdn2d_impl(x, f, y, N, C, H, W, W, 0, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, xbs, ybs,
                           epi, stream);
 }
 
 extern "C" int n3d_upfirdn2d_pitched(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t x_row_stride,
-                                     int fh, int fw, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
-                                     int pady1, int flip, float gain, int64_t xbs, int64_t ybs, const n3d_epilogue* epi,
-                                     n3d_stream_t stream) {
-    return upfirdn2d_impl(x, f, y, N, C, H, W, x_row_stride ? x_row_stride : W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0,
-                          pady1, flip, gain, xbs, ybs, epi, stream);
+                                     int64_t y_row_stride, int fh, int fw, int upx, int upy, int downx, int downy, int padx0,
+                                     int padx1, int pady0, int pady1, int flip, float gain, int64_t xbs, int64_t ybs,
+                                     const n3d_epilogue* epi, n3d_stream_t stream) {
+    return upfirdn2d_impl(x, f, y, N, C, H, W, x_row_stride ? x_row_stride : W, y_row_stride, fh, fw, upx, upy, downx, downy, padx0,
+                          padx1, pady0, pady1, flip, gain, xbs, ybs, epi, stream);
 }

@@ -207,7 +207,9 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3
-    x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
-    if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 1):
+    if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2] + 1, x.shape[3] + 1, 3, 1):
+        # the (W+1)-wide FIR output goes to the stride-2 kernel with rows padded to 16 bytes (aligned float4 FIR stores)
+        x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2], _row_pitch=True)
         return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
+    x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
     return cg.conv_launch(x, L.wt, 3, 1, L.out_channels, epilogue=epi, out=out)

@@ -97,7 +97,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         assert (ksize == 3 and mode in (0, 1, 2)) or (ksize == 1 and mode == 0)
     else:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
-    if x.stride()[1:] != (h * w, w, 1):
+    pitched_in = bf16x3 and mode == 1 and ksize == 3 and x.stride(3) == 1 and x.stride(2) > w and x.stride(1) == h * x.stride(2)
+    if not pitched_in and x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
     if out is not None:
@@ -118,6 +119,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
     d.style_stride = style.stride(0) if style is not None else 0
     d.y_row_stride = y.stride(2)
+    d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))

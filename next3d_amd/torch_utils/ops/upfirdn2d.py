@@ -53,7 +53,7 @@ def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=Fals
     return f.to(device=device)
 
 
-def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None):
+def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pitch=False):
     upx, upy = up
     downx, downy = down
     px0, px1, py0, py1 = padding
@@ -63,14 +63,17 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None):
     oh = (h * upy + py0 + py1 - fh + downy) // downy
     if ow < 1 or oh < 1:
         raise RuntimeError('upfirdn2d: output would be empty')
-    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().n3d_upfirdn2d_pitched(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y), n, c, h, w, x.stride(2), fh, fw, upx, upy,
+    if row_pitch:           # rows padded to 16 bytes (odd widths): the [..., :ow] view of the wider buffer
+        y = torch.empty([n, c, oh, (ow + 3) // 4 * 4], dtype=x.dtype, device=x.device)[..., :ow]
+    else:
+        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().n3d_upfirdn2d_pitched(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y), n, c, h, w, x.stride(2), y.stride(2), fh, fw, upx, upy,
                                                 downx, downy, px0, px1, py0, py1, 1 if flip_filter else 0, float(gain),
                                                 x.stride(0), y.stride(0), epilogue, _lib.stream()))
     return y
 
 
-def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda', _epilogue=None):
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda', _epilogue=None, _row_pitch=False):
     """Pad, upsample, filter, downsample a batch of 2-D images (see the reference docstring, upfirdn2d.py:120-160)."""
     assert isinstance(x, torch.Tensor) and impl in ['ref', 'cuda']
     if impl == 'ref':
@@ -86,7 +89,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     # dense planes, or rows with a pitch (a [..., :W] view of a wider buffer: conv_launch(..., row_pitch=True))
     x = x if (x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)) else x.contiguous()
     if f.ndim == 2:
-        return _launch(x, f.contiguous(), up, down, padding, flip_filter, gain, _epilogue)
+        return _launch(x, f.contiguous(), up, down, padding, flip_filter, gain, _epilogue, _row_pitch)
     # separable: horizontal pass then vertical pass, gain split as sqrt per pass (upfirdn2d.py:240-244)
     px0, px1, py0, py1 = padding
     g = float(gain) ** 0.5

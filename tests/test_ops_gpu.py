@@ -301,6 +301,25 @@ def test_conv2d_stride2_bf16x3(dev, N, I, OC, H, W):
     y = cg.conv_launch(t(x), wt16, 3, 1, OC, epilogue=_lib.make_epilogue(const_scale=0.5, bias=tb, act='lrelu', residual=tres), bf16x3=True)
     err = float((y.cpu() - ref2).abs().max())
     assert err <= 1e-4 * max(1.0, float(ref2.abs().max())), err
+    # pitched input rows (what the FIR in front of the layer hands over): NaNs in the padding must not leak
+    buf = torch.full((N, I, H, (W + 3) // 4 * 4 + 4), float('nan'), device=dev)
+    xv = buf[..., :W]
+    xv.copy_(t(x))
+    yp = cg.conv_launch(xv, wt16, 3, 1, OC, ksplit=1, bf16x3=True)
+    assert torch.equal(yp, cg.conv_launch(t(x), wt16, 3, 1, OC, ksplit=1, bf16x3=True))
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 16, 16), (1, 2, 128, 256), (1, 2, 64, 64), (2, 1, 33, 128)])
+def test_upfirdn2d_pad2_pitched_output(dev, shape):
+    """The FIR in front of a stride-2 conv (pad 2, output (H+1) x (W+1)) written with rows padded to 16 bytes: the
+    [..., :OW] view equals the dense result (aligned float4 kernel when the input rows are aligned)."""
+    from next3d_amd.torch_utils.ops import upfirdn2d
+    x = _gen(shape, 75)
+    f = O.setup_filter((1, 3, 3, 1)) + 0.01 * torch.arange(16.).reshape(4, 4)
+    ref = O.upfirdn2d(x, f, padding=[2, 2, 2, 2])
+    y = upfirdn2d.upfirdn2d(x.to(dev), f.to(dev), padding=[2, 2, 2, 2], _row_pitch=True)
+    assert y.shape == ref.shape and y.stride(2) % 4 == 0 and y.stride(2) >= y.shape[3]
+    _close(y, ref, atol=1e-5)
 
 
 @pytest.mark.parametrize('bf16x3', [False, True])
