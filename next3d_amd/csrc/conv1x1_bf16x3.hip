@@ -173,6 +173,23 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
             }
         return;
     }
+    if (res_up && linear && m0 + BM <= p.O) {
+        // toRGB with the fused skip-image upsample (every toRGB but the first of a network), straight-line: bias, clamp at +inf
+        // when absent, 4 taps of the half-resolution image
+        const float clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
+        float* d0 = dst + (int64_t)(m0 + 4 * half) * yplane;
+        const float* r0 = res + (int64_t)(m0 + 4 * half) * lplane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
+                float v = (acc[mt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half]) * E.gain;
+                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                d0[(int64_t)ol * yplane] = v + n3d_up2_apply(up2, r0 + (int64_t)ol * lplane);
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -270,7 +270,9 @@ class TriPlaneGenerator(torch.nn.Module):
         crop = torch.empty(N, 32, 64, 64, **f32)
         _lib.check(L.n3d_resize_aa(_lib.ptr(front), _lib.ptr(crop), _lib.ptr(bbox), None, N, 32, 256, 256, 64, 64, 0, _lib.stream()))
         mouths = S.mouth(crop, eg3d_ws, noise_mode)
-        stitch_in = front.clone()
+        # the mouth is pasted into the front plane in place (the reference copies it first, :158-160); a copy is kept only
+        # when the stage tensors are requested for inspection
+        stitch_in = front.clone() if getattr(self, 'keep_stages', False) else front
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
         if ident is None and self.overlap_static:
