@@ -217,6 +217,10 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
  * — bilinear, zeros, align_corners=False, un-masked as in the reference (tat/triplane_next3d.py:218,225). */
 int n3d_texture_project(const float* textures, const float* grid, float* out, int N, int C, int TH, int TW, int H, int W,
                         int views, int view_a, int view_b, n3d_stream_t stream);
+/* The same for up to 4 planes in ONE launch: plane k = views view_a[k] (+ view_b[k] unless < 0) -> outs[k] [N,C,H,W].
+ * (host arrays; the front / side / top planes of triplane_next3d.py:223-230 are one call) */
+int n3d_texture_project_planes(const float* textures, const float* grid, float* const* outs, const int* view_a, const int* view_b,
+                               int planes, int N, int C, int TH, int TW, int H, int W, int views, n3d_stream_t stream);
 /* gen_mouth_mask (tat/triplane_next3d.py:330-344) on the device: lm2d [N,Lm,2] -> bbox [N,4] int32 (y0,y1,x0,x1). */
 int n3d_mouth_bbox(const float* lm2d, int* bbox, int N, int Lm, n3d_stream_t stream);
 /* F.interpolate(mode='bilinear', antialias=True, align_corners=False) = ATen _upsample_bilinear2d_aa

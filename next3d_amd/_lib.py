@@ -67,6 +67,7 @@ _SIGNATURES = {
     'n3d_rasterize_views': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 4 +
                             [c_int, c_int, c_void_p]),
     'n3d_texture_project': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    'n3d_texture_project_planes': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     'n3d_mouth_bbox': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'n3d_resize_aa': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     'n3d_normalize_2nd_moment': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),

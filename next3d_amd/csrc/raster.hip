@@ -297,14 +297,16 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(float* __restrict__ al
 }
 
 // out_plane[n][c][y][x] = sum over the plane's views of grid_sample(textures[n][c], grid[n*views+view][y][x])
+// `planes` > 1: the caller's plane list (view_a[k], view_b[k], out[k]) is processed in ONE launch (blockIdx.y = plane).
+struct TexProjPlanes { float* out[4]; int view_a[4]; int view_b[4]; };
 __global__ __launch_bounds__(256) void texture_project_kernel(const float* __restrict__ tex, const float* __restrict__ grid,
-                                                              float* __restrict__ out, int N, int C, int TH, int TW, int H, int W,
-                                                              int views, int view_a, int view_b) {
+                                                              TexProjPlanes pl, int N, int C, int TH, int TW, int H, int W, int views) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * H * W) return;
+    const int k = blockIdx.y, view_a = pl.view_a[k], view_b = pl.view_b[k];
     const int pix = (int)(i % ((int64_t)H * W)), n = (int)(i / ((int64_t)H * W));
     const float* tn = tex + (int64_t)n * C * TH * TW;
-    float* on = out + (int64_t)n * C * H * W + pix;
+    float* on = pl.out[k] + (int64_t)n * C * H * W + pix;
     const float* ga = grid + (((int64_t)n * views + view_a) * H * W + pix) * 2;
     const float ua = ga[0], va = ga[1];
     float ub = 0.f, vb = 0.f;
@@ -460,13 +462,24 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
 
 int n3d_texture_project(const float* textures, const float* grid, float* out, int N, int C, int TH, int TW, int H, int W,
                         int views, int view_a, int view_b, n3d_stream_t stream_) {
+    float* outs[1] = {out};
+    return n3d_texture_project_planes(textures, grid, outs, &view_a, &view_b, 1, N, C, TH, TW, H, W, views, stream_);
+}
+
+int n3d_texture_project_planes(const float* textures, const float* grid, float* const* outs, const int* view_a, const int* view_b,
+                               int planes, int N, int C, int TH, int TW, int H, int W, int views, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    N3D_CHECK(N >= 0 && C > 0 && view_a >= 0 && view_a < views && view_b < views, "texture_project: bad arguments");
+    N3D_CHECK(N >= 0 && C > 0 && planes >= 1 && planes <= 4 && outs && view_a && view_b, "texture_project: bad arguments");
     if (N == 0) return 0;
-    N3D_CHECK(textures && grid && out, "texture_project: null tensor");
-    N3dProfScope prof(N3D_K_RASTER, stream, 8.0 * N * C * (double)H * W, 4.0 * N * C * ((double)H * W + (double)TH * TW));
-    hipLaunchKernelGGL(texture_project_kernel, dim3((unsigned)cdiv64((int64_t)N * H * W, 256)), dim3(256), 0, stream, textures, grid,
-                       out, N, C, TH, TW, H, W, views, view_a, view_b);
+    N3D_CHECK(textures && grid, "texture_project: null tensor");
+    TexProjPlanes pl = {};
+    for (int k = 0; k < planes; ++k) {
+        N3D_CHECK(outs[k] && view_a[k] >= 0 && view_a[k] < views && view_b[k] < views, "texture_project: bad plane %d", k);
+        pl.out[k] = outs[k]; pl.view_a[k] = view_a[k]; pl.view_b[k] = view_b[k];
+    }
+    N3dProfScope prof(N3D_K_RASTER, stream, 8.0 * planes * N * C * (double)H * W, 4.0 * planes * N * C * ((double)H * W + (double)TH * TW));
+    hipLaunchKernelGGL(texture_project_kernel, dim3((unsigned)cdiv64((int64_t)N * H * W, 256), planes), dim3(256), 0, stream, textures, grid,
+                       pl, N, C, TH, TW, H, W, views);
     N3D_LAUNCH_CHECK();
     return 0;
 }

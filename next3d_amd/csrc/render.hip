@@ -287,14 +287,20 @@ __global__ __launch_bounds__(64) void render_rays_kernel(RenderParams p) {
     }
 }
 
-// global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them)
-__global__ __launch_bounds__(1024) void render_depth_bounds_kernel(const float* __restrict__ tlin, const float* __restrict__ jitter,
-                                                                   int64_t rays, int Sc, float delta, float* __restrict__ bounds) {
-    __shared__ float smin[16], smax[16];
-    float lo = INFINITY, hi = -INFINITY;
-    for (int64_t r = threadIdx.x; r < rays; r += blockDim.x) {
-        lo = fminf(lo, __fadd_rn(tlin[0], __fmul_rn(jitter[r * Sc], delta)));
-        hi = fmaxf(hi, __fadd_rn(tlin[Sc - 1], __fmul_rn(jitter[r * Sc + Sc - 1], delta)));
+// global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
+// block reduces a slice and merges with integer atomics on the float bit patterns (the depths are positive, so the bit
+// patterns order like the values); bounds_ws is initialised by a one-thread launch in front.
+__global__ void render_depth_bounds_init_kernel(float* __restrict__ bounds) {
+    bounds[0] = INFINITY; bounds[1] = 0.f;
+}
+__global__ __launch_bounds__(256) void render_depth_bounds_kernel(const float* __restrict__ tlin, const float* __restrict__ jitter,
+                                                                  int64_t rays, int Sc, float delta, float* __restrict__ bounds) {
+    __shared__ float smin[4], smax[4];
+    float lo = INFINITY, hi = 0.f;
+    const float t0 = tlin[0], t1 = tlin[Sc - 1];
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (int64_t)gridDim.x * blockDim.x) {
+        lo = fminf(lo, __fadd_rn(t0, __fmul_rn(jitter[r * Sc], delta)));
+        hi = fmaxf(hi, __fadd_rn(t1, __fmul_rn(jitter[r * Sc + Sc - 1], delta)));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(1024) void render_depth_bounds_kernel(const float* 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
-        bounds[0] = lo; bounds[1] = hi;
+        atomicMin(reinterpret_cast<unsigned int*>(bounds), __float_as_uint(lo));
+        atomicMax(reinterpret_cast<unsigned int*>(bounds) + 1, __float_as_uint(hi));
     }
 }
 
@@ -397,8 +404,11 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
-    hipLaunchKernelGGL(render_depth_bounds_kernel, dim3(1), dim3(1024), 0, stream, tlin, jitter, (int64_t)N * R * R, Sc,
-                       depth_delta, bounds_ws);
+    hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, bounds_ws);
+    N3D_LAUNCH_CHECK();
+    const int64_t nrays = (int64_t)N * R * R;
+    hipLaunchKernelGGL(render_depth_bounds_kernel, dim3((unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256))), dim3(256), 0, stream,
+                       tlin, jitter, nrays, Sc, depth_delta, bounds_ws);
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(render_rays_kernel, dim3(R * R, N), dim3(64), lds, stream, p);
     N3D_LAUNCH_CHECK();

@@ -217,13 +217,14 @@ class TriPlaneGenerator(torch.nn.Module):
     def project_textures(self, textures, grid):
         """reference triplane_next3d.py:223-230: sample the neural texture through the rasterised uv grids -> [front, side, top]."""
         N, views, H, W = textures.shape[0], len(RENDERING_VIEWS), 256, 256
-        L = _lib.lib()
-        planes = []
-        for va, vb in ((0, -1), (1, 2), (3, -1)):
-            out = torch.empty(N, textures.shape[1], H, W, dtype=torch.float32, device=textures.device)
-            _lib.check(L.n3d_texture_project(_lib.ptr(textures), _lib.ptr(grid), _lib.ptr(out), N, textures.shape[1],
-                                             textures.shape[2], textures.shape[3], H, W, views, va, vb, _lib.stream()))
-            planes.append(out)
+        import ctypes
+        cfg = ((0, -1), (1, 2), (3, -1))                     # front, side (views 1 + 2), top
+        planes = [torch.empty(N, textures.shape[1], H, W, dtype=torch.float32, device=textures.device) for _ in cfg]
+        outs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in planes])
+        va = (ctypes.c_int * 3)(*[a for a, _ in cfg])
+        vb = (ctypes.c_int * 3)(*[b for _, b in cfg])
+        _lib.check(_lib.lib().n3d_texture_project_planes(_lib.ptr(textures), _lib.ptr(grid), outs, va, vb, 3, N, textures.shape[1],
+                                                         textures.shape[2], textures.shape[3], H, W, views, _lib.stream()))
         return planes
 
     def rasterize(self, v, lms, textures):
