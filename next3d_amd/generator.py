@@ -189,7 +189,7 @@ class TriPlaneGenerator(torch.nn.Module):
     def raster_geometry(self, v, lms):
         """The texture-independent half of `rasterize` (reference triplane_next3d.py:190-222): z-buffer the four orthographic
         views of the mesh -> (uv sampling grid [N*4,256,256,2], alpha [N,3,256,256], mouth box [N,4] int32).  It depends only
-        on the vertices, so `_planes` issues it on the side stream, under the texture backbone's convolutions."""
+        on the vertices; `_planes` runs it first, before any other stream is active."""
         S = self._prep()
         dev, N, V, Lm, F = v.device, v.shape[0], v.shape[1], lms.shape[1], S.faces.shape[0]
         views, H, W = len(RENDERING_VIEWS), 256, 256

@@ -1,0 +1,369 @@
+"""-m gpu parity of the non-convolution kernels of the path — rasteriser + flood fill, texture projection, mouth box,
+antialiased resize, plane blend, volume renderer, point queries — each called through the C ABI (include/n3d.h) on small
+seeded inputs and compared with the CPU oracle (oracle/raster.py + raster_ref.c, oracle/renderer.py) or with the ATen op
+the reference calls.  The whole-generator goldens (test_generator_gpu.py) cover the same kernels on the demo mesh only;
+these cases add ragged sizes, degenerate / duplicated faces, out-of-range sampling coordinates and empty batches."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cases, generator as ogen, raster, renderer
+
+pytestmark = pytest.mark.gpu
+VIEWS = ogen.RENDERING_VIEWS
+
+
+def _gen(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _rand(shape, seed, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def _md(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ rasteriser
+def _soup(seed, n_faces=80):
+    """Random overlapping triangles; the last three faces are a duplicate of face 0 (a z tie: the lower index must win,
+    its uv attributes differ), a zero-area face and a face with a repeated vertex."""
+    v = _rand((1, 3 * n_faces, 3), seed, -0.11, 0.11)
+    faces = torch.arange(3 * n_faces, dtype=torch.int64).reshape(n_faces, 3)
+    faces = torch.cat([faces, faces[:1], torch.tensor([[5, 5, 9]]), torch.tensor([[3, 4, 3]])], 0)
+    uv = _rand((faces.shape[0], 3, 3), seed + 1, -1.0, 1.0)
+    return v, faces, uv
+
+
+def _cube(half=0.07):
+    """Closed box, turned so that no face is edge-on in any of the four views (an edge-on face is a sliver one float ulp
+    wide, whose coverage would depend on the rounding of the vertex transform): 2-3 big faces per view."""
+    s = half
+    v = torch.tensor([[[-s, -s, -s], [s, -s, -s], [s, s, -s], [-s, s, -s], [-s, -s, s], [s, -s, s], [s, s, s], [-s, s, s]]],
+                     dtype=torch.float32) * torch.tensor([1.0, 0.83, 0.91])
+    v = torch.matmul(v, raster.angle2matrix([17.0, 24.0, 9.0])[0])
+    quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (3, 2, 6, 7), (4, 5, 1, 0)]
+    faces = []
+    for a, b, c, d in quads:                       # both windings: whatever the view, one of each pair is front-facing
+        faces += [[a, b, c], [a, c, d], [a, c, b], [a, d, c]]
+    faces = torch.tensor(faces, dtype=torch.int64)
+    uvq = torch.tensor([[-0.9, -0.9, 1.0], [0.9, -0.9, 1.0], [0.9, 0.9, 1.0], [-0.9, 0.9, 1.0]])
+    corner = {0: 0, 1: 1, 2: 2, 3: 3, 4: 1, 5: 0, 6: 3, 7: 2}
+    uv = torch.stack([torch.stack([uvq[corner[int(i)]] for i in f]) for f in faces])
+    return v, faces, uv
+
+
+def _oracle_views(v, lms, faces, face_uv, mask, size, fill, binarize_view):
+    """oracle.generator.rasterize (triplane_next3d.py:190-222) for an arbitrary mesh, mask and image size."""
+    N = v.shape[0]
+    grids, alphas = [], []
+    for k, view in enumerate(VIEWS):
+        tform = raster.angle2matrix(view)
+        tv = raster.orth_project(v, tform, ogen.ORTH_SHIFT, ogen.ORTH_SCALE)
+        tv[:, :, 2] = tv[:, :, 2] + 10
+        rendering = raster.pytorch3d_rasterizer(tv, faces, face_uv, size)
+        vis = rendering[:, -1:]
+        grid = rendering[:, :-1].permute(0, 2, 3, 1)[:, :, :, :2]
+        alpha = F.grid_sample(mask[None, None].expand(N, -1, -1, -1), grid, align_corners=False) * vis
+        if fill:
+            alpha = raster.fill_mouth(alpha)
+            if k == binarize_view:
+                alpha = alpha.bool().float()
+        grids.append(grid)
+        alphas.append(alpha[:, 0])
+    lm2d = raster.orth_project(lms, raster.angle2matrix(VIEWS[0]), ogen.ORTH_SHIFT, ogen.ORTH_SCALE)[:, :, :2]
+    return torch.stack(grids, 1), torch.stack(alphas, 1), lm2d          # [N,4,S,S,2], [N,4,S,S], [N,Lm,2]
+
+
+def _gpu_views(dev, v, lms, faces, face_uv, mask, size, fill, binarize_view):
+    from next3d_amd import _lib
+    N, V, Lm, Fn, nv = v.shape[0], v.shape[1], lms.shape[1], faces.shape[0], len(VIEWS)
+    rot = torch.cat([raster.angle2matrix(a) for a in VIEWS], 0).contiguous().to(dev)
+    t = dict(dtype=torch.float32, device=dev)
+    tv, zb = torch.empty(N * nv * V * 3, **t), torch.empty(N * nv * size * size, dtype=torch.int64, device=dev)
+    grid, alpha, lm2d = torch.empty(N * nv, size, size, 2, **t), torch.empty(N, nv, size, size, **t), torch.empty(N, Lm, 2, **t)
+    vd, ld, fd = v.contiguous().to(dev), lms.contiguous().to(dev), faces.to(torch.int32).contiguous().to(dev)
+    ud, md = face_uv.contiguous().to(dev), mask.contiguous().to(dev)
+    sh = ogen.ORTH_SHIFT.reshape(-1).tolist()
+    _lib.check(_lib.lib().n3d_rasterize_views(_lib.ptr(vd), _lib.ptr(ld), _lib.ptr(rot), _lib.ptr(fd), _lib.ptr(ud), _lib.ptr(md),
+                                              mask.shape[0], mask.shape[1], _lib.ptr(tv), _lib.ptr(zb), _lib.ptr(grid), _lib.ptr(alpha),
+                                              _lib.ptr(lm2d), N, V, Lm, Fn, nv, size, size, sh[0], sh[1], sh[2], float(ogen.ORTH_SCALE.item()),
+                                              1 if fill else 0, binarize_view, _lib.stream()))
+    torch.cuda.synchronize()
+    return grid.reshape(N, nv, size, size, 2).cpu(), alpha.cpu(), lm2d.cpu()
+
+
+@pytest.mark.parametrize('size', [256, 100, 64])
+def test_rasterize_views_triangle_soup(dev, size):
+    """Coverage, z order, tie rule and barycentric uv of random overlapping triangles against oracle/raster_ref.c.  The
+    vertex transform is evaluated in a different order on the two sides, so a pixel whose centre sits within rounding of an
+    edge (or of two equally deep faces) may resolve differently: at most 0.1 % of the pixels may disagree."""
+    v0, faces, uv = _soup(11 + size)
+    v = torch.cat([v0, v0.flip(1) * 0.9], 0)                                       # batch of 2 different meshes
+    lms = _rand((2, 68, 3), 5, -0.1, 0.1)
+    mask = torch.ones(8, 8)
+    g_ref, a_ref, l_ref = _oracle_views(v, lms, faces, uv, mask, size, False, -1)
+    g, a, l = _gpu_views(dev, v, lms, faces, uv, mask, size, False, -1)
+    cov, cov_ref = a > 0, a_ref > 0                                                # alpha = mask sample (> 0 inside the mask) x visibility
+    cov_bad = float((cov != cov_ref).float().mean())
+    uv_err = (g - g_ref).abs().amax(-1)
+    uv_bad = float((uv_err > 1e-4).float().mean())
+    same = uv_err <= 1e-4
+    print(f'size {size}: coverage {float(cov_ref.float().mean()):.3f}, coverage mismatch {cov_bad:.2e}, uv mismatch {uv_bad:.2e}, '
+          f'lm2d {_md(l, l_ref):.2e}')
+    assert 0.05 < float(cov_ref.float().mean()) < 0.95
+    assert cov_bad <= 1e-3 and uv_bad <= 1e-3
+    assert float((a - a_ref).abs()[same].max()) <= 1e-4
+    assert _md(l, l_ref) <= 1e-6
+
+
+def test_rasterize_views_tie_rule_and_empty_batch(dev):
+    """Two coincident triangles (both windings, so every view that sees them sees a tie): the LOWER face index must win
+    (PyTorch3D keeps the first face on equal depth) — the faces carry different uv attributes, so a wrong winner shows on
+    every covered pixel.  N = 0 is a no-op."""
+    from next3d_amd import _lib
+    v = torch.tensor([[[-0.09, -0.07, 0.01], [0.08, -0.05, 0.03], [0.01, 0.09, -0.02]]])
+    faces = torch.tensor([[0, 1, 2], [0, 1, 2], [0, 2, 1], [0, 2, 1]])
+    uv = torch.stack([torch.full((3, 3), x) for x in (-0.6, 0.7, 0.2, -0.3)])
+    lms = torch.zeros(1, 68, 3)
+    g_ref, a_ref, _ = _oracle_views(v, lms, faces, uv, torch.ones(4, 4), 64, False, -1)
+    g, a, _ = _gpu_views(dev, v, lms, faces, uv, torch.ones(4, 4), 64, False, -1)
+    seen = a_ref > 0
+    assert int(seen[0, 0].sum()) > 100
+    vals = {round(float(x), 3) for x in torch.unique(g_ref[seen])}
+    assert vals <= {-0.6, 0.2} and len(vals) >= 1                       # faces 0 / 2 win, never 1 / 3
+    assert float(((g - g_ref).abs().amax(-1) > 1e-5).float().mean()) <= 1e-3
+    p = _lib.ptr(torch.zeros(16, device=dev))
+    assert _lib.lib().n3d_rasterize_views(p, p, p, p, p, p, 4, 4, p, p, p, p, p, 0, 3, 68, 4, 4, 64, 64, 0.0, 0.0, 0.0, 5.0, 1, 1,
+                                          _lib.stream()) == 0
+
+
+@pytest.mark.parametrize('size', [256, 100])
+def test_rasterize_views_fill_mouth(dev, size):
+    """fill_mouth (vr/renderer.py:583-602, cv2.floodFill from (0,0) in FIXED_RANGE mode): a box whose faces sample a uv
+    mask with interior holes, a notch open to the border and grey (bilinearly interpolated) rims.  Interior holes become 1,
+    the border-connected background stays, view 1 is additionally binarised (the reference's alpha_side)."""
+    v, faces, uv = _cube()
+    v = torch.cat([v, v * torch.tensor([0.8, 1.1, 0.7])], 0)
+    lms = _rand((2, 68, 3), 6, -0.1, 0.1)
+    mask = torch.ones(32, 32)
+    mask[6:10, 7:12] = 0; mask[20:27, 18:22] = 0; mask[14:16, 3:5] = 0.5; mask[:5, 14:17] = 0; mask[28:, :] = 0
+    _, a_nofill, _ = _oracle_views(v, lms, faces, uv, mask, size, False, -1)
+    g_ref, a_ref, _ = _oracle_views(v, lms, faces, uv, mask, size, True, 1)
+    g, a, _ = _gpu_views(dev, v, lms, faces, uv, mask, size, True, 1)
+    filled = int(((a_ref == 1) & (a_nofill < 1)).sum())
+    bad = int(((a * 255).round() != (a_ref * 255).round()).sum())
+    print(f'size {size}: pixels the fill changed {filled}, mismatching {bad}, uv err {_md(g, g_ref):.2e}')
+    assert filled > 50                                             # the case does exercise the fill
+    assert bad <= 4
+    assert _md(a[:, 1], a[:, 1].bool().float()) == 0
+    g2, a2, _ = _gpu_views(dev, v, lms, faces, uv, mask, size, False, -1)
+    assert int(((a2 * 255).round() != (a_nofill * 255).round()).sum()) <= 4 and torch.equal(g2, g)
+
+
+def test_texture_project_matches_grid_sample(dev):
+    """triplane_next3d.py:223-230: F.grid_sample(textures, uv, bilinear, zeros, align_corners=False), the side plane being
+    the sum of two views; coordinates beyond [-1,1] exercise the zero padding.  One-plane and three-plane entry points."""
+    from next3d_amd import _lib
+    N, C, TH, TW, S, nv = 2, 5, 24, 40, 33, 4
+    tex = _gen((N, C, TH, TW), 21)
+    grid = _rand((N * nv, S, S, 2), 22, -1.3, 1.3)
+    grid[0, :4, :4] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0], [-1.0 + 1.0 / TW, 1.0 - 1.0 / TH]])[None, :, :].expand(4, -1, -1)
+    gs = lambda view: F.grid_sample(tex, grid.reshape(N, nv, S, S, 2)[:, view], mode='bilinear', padding_mode='zeros', align_corners=False)
+    ref = [gs(0), gs(1) + gs(2), gs(3)]
+    td, gd = tex.to(dev), grid.to(dev)
+    outs = [torch.empty(N, C, S, S, device=dev) for _ in range(3)]
+    L = _lib.lib()
+    _lib.check(L.n3d_texture_project_planes(_lib.ptr(td), _lib.ptr(gd), (ctypes.c_void_p * 3)(*[o.data_ptr() for o in outs]),
+                                            (ctypes.c_int * 3)(0, 1, 3), (ctypes.c_int * 3)(-1, 2, -1), 3, N, C, TH, TW, S, S, nv, _lib.stream()))
+    for o, r in zip(outs, ref):
+        assert _md(o, r) <= 2e-6 * max(1.0, float(r.abs().max()))
+    one = torch.empty(N, C, S, S, device=dev)
+    _lib.check(L.n3d_texture_project(_lib.ptr(td), _lib.ptr(gd), _lib.ptr(one), N, C, TH, TW, S, S, nv, 1, 2, _lib.stream()))
+    assert torch.equal(one, outs[1])
+    assert L.n3d_texture_project(None, None, _lib.ptr(one), 0, C, TH, TW, S, S, nv, 0, -1, _lib.stream()) == 0      # empty batch
+    assert L.n3d_texture_project(_lib.ptr(td), _lib.ptr(gd), _lib.ptr(one), N, C, TH, TW, S, S, nv, 4, -1, _lib.stream()) != 0
+    assert 'texture_project' in L.n3d_last_error().decode()
+
+
+def test_mouth_bbox_matches_gen_mouth_mask(dev):
+    """gen_mouth_mask (triplane_next3d.py:330-344): numpy float32 extents, int truncation, python floor division —
+    bit-exact on random landmark sets, including boxes that leave the image and negative coordinates."""
+    from next3d_amd import _lib
+    lm = _rand((96, 68, 2), 31, -0.9, 0.9)
+    lm[:32] *= 0.25                                    # small mouths (the realistic regime: 30-60 pixel boxes)
+    lm[90:] -= 1.2                                     # negative pixel coordinates
+    ref = raster.gen_mouth_mask(lm)
+    out = torch.empty(96, 4, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().n3d_mouth_bbox(_lib.ptr(lm.to(dev)), _lib.ptr(out), 96, 68, _lib.stream()))
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), np.asarray(ref).astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------------ antialiased resize
+def _resize(dev, src, dst, src_box, dst_box, dst_square):
+    from next3d_amd import _lib
+    N, C, SH, SW = src.shape
+    _lib.check(_lib.lib().n3d_resize_aa(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(src_box), _lib.ptr(dst_box), N, C, SH, SW, dst.shape[2],
+                                        dst.shape[3], dst_square, _lib.stream()))
+    return dst
+
+
+@pytest.mark.parametrize('shape,out', [((2, 3, 256, 256), (64, 64)), ((1, 4, 64, 64), (128, 128)), ((1, 2, 37, 53), (20, 64)),
+                                       ((2, 2, 128, 128), (128, 128)), ((1, 1, 200, 90), (7, 5))])
+def test_resize_aa_matches_aten(dev, shape, out):
+    """F.interpolate(mode='bilinear', antialias=True, align_corners=False) (superresolution.py:282-286): down-, up- and
+    mixed scaling, identity."""
+    x = _gen(shape, 41)
+    ref = F.interpolate(x, size=out, mode='bilinear', align_corners=False, antialias=True)
+    y = _resize(dev, x.to(dev), torch.empty(shape[0], shape[1], *out, device=dev), None, None, 0)
+    assert _md(y, ref) <= 5e-6
+
+
+def test_resize_aa_crop_and_paste_boxes(dev):
+    """The mouth crop (triplane_next3d.py:151-152: per-sample box -> 64²) and the paste back (:156-163: 256² -> s×s into the
+    box, everything else untouched), boxes of different sizes per sample."""
+    x = _gen((3, 4, 256, 256), 42)
+    boxes = torch.tensor([[82, 122, 108, 148], [10, 67, 190, 247], [100, 200, 3, 103]], dtype=torch.int32)
+    crop = _resize(dev, x.to(dev), torch.empty(3, 4, 64, 64, device=dev), boxes.to(dev), None, 0)
+    for i, (y0, y1, x0, x1) in enumerate(boxes.tolist()):
+        ref = F.interpolate(x[i:i + 1, :, y0:y1, x0:x1], size=(64, 64), mode='bilinear', antialias=True)
+        assert _md(crop[i:i + 1], ref) <= 5e-6
+    src = _gen((3, 4, 256, 256), 43)
+    dst0 = _gen((3, 4, 256, 256), 44)
+    dst = _resize(dev, src.to(dev), dst0.clone().to(dev), None, boxes.to(dev), 1)
+    for i, (y0, y1, x0, x1) in enumerate(boxes.tolist()):
+        s = y1 - y0
+        ref = dst0[i:i + 1].clone()
+        ref[:, :, y0:y1, x0:x1] = F.interpolate(src[i:i + 1], size=(s, s), mode='bilinear', antialias=True)
+        assert _md(dst[i:i + 1], ref) <= 5e-6
+        outside = torch.ones(256, 256, dtype=torch.bool); outside[y0:y1, x0:x1] = False
+        assert torch.equal(dst[i].cpu()[:, outside], dst0[i][:, outside])
+
+
+# ------------------------------------------------------------------------------------------------ blend + renderer
+def test_blend_planes_and_layout(dev):
+    """triplane_next3d.py:171-174, written channels-last; n3d_planes_to_channels_last is the plain layout change."""
+    from next3d_amd import _lib
+    N, H, W = 2, 24, 40
+    front, side, top, stat = _gen((N, 32, H, W), 51), _gen((N, 32, H, W), 52), _gen((N, 32, H, W), 53), _gen((N, 96, H, W), 54)
+    alpha = _rand((N, 3, H, W), 55)
+    alpha[:, :, :4] = 0; alpha[:, :, 4:8] = 1
+    dyn = torch.cat([front, side, top], 1).view(N, 3, 32, H, W)
+    a = alpha.unsqueeze(2)
+    ref = dyn * a + stat.view(N, 3, 32, H, W) * (1 - a)
+    out = torch.empty(N, 3, H, W, 32, device=dev)
+    L = _lib.lib()
+    d = [t.to(dev) for t in (front, side, top, stat, alpha)]
+    _lib.check(L.n3d_blend_planes(*[_lib.ptr(t) for t in d], _lib.ptr(out), N, H, W, _lib.stream()))
+    assert _md(out.permute(0, 1, 4, 2, 3), ref) <= 1e-6
+    cl = torch.empty(N, 3, H, W, 32, device=dev)
+    refd = ref.contiguous().to(dev)
+    _lib.check(L.n3d_planes_to_channels_last(_lib.ptr(refd), _lib.ptr(cl), N, H, W, _lib.stream()))
+    assert torch.equal(cl.permute(0, 1, 4, 2, 3).cpu(), ref)
+
+
+def _decoder(seed):
+    """A seeded OSGDecoder (triplane_next3d.py:353-357) as the oracle's parameter dict and as the kernel's pre-scaled arrays."""
+    P = {'decoder.net.0.weight': _gen((64, 32), seed), 'decoder.net.0.bias': _gen((64,), seed + 1, 0.3),
+         'decoder.net.2.weight': _gen((33, 64), seed + 2), 'decoder.net.2.bias': _gen((33,), seed + 3, 0.3)}
+    w1 = (P['decoder.net.0.weight'] / np.sqrt(32)).contiguous()
+    w2t = torch.cat([(P['decoder.net.2.weight'] / np.sqrt(64)).t(), torch.zeros(64, 1)], 1).contiguous()
+    return P, (w1, P['decoder.net.0.bias'], w2t, P['decoder.net.2.bias'])
+
+
+def _channels_last(planes):
+    return planes.permute(0, 1, 3, 4, 2).contiguous()
+
+
+@pytest.mark.parametrize('R,Sc,Sf,PH,PW', [(8, 48, 48, 32, 32), (6, 24, 24, 16, 40), (5, 96, 96, 32, 32), (4, 12, 0, 8, 8), (4, 64, 17, 24, 24)])
+def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
+    """Ray sampler + two-pass importance renderer + decoder + ray marcher (vr/renderer.py:95-268, vr/ray_marcher.py:27-66)
+    on random tri-planes: 48+48 (the headline configuration), 24+24, 96+96 (gen_videos' sampling multiplier 2), coarse only,
+    and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star); the importance pass is
+    discontinuous in the coarse weights, so at most 1 % of the rays may exceed it."""
+    from next3d_amd import _lib, camera_utils
+    N = 2
+    planes = _gen((N, 3, 32, PH, PW), 60 + R, 2.0)
+    P, (w1, b1, w2t, b2) = _decoder(61)
+    c = torch.cat([camera_utils.demo_camera_params(angle_y=a, angle_p=-0.2)[0] for a in (0.35, -0.3)], 0).float()
+    ray_o, ray_d = renderer.ray_sampler(c[:, :16].reshape(N, 4, 4), c[:, 16:25].reshape(N, 3, 3), R)
+    jitter, u = cases.rng_inputs(N, R, Sc, max(Sf, 1))
+    u = u[:, :Sf]
+    opts = dict(depth_resolution=Sc, depth_resolution_importance=Sf, ray_start=2.25, ray_end=3.3, box_warp=1)
+    rgb, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, opts, jitter, u)
+    t = dict(dtype=torch.float32, device=dev)
+    feat, dep, ws_, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(N, R * R, **t), torch.empty(2, **t)
+    d = [x.contiguous().to(dev) for x in (_channels_last(planes), c[:, :16], c[:, 16:25], torch.linspace(2.25, 3.3, Sc), jitter,
+                                           u if Sf else torch.zeros(1), w1, b1, w2t, b2)]
+    _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
+                                          Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
+    e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
+    e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
+    e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
+    print(f'R{R} {Sc}+{Sf}: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, '
+          f'wsum max {float(e_w.max()):.2e}')
+    for e in (e_rgb, e_dep, e_w):
+        assert float((e > 1e-3).float().mean()) <= 0.01
+        assert float(e.median()) <= 1e-4
+
+
+def test_render_rays_empty_space(dev):
+    """Zero density everywhere: all weights are 0, the composite colour is 0 (-> -1 after rgb*2-1), the depth is 0/0 ->
+    nan_to_num(inf) -> clamped to the GLOBAL maximum sample depth of the batch (ray_marcher.py:52-54; the kernel's
+    depth-bounds pre-pass), identically for every ray."""
+    from next3d_amd import _lib, camera_utils
+    N, R, Sc, Sf, PH, PW = 3, 16, 48, 48, 8, 8
+    planes = torch.zeros(N, 3, 32, PH, PW)
+    P, (w1, b1, w2t, b2) = _decoder(62)
+    b2 = b2.clone(); b2[0] = -200.0
+    P['decoder.net.2.bias'] = b2
+    c = torch.cat([camera_utils.demo_camera_params(angle_y=a, angle_p=-0.1)[0] for a in (0.3, 0.0, -0.3)], 0).float()
+    ray_o, ray_d = renderer.ray_sampler(c[:, :16].reshape(N, 4, 4), c[:, 16:25].reshape(N, 3, 3), R)
+    jitter, u = cases.rng_inputs(N, R, Sc, Sf, seed=7)
+    opts = dict(depth_resolution=Sc, depth_resolution_importance=Sf, ray_start=2.25, ray_end=3.3, box_warp=1)
+    rgb, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, opts, jitter, u)
+    assert float(wsum.max()) == 0 and float(depth.min()) == float(depth.max()) > 3.3
+    t = dict(dtype=torch.float32, device=dev)
+    feat, dep, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(2, **t)
+    d = [x.contiguous().to(dev) for x in (_channels_last(planes), c[:, :16], c[:, 16:25], torch.linspace(2.25, 3.3, Sc), jitter, u, w1, b1, w2t, b2)]
+    _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), None, _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
+                                          float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
+    assert float(feat.min()) == -1.0 and float(feat.max()) == -1.0
+    assert _md(dep, torch.full_like(dep, float(depth.max())).cpu()) <= 5e-7
+    lo = (torch.linspace(2.25, 3.3, Sc)[0] + jitter[:, :, 0, 0] * ((3.3 - 2.25) / (Sc - 1))).min()
+    assert abs(float(bounds[0]) - float(lo)) <= 5e-7 and abs(float(bounds[1]) - float(depth.max())) <= 5e-7
+
+
+def test_render_rays_rejects_bad_arguments(dev):
+    from next3d_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, device=dev)
+    p = _lib.ptr(x)
+    assert L.n3d_render_rays(p, p, p, p, p, p, p, p, p, p, p, p, None, p, 1, 4, 3, 0, 8, 8, 0.1, 2.0, _lib.stream()) != 0      # Sc < 4
+    assert 'render_rays' in L.n3d_last_error().decode()
+    assert L.n3d_render_rays(p, p, p, p, p, p, p, p, p, p, p, p, None, p, 1, 4, 200, 100, 8, 8, 0.1, 2.0, _lib.stream()) != 0  # too many samples
+    assert L.n3d_render_rays(None, p, p, p, p, p, p, p, p, p, p, p, None, p, 1, 4, 8, 0, 8, 8, 0.1, 2.0, _lib.stream()) != 0    # null planes
+
+
+@pytest.mark.parametrize('M', [1, 63, 257, 4099])
+def test_sample_points_matches_oracle(dev, M):
+    """ImportanceRenderer.run_model (vr/renderer.py:149-155) at ragged point counts; a third of the points lie outside the
+    box (grid_sample's zero padding)."""
+    from next3d_amd import _lib
+    N, PH, PW = 2, 20, 28
+    planes = _gen((N, 3, 32, PH, PW), 70, 0.7)
+    P, (w1, b1, w2t, b2) = _decoder(71)
+    coords = _rand((N, M, 3), 72 + M, -0.75, 0.75)
+    ref = ogen.run_model(P, planes, coords, dict(box_warp=1))
+    rgb, sigma = torch.empty(N, M, 32, device=dev), torch.empty(N, M, 1, device=dev)
+    d = [x.contiguous().to(dev) for x in (_channels_last(planes), coords, w1, b1, w2t, b2)]
+    _lib.check(_lib.lib().n3d_sample_points(*[_lib.ptr(x) for x in d], _lib.ptr(rgb), _lib.ptr(sigma), N, M, PH, PW, 2.0, _lib.stream()))
+    assert _md(rgb, ref['rgb']) <= 1e-4
+    assert _md(sigma, ref['sigma']) <= 1e-4 * max(1.0, float(ref['sigma'].abs().max()))
+    assert _lib.lib().n3d_sample_points(*[_lib.ptr(x) for x in d], _lib.ptr(rgb), _lib.ptr(sigma), N, 0, PH, PW, 2.0, _lib.stream()) == 0
