@@ -155,7 +155,7 @@ def main():
         _lib.prof_reset()
         c16, c32 = prof['conv2d_bf16x3'], prof['conv2d']
         if c16['ms'] >= c32['ms']:       # dominant kernel family: split-bf16 conv on the bf16 matrix cores
-            dom, name, peak = c16, ('3x3 split-bf16 conv family: conv2d_bf16x3_kernel + conv2d_up_bf16x3_kernel + conv2d_s2_bf16x3_kernel '
+            dom, name, peak = c16, ('3x3 split-bf16 conv family: conv2d_p_bf16x3_kernel (persistent) + conv2d_bf16x3_kernel + conv2d_up_bf16x3_kernel + conv2d_s2_bf16x3_kernel '
                                     '(all launches of the step)'), PEAK_BF16_MFMA_TFLOPS / 3.0
         else:                            # N3D_PRECISION=fp32: fp32-MFMA conv
             dom, name, peak = c32, 'conv2d_mfma_kernel (all launches of the step)', PEAK_FP32_MFMA_TFLOPS

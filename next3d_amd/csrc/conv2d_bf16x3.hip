@@ -38,6 +38,7 @@ struct Conv16Params {
 
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
+int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
 
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
 
@@ -716,7 +717,11 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     const dim3 grid((unsigned)nblk);
     if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
-    else if (big) hipLaunchKernelGGL((conv2d_bf16x3_kernel<8, false>), grid, dim3(512), 0, stream, p);
+    else if (big) {
+        int launched = 0;                  // several tiles per CU: the persistent kernel (K loop pipelined across tiles)
+        if (p.ksplit == 1 && p.dbg == 0 && conv2d_p_bf16x3_try_launch(d, p.tiles_x, p.tiles_y, stream, &launched) != 0) return -1;
+        if (!launched) hipLaunchKernelGGL((conv2d_bf16x3_kernel<8, false>), grid, dim3(512), 0, stream, p);
+    }
     else if (d->W < 32) hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, false>), grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();

@@ -217,6 +217,36 @@ def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 256, 256), (3, 48, 256, 144, 160), (3, 32, 128, 250, 200), (1, 128, 128, 512, 512)])
+def test_conv2d_bf16x3_persistent(dev, N, I, OC, H, W):
+    """Layers with >= 2 tiles per CU take the persistent kernel (conv2d_p_bf16x3.hip: K loop pipelined across tiles, epilogue
+    under the other wave role's MFMA block).  Cases: even tile counts; an odd number of 16-channel chunks (the LDS buffer parity
+    flips from tile to tile) with a tile count that does not divide by 8 XCDs x 32 workgroups; ragged image edges; the 512²
+    super-resolution shape.  Checked with the full layer epilogue (style, demodulation, noise, bias, leaky ReLU, clamp), with the
+    bare linear epilogue, and against the plain kernel (forced by a split-K of 2)."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    assert _lib.lib().n3d_conv2d_bf16x3_blocks(N, OC, H, W, 0) >= 512
+    x, w = _gen((N, I, H, W), 80), _gen((OC, I, 3, 3), 81) / np.sqrt(I * 9)
+    s, d, b = _gen((N, I), 82), _gen((N, OC), 83).abs() + 0.5, _gen((OC,), 84)
+    noise, ns = _gen((H, W), 85), torch.tensor(0.4)
+    ref_plain = F.conv2d(x, w, padding=1)
+    ref_full = O.bias_act(F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None] * 0.8 + noise * ns, b, act='lrelu', gain=1.2, clamp=1.5)
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    y = cg.conv_launch(t(x), wt16, 3, 0, OC, ksplit=1, bf16x3=True)
+    err = float((y.cpu() - ref_plain).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_plain.abs().max())), err
+    y2 = cg.conv_launch(t(x), wt16, 3, 0, OC, ksplit=2, bf16x3=True)                 # split-K -> the plain kernel + reduction pass
+    assert float((y - y2).abs().max()) <= 2e-5 * max(1.0, float(ref_plain.abs().max()))
+    epi = _lib.make_epilogue(row_scale=t(d), noise=t(noise), noise_strength=t(ns), bias=t(b), const_scale=0.8, act='lrelu', gain=1.2, clamp=1.5)
+    y = cg.conv_launch(t(x), wt16, 3, 0, OC, style=t(s), epilogue=epi, ksplit=1, bf16x3=True)
+    err = float((y.cpu() - ref_full).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
+    assert torch.equal(y, cg.conv_launch(t(x), wt16, 3, 0, OC, style=t(s), epilogue=epi, ksplit=1, bf16x3=True))       # run-to-run bitwise
+
+
 @pytest.mark.parametrize('N,I,OC,H,W', [(2, 32, 128, 32, 32), (1, 64, 100, 7, 45), (1, 512, 256, 64, 64), (1, 16, 64, 4, 33),
                                        (4, 512, 512, 16, 16), (2, 128, 70, 8, 8), (1, 32, 64, 9, 13), (4, 64, 256, 66, 34),
                                        (1, 16, 64, 40, 3), (1, 16, 8, 1, 1)])
