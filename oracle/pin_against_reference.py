@@ -2,7 +2,8 @@
 """oracle/pin_against_reference.py — pins the oracle to the REAL reference and writes the golden
 fixtures (TEST INFRASTRUCTURE; runs only in the build container, where /root/reference exists).
 
-  python oracle/pin_against_reference.py            # compare + (re)write tests/golden/*.npz
+  python oracle/pin_against_reference.py                      # compare + (re)write tests/golden/*.npz
+  python oracle/pin_against_reference.py --only case_r64_s96  # one case; the shared fixtures are left untouched
 
 What it does, per case:
   1. builds the reference TriPlaneGenerator from its own constructors (oracle/ref_shims.py),
@@ -44,6 +45,9 @@ CASES = {
     'case_r32_s24': dict(seeds=[0], yaws=[0.4], R=32, Sc=24, Sf=24, psi=0.7),
     # BASELINE.json configs[1] shape at N=2: R=64, 48+48, two seeds / two cameras
     'case_r64_s48': dict(seeds=[1, 2], yaws=[0.0, -0.4], R=64, Sc=48, Sf=48, psi=0.7),
+    # gen_videos_next3d.py's default sampling multiplier 2: 96 + 96 samples, wide yaws, another
+    # truncation, BOTH meshes perturbed (4x the amplitude: other faces win the z-buffer, the mouth boxes change size)
+    'case_r64_s96': dict(seeds=[3, 4], yaws=[0.6, -0.6], R=64, Sc=96, Sf=96, psi=0.5, mesh_jitter=0.002, jitter_all=True),
 }
 
 
@@ -52,6 +56,7 @@ def sub(t, step):
 
 
 def main():
+    only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     uv_mask = n3d_mesh.synthetic_uv_face_mask()
@@ -61,9 +66,10 @@ def main():
     ref_sd = G.state_dict()
 
     # --- state-dict inventory (spec fixture)
-    with open(os.path.join(GOLDEN, 'ref_state_dict_spec.txt'), 'w') as fh:
-        for k in sorted(ref_sd):
-            fh.write(f'{k} {tuple(ref_sd[k].shape)} {ref_sd[k].dtype}\n')
+    if only is None:
+        with open(os.path.join(GOLDEN, 'ref_state_dict_spec.txt'), 'w') as fh:
+            for k in sorted(ref_sd):
+                fh.write(f'{k} {tuple(ref_sd[k].shape)} {ref_sd[k].dtype}\n')
 
     # --- synthetic weights -> reference
     sd = n3d_spec.synthetic_state_dict(seed=0)
@@ -80,8 +86,9 @@ def main():
 
     v_demo = n3d_mesh.parse_obj_vertices(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
     lms = n3d_mesh.parse_landmarks(os.path.join(ref_shims.REF, 'data/demo/demo_kpt2d.txt'))
-    np.savez_compressed(os.path.join(GOLDEN, 'demo_inputs.npz'), verts=v_demo[0].numpy(), landmarks=lms[0].numpy(),
-                        faces=faces.numpy().astype(np.int32), uvs=uvs.numpy(), uvfaces=uvfaces.numpy().astype(np.int32))
+    if only is None:
+        np.savez_compressed(os.path.join(GOLDEN, 'demo_inputs.npz'), verts=v_demo[0].numpy(), landmarks=lms[0].numpy(),
+                            faces=faces.numpy().astype(np.int32), uvs=uvs.numpy(), uvfaces=uvfaces.numpy().astype(np.int32))
 
     stages = {}
     hooks = []
@@ -97,6 +104,8 @@ def main():
 
     overall_ok = True
     for cname, cfg in CASES.items():
+        if only is not None and cname != only:
+            continue
         N = len(cfg['seeds'])
         R, Sc, Sf = cfg['R'], cfg['Sc'], cfg['Sf']
         G.rendering_kwargs['depth_resolution'] = Sc
@@ -116,7 +125,9 @@ def main():
         v = torch.cat((v_demo, lms), 1).repeat(N, 1, 1)
         if N > 1:   # perturb the second mesh a little so the batch is not degenerate
             g = torch.Generator().manual_seed(1234)
-            v[1] = v[1] + 0.0005 * torch.randn(v[1].shape, generator=g)
+            v[1] = v[1] + cfg.get('mesh_jitter', 0.0005) * torch.randn(v[1].shape, generator=g)
+            if cfg.get('jitter_all', False):
+                v[0] = v[0] + cfg.get('mesh_jitter', 0.0005) * torch.randn(v[0].shape, generator=g)
 
         jitter, u = cases.rng_inputs(N, R, Sc, Sf)
 

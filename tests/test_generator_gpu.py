@@ -39,7 +39,7 @@ def _md(a, b):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s96'])
 def test_forward_matches_reference_golden(G, dev, case, precision):
     from next3d_amd import layers
     layers.set_precision(precision)
@@ -80,7 +80,7 @@ def test_forward_matches_reference_golden(G, dev, case, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s96'])
 def test_sample_mixed_matches_reference_golden(G, dev, case):
     """G.sample / G.sample_mixed (shape-extraction point queries, triplane_next3d.py:232-322) against the reference's own
     outputs; the planes are cached on the first call and re-used by the second (the reference rebuilds them per chunk)."""
