@@ -22,11 +22,13 @@ def state():
     return sd
 
 
-def test_oracle_reproduces_reference_golden(state):
-    """configs[0] of BASELINE.json (1 seed, R=32, 24+24 samples, fp32 CPU): oracle == reference outputs, bit for bit."""
-    g = np.load(os.path.join(GOLDEN, 'case_r32_s24.npz'))
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s96'])
+def test_oracle_reproduces_reference_golden(state, case):
+    """configs[0] of BASELINE.json (1 seed, R=32, 24+24 samples, fp32 CPU) and the 96+96-sample case with two perturbed meshes
+    (mouth boxes of different sizes): oracle == reference outputs, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, case + '.npz'))
     R, Sc, Sf = int(g['R']), int(g['Sc']), int(g['Sf'])
-    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    jitter, u = cases.rng_inputs(g['z'].shape[0], R, Sc, Sf)
     rk = dict(RK, depth_resolution=Sc, depth_resolution_importance=Sf)
     ws = ogen.mapping(state, torch.from_numpy(g['z']), torch.from_numpy(g['c_cond']), rk, truncation_psi=float(g['psi']),
                       truncation_cutoff=int(g['cutoff']))
