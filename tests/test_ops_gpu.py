@@ -217,12 +217,13 @@ def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
 
 
-@pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 256, 256), (3, 48, 256, 144, 160), (3, 32, 128, 250, 200), (1, 128, 128, 512, 512)])
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 256, 256), (3, 48, 256, 144, 160), (3, 32, 128, 250, 200), (1, 128, 128, 512, 512),
+                                       (4, 512, 256, 128, 128)])
 def test_conv2d_bf16x3_persistent(dev, N, I, OC, H, W):
     """Layers with >= 2 tiles per CU take the persistent kernel (conv2d_p_bf16x3.hip: K loop pipelined across tiles, epilogue
     under the other wave role's MFMA block).  Cases: even tile counts; an odd number of 16-channel chunks (the LDS buffer parity
     flips from tile to tile) with a tile count that does not divide by 8 XCDs x 32 workgroups; ragged image edges; the 512²
-    super-resolution shape.  Checked with the full layer epilogue (style, demodulation, noise, bias, leaky ReLU, clamp), with the
+    super-resolution shape; the deepest eligible layer (512 input channels: 32 chunks, two style values per filling thread).  Checked with the full layer epilogue (style, demodulation, noise, bias, leaky ReLU, clamp), with the
     bare linear epilogue, and against the plain kernel (forced by a split-K of 2)."""
     import torch.nn.functional as F
     from next3d_amd import _lib
