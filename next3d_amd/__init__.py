@@ -26,4 +26,13 @@ def install_dropin(model=False):
         sys.modules['torch_utils.ops.' + name] = mod
         setattr(sys.modules['torch_utils.ops'], name, mod)
     if model:
-        sys.modules['training_avatar_texture.triplane_next3d'] = importlib.import_module(f'{__name__}.generator')
+        try:
+            parent = importlib.import_module('training_avatar_texture')
+        except ImportError:                                     # stand-alone use (no reference tree on sys.path): an empty parent package
+            import types
+            parent = types.ModuleType('training_avatar_texture')
+            parent.__path__ = []
+            sys.modules['training_avatar_texture'] = parent
+        gen = importlib.import_module(f'{__name__}.generator')
+        sys.modules['training_avatar_texture.triplane_next3d'] = gen
+        parent.triplane_next3d = gen

@@ -3,6 +3,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -167,3 +168,85 @@ def test_abi_struct_layouts_match_ctypes(tmp_path):
         assert got[(cname, 'size')] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_operator_api_matches_reference_signatures():
+    """B1: every function of the reference's operator layer exists here with the SAME argument list (names, order,
+    defaults) — `tests/golden/ref_ops_api.txt` is read off the reference's source by oracle/dump_ref_api.py.  Extra arguments
+    are allowed only after the reference's and only as private (`_name`) keywords."""
+    import ast
+    ops_dir = os.path.join(REPO, 'next3d_amd', 'torch_utils', 'ops')
+    checked = 0
+    for line in open(os.path.join(GOLDEN, 'ref_ops_api.txt')):
+        line = line.strip()
+        if not line:
+            continue
+        qual, ref_args = line.split('(', 1)
+        mod, name = qual.split('.')
+        ref_args = ref_args[:-1]
+        tree = ast.parse(open(os.path.join(ops_dir, mod + '.py')).read())
+        fns = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+        assert name in fns, f'{qual} is missing'
+        ours = ast.unparse(fns[name].args)
+        assert ours == ref_args or ours.startswith(ref_args + ', _'), f'{qual}: ({ours}) != reference ({ref_args})'
+        checked += 1
+    assert checked >= 17
+    from next3d_amd.torch_utils.ops import bias_act
+    # activation table: names, default alpha / gain and the plugin's activation index (bias_act.py:23-33) — read by the
+    # reference's layer constructors (networks_stylegan2.py:159,301)
+    want = {'linear': (0, 1, 1), 'relu': (0, np.sqrt(2), 2), 'lrelu': (0.2, np.sqrt(2), 3), 'tanh': (0, 1, 4), 'sigmoid': (0, 1, 5),
+            'elu': (0, 1, 6), 'selu': (0, 1, 7), 'softplus': (0, 1, 8), 'swish': (0, np.sqrt(2), 9)}
+    assert sorted(bias_act.activation_funcs) == sorted(want)
+    for k, (a, g, idx) in want.items():
+        spec_ = bias_act.activation_funcs[k]
+        assert (spec_.def_alpha, float(spec_.def_gain), spec_.cuda_idx) == (a, float(g), idx), k
+
+
+def test_install_dropin_aliases_reference_module_paths():
+    """install_dropin(): `torch_utils.ops.*` (and with model=True the generator module) resolve to this package — what makes
+    un-pickled reference network code call libn3d.so (torch_utils/persistence.py:218 resolves imports at load time)."""
+    import subprocess
+    code = ("import sys, next3d_amd; next3d_amd.install_dropin(model=True);"
+            "import torch_utils.ops.bias_act as b, torch_utils.ops.upfirdn2d as u, torch_utils.ops.conv2d_resample as c;"
+            "from torch_utils.ops import fma, filtered_lrelu, conv2d_gradfix;"
+            "import training_avatar_texture.triplane_next3d as t;"
+            "assert all(m.__name__.startswith('next3d_amd.') for m in (b, u, c, fma, filtered_lrelu, conv2d_gradfix, t)), "
+            "[m.__name__ for m in (b, u, c, t)];"
+            "assert hasattr(t, 'TriPlaneGenerator') and callable(u.setup_filter) and callable(c.conv2d_resample); print('ok')")
+    r = subprocess.run([sys.executable, '-c', code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
+def test_reference_network_code_binds_to_this_operator_layer():
+    """With install_dropin() the REFERENCE's own layer classes (training_avatar_texture/networks_stylegan2.py) import this
+    package's ops: the constructors read `bias_act.activation_funcs` / `upfirdn2d.setup_filter` from it, and a forward on CPU
+    tensors ends in this package's loud "HIP device only" error instead of the reference's `_ref` fallback — i.e. reference
+    network code un-pickled after install_dropin() runs on libn3d.so and nothing else."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+import torch
+from next3d_amd import mesh
+from oracle import ref_shims
+ref_shims.install(mesh.synthetic_uv_face_mask()[0, 0].numpy())
+import next3d_amd
+next3d_amd.install_dropin()
+from training_avatar_texture import networks_stylegan2 as ns
+assert ns.bias_act.__name__ == 'next3d_amd.torch_utils.ops.bias_act' and ns.conv2d_resample.__name__ == 'next3d_amd.torch_utils.ops.conv2d_resample'
+layer = ns.SynthesisLayer(16, 16, w_dim=32, resolution=8, up=2)
+rgb = ns.ToRGBLayer(16, 3, w_dim=32)
+fc = ns.FullyConnectedLayer(32, 16, activation='lrelu')
+assert tuple(layer.resample_filter.shape) == (4, 4) and abs(float(layer.resample_filter.sum()) - 1) < 1e-6
+x, w = torch.randn(1, 16, 4, 4), torch.randn(1, 32)
+for fn in (lambda: layer(x, w, noise_mode='const'), lambda: rgb(x, w), lambda: fc(w)):
+    try:
+        fn()
+    except RuntimeError as e:
+        assert 'HIP device' in str(e), e
+    else:
+        raise SystemExit('the reference layer ran on CPU: it did not go through libn3d.so')
+print('ok')
+""" % REPO
+    r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
