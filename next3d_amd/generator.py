@@ -93,6 +93,18 @@ class TriPlaneGenerator(torch.nn.Module):
                 t = torch.zeros(shape)
             _attach(self, name, t, is_buffer=(leaf in _BUFFER_LEAVES))
 
+        # plain attributes callers of the reference read on the sub-networks (viz/renderer.py:277,321: G.backbone.num_ws,
+        # G.backbone.mapping.w_avg; triplane_next3d.py:65: mapping_ws = 2 x texture_backbone.num_ws)
+        for net, (res, ch) in (('texture_backbone', (256, 32)), ('backbone', (256, 96)), ('mouth_backbone', (256, 32)),
+                               ('neural_blending', (256, 32))):
+            node = getattr(self, net)
+            node.z_dim, node.c_dim, node.w_dim, node.img_resolution, node.img_channels, node.num_ws = z_dim, c_dim, w_dim, res, ch, 14
+            node.synthesis.num_ws, node.synthesis.img_resolution, node.synthesis.img_channels = 14, res, ch
+            if hasattr(node, 'mapping'):
+                node.mapping.num_ws = 28 if net == 'backbone' else 14
+                node.mapping.z_dim, node.mapping.c_dim, node.mapping.w_dim, node.mapping.num_layers = z_dim, c_dim, w_dim, 2
+        self.superresolution.input_resolution = 128
+
         if uv_face_mask is None:      # reference: cv2.imread('data/ffhq/uv_face_eye_mask.png') (triplane_next3d.py:91)
             uv_face_mask = self._load_uv_mask('data/ffhq/uv_face_eye_mask.png')
         self.uv_face_mask = torch.nn.functional.interpolate(uv_face_mask.float(), [256, 256])

@@ -250,3 +250,39 @@ print('ok')
 """ % REPO
     r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
+def test_reload_modules_path_against_the_real_reference():
+    """B2, live: what `gen_samples_next3d.py --reload_modules=True` does (:151-157) — construct THIS TriPlaneGenerator
+    from the reference generator's init_args / init_kwargs and `misc.copy_params_and_buffers(G, G_new, require_all=True)` — with
+    the reference's own `misc` and a reference-built G; then every tensor must be equal and the attributes the scripts / viz read
+    must agree."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+import torch
+from next3d_amd import mesh
+from oracle import ref_shims, pin_against_reference as pin
+ref_shims.install(mesh.synthetic_uv_face_mask()[0, 0].numpy())
+G = ref_shims.build_reference_generator(pin.RENDERING_KWARGS)
+from torch_utils import misc                                            # the reference's
+from next3d_amd.generator import TriPlaneGenerator
+G_new = TriPlaneGenerator(*G.init_args, uv_face_mask=mesh.synthetic_uv_face_mask(), **G.init_kwargs).eval().requires_grad_(False)
+misc.copy_params_and_buffers(G, G_new, require_all=True)
+ref = dict(misc.named_params_and_buffers(G)); new = dict(misc.named_params_and_buffers(G_new))
+assert set(ref) == set(new), (sorted(set(ref) - set(new))[:5], sorted(set(new) - set(ref))[:5])
+for k, v in ref.items():
+    assert v.shape == new[k].shape and v.dtype == new[k].dtype and torch.equal(v.detach(), new[k].detach()), k
+for path in ('z_dim', 'c_dim', 'w_dim', 'img_resolution', 'img_channels', 'neural_rendering_resolution', 'backbone.num_ws',
+             'backbone.mapping.num_ws', 'texture_backbone.num_ws', 'backbone.img_channels', 'texture_backbone.img_channels',
+             'superresolution.input_resolution'):
+    a, b = G, G_new
+    for part in path.split('.'):
+        a, b = getattr(a, part), getattr(b, part)
+    assert a == b, (path, a, b)
+assert G_new.rendering_kwargs == G.rendering_kwargs and torch.equal(G.backbone.mapping.w_avg, G_new.backbone.mapping.w_avg)
+print('ok', len(ref))
+""" % REPO
+    r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
