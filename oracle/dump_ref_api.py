@@ -25,12 +25,27 @@ def signatures(path, names):
     return {name: found.get(name) for name in names}
 
 
+MODEL_METHODS = ['__init__', 'mapping', 'synthesis', 'sample', 'sample_mixed', 'forward']     # triplane_next3d.py:41-328 (B2)
+
+
+def class_methods(path, cls, names):
+    tree = ast.parse(open(path).read())
+    for n in tree.body:
+        if isinstance(n, ast.ClassDef) and n.name == cls:
+            found = {m.name: ast.unparse(m.args) for m in n.body if isinstance(m, ast.FunctionDef)}
+            return {name: found.get(name) for name in names}
+    raise KeyError(cls)
+
+
 def main():
     out = []
     for mod, names in API.items():
         for name, sig in signatures(os.path.join(REF, 'torch_utils', 'ops', mod + '.py'), names).items():
             assert sig is not None, (mod, name)
             out.append(f'{mod}.{name}({sig})')
+    for name, sig in class_methods(os.path.join(REF, 'training_avatar_texture', 'triplane_next3d.py'), 'TriPlaneGenerator', MODEL_METHODS).items():
+        assert sig is not None, name
+        out.append(f'TriPlaneGenerator.{name}({sig})')
     with open(os.path.join(REPO, 'tests', 'golden', 'ref_ops_api.txt'), 'w') as fh:
         fh.write('\n'.join(out) + '\n')
     print('\n'.join(out))

@@ -184,13 +184,27 @@ def test_operator_api_matches_reference_signatures():
         qual, ref_args = line.split('(', 1)
         mod, name = qual.split('.')
         ref_args = ref_args[:-1]
+        if mod == 'TriPlaneGenerator':        # B2: same leading arguments; extra keyword inputs only between them and **synthesis_kwargs
+            tree = ast.parse(open(os.path.join(REPO, 'next3d_amd', 'generator.py')).read())
+            cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'TriPlaneGenerator'][0]
+            ours = {m.name: ast.unparse(m.args) for m in cls.body if isinstance(m, ast.FunctionDef)}[name]
+            if not ref_args.endswith(', **synthesis_kwargs'):
+                assert ours == ref_args, (name, ours)
+                checked += 1
+                continue
+            lead = ref_args[:-len(', **synthesis_kwargs')]
+            assert ours.startswith(lead) and ours.endswith('**synthesis_kwargs'), (name, ours)
+            extra = ours[len(lead):-len('**synthesis_kwargs')].strip(', ')
+            assert all('=' in a for a in extra.split(', ') if a), f'{name}: extra positional argument in ({ours})'
+            checked += 1
+            continue
         tree = ast.parse(open(os.path.join(ops_dir, mod + '.py')).read())
         fns = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
         assert name in fns, f'{qual} is missing'
         ours = ast.unparse(fns[name].args)
         assert ours == ref_args or ours.startswith(ref_args + ', _'), f'{qual}: ({ours}) != reference ({ref_args})'
         checked += 1
-    assert checked >= 17
+    assert checked >= 23
     from next3d_amd.torch_utils.ops import bias_act
     # activation table: names, default alpha / gain and the plugin's activation index (bias_act.py:23-33) — read by the
     # reference's layer constructors (networks_stylegan2.py:159,301)
