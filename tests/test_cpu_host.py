@@ -300,3 +300,24 @@ print('ok', len(ref))
 """ % REPO
     r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_layout_grid_tiling():
+    """frames.layout_grid == the helper of gen_videos_next3d.py:35-49 (tiling part; the float -> uint8 conversion is a GPU kernel):
+    frame b lands at grid row b // grid_w, column b % grid_w."""
+    from next3d_amd import frames
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (6, 3, 4, 5), generator=g, dtype=torch.uint8)
+    for grid_w, grid_h in ((3, 2), (2, 3), (6, 1), (None, 2)):
+        out = frames.layout_grid(img, grid_w=grid_w, grid_h=grid_h, float_to_uint8=False)
+        gw = grid_w if grid_w is not None else 6 // grid_h
+        assert out.shape == (grid_h * 4, gw * 5, 3) and out.dtype == np.uint8
+        for b in range(6):
+            gy, gx = b // gw, b % gw
+            assert np.array_equal(out[gy * 4:(gy + 1) * 4, gx * 5:(gx + 1) * 5], img[b].permute(1, 2, 0).numpy())
+    chw = frames.layout_grid(img, grid_w=3, grid_h=2, float_to_uint8=False, chw_to_hwc=False, to_numpy=False)
+    assert tuple(chw.shape) == (3, 8, 15) and torch.equal(chw[:, 4:8, 5:10], img[4])
+    with pytest.raises(AssertionError):
+        frames.layout_grid(img, grid_w=4, grid_h=2, float_to_uint8=False)
+    with pytest.raises(RuntimeError):
+        frames.layout_grid(img.float(), grid_w=3, grid_h=2)          # CPU tensor: no fallback for the conversion

@@ -367,3 +367,15 @@ def test_sample_points_matches_oracle(dev, M):
     assert _md(rgb, ref['rgb']) <= 1e-4
     assert _md(sigma, ref['sigma']) <= 1e-4 * max(1.0, float(ref['sigma'].abs().max()))
     assert _lib.lib().n3d_sample_points(*[_lib.ptr(x) for x in d], _lib.ptr(rgb), _lib.ptr(sigma), N, 0, PH, PW, 2.0, _lib.stream()) == 0
+
+
+def test_layout_grid_uint8_frames(dev):
+    """The video scripts' output step (gen_videos_next3d.py:35-49, :171): float frames -> uint8 on the device -> tiled grid."""
+    from next3d_amd import frames
+    img = _gen((4, 3, 16, 24), 90, 0.8)
+    ref = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8)
+    out = frames.layout_grid(img.to(dev), grid_w=2, grid_h=2)
+    assert out.shape == (32, 48, 3) and out.dtype == np.uint8
+    for b in range(4):
+        gy, gx = b // 2, b % 2
+        assert np.array_equal(out[gy * 16:(gy + 1) * 16, gx * 24:(gx + 1) * 24], ref[b].permute(1, 2, 0).numpy())
