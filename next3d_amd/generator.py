@@ -33,6 +33,12 @@ def angle2matrix(angles_deg):
     return torch.reshape(R, (-1, 3, 3))
 
 
+def _require_hip(dev):
+    if dev.type != 'cuda':
+        raise RuntimeError('TriPlaneGenerator runs on a HIP device only: move it with .to("cuda") '
+                           '(no CPU fallback; the CPU restatement is oracle/, test infrastructure)')
+
+
 class _Node(torch.nn.Module):
     """Anonymous container used to reproduce the reference's dotted parameter names."""
 
@@ -140,9 +146,7 @@ class TriPlaneGenerator(torch.nn.Module):
         if self._prepared is not None:
             return self._prepared
         dev = self.device
-        if dev.type != 'cuda':
-            raise RuntimeError('TriPlaneGenerator runs on a HIP device only: move it with .to("cuda") '
-                               '(no CPU fallback; the CPU restatement is oracle/, test infrastructure)')
+        _require_hip(dev)
         _lib.lib()
         P = {k: v.detach() for k, v in self.state_dict().items()}
         S = type('Prepared', (), {})()
