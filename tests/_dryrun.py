@@ -1,0 +1,60 @@
+"""Recording stand-in for libn3d.so used by the CPU dry-run tests (tests/test_cpu_orchestration.py): marshals every argument as
+ctypes would, re-checks the convolution entry points' preconditions, launches nothing.  `patches()` -> (list of (object,
+attribute, replacement), list the recorder appends the entry-point names to)."""
+import contextlib
+
+import torch
+
+
+class _Stream:
+    cuda_stream = 0
+
+    def wait_stream(self, s): pass
+
+    def record_event(self): return None
+
+    def wait_event(self, e): pass
+
+
+def _check_conv_desc(name, d):
+    bf16x3 = name == 'n3d_conv2d_bf16x3'
+    assert d.N >= 0 and d.I > 0 and d.O > 0 and d.H > 0 and d.W > 0, (name, d.N, d.I, d.O, d.H, d.W)
+    assert d.x and d.wt and d.y, name
+    assert d.ksize in (1, 3) and 0 <= d.mode <= 2
+    if bf16x3:
+        assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)
+        assert d.x_row_stride in (0, d.W) or (d.ksize == 3 and d.mode == 1)
+        assert d.I * d.H * d.W * 4 < 2 ** 31
+        assert not (d.epi.residual_up_filter and d.ksize == 3)
+    ow = 2 * d.W + 1 if d.mode == 2 else ((d.W - 3) // 2 + 1 if (d.mode == 1 and d.ksize == 3) else d.W)
+    assert d.y_row_stride == 0 or d.y_row_stride >= ow, (name, d.mode, d.W, d.y_row_stride)
+    assert d.ksplit <= 1 or d.workspace, name
+    assert not d.epi.noise or d.epi.noise_strength
+    assert 1 <= d.epi.act <= 9
+
+
+def patches():
+    from next3d_amd import _lib, generator
+    real = _lib.lib()                                            # the built library loads without a GPU
+    calls = []
+
+    class Recorder:
+        def __getattr__(self, name):
+            res, argtypes = _lib._SIGNATURES[name]
+            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_abi_version', 'n3d_last_error'):
+                return getattr(real, name)                       # pure host functions: the real ones
+
+            def fn(*args):
+                assert len(args) == len(argtypes), (name, len(args), len(argtypes))
+                for a, t in zip(args, argtypes):
+                    t.from_param(a)                              # raises exactly where a real ctypes call would
+                if name in ('n3d_conv2d', 'n3d_conv2d_bf16x3'):
+                    _check_conv_desc(name, getattr(args[0], '_obj', args[0]))
+                calls.append(name)
+                return 0
+            return fn
+
+    rec = Recorder()
+    return [(_lib, 'lib', lambda: rec), (_lib, 'require_device', lambda *a: None), (_lib, 'stream', lambda: None),
+            (generator, '_require_hip', lambda d: None), (torch.cuda, 'current_stream', lambda *a, **k: _Stream()),
+            (torch.cuda, 'Stream', lambda *a, **k: _Stream()), (torch.cuda, 'stream', lambda s: contextlib.nullcontext())], calls

@@ -4,71 +4,23 @@ re-checks the preconditions the C entry points enforce (N3D_CHECK in conv2d_bf16
 It covers configurations the GPU tests do not run: batch 8 per GPU (BASELINE.json configs[3]), batch 3, a 128² neural render
 (no resize in front of the super-resolution, superresolution.py:282), coarse-only sampling, the cached call patterns.
 No arithmetic happens here (outputs are uninitialised memory); numerics are the GPU tests' business."""
-import contextlib
-import ctypes
+import os
+import subprocess
+import sys
 from collections import Counter
 
 import pytest
 import torch
 
 
-class _Stream:
-    cuda_stream = 0
-
-    def wait_stream(self, s): pass
-
-    def record_event(self): return None
-
-    def wait_event(self, e): pass
-
-
-def _check_conv_desc(name, d):
-    bf16x3 = name == 'n3d_conv2d_bf16x3'
-    assert d.N >= 0 and d.I > 0 and d.O > 0 and d.H > 0 and d.W > 0, (name, d.N, d.I, d.O, d.H, d.W)
-    assert d.x and d.wt and d.y, name
-    assert d.ksize in (1, 3) and 0 <= d.mode <= 2
-    if bf16x3:
-        assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)
-        assert d.x_row_stride in (0, d.W) or (d.ksize == 3 and d.mode == 1)
-        assert d.I * d.H * d.W * 4 < 2 ** 31
-        assert not (d.epi.residual_up_filter and d.ksize == 3)
-    ow = 2 * d.W + 1 if d.mode == 2 else ((d.W - 3) // 2 + 1 if (d.mode == 1 and d.ksize == 3) else d.W)
-    assert d.y_row_stride == 0 or d.y_row_stride >= ow, (name, d.mode, d.W, d.y_row_stride)
-    assert d.ksplit <= 1 or d.workspace, name
-    assert not d.epi.noise or d.epi.noise_strength
-    assert 1 <= d.epi.act <= 9
+import _dryrun
 
 
 @pytest.fixture
 def dry(monkeypatch):
-    from next3d_amd import _lib, generator
-    real = _lib.lib()                                            # the built library loads without a GPU
-    calls = []
-
-    class Recorder:
-        def __getattr__(self, name):
-            res, argtypes = _lib._SIGNATURES[name]
-            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_abi_version', 'n3d_last_error'):
-                return getattr(real, name)                       # pure host functions: the real ones
-
-            def fn(*args):
-                assert len(args) == len(argtypes), (name, len(args), len(argtypes))
-                for a, t in zip(args, argtypes):
-                    t.from_param(a)                              # raises exactly where a real ctypes call would
-                if name in ('n3d_conv2d', 'n3d_conv2d_bf16x3'):
-                    _check_conv_desc(name, getattr(args[0], "_obj", args[0]))
-                calls.append(name)
-                return 0
-            return fn
-
-    rec = Recorder()
-    monkeypatch.setattr(_lib, 'lib', lambda: rec)
-    monkeypatch.setattr(_lib, 'require_device', lambda *a: None)
-    monkeypatch.setattr(_lib, 'stream', lambda: None)
-    monkeypatch.setattr(generator, '_require_hip', lambda d: None)
-    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: _Stream())
-    monkeypatch.setattr(torch.cuda, 'Stream', lambda *a, **k: _Stream())
-    monkeypatch.setattr(torch.cuda, 'stream', lambda s: contextlib.nullcontext())
+    pts, calls = _dryrun.patches()
+    for obj, attr, val in pts:
+        monkeypatch.setattr(obj, attr, val)
     return calls
 
 
@@ -108,3 +60,46 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert tuple(smp['rgb'].shape) == (N, 1000, 32) and tuple(smp['sigma'].shape) == (N, 1000, 1) and dry == ['n3d_sample_points']
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R)     # noise_mode defaults to 'random' (training only)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
+def test_reference_networks_drive_this_operator_layer_dry_run():
+    """B1 at the call-pattern level: the REFERENCE's own SynthesisNetwork (StyleGAN2 texture backbone, fused
+    modulated convolutions = grouped conv2d_resample calls, up-sampling layers, toRGB + skip upsample) and its StyleUNet run on
+    this package's `torch_utils.ops.*` after install_dropin(), against the recording stand-in: every call the reference's network
+    code makes is accepted by this operator layer and ends in well-formed libn3d.so launches."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+import torch
+from collections import Counter
+from next3d_amd import mesh
+from oracle import ref_shims
+ref_shims.install(mesh.synthetic_uv_face_mask()[0, 0].numpy())
+import next3d_amd
+next3d_amd.install_dropin()
+import _dryrun
+pts, calls = _dryrun.patches()
+for obj, attr, val in pts:
+    setattr(obj, attr, val)
+from training_avatar_texture import networks_stylegan2 as ns, networks_stylegan2_styleunet as nu
+assert ns.conv2d_resample.__name__.startswith('next3d_amd.') and nu.upfirdn2d.__name__.startswith('next3d_amd.')
+with torch.no_grad():
+    net = ns.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=32, channel_base=32768, channel_max=512, num_fp16_res=0,
+                              fused_modconv_default='inference_only').eval().requires_grad_(False)
+    img = net(torch.randn(2, net.num_ws, 512), noise_mode='const')
+    assert tuple(img.shape) == (2, 32, 64, 64), img.shape
+    c1 = Counter(calls)
+    assert c1['n3d_conv2d'] + c1['n3d_conv2d_bf16x3'] >= 2 * (2 * 5 - 1 + 5) and c1['n3d_upfirdn2d'] + c1['n3d_upfirdn2d_pitched'] >= 4, c1
+    calls.clear()
+    unet = nu.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=32, in_size=64, final_size=16, cond_channels=32, num_cond_res=64,
+                               channel_base=32768, channel_max=512, num_fp16_res=0, fused_modconv_default='inference_only').eval().requires_grad_(False)
+    out = unet(torch.randn(1, 32, 64, 64), torch.randn(1, unet.num_ws, 512), noise_mode='const')
+    assert tuple(out.shape) == (1, 32, 64, 64), out.shape
+    c2 = Counter(calls)
+    assert c2['n3d_conv2d'] + c2['n3d_conv2d_bf16x3'] > 10 and c2['n3d_upfirdn2d'] + c2['n3d_upfirdn2d_pitched'] > 2, c2
+print('ok', dict(c1), dict(c2))
+""" % (repo, os.path.join(repo, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
