@@ -65,7 +65,8 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
 @pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
 def test_reference_networks_drive_this_operator_layer_dry_run():
     """B1 at the call-pattern level: the REFERENCE's own SynthesisNetwork (StyleGAN2 texture backbone, fused
-    modulated convolutions = grouped conv2d_resample calls, up-sampling layers, toRGB + skip upsample) and its StyleUNet run on
+    modulated convolutions = grouped conv2d_resample calls, up-sampling layers, toRGB + skip upsample), its StyleUNet and its
+    super-resolution module (superresolution.py:264-290, conv_clamp 256, 512² output) run on
     this package's `torch_utils.ops.*` after install_dropin(), against the recording stand-in: every call the reference's network
     code makes is accepted by this operator layer and ends in well-formed libn3d.so launches."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,7 +100,15 @@ with torch.no_grad():
     assert tuple(out.shape) == (1, 32, 64, 64), out.shape
     c2 = Counter(calls)
     assert c2['n3d_conv2d'] + c2['n3d_conv2d_bf16x3'] > 10 and c2['n3d_upfirdn2d'] + c2['n3d_upfirdn2d_pitched'] > 2, c2
-print('ok', dict(c1), dict(c2))
+    calls.clear()
+    from training_avatar_texture import superresolution as rsr
+    srn = rsr.SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True, channel_base=32768,
+                                        channel_max=512, fused_modconv_default='inference_only').eval().requires_grad_(False)
+    big = srn(torch.randn(1, 3, 64, 64), torch.randn(1, 32, 64, 64), torch.randn(1, 14, 512), noise_mode='none')
+    assert tuple(big.shape) == (1, 3, 512, 512), big.shape
+    c3 = Counter(calls)
+    assert c3['n3d_conv2d'] + c3['n3d_conv2d_bf16x3'] == 6 and c3['n3d_upfirdn2d'] + c3['n3d_upfirdn2d_pitched'] == 4, c3    # 2 x (conv0 up, conv1, toRGB); 2 up FIRs + 2 skip upsamples
+print('ok', dict(c1), dict(c2), dict(c3))
 """ % (repo, os.path.join(repo, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
