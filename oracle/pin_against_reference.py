@@ -48,6 +48,9 @@ CASES = {
     # gen_videos_next3d.py's default sampling multiplier 2: 96 + 96 samples, wide yaws, another
     # truncation, BOTH meshes perturbed (4x the amplitude: other faces win the z-buffer, the mouth boxes change size)
     'case_r64_s96': dict(seeds=[3, 4], yaws=[0.6, -0.6], R=64, Sc=96, Sf=96, psi=0.5, mesh_jitter=0.002, jitter_all=True),
+    # BASELINE.json configs[1] EXACTLY as bench.py runs it: batch 4, seeds 0-3, demo_batch's yaw pattern, R=64, 48+48, psi 0.7
+    # (mesh 1 perturbed as in the other batched cases so that the four samples do not share one z-buffer)
+    'case_r64_s48_b4': dict(seeds=[0, 1, 2, 3], yaws=[0.4, 0.0, -0.4, 0.4], R=64, Sc=48, Sf=48, psi=0.7),
 }
 
 

@@ -39,7 +39,7 @@ def _md(a, b):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s96'])
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s96', 'case_r64_s48_b4'])
 def test_forward_matches_reference_golden(G, dev, case, precision):
     from next3d_amd import layers
     layers.set_precision(precision)
