@@ -39,10 +39,15 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
     return x
 
 
-def setup_filter(taps=(1, 3, 3, 1), normalize=True, gain=1.0):
-    """torch_utils/ops/upfirdn2d.py:72-116: <8 taps => outer product, normalised to sum 1."""
+def setup_filter(taps=(1, 3, 3, 1), normalize=True, gain=1.0, separable=None):
+    """torch_utils/ops/upfirdn2d.py:72-116: 1-D taps => outer product when fewer than 8, else kept separable (1-D);
+    normalised to sum 1."""
     f = torch.as_tensor(taps, dtype=torch.float32)
-    if f.ndim == 1 and f.numel() < 8:
+    if f.ndim == 0:
+        f = f[None]
+    if separable is None:
+        separable = (f.ndim == 1 and f.numel() >= 8)
+    if f.ndim == 1 and not separable:
         f = torch.outer(f, f)
     if normalize:
         f = f / f.sum()
@@ -57,16 +62,23 @@ def _pad4(padding):
     return [int(p) for p in padding]
 
 
+def _xy(s):
+    return (int(s), int(s)) if isinstance(s, int) else (int(s[0]), int(s[1]))
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1.0):
-    """torch_utils/ops/upfirdn2d.py:169-213 (_upfirdn2d_ref): zero-insert, pad/crop, FIR, decimate."""
+    """torch_utils/ops/upfirdn2d.py:169-213 (_upfirdn2d_ref): zero-insert, pad/crop, FIR, decimate; `up` / `down` are ints or
+    (x, y) pairs, `f` is [fh,fw], a separable [taps] or None (identity tap)."""
     n, c, h, w = x.shape
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32)
+    upx, upy = _xy(up)
+    downx, downy = _xy(down)
     px0, px1, py0, py1 = _pad4(padding)
-    if up > 1:
-        z = x.new_zeros(n, c, h, up, w, up)
-        z[:, :, :, 0, :, 0] = x
-        x = z.reshape(n, c, h * up, w * up)
+    assert w * upx + px0 + px1 >= f.shape[-1] and h * upy + py0 + py1 >= f.shape[0]
+    x = x.reshape(n, c, h, 1, w, 1)
+    x = F.pad(x, [0, upx - 1, 0, 0, 0, upy - 1])                          # zeros AFTER each sample (:188-190)
+    x = x.reshape(n, c, h * upy, w * upx)
     x = F.pad(x, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
     x = x[:, :, max(-py0, 0): x.shape[2] - max(-py1, 0), max(-px0, 0): x.shape[3] - max(-px1, 0)]
     f = f * (gain ** (f.ndim / 2))
@@ -78,7 +90,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1.0):
     else:
         x = F.conv2d(x, f[None, None, None, :].repeat(c, 1, 1, 1), groups=c)
         x = F.conv2d(x, f[None, None, :, None].repeat(c, 1, 1, 1), groups=c)
-    return x[:, :, ::down, ::down]
+    return x[:, :, ::downy, ::downx]
 
 
 def upsample2d(x, f, up=2, gain=1.0):

@@ -49,6 +49,19 @@ def test_oracle_reproduces_reference_golden(state, case):
     assert np.abs(st['blended_planes'][..., ::8, ::8].numpy() - g['blended_planes_sub8']).max() <= 1e-6
 
 
+def test_operator_oracle_reproduces_reference_ref_ops():
+    """oracle/ops.py against the outputs of the reference's own _bias_act_ref / _upfirdn2d_ref / _filtered_lrelu_ref
+    (tests/golden/ref_ops.npz, oracle/pin_ops_against_reference.py): all 9 activations with gain / clamp / alpha and the bias
+    along dim 0 / 1 / 3, 2-D / separable / asymmetric filters, per-axis up x down, negative padding, flips — bit for bit."""
+    import _ref_ops
+    mod = {'bias_act': O.bias_act, 'upfirdn2d': O.upfirdn2d, 'filtered_lrelu': O.filtered_lrelu}
+    cases_ = _ref_ops.load()
+    assert len(cases_) >= 49 and {c[1] for c in cases_} == {'bias_act', 'upfirdn2d', 'filtered_lrelu'}
+    for i, op, kw, t, y_ref in cases_:
+        y = _ref_ops.run(mod, op, kw, t, O.setup_filter)
+        assert y.shape == y_ref.shape and torch.equal(y, y_ref), (i, op, kw)
+
+
 def test_upfirdn2d_against_direct_definition():
     """upfirdn2d == explicit zero-insert / pad / correlate-with-flipped-filter / decimate, on ragged shapes."""
     g = torch.Generator().manual_seed(0)

@@ -46,6 +46,18 @@ def test_bias_act_f16_and_errors(dev):
     assert bias_act.bias_act(torch.empty(0, 4, device=dev), None).numel() == 0
 
 
+def test_operator_layer_matches_reference_ref_ops(dev):
+    """The B1 operator layer on libn3d.so against the REFERENCE's own _bias_act_ref / _upfirdn2d_ref / _filtered_lrelu_ref
+    outputs (tests/golden/ref_ops.npz): every activation, separable / asymmetric filters, per-axis up x down, negative
+    padding, flips.  fp32 end to end: tolerance at fp32 round-off (transcendentals: device libm vs host libm)."""
+    import _ref_ops
+    from next3d_amd.torch_utils.ops import bias_act, filtered_lrelu, upfirdn2d
+    mod = {'bias_act': bias_act.bias_act, 'upfirdn2d': upfirdn2d.upfirdn2d, 'filtered_lrelu': filtered_lrelu.filtered_lrelu}
+    for i, op, kw, t, y_ref in _ref_ops.load():
+        y = _ref_ops.run(mod, op, kw, t, upfirdn2d.setup_filter, to=lambda v: v.to(dev))
+        _close(y, y_ref, atol=1e-5 if op != 'bias_act' else 4e-6)
+
+
 UF_CASES = [
     # (shape, up, down, padding, gain)  — the three hot shapes of SURVEY §8(a7) + odd ones
     ((2, 5, 17, 17), 1, 1, [1, 1, 1, 1], 4.0),
