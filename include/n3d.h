@@ -87,6 +87,16 @@ int n3d_upfirdn2d_pitched(const float* x, const float* f, float* y, int N, int C
                           int pady0, int pady1, int flip, float gain, int64_t x_batch_stride, int64_t y_batch_stride,
                           const n3d_epilogue* epi, n3d_stream_t stream);
 
+/* ---- filtered_lrelu: replaces filtered_lrelu_plugin.filtered_lrelu forward (torch_utils/ops/filtered_lrelu.cpp:20, kernel
+ *      filtered_lrelu.cu:143-144; semantics of _filtered_lrelu_ref, filtered_lrelu.py:123-155) in ONE launch:
+ *        y = upfirdn2d( clamp(lrelu(upfirdn2d(x + b[c], fu, up, pad, gain=up^2), slope) * gain), fd, down )
+ *      x [N,C,H,W] -> y [N,C,OH,OW], OH = (H*up + py0 + py1 - (fuh-1) - (fdh-1) + (down-1)) / down (same for W).
+ *      fu [fuh,fuw] / fd [fdh,fdw] float32 2-D taps, NULL = a single unit tap (sizes 1); b [C] or NULL; clamp < 0: none;
+ *      flip as upfirdn2d's flip_filter.  The up-sampled intermediate stays in LDS. */
+int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const float* b, float* y, int N, int C, int H, int W,
+                       int fuh, int fuw, int fdh, int fdw, int up, int down, int px0, int px1, int py0, int py1, float gain,
+                       float slope, float clamp, int flip, n3d_stream_t stream);
+
 /* ---- conv2d weight preparation (done once per model): w [O,I,k,k] -> wt [k*k][I][OP] (K-major, the layout
  *      the MFMA kernel streams; OP = O rounded up to a multiple of 4, zero padded, so rows are 16-byte aligned)
  *      and, when wsq != NULL, wsq[o*I+i] = sum_k w[o,i,k]^2 (for demodulation). */
@@ -168,6 +178,11 @@ int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int nu
 int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p,
             int64_t c_nc, int64_t c_p, n3d_stream_t stream);
 int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t stream);
+/* n3d_cast: float16 <-> float32 (N3D_F16 / N3D_F32), round to nearest even — the `x.to(dtype)` conversions at the
+ * boundaries of the reference's fp16 blocks (tat/networks_stylegan2.py:548-552; tat/superresolution.py:210-217).  The
+ * operator layer uses it to run fp16 tensors through the fp32-accumulating kernels: fp16 storage between operators,
+ * exactly the rounding points of the reference's fp16 path. */
+int n3d_cast(const void* x, void* y, int64_t numel, int src_dtype, int dst_dtype, n3d_stream_t stream);
 
 /* ---- tri-plane blend (tat/triplane_next3d.py:171-174): planes = dyn * alpha + static * (1 - alpha), written
  *      CHANNELS-LAST [N,3,H,W,32] (one texel's 32 channels contiguous) for the renderer's gathers.

@@ -55,6 +55,7 @@ _SIGNATURES = {
                               ctypes.POINTER(Epilogue), c_void_p]),
     'n3d_upfirdn2d_pitched': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_int64, c_int64] + [c_int] * 11 +
                               [c_float, c_int64, c_int64, ctypes.POINTER(Epilogue), c_void_p]),
+    'n3d_filtered_lrelu': (c_int, [c_void_p] * 5 + [c_int] * 14 + [c_float] * 3 + [c_int, c_void_p]),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_prep_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -74,6 +75,7 @@ _SIGNATURES = {
     'n3d_truncate_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'n3d_fma': (c_int, [c_void_p] * 4 + [c_int64] * 6 + [c_void_p]),
     'n3d_to_uint8': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'n3d_cast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'n3d_fc_multi': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'n3d_fc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
                        c_float, c_int, c_int, c_void_p]),
@@ -126,6 +128,22 @@ def require_device(*tensors):
         if t is not None and t.device.type != 'cuda':
             raise RuntimeError('n3d ops run on a HIP device only (got a %s tensor); the CPU restatement lives in '
                                'oracle/ and is test infrastructure, not a fallback' % t.device.type)
+
+
+def cast(t, dtype):
+    """float16 <-> float32 conversion on libn3d.so (n3d_cast); a tensor that already has `dtype` is returned as is.  Any other
+    dtype raises: the kernels behind the operator layer compute in float32 and store float32 or float16 only."""
+    import torch as _t
+    if t.dtype == dtype:
+        return t
+    codes = {_t.float32: 0, _t.float16: 1}
+    if t.dtype not in codes or dtype not in codes:
+        raise RuntimeError(f'n3d ops take float32 or float16 tensors (got {t.dtype} -> {dtype})')
+    require_device(t)
+    t = t.contiguous()
+    y = _t.empty(t.shape, dtype=dtype, device=t.device)
+    check(lib().n3d_cast(ptr(t), ptr(y), t.numel(), codes[t.dtype], codes[dtype], stream()))
+    return y
 
 
 def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, residual=None, const_scale=1.0,

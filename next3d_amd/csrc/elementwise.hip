@@ -4,6 +4,8 @@
 //                          (MappingNetwork.forward :255-267)
 //   fma                  : a * b + c with NCHW / per-(n,c) / per-pixel broadcasting     (torch_utils/ops/fma.py:17-28)
 //   to_uint8             : (img * 127.5 + 128).clamp(0, 255) -> uint8              (gen_samples_next3d.py:201)
+//   cast                 : float16 <-> float32 (the reference's `x.to(dtype)` at the fp16 block boundaries,
+//                          training_avatar_texture/networks_stylegan2.py:548-552, :57-59)
 #include "common.h"
 
 // one wave per row
@@ -56,6 +58,21 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__
     }
 }
 
+// 8 elements per thread (16-byte accesses on the half side, 2 x 16 on the float side); the tail is done element-wise
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(256) void cast_kernel(const SRC* __restrict__ x, DST* __restrict__ y, int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        SRC v[8];
+        DST o[8];
+        __builtin_memcpy(v, x + i * 8, sizeof(v));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (DST)v[k];          // f32 -> f16: round to nearest even (v_cvt_f16_f32), as ATen
+        __builtin_memcpy(y + i * 8, o, sizeof(o));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = (DST)x[n8 * 8 + threadIdx.x];
+}
+
 static inline int grid_for(int64_t n) { const int64_t g = cdiv64(n, 256); return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
 extern "C" {
@@ -101,6 +118,21 @@ int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t s
     N3D_CHECK(x && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 3) == 0, "to_uint8: null or misaligned tensor");
     N3dProfScope prof(N3D_K_MISC, stream, 2.0 * numel, 5.0 * numel);
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, stream, x, y, numel / 4);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_cast(const void* x, void* y, int64_t numel, int src_dtype, int dst_dtype, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(numel >= 0, "cast: bad size");
+    N3D_CHECK((src_dtype == N3D_F32 && dst_dtype == N3D_F16) || (src_dtype == N3D_F16 && dst_dtype == N3D_F32),
+              "cast: float32 <-> float16 only");
+    if (numel == 0) return 0;
+    N3D_CHECK(x && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cast: null or misaligned tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 6.0 * numel);
+    const int grid = grid_for(cdiv64(numel, 8));
+    if (src_dtype == N3D_F32) hipLaunchKernelGGL((cast_kernel<float, _Float16>), dim3(grid), dim3(256), 0, stream, (const float*)x, (_Float16*)y, numel);
+    else hipLaunchKernelGGL((cast_kernel<_Float16, float>), dim3(grid), dim3(256), 0, stream, (const _Float16*)x, (float*)y, numel);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -1,6 +1,12 @@
 """conv2d / conv_transpose2d front-ends with the reference's names (torch_utils/ops/conv2d_gradfix.py:37-45),
 executed by the fp32-MFMA implicit-GEMM kernel of libn3d.so (forward only; `enabled` / `no_weight_gradients`
-exist for import compatibility and have no effect at inference)."""
+exist for import compatibility and have no effect at inference).
+
+dtypes: float32, or float16 for BOTH input and weight (what the reference's fp16 blocks pass, networks_stylegan2.py:84-88
+`w.to(x.dtype)`): fp16 tensors are converted on the device (n3d_cast), multiplied with float32 accumulation and the result is
+stored as float16 — fp16 x fp16 products are exact in fp32, so this is the arithmetic of an fp16 convolution with fp32
+accumulation (cuDNN's default for half).  Anything else raises RuntimeError (the analogue of ATen's dtype check) — a
+non-float32 pointer never reaches a float32 kernel."""
 import contextlib
 
 import torch
@@ -16,9 +22,17 @@ def no_weight_gradients(disable=True):
     yield
 
 
+def _as_f32(t, what):
+    """float32 view of a float32 / float16 DEVICE tensor (converted by n3d_cast); other dtypes raise."""
+    if t.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'{what}: float32 or float16 expected, got {t.dtype}')
+    return _lib.cast(t, torch.float32)
+
+
 def prep_weight(w, want_sq=False):
     """[O,I,k,k] -> K-major [k*k, I, O] (+ optional per-(o,i) sum of squares for demodulation)."""
     _lib.require_device(w)
+    w = _as_f32(w, 'conv2d weight')
     o, i, kh, kw = w.shape
     if kh != kw or kh not in (1, 3):
         raise RuntimeError(f'conv2d: kernel {kh}x{kw} unsupported (1x1 or 3x3)')
@@ -32,6 +46,7 @@ def prep_weight(w, want_sq=False):
 def prep_weight_bf16x3(w):
     """[O,I,k,k] fp32 (k = 3 or 1) -> split-bf16 K-major tiles for the bf16x3 kernels (see include/n3d.h)."""
     _lib.require_device(w)
+    w = _as_f32(w, 'conv2d weight')
     o, i, kh, kw = w.shape
     if kh != kw or kh not in (1, 3) or i % 16 != 0:
         raise RuntimeError('prep_weight_bf16x3: needs a 3x3 or 1x1 kernel and I % 16 == 0')
@@ -90,8 +105,21 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
     `out` may itself be such a view."""
+    _lib.require_device(x, wt, style, out)
     n, i, h, w = x.shape
     o = out_channels
+    out_dtype = x.dtype
+    if x.dtype != torch.float32:            # fp16 activations: fp32 arithmetic, fp16 storage (module docstring)
+        if out is not None:
+            raise RuntimeError('conv2d: an `out` buffer needs a float32 input')
+        x = _as_f32(x, 'conv2d input')
+        row_pitch = False
+    if style is not None and style.dtype != torch.float32:
+        raise RuntimeError(f'conv2d: float32 styles expected, got {style.dtype}')
+    if not bf16x3 and wt.dtype != torch.float32:
+        raise RuntimeError(f'conv2d: prepared weights must be float32 (prep_weight), got {wt.dtype}')
+    if out is not None and out.dtype != torch.float32:
+        raise RuntimeError(f'conv2d: float32 output buffer expected, got {out.dtype}')
     if bf16x3:
         assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (ksize * ksize, i // 16, 2, 2, (o + 63) // 64 * 64, 8)
         assert (ksize == 3 and mode in (0, 1, 2)) or (ksize == 1 and mode == 0)
@@ -123,11 +151,13 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
-    return y
+    return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)
 
 
 def _grouped(x, weight, groups, ksize, mode, transposed):
     """groups == batch-folded samples (modulated_conv2d's fused path reshapes x to [1, N*I, H, W])."""
+    if weight.dtype != x.dtype:
+        raise RuntimeError(f'conv2d: input ({x.dtype}) and weight ({weight.dtype}) must have the same dtype')
     n, ci, h, w = x.shape
     ig = ci // groups
     outs = []
@@ -155,6 +185,8 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
         mode = 1
     else:
         raise RuntimeError(f'conv2d: stride={stride} padding={pad} kernel={k} is outside the generator-forward path')
+    if weight.dtype != input.dtype:
+        raise RuntimeError(f'conv2d: input ({input.dtype}) and weight ({weight.dtype}) must have the same dtype')
     if groups == 1:
         return conv_launch(input, prep_weight(weight), k, mode, weight.shape[0])
     return _grouped(input, weight, groups, k, mode, transposed=False)
@@ -167,6 +199,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     pad = padding if isinstance(padding, int) else padding[0]
     if stride != 2 or pad != 0 or weight.shape[2] != 3 or output_padding != 0 or dilation != 1 or bias is not None:
         raise RuntimeError('conv_transpose2d: only 3x3 / stride 2 / padding 0 is on the generator-forward path')
+    if weight.dtype != input.dtype:
+        raise RuntimeError(f'conv_transpose2d: input ({input.dtype}) and weight ({weight.dtype}) must have the same dtype')
     if groups == 1:
         return conv_launch(input, prep_weight(weight.transpose(0, 1)), 3, 2, weight.shape[1])
     return _grouped(input, weight, groups, 3, 2, transposed=True)

@@ -1,31 +1,42 @@
-"""upfirdn2d family — same Python signatures as reference torch_utils/ops/upfirdn2d.py:72-389, forward only, HIP only."""
-import numpy as np
+"""upfirdn2d family — the Python signatures of the reference's torch_utils/ops/upfirdn2d.py (:72 setup_filter, :120 upfirdn2d,
+:279 filter2d, :315 upsample2d, :354 downsample2d), forward only, executed by libn3d.so (n3d_upfirdn2d_pitched).
+
+float32 tensors run directly; float16 tensors (the reference's fp16 blocks, superresolution.py:210-217) are converted on the
+device (n3d_cast), filtered with float32 accumulation and stored back as float16 — the same rounding points as the
+reference's fp16 kernel (upfirdn2d.cu accumulates in float for half inputs, :36 `scalar_t`/`float` split).
+"""
 import torch
 
 from ... import _lib
 
 
+# ---------------------------------------------------------------------------------------------- argument normalisation
+def _ints(value, count, what):
+    """int or sequence of ints -> tuple of `count` ints (a shorter sequence of length count/2 is repeated per axis)."""
+    seq = [value] * count if isinstance(value, int) else list(value)
+    if not all(isinstance(v, int) for v in seq):
+        raise AssertionError(f'{what} must be an int or a sequence of ints')
+    if len(seq) * 2 == count:
+        seq = [v for v in seq for _ in range(2)]
+    if len(seq) != count:
+        raise AssertionError(f'{what}: expected {count} values, got {len(seq)}')
+    return tuple(seq)
+
+
 def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    assert isinstance(scaling, (list, tuple)) and all(isinstance(x, int) for x in scaling)
-    sx, sy = scaling
+    """-> (x factor, y factor), both >= 1."""
+    sx, sy = _ints(scaling, 2, 'scaling')
     assert sx >= 1 and sy >= 1
     return sx, sy
 
 
 def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple)) and all(isinstance(x, int) for x in padding)
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    px0, px1, py0, py1 = padding
-    return px0, px1, py0, py1
+    """-> (x before, x after, y before, y after); negative values crop."""
+    return _ints(padding, 4, 'padding')
 
 
 def _get_filter_size(f):
+    """-> (taps along x, taps along y); no filter counts as a single tap."""
     if f is None:
         return 1, 1
     assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
@@ -33,30 +44,29 @@ def _get_filter_size(f):
 
 
 def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
-    """FIR taps as a float32 tensor: 1-D (separable, >= 8 taps) or 2-D outer product."""
-    if f is None:
-        f = 1
-    f = torch.as_tensor(f, dtype=torch.float32)
-    assert f.ndim in [0, 1, 2] and f.numel() > 0
-    if f.ndim == 0:
-        f = f[np.newaxis]
+    """FIR taps for the functions below: a float32 [taps] (separable) or [fh, fw] tensor.  1-D input becomes an outer
+    product unless it has 8 or more taps (or `separable` says otherwise); `gain` is split evenly over the two passes of a
+    separable filter."""
+    taps = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    if taps.ndim == 0:
+        taps = taps.reshape(1)
+    assert taps.ndim in [1, 2] and taps.numel() > 0
     if separable is None:
-        separable = (f.ndim == 1 and f.numel() >= 8)
-    if f.ndim == 1 and not separable:
-        f = f.ger(f)
-    assert f.ndim == (1 if separable else 2)
+        separable = taps.ndim == 1 and taps.numel() >= 8
+    if taps.ndim == 1 and not separable:
+        taps = taps[:, None] * taps[None, :]
+    assert taps.ndim == (1 if separable else 2)
     if normalize:
-        f = f / f.sum()
+        taps = taps / taps.sum()
     if flip_filter:
-        f = f.flip(list(range(f.ndim)))
-    f = f * (gain ** (f.ndim / 2))
-    return f.to(device=device)
+        taps = taps.flip(list(range(taps.ndim)))
+    return (taps * gain ** (taps.ndim / 2)).to(device=device)
 
 
+# ---------------------------------------------------------------------------------------------- launch
 def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pitch=False):
-    upx, upy = up
-    downx, downy = down
-    px0, px1, py0, py1 = padding
+    """One n3d_upfirdn2d_pitched launch on float32 data; `up`, `down` = (x, y) pairs, `padding` = 4 ints, f2d = [fh, fw]."""
+    (upx, upy), (downx, downy), (px0, px1, py0, py1) = up, down, padding
     n, c, h, w = x.shape
     fh, fw = f2d.shape
     ow = (w * upx + px0 + px1 - fw + downx) // downx
@@ -73,48 +83,73 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pit
     return y
 
 
+def _planes_ok(x):
+    """dense planes, or rows with a pitch (a [..., :W] view of a wider buffer: conv_launch(..., row_pitch=True))"""
+    return x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda', _epilogue=None, _row_pitch=False):
-    """Pad, upsample, filter, downsample a batch of 2-D images (see the reference docstring, upfirdn2d.py:120-160)."""
+    """Zero-stuff by `up`, pad / crop, correlate with the (flipped unless `flip_filter`) taps, keep every `down`-th sample."""
     assert isinstance(x, torch.Tensor) and impl in ['ref', 'cuda']
     if impl == 'ref':
         raise RuntimeError("impl='ref' is not part of the product: the CPU restatement is oracle/ops.py (tests only)")
     _lib.require_device(x, f)
     assert x.ndim == 4
-    if x.dtype != torch.float32:
-        raise RuntimeError('upfirdn2d: this build computes in float32 only')
+    if x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'upfirdn2d: float32 or float16 input expected, got {x.dtype}')
     up, down, padding = _parse_scaling(up), _parse_scaling(down), _parse_padding(padding)
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-    assert f.dtype == torch.float32 and f.ndim in [1, 2]
-    # dense planes, or rows with a pitch (a [..., :W] view of a wider buffer: conv_launch(..., row_pitch=True))
-    x = x if (x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)) else x.contiguous()
+    if f.dtype != torch.float32 or f.ndim not in [1, 2]:
+        raise RuntimeError('upfirdn2d: the filter must be a 1-D or 2-D float32 tensor (setup_filter)')
+    out_dtype = x.dtype
+    if x.dtype == torch.float16:                      # fp16 storage, fp32 arithmetic
+        x = _lib.cast(x, torch.float32)
+    elif not _planes_ok(x):
+        x = x.contiguous()
     if f.ndim == 2:
-        return _launch(x, f.contiguous(), up, down, padding, flip_filter, gain, _epilogue, _row_pitch)
-    # separable: horizontal pass then vertical pass, gain split as sqrt per pass (upfirdn2d.py:240-244)
-    px0, px1, py0, py1 = padding
-    g = float(gain) ** 0.5
-    x = _launch(x, f.unsqueeze(0).contiguous(), (up[0], 1), (down[0], 1), (px0, px1, 0, 0), flip_filter, g)
-    return _launch(x, f.unsqueeze(1).contiguous(), (1, up[1]), (1, down[1]), (0, 0, py0, py1), flip_filter, g, _epilogue)
+        y = _launch(x, f.contiguous(), up, down, padding, flip_filter, gain, _epilogue, _row_pitch and out_dtype == torch.float32)
+    else:   # separable: a row pass with the taps along x, then a column pass; each takes sqrt(gain)
+        g = float(gain) ** 0.5
+        rows = _launch(x, f[None, :].contiguous(), (up[0], 1), (down[0], 1), padding[:2] + (0, 0), flip_filter, g)
+        y = _launch(rows, f[:, None].contiguous(), (1, up[1]), (1, down[1]), (0, 0) + padding[2:], flip_filter, g, _epilogue)
+    return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------- convenience wrappers
+def _margins(taps, factor, upsampling):
+    """Padding (before, after) that keeps an image aligned when it is filtered with `taps` taps around a x`factor` resampling:
+    the filter's centre of mass sits on the sample grid of the LOW-rate side."""
+    if upsampling:
+        return (taps + factor - 1) // 2, (taps - factor) // 2
+    return (taps - factor + 1) // 2, (taps - factor) // 2
+
+
+def _resample(x, f, up, down, padding, flip_filter, gain, impl):
+    ux, uy = _parse_scaling(up)
+    dx, dy = _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    if (ux, uy) != (1, 1):
+        mx, my = _margins(fw, ux, True), _margins(fh, uy, True)
+    elif (dx, dy) != (1, 1):
+        mx, my = _margins(fw, dx, False), _margins(fh, dy, False)
+    else:                                   # plain filtering: 'same' size (odd taps centred, even taps lean to the front)
+        mx, my = (fw // 2, (fw - 1) // 2), (fh // 2, (fh - 1) // 2)
+    pad = [px0 + mx[0], px1 + mx[1], py0 + my[0], py1 + my[1]]
+    return upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip_filter, gain=gain * ux * uy, impl=impl)
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
-    px0, px1, py0, py1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
-    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    """Filter without changing the size (plus `padding`)."""
+    return _resample(x, f, 1, 1, padding, flip_filter, gain, impl)
 
 
 def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
-    upx, upy = _parse_scaling(up)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
-    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+    """Enlarge by an integer factor; the signal magnitude is kept (gain x factor^2 compensates the inserted zeros)."""
+    return _resample(x, f, up, 1, padding, flip_filter, gain, impl)
 
 
 def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
-    downx, downy = _parse_scaling(down)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    fw, fh = _get_filter_size(f)
-    p = [px0 + (fw - downx + 1) // 2, px1 + (fw - downx) // 2, py0 + (fh - downy + 1) // 2, py1 + (fh - downy) // 2]
-    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+    """Shrink by an integer factor."""
+    return _resample(x, f, 1, down, padding, flip_filter, gain, impl)

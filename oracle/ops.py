@@ -107,8 +107,10 @@ def downsample2d(x, f, down=2, gain=1.0):
     return upfirdn2d(x, f, down=down, padding=p, gain=gain)
 
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, quant=None):
     """torch_utils/ops/conv2d_resample.py:48-143 — the branches the generator reaches.
+    `quant` (optional callable) is applied to the result of every internal convolution / FIR pass: with
+    `lambda t: t.half().float()` this emulates the storage rounding of the reference's fp16 path on fp32 arithmetic.
 
     flip_weight=True means correlation (= F.conv2d).  For up>1 the reference transposes the
     weight and calls conv_transpose2d with flip_weight inverted (:114-131), i.e. for the
@@ -124,12 +126,18 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         px0 += (fw - down + 1) // 2; px1 += (fw - down) // 2
         py0 += (fh - down + 1) // 2; py1 += (fh - down) // 2
 
+    q = quant if quant is not None else (lambda t: t)
+    _fir = globals()['upfirdn2d']
+
+    def upfirdn2d(*a, **k):                                    # every FIR pass of this function is quantised
+        return q(_fir(*a, **k))
+
     def conv(x, w, stride=1, pad=(0, 0), transpose=False, flip=True):
         if not flip and (w.shape[2] > 1 or w.shape[3] > 1):
             w = w.flip([2, 3])
         if transpose:
-            return F.conv_transpose2d(x, w, stride=stride, padding=pad, groups=groups)
-        return F.conv2d(x, w, stride=stride, padding=pad, groups=groups)
+            return q(F.conv_transpose2d(x, w, stride=stride, padding=pad, groups=groups))
+        return q(F.conv2d(x, w, stride=stride, padding=pad, groups=groups))
 
     if kw == 1 and kh == 1 and down > 1 and up == 1:          # :96
         x = upfirdn2d(x, f, down=down, padding=[px0, px1, py0, py1])

@@ -112,3 +112,30 @@ print('ok', dict(c1), dict(c2), dict(c3))
 """ % (repo, os.path.join(repo, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().startswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_operator_layer_dtype_handling_dry_run(dry):
+    """B1 takes float32 or float16 (fp16 tensors are converted by n3d_cast around the fp32-accumulating kernels: the call
+    sequence shows the conversions); anything else — or an input / weight dtype mismatch — raises RuntimeError before any
+    pointer could reach a float32 kernel (fp16 pointers used to be passed to fp32 kernels unchecked)."""
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg, conv2d_resample, filtered_lrelu, fma, upfirdn2d
+    x, w = torch.randn(2, 16, 12, 12), torch.randn(8, 16, 3, 3)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    y = conv2d_resample.conv2d_resample(x.half().contiguous(memory_format=torch.channels_last), w.half(), f=f, up=2, padding=1, flip_weight=False)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (2, 8, 24, 24)
+    assert dry == ['n3d_cast', 'n3d_conv2d_prep_weight', 'n3d_cast', 'n3d_conv2d', 'n3d_cast', 'n3d_cast', 'n3d_upfirdn2d_pitched', 'n3d_cast']
+    dry.clear()
+    y = conv2d_resample.conv2d_resample(x, w, f=f, down=2, padding=1)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (2, 8, 6, 6) and 'n3d_cast' not in dry
+    y = filtered_lrelu.filtered_lrelu(x.half(), fu=f, fd=f, b=torch.randn(16).half(), up=2, down=2, padding=[3, 2, 3, 2])
+    assert y.dtype == torch.float16 and tuple(y.shape) == (2, 16, 12, 12) and dry.count('n3d_filtered_lrelu') == 1
+    for bad in (lambda: conv2d_resample.conv2d_resample(x.double(), w.double(), padding=1),
+                lambda: cg.conv2d(x.half(), w, padding=1), lambda: cg.conv2d(x, w.half(), padding=1),
+                lambda: cg.conv_transpose2d(x.half(), w.transpose(0, 1), stride=2),
+                lambda: cg.conv_launch(x.to(torch.bfloat16), cg.prep_weight(w), 3, 0, 8),
+                lambda: cg.conv_launch(x, cg.prep_weight(w).half(), 3, 0, 8),
+                lambda: cg.prep_weight(w.to(torch.bfloat16)), lambda: upfirdn2d.upfirdn2d(x.double(), f),
+                lambda: upfirdn2d.upfirdn2d(x, f.double()), lambda: fma.fma(x.half(), x, x),
+                lambda: filtered_lrelu.filtered_lrelu(x.to(torch.bfloat16))):
+        with pytest.raises(RuntimeError):
+            bad()

@@ -416,3 +416,101 @@ def test_filtered_lrelu_fma_and_small_kernels(dev):
     out = torch.empty(img.shape, dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img.to(dev)), _lib.ptr(out), img.numel(), _lib.stream()))
     assert torch.equal(out.cpu(), (img * 127.5 + 128).clamp(0, 255).to(torch.uint8))
+
+
+def test_reference_fp16_block_call_sequence_through_operator_layer(dev):
+    """the reference's DEFAULT super-resolution mode is fp16 (superresolution.py:36,210-217 — no script passes
+    force_fp32).  This drives the call sequence of one fp16 SynthesisBlock (networks_stylegan2.py:548-586 -> modulated_conv2d
+    :56-91 fp16 branch -> grouped conv2d_resample, bias_act with conv_clamp=256, toRGB, fp32 skip image) through the B1
+    operator layer with fp16 / channels_last tensors, and compares with the CPU oracle run on fp32 arithmetic with the
+    SAME fp16 rounding points (storage after every conv / FIR / bias_act).  Tolerance: the two sides differ only by the
+    accumulation order inside a convolution, which can move a result across an fp16 rounding boundary -> a few fp16 ulps
+    (2^-11 relative) of the tensor's magnitude."""
+    from next3d_amd.torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+    q = lambda t: t.half().float()
+    N, I, O_, R, clamp = 2, 32, 64, 16, 256
+    x0, wl = _gen((N, I, R, R), 50), _gen((N, 512), 51)
+    P = {'c0.w': _gen((O_, I, 3, 3), 52), 'c0.b': _gen((O_,), 53) * 0.1, 'c0.aw': _gen((I, 512), 54), 'c0.ab': torch.ones(I),
+         'c0.noise': _gen((2 * R, 2 * R), 55), 'c0.ns': torch.tensor(0.1),
+         'c1.w': _gen((O_, O_, 3, 3), 56), 'c1.b': _gen((O_,), 57) * 0.1, 'c1.aw': _gen((O_, 512), 58), 'c1.ab': torch.ones(O_),
+         'c1.noise': _gen((2 * R, 2 * R), 59), 'c1.ns': torch.tensor(0.1),
+         'rgb.w': _gen((3, O_, 1, 1), 60), 'rgb.b': _gen((3,), 61) * 0.1, 'rgb.aw': _gen((O_, 512), 62), 'rgb.ab': torch.ones(O_)}
+    img0 = _gen((N, 3, R, R), 63)
+    f = O.setup_filter((1, 3, 3, 1))
+
+    def modconv(x, wt, styles, f_, up, demod, ops, dt):
+        """modulated_conv2d, fused branch, fp16 pre-normalisation included (:56-59)."""
+        o, i, kh, kw = wt.shape
+        if dt == torch.float16 and demod:
+            wt = wt * (1 / np.sqrt(i * kh * kw) / wt.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+            styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+        w = wt.unsqueeze(0) * styles.reshape(N, 1, -1, 1, 1)
+        if demod:
+            w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(N, -1, 1, 1, 1)
+        return ops['resample'](x.reshape(1, -1, *x.shape[2:]), w.reshape(-1, i, kh, kw), f_, up, kh // 2).reshape(N, -1, x.shape[2] * up, x.shape[3] * up)
+
+    def block(x, img, ops, dt, to):
+        affine = lambda k: to(wl) @ (to(P[k + '.aw']).t() / np.sqrt(512)) + to(P[k + '.ab'])
+        x = ops['cast'](x)
+        x = modconv(x, to(P['c0.w']), affine('c0'), to(f), 2, True, ops, dt)
+        x = ops['add'](x, to(P['c0.noise'] * P['c0.ns']))
+        x = ops['bias_act'](x, to(P['c0.b']), 'lrelu', clamp)
+        x = modconv(x, to(P['c1.w']), affine('c1'), to(f), 1, True, ops, dt)
+        x = ops['add'](x, to(P['c1.noise'] * P['c1.ns']))
+        x = ops['bias_act'](x, to(P['c1.b']), 'lrelu', clamp)
+        y = modconv(x, to(P['rgb.w']), affine('rgb') / np.sqrt(O_), None, 1, False, ops, dt)
+        y = ops['bias_act'](y, to(P['rgb.b']), 'linear', clamp)
+        img = ops['up'](img, to(f)) + y.float()
+        return x, img
+
+    gpu = {'cast': lambda t: t.to(dtype=torch.float16, memory_format=torch.channels_last),
+           'resample': lambda x, w, f_, up, pad: conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=f_, up=up, padding=pad, groups=N,
+                                                                               flip_weight=(up == 1)),
+           'add': lambda x, nz: x.add_(nz.to(x.dtype)),
+           'bias_act': lambda x, b, act, cl: bias_act.bias_act(x, b.to(x.dtype), act=act, clamp=cl),
+           'up': lambda img, f_: upfirdn2d.upsample2d(img, f_)}
+    cpu = {'cast': q,
+           'resample': lambda x, w, f_, up, pad: O.conv2d_resample(x, q(w), f=f_, up=up, padding=pad, groups=N, flip_weight=(up == 1), quant=q),
+           'add': lambda x, nz: q(x + q(nz)),
+           'bias_act': lambda x, b, act, cl: q(O.bias_act(x, q(b), act=act, clamp=cl)),
+           'up': lambda img, f_: O.upsample2d(img, f_)}
+    xg, ig = block(x0.to(dev), img0.to(dev), gpu, torch.float16, lambda t: t.to(dev))
+    xc, ic = block(x0, img0, cpu, torch.float16, lambda t: t)
+    assert xg.dtype == torch.float16 and ig.dtype == torch.float32
+    ulp = 2.0 ** -11
+    ex, ei = float((xg.float().cpu() - xc).abs().max()), float((ig.cpu() - ic).abs().max())
+    print('fp16 block: x absmax', float(xc.abs().max()), 'err', ex, '| img absmax', float(ic.abs().max()), 'err', ei)
+    assert ex <= 8 * ulp * float(xc.abs().max()) and ei <= 8 * ulp * float(ic.abs().max())
+
+
+def test_operator_layer_fp16_and_dtype_errors(dev):
+    """fp16 tensors run (fp32 accumulation, fp16 storage); unsupported or mixed dtypes raise instead of reaching a float32
+    kernel with a non-float32 pointer."""
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg, conv2d_resample, filtered_lrelu, fma, upfirdn2d
+    x, w = _gen((2, 16, 12, 12), 70), _gen((8, 16, 3, 3), 71) / 12
+    f = O.setup_filter((1, 3, 3, 1))
+    q = lambda t: t.half().float()
+    y = conv2d_resample.conv2d_resample(x.half().to(dev), w.half().to(dev), f=f.to(dev), padding=1)
+    assert y.dtype == torch.float16
+    _close(y.float(), q(O.conv2d_resample(q(x), q(w), f=f, padding=1)), atol=4e-3, rtol=2e-3)
+    y = upfirdn2d.upfirdn2d(x.half().to(dev), f.to(dev), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert y.dtype == torch.float16
+    _close(y.float(), q(O.upfirdn2d(q(x), f, up=2, padding=[2, 1, 2, 1], gain=4)), atol=2e-3, rtol=2e-3)
+    y = filtered_lrelu.filtered_lrelu(x.half().to(dev), fu=f.to(dev), fd=f.to(dev), b=_gen((16,), 72).half().to(dev), up=2, down=2, padding=[3, 2, 3, 2])
+    assert y.dtype == torch.float16
+    _close(y.float(), q(O.filtered_lrelu(q(x), fu=f, fd=f, b=q(_gen((16,), 72)), up=2, down=2, padding=[3, 2, 3, 2])), atol=4e-3, rtol=2e-3)
+    a, b, c = _gen((2, 4, 5, 5), 73), _gen((2, 4, 1, 1), 74), _gen((1, 1, 5, 5), 75)
+    y = fma.fma(a.half().to(dev), b.half().to(dev), c.half().to(dev))
+    assert y.dtype == torch.float16
+    _close(y.float(), q(q(a) * q(b) + q(c)), atol=2e-3, rtol=2e-3)
+    for bad in (lambda: conv2d_resample.conv2d_resample(x.double().to(dev), w.double().to(dev), padding=1),
+                lambda: cg.conv2d(x.half().to(dev), w.to(dev), padding=1),
+                lambda: cg.conv2d(x.to(dev), w.half().to(dev), padding=1),
+                lambda: cg.conv_launch(x.to(torch.bfloat16).to(dev), cg.prep_weight(w.to(dev)), 3, 0, 8),
+                lambda: cg.prep_weight(w.to(torch.bfloat16).to(dev)),
+                lambda: upfirdn2d.upfirdn2d(x.double().to(dev), f.to(dev)),
+                lambda: upfirdn2d.upfirdn2d(x.to(dev), f.double().to(dev)),
+                lambda: fma.fma(a.half().to(dev), b.to(dev), c.to(dev)),
+                lambda: filtered_lrelu.filtered_lrelu(x.to(torch.bfloat16).to(dev))):
+        with pytest.raises(RuntimeError):
+            bad()
