@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — generator-forward frames/s of the Next3D hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]          (N > 1: spawns one process per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W                            (the driver's launch line; same result)
 
 One "step" = one pass of the hot path over one batch: `G.mapping` + `G.synthesis` for B=4 seeds per GPU at
 512² output, 64² neural render, 48 coarse + 48 importance depth samples, trunc 0.7, demo mesh (BASELINE.json
 configs[1]); inputs are resident in HBM before the timed region.  With N GPUs every rank renders its own B seeds
 (independent seeds shard with no data-path collective — weak scaling) and the finished uint8 frames are gathered to
-rank 0 over RCCL inside the timed step (north_star: "RCCL over xGMI only for the final gather").
-Rank 0 prints ONE JSON line; `roofline` is the dominant kernel family — the 3x3 split-bf16 convolutions on the bf16 matrix
-cores (fp32-MFMA convolutions with N3D_PRECISION=fp32) — timed with HIP events on the launch stream; `cpu_baseline` is the
-CPU oracle (a port of the reference's fp32 path) timed on the host cores.
+rank 0 over RCCL (north_star: "RCCL over xGMI only for the final gather"); the gather of step k runs on RCCL's stream
+while step k+1 computes and is joined before step k+2 is enqueued.
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 only, all measured by this process):
+  roofline       the dominant kernel family (3x3 split-bf16 convolutions, bf16 matrix cores) timed with HIP events on the
+                 launch stream, against 2500/3 TFLOP/s; `traffic` from the committed rocprofv3 --pmc profile of this build
+  roofline_fp32  the same K steps with N3D_PRECISION=fp32 arithmetic (v_mfma_f32_32x32x2_f32 everywhere): frames/s and the
+                 conv family against 157.3 TFLOP/s
+  config3        gen_videos_next3d.py's 2x2-grid, 120-frame camera orbit over a fixed mesh (BASELINE.json configs[2])
+  config5        reenact_avatar_next3d.py's loop: one identity, a new FLAME mesh per frame (configs[4], synthetic sequence)
+  cpu_baseline   the CPU oracle (a port of the reference's fp32 path) timed on the host cores.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +36,9 @@ sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
+TRAFFIC_PROFILE = os.path.join(REPO, 'profiles', 'r02_traffic_pmc.json')
+CONV_FAMILY = ('3x3 split-bf16 conv family: every conv2d*_bf16x3 kernel launched by n3d_conv2d_bf16x3 with ksize 3 '
+               '(stride 1 incl. the persistent and pre-split variants, transposed stride 2, stride 2; all launches of the step)')
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -34,7 +46,8 @@ def cpu_baseline(seconds_budget=25.0):
     on the host cores: N=1 frames of the same workload (R=64, 48+48), bounded sample."""
     from next3d_amd import demo, mesh, spec
     from oracle import cases, generator as ogen
-    threads = min(os.cpu_count() or 1, 64)
+    host = os.cpu_count() or 1
+    threads = min(host, 64)                 # torch's intra-op pool stops scaling well before that on this workload
     torch.set_num_threads(threads)
     d = demo.demo_arrays()
     sd = spec.synthetic_state_dict(0)
@@ -53,8 +66,56 @@ def cpu_baseline(seconds_budget=25.0):
         frame()
         n += 1
     dt = time.time() - t0
-    return {'value': n / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} frames, batch 1, 512²/64²/48+48, fp32, torch-CPU oracle with {threads} threads'}
+    return {'value': n / dt, 'unit': 'frames/s', 'cores': threads, 'host_cores': host, 'kind': 'port',
+            'sample': f'{n} frames, batch 1, 512²/64²/48+48, fp32, torch-CPU oracle with {threads} threads '
+                      f'(host reports {host} logical cores)'}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(argv, n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU (what
+    train_next3d.py:100-103 does with torch.multiprocessing.spawn); rank 0's JSON line is the child's stdout."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def spawn_selftest():
+    """--selftest-spawn (CPU, gloo): the launch / rendezvous / gather plumbing of the multi-GPU path with a tiny stand-in
+    for the frames — tests/test_cpu_distributed.py runs `python bench.py --gpus 2 --selftest-spawn`."""
+    import torch.distributed as dist
+    from next3d_amd.sharding import AsyncFrameGather
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo')
+    gat = AsyncFrameGather(torch.empty(2, 3, 4, 4, dtype=torch.uint8), dst=0)
+    for step in range(3):
+        gat.submit(torch.full((2, 3, 4, 4), 10 * rank + step, dtype=torch.uint8))
+    gat.drain()
+    dist.barrier()
+    if rank == 0:
+        got = [int(t[0, 0, 0, 0]) for t in gat.received]
+        print(json.dumps({'selftest': 'spawn', 'n_gpus': world, 'gathered_last_step': got, 'ok': got == [10 * r + 2 for r in range(world)]}))
+    dist.destroy_process_group()
+
+
+def orbit_cameras(frames, device):
+    """gen_videos_next3d.py:133-137: yaw / pitch walk of the camera over `frames` frames -> [frames, 25]."""
+    from next3d_amd import camera_utils
+    piv = torch.tensor([0, 0, 0.2], dtype=torch.float32)
+    K = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]])
+    out = []
+    for k in range(frames):
+        cam = camera_utils.LookAtPoseSampler.sample(3.14 / 2 + 0.35 * math.sin(2 * 3.14 * k / (frames // 2)),
+                                                    3.14 / 2 - 0.05 + 0.25 * math.cos(2 * 3.14 * k / (frames // 2)), piv, radius=2.7)
+        out.append(torch.cat([cam.reshape(-1, 16), K.reshape(-1, 9)], 1))
+    return torch.cat(out, 0).to(device)
 
 
 def main():
@@ -63,17 +124,23 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='seeds per GPU per step (BASELINE.json configs[1]: 4)')
+    ap.add_argument('--prewarm-seconds', type=float, default=2.0, help='un-counted steps before the warm-up (clock ramp)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip roofline_fp32 / config3 / config5')
+    ap.add_argument('--serial-gather', action='store_true', help='join the frame gather of step k before step k+1 is enqueued')
+    ap.add_argument('--selftest-spawn', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(sys.argv[1:], args.gpus))
+    if args.selftest_spawn:
+        return spawn_selftest()
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -82,7 +149,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)        # 'nccl' == RCCL on ROCm
 
-    from next3d_amd import _lib, demo
+    from next3d_amd import _lib, demo, layers
     _lib.lib()
     G, _ = demo.build_generator(dev)
     B = args.batch
@@ -94,29 +161,43 @@ def main():
     u = torch.rand((B * R * R, Sf), device=dev, generator=g)
 
     from next3d_amd.sharding import AsyncFrameGather
-    # asynchronous (host never blocks) gather of the finished frames, one per step (sharding.AsyncFrameGather)
     gatherer = AsyncFrameGather(torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev), dst=0)
 
-    def drain():
-        gatherer.drain()
+    def to_frames(img):
+        frames = torch.empty(img.shape, dtype=torch.uint8, device=img.device)     # gen_samples_next3d.py:201 (NCHW kept)
+        _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img), _lib.ptr(frames), img.numel(), _lib.stream()))
+        return frames
 
     def step():
-        # the previous step's gather is joined BEFORE this step's kernels are enqueued: the rasteriser must not overlap another
-        # stream's kernels, and an RCCL gather kernel is exactly that
-        gatherer.drain()
+        if args.serial_gather:
+            gatherer.drain()
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
         img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)['image']
-        frames = torch.empty(img.shape, dtype=torch.uint8, device=dev)       # gen_samples_next3d.py:201 (NCHW kept)
-        _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img), _lib.ptr(frames), img.numel(), _lib.stream()))
-        gatherer.submit(frames)
+        frames = to_frames(img)
+        gatherer.submit(frames)          # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
 
     def sync():
-        drain()
+        gatherer.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    # un-counted pre-warm: the first launches page the code objects in and the chip ramps its clocks; a 0.3 s timed region
+    # right after a cold start measured 11 % low on a fresh box (round 1)
+    t_pre = time.perf_counter()
+    step()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync()
@@ -133,42 +214,42 @@ def main():
     # the inputs do not change between steps, so pipelined steps must return identical frames: a cheap guard against stream
     # races in exactly the configuration that was timed (tests/test_generator_gpu.py has the per-stage version)
     fa = step().clone(); fb = step().clone(); fc = step()
-    torch.cuda.synchronize()
+    sync()
     reproducible = bool(torch.equal(fa, fb) and torch.equal(fb, fc))
 
-    roofline = None
-    if not args.no_roofline:
-        # same K steps again with per-launch HIP events on the launch stream (kept out of the timed region above so
-        # the event records cannot perturb `value`)
-        # ... and with the static-backbone side stream switched off for this pass: two streams' kernels overlap in time, which
-        # would stretch every family's event time; the roofline wants each kernel's own duration
+    def conv_profile(steps):
+        """`steps` steps with per-launch HIP events on the launch stream (outside the timed region; the static-backbone side
+        stream is switched off for this pass so that every kernel's event time is its own duration) -> n3d_prof_read()."""
         overlap, G.overlap_static = G.overlap_static, False
         step(); torch.cuda.synchronize()
         _lib.prof_reset()
         _lib.prof_enable(True)
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         G.overlap_static = overlap
         prof = _lib.prof_read()
         _lib.prof_reset()
-        c16, c32 = prof['conv2d_bf16x3'], prof['conv2d']
-        if c16['ms'] >= c32['ms']:       # dominant kernel family: split-bf16 conv on the bf16 matrix cores
-            dom, name, peak = c16, ('3x3 split-bf16 conv family: conv2d_p_bf16x3_kernel (persistent) + conv2d_bf16x3_kernel + conv2d_up_bf16x3_kernel + conv2d_s2_bf16x3_kernel '
-                                    '(all launches of the step)'), PEAK_BF16_MFMA_TFLOPS / 3.0
-        else:                            # N3D_PRECISION=fp32: fp32-MFMA conv
-            dom, name, peak = c32, 'conv2d_mfma_kernel (all launches of the step)', PEAK_FP32_MFMA_TFLOPS
+        return prof
+
+    single = world == 1
+    roofline = None
+    if not args.no_roofline:
+        prof = conv_profile(args.steps)
+        dom, peak = prof['conv2d_bf16x3'], PEAK_BF16_MFMA_TFLOPS / 3.0
+        name = CONV_FAMILY
+        if layers.PRECISION != 'bf16x3':
+            dom, peak, name = prof['conv2d'], PEAK_FP32_MFMA_TFLOPS, 'conv2d_mfma_kernel family (fp32 MFMA; all launches of the step)'
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-        traffic = traffic_x2 = None   # HBM bytes per launch of the roofline family: PMC passes cannot run inside bench.py, so the
-        tpath = os.path.join(REPO, 'profiles', 'r01_traffic_pmc.json')       # committed rocprofv3 --pmc result is attached
-        if dom is c16 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            # raw FETCH_SIZE + WRITE_SIZE; the guide's gfx950 x2 correction applies to 16-byte-per-lane reads only (here: the
-            # weight slabs, which mostly hit L2), the activation patches are read 4 bytes per lane -> raw is the estimate, x2 the bound
+        traffic = traffic_x2 = traffic_src = None   # HBM bytes per launch: PMC passes cannot run inside bench.py -> the committed
+        if layers.PRECISION == 'bf16x3' and os.path.exists(TRAFFIC_PROFILE):     # rocprofv3 --pmc result of THIS build is attached
+            tj = json.load(open(TRAFFIC_PROFILE))
             traffic, traffic_x2 = tj['traffic_bytes_per_launch_raw'], tj['traffic_bytes_per_launch_fetch_x2']
+            traffic_src = 'profiles/' + os.path.basename(TRAFFIC_PROFILE)
+        convs = ('conv2d_bf16x3', 'conv2d', 'conv1x1_bf16x3')
         roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                    'traffic_fetch_x2_upper_bound': traffic_x2,
+                    'traffic_fetch_x2_upper_bound': traffic_x2, 'traffic_source': traffic_src,
                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                     'kernel': name,
                     'note': 'achieved = algorithmic (fp32-equivalent) conv flops / HIP-event time of the family; for bf16x3 the '
@@ -176,16 +257,78 @@ def main():
                     'launches_per_step': dom['launches'] / args.steps,
                     'algorithmic_gflop_per_step': dom['flops'] / args.steps / 1e9,
                     'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
-                    'all_conv_tflops': (c16['flops'] + c32['flops'] + prof['conv1x1_bf16x3']['flops']) /
-                                       ((c16['ms'] + c32['ms'] + prof['conv1x1_bf16x3']['ms']) * 1e-3) / 1e12,
+                    'all_conv_tflops': sum(prof[k]['flops'] for k in convs) / (sum(prof[k]['ms'] for k in convs) * 1e-3) / 1e12,
                     'family_ms_per_step': {k: round(p['ms'] / args.steps, 4) for k, p in prof.items()}}
 
+    extras = {}
+    if single and not args.no_extras:
+        kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+        # ---- strict-fp32 arithmetic (N3D_PRECISION=fp32): the same K steps on v_mfma_f32_32x32x2_f32
+        if layers.PRECISION == 'bf16x3':
+            layers.set_precision('fp32')
+            step(); step(); torch.cuda.synchronize()
+            k32 = max(3, args.steps // 2)
+            t32 = timed(step, k32)
+            p32 = conv_profile(k32)['conv2d']
+            a32 = p32['flops'] / (p32['ms'] * 1e-3) / 1e12 if p32['ms'] > 0 else 0.0
+            extras['roofline_fp32'] = {'value': k32 * B / t32, 'unit': 'frames/s', 'ms_per_step': 1e3 * t32 / k32, 'steps': k32, 'dtype': 'f32',
+                                       'bound': 'mfma', 'achieved': a32, 'peak': PEAK_FP32_MFMA_TFLOPS, 'frac': a32 / PEAK_FP32_MFMA_TFLOPS,
+                                       'kernel': 'conv2d_mfma_kernel family (v_mfma_f32_32x32x2_f32, bit-equivalent to an fmaf chain)',
+                                       'algorithmic_gflop_per_step': p32['flops'] / k32 / 1e9}
+            layers.set_precision('bf16x3')
+            step(); torch.cuda.synchronize()
+        # ---- configs[2]: 2x2 grid (batch 4 = one video frame), 120-frame orbit, fixed mesh (gen_videos_next3d.py:126-158)
+        grid_seeds = [10720, 12374, 13393, 17099]                       # README.md:48
+        zg, _, cg_cond, vg = demo.demo_batch(grid_seeds[:B], device=dev)
+        wsg = G.mapping(zg, cg_cond, truncation_psi=0.7, truncation_cutoff=14)
+        cams = orbit_cameras(120, dev)
+        cam_of = lambda k: cams[k % 120:k % 120 + 1].expand(B, -1).contiguous()
+        it = [0]
+
+        def orbit(cached, kw_):
+            k = it[0]; it[0] += 1
+            to_frames(G.synthesis(wsg, cam_of(k), vg, use_cached_backbone=cached, **kw_)['image'])
+        G.synthesis(wsg, cam_of(0), vg, cache_backbone=True, **kw); torch.cuda.synchronize()
+        t_c = timed(lambda: orbit(True, kw), 120)
+        t_u = timed(lambda: orbit(False, kw), 24)
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = 96, 96     # sampling_multiplier 2
+        j2 = torch.rand((B, R * R, 96, 1), device=dev, generator=g)
+        u2 = torch.rand((B * R * R, 96), device=dev, generator=g)
+        kw2 = dict(kw, depth_jitter=j2, importance_u=u2)
+        orbit(True, kw2); torch.cuda.synchronize()
+        t_c2 = timed(lambda: orbit(True, kw2), 60)
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+        extras['config3'] = {'workload': 'gen_videos_next3d.py: 2x2 grid (batch 4 = one video frame), 120-frame camera orbit, fixed FLAME '
+                                         'mesh, uint8 frames; images/s = 4 x video frames/s',
+                             'cached_planes_images_per_s': 120 * B / t_c, 'cached_planes_video_fps': 120 / t_c,
+                             'uncached_images_per_s': 24 * B / t_u, 'uncached_video_fps': 24 / t_u,
+                             'cached_planes_96+96_images_per_s': 60 * B / t_c2, 'unit': 'frames/s', 'frames_timed': [120, 24, 60]}
+        # ---- configs[4]: reenactment — one identity (ws), a NEW mesh per frame (reenact_avatar_next3d.py:139-164); data/obama is
+        # not in the tree: demo mesh + seeded smooth per-frame perturbation (sigma 1 mm), 4 consecutive frames per step
+        zr, cr, cr_cond, vr = demo.demo_batch([0] * B, yaws=[0.0] * B, device=dev)
+        wsr = G.mapping(zr, cr_cond, truncation_psi=0.7, truncation_cutoff=14)
+        gq = torch.Generator(device=dev).manual_seed(7)
+        F_ = 64
+        drift = torch.cumsum(torch.randn(F_ + B, 1, 3, device=dev, generator=gq) * 2e-4, 0) + torch.randn(F_ + B, vr.shape[1], 3, device=dev, generator=gq) * 1e-4
+        meshes = vr[:1] + drift
+        G.synthesis(wsr, cr, meshes[:B].contiguous(), cache_identity=True, **kw); torch.cuda.synchronize()
+        it[0] = 0
+
+        def reenact(cached):
+            k = it[0] % (F_ // B); it[0] += 1
+            to_frames(G.synthesis(wsr, cr, meshes[k * B:(k + 1) * B].contiguous(), use_cached_identity=cached, **kw)['image'])
+        t_rc = timed(lambda: reenact(True), 32)
+        t_ru = timed(lambda: reenact(False), 16)
+        extras['config5'] = {'workload': 'reenact_avatar_next3d.py loop: one identity, a new FLAME mesh + landmarks per frame (synthetic '
+                                         'smooth sequence; data/obama is not in the tree), 4 consecutive frames per step, camera fixed',
+                             'cached_identity_frames_per_s': 32 * B / t_rc, 'uncached_frames_per_s': 16 * B / t_ru, 'unit': 'frames/s',
+                             'frames_timed': [32 * B, 16 * B]}
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
-        from next3d_amd import layers
         precision_dtype = 'bf16x3 (split-bf16 operands, f32 accumulate; f32 elsewhere)' if layers.PRECISION == 'bf16x3' else 'f32'
         frames = args.steps * B * world
         print(json.dumps({
@@ -195,11 +338,12 @@ def main():
             'config': {'workload': f'BASELINE.json configs[1]: batch={B} seeds per GPU, 512² output, 64² neural render, '
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,
-                       'gather': 'RCCL gather of uint8 frames to rank 0' if world > 1 else 'none'},
-            'frames_bitwise_reproducible': reproducible, 'roofline': roofline, 'cpu_baseline': cpu}))
+                       'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if world > 1 else 'none',
+                       'prewarm_seconds': args.prewarm_seconds},
+            'frames_bitwise_reproducible': reproducible, 'roofline': roofline, **extras, 'cpu_baseline': cpu}))
         if not reproducible:
             print('bench.py: pipelined steps returned different frames', file=sys.stderr)
-    drain()
+    gatherer.drain()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -114,23 +114,40 @@ class TriPlaneGenerator(torch.nn.Module):
         if uv_face_mask is None:      # reference: cv2.imread('data/ffhq/uv_face_eye_mask.png') (triplane_next3d.py:91)
             uv_face_mask = self._load_uv_mask('data/ffhq/uv_face_eye_mask.png')
         self.uv_face_mask = torch.nn.functional.interpolate(uv_face_mask.float(), [256, 256])
+        # super-resolution settings the reference derives in its constructors (superresolution.py:264-278, triplane_next3d.py:181-183)
+        sr_module = rendering_kwargs.get('superresolution_module', 'training_avatar_texture.superresolution.SuperresolutionHybrid8XDC')
+        if not str(sr_module).endswith('SuperresolutionHybrid8XDC'):
+            raise RuntimeError(f'superresolution_module {sr_module!r}: only SuperresolutionHybrid8XDC (512x512) is implemented')
+        self.sr_conv_clamp = 256 if sr_num_fp16_res > 0 else None        # (256 if use_fp16 else None); kept under force_fp32
+        self._drop_derived()
+
+    def _drop_derived(self):
+        """Forget everything derived from the parameters: prepared weights AND the cross-call caches (blended planes,
+        identity networks) — they are stale after a weight reload / device move / in-place update."""
         self._prepared = None
+        self._last_planes = None
+        self._identity_cache = None
+        self._param_stamp = None
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
     def _load_uv_mask(path):
-        if os.path.exists(path):
-            from PIL import Image
-            m = np.asarray(Image.open(path).convert('RGB'), dtype=np.float32)[:, :, 0] / 255.
-            return torch.from_numpy(m)[None, None].contiguous()
-        return mesh.synthetic_uv_face_mask()
+        """The reference reads this cwd-relative file with cv2 and keeps channel 0 of the BGR image, i.e. BLUE
+        (triplane_next3d.py:91); a missing file crashes it.  Same here: no silent stand-in — pass `uv_face_mask=` explicitly
+        (as the demo / tests do with mesh.synthetic_uv_face_mask()) to run without the asset."""
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} not found (relative to the current directory, as in the reference); run from the '
+                               'repository root that holds data/ffhq/, or pass uv_face_mask= to the constructor')
+        from PIL import Image
+        m = np.asarray(Image.open(path).convert('RGB'), dtype=np.float32)[:, :, 2] / 255.       # cv2 BGR channel 0 == RGB channel 2
+        return torch.from_numpy(m)[None, None].contiguous()
 
     def _apply(self, fn, *a, **k):
-        self._prepared = None
+        self._drop_derived()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._prepared = None
+        self._drop_derived()
         return super().load_state_dict(*a, **k)
 
     @property
@@ -138,8 +155,16 @@ class TriPlaneGenerator(torch.nn.Module):
         return next(self.parameters()).device
 
     def refresh(self):
-        """Drop derived constants (call after mutating parameters in place)."""
-        self._prepared = None
+        """Drop derived constants and caches (in-place parameter updates are also detected by `_check_params`)."""
+        self._drop_derived()
+
+    def _check_params(self):
+        """In-place updates (misc.copy_params_and_buffers after a first forward, an optimizer step) bump the tensors' version
+        counters: a changed sum invalidates the prepared weights and the caches.  Called once per mapping / synthesis call."""
+        stamp = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        if self._param_stamp is not None and stamp != self._param_stamp:
+            self._drop_derived()
+        self._param_stamp = stamp
 
     def _prep(self):
         """Derived per-model constants: K-major conv weights, squared-weight sums, scaled decoder weights, mesh tables."""
@@ -155,7 +180,7 @@ class TriPlaneGenerator(torch.nn.Module):
         S.static = networks.SynthesisNet(P, 'backbone.synthesis')
         S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64)
         S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256)
-        S.sr = networks.SuperRes8XDC(P, 'superresolution')
+        S.sr = networks.SuperRes8XDC(P, 'superresolution', conv_clamp=self.sr_conv_clamp)
         lr = float(self.rendering_kwargs.get('decoder_lr_mul', 1))
         S.dec_w1 = (P['decoder.net.0.weight'] * (lr / np.sqrt(32))).contiguous()
         S.dec_b1 = (P['decoder.net.0.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.0.bias']
@@ -176,6 +201,7 @@ class TriPlaneGenerator(torch.nn.Module):
     # ------------------------------------------------------------------ reference API
     def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         """reference triplane_next3d.py:111-115 + MappingNetwork.forward (networks_stylegan2.py:233-268)."""
+        self._check_params()
         S = self._prep()
         P = S.P
         if self.rendering_kwargs['c_gen_conditioning_zero']:
@@ -270,7 +296,7 @@ class TriPlaneGenerator(torch.nn.Module):
         # The static tri-plane backbone depends only on the latents: it runs on a second HIP stream so that its low-resolution
         # layers (a handful of workgroups each) overlap the texture -> mouth -> blending chain.
         cur = torch.cuda.current_stream()
-        ident = getattr(self, '_identity_cache', None) if use_cached_identity else None
+        ident = self._identity_cache if use_cached_identity else None
         static = None
         if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
             textures, static = ident
@@ -342,24 +368,27 @@ class TriPlaneGenerator(torch.nn.Module):
         `use_cached_backbone` (reference signature; semantics of upstream training/triplane.py:67-72) keep the blended planes
         across calls (camera orbits); `cache_identity` / `use_cached_identity` keep only the latent-dependent networks
         (texture + static backbone) so that a new mesh per frame re-runs just raster -> mouth -> blending."""
-        noise_mode = synthesis_kwargs.get('noise_mode', 'random')
-        if noise_mode == 'random':
-            raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
+        noise_mode = synthesis_kwargs.get('noise_mode', 'random')       # the reference's default (networks_stylegan2.py:311)
+        if noise_mode not in ('random', 'const', 'none'):
+            raise RuntimeError(f'noise_mode {noise_mode!r}: random / const / none')
         if neural_rendering_resolution is None:
             neural_rendering_resolution = self.neural_rendering_resolution
         else:
             self.neural_rendering_resolution = neural_rendering_resolution
+        self._check_params()
         S = self._prep()
         ws = ws.to(device=self.device, dtype=torch.float32)
-        if use_cached_backbone and getattr(self, '_last_planes', None) is not None:
-            planes, eg3d_ws = self._last_planes
+        eg3d_ws = ws[:, :S.texture.num_ws]             # always the CURRENT latents (upstream training/triplane.py:67-72 caches planes only)
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
         else:
-            planes, eg3d_ws = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity)
+            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity)
         if cache_backbone:
-            self._last_planes = (planes, eg3d_ws)
+            self._last_planes = planes
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
         rgb_image = feature_image[:, :3]
-        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa)
+        sr_noise = self.rendering_kwargs.get('superresolution_noise_mode', 'none')     # triplane_next3d.py:182
+        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
     def sample_mixed(self, coordinates, directions, ws, v, truncation_psi=1, truncation_cutoff=None, update_emas=False,
@@ -371,14 +400,15 @@ class TriPlaneGenerator(torch.nn.Module):
         noise_mode = synthesis_kwargs.get('noise_mode', 'random')
         if noise_mode == 'random':
             raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
+        self._check_params()
         S = self._prep()
         ws = ws.to(device=self.device, dtype=torch.float32)
-        if use_cached_backbone and getattr(self, '_last_planes', None) is not None:
-            planes, _ = self._last_planes
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
         else:
-            planes, eg3d_ws = self._planes(ws, v, noise_mode)
+            planes, _ = self._planes(ws, v, noise_mode)
             if cache_backbone:
-                self._last_planes = (planes, eg3d_ws)
+                self._last_planes = planes
         coords = coordinates.to(device=self.device, dtype=torch.float32).contiguous()
         N, M = coords.shape[0], coords.shape[1]
         if N != planes.shape[0] or coords.shape[2] != 3:

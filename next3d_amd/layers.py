@@ -154,15 +154,24 @@ class StyleBank:
         return out
 
 
-def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None):
+def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
-    StyleBank; otherwise they are computed here from the latent `w`."""
+    StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
+    'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
+    the device generator like the reference) — the kernels' epilogue takes one noise image per launch, so that mode runs
+    the layer sample by sample."""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
         dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
-    noise = L.noise_const if noise_mode == 'const' else None
-    if noise_mode == 'random':
-        raise RuntimeError("noise_mode='random' is a training-time path; inference uses 'const' or 'none'")
+    if noise_mode not in ('random', 'const', 'none'):
+        raise RuntimeError(f'noise_mode {noise_mode!r}: random / const / none')
+    if noise_mode == 'random' and L.noise_const is not None and _noise is None:
+        n = x.shape[0]
+        draws = torch.randn([n, *L.noise_const.shape], dtype=torch.float32, device=L.noise_const.device)
+        outs = [synthesis_layer(L, x[i:i + 1], w, fir, up=up, noise_mode='random', conv_clamp=conv_clamp, gain=gain, styles=styles[i:i + 1],
+                                dcoef=dcoef[i:i + 1], out=None if out is None else out[i:i + 1], _noise=draws[i]) for i in range(n)]
+        return out if out is not None else torch.cat(outs, 0)
+    noise = _noise if _noise is not None else (L.noise_const if noise_mode == 'const' else None)
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:

@@ -74,7 +74,7 @@ class MeshSequence:
             for i in range(start, stop, n):
                 if drop_last and i + n > stop:
                     return
-                yield torch.from_numpy(np.ascontiguousarray(self.data[i:min(i + n, stop)]))
+                yield torch.from_numpy(np.array(self.data[i:min(i + n, stop)]))      # a writable copy, not a view of the read-only map
             return
         copy_stream = torch.cuda.Stream(device=device)
         stage = [torch.empty(n, self.V + self.L, 3, dtype=torch.float32).pin_memory() for _ in range(2)]

@@ -197,14 +197,15 @@ class StyleUNet:
 
 
 class SuperRes8XDC:
-    def __init__(self, P, prefix):
-        self.block0 = _Block(P, f'{prefix}.block0', 32, conv_clamp=256)
-        self.block1 = _Block(P, f'{prefix}.block1', 256, conv_clamp=256)
+    def __init__(self, P, prefix, conv_clamp=256):
+        """conv_clamp: 256 when the model was built with sr_num_fp16_res > 0, else None (superresolution.py:273-278)."""
+        self.block0 = _Block(P, f'{prefix}.block0', 32, conv_clamp=conv_clamp)
+        self.block1 = _Block(P, f'{prefix}.block1', 256, conv_clamp=conv_clamp)
         self.fir = P[f'{prefix}.block0.resample_filter']
         self.input_resolution = 128
         self._banks = {}
 
-    def __call__(self, rgb, x, ws, resize_fn):
+    def __call__(self, rgb, x, ws, resize_fn, noise_mode='none'):
         """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286).  Every layer is driven by the
         LAST latent of `ws` (`ws[:, -1:].repeat(1, 3, 1)`, :280): all StyleBank jobs read that one slot."""
         ws = _ws3(ws)
@@ -219,8 +220,8 @@ class SuperRes8XDC:
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, 'none', side)
-        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, 'none', side)
+        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side)
+        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return rgb

@@ -67,3 +67,21 @@ def test_two_rank_gather_gloo():
         p.join(100)
         assert p.exitcode == 0
     assert q.get() == [0, 1, 2, 3, 4, 5]
+
+
+@pytest.mark.timeout(180)
+def test_bench_self_spawns_for_multi_gpu():
+    """`python bench.py --gpus 2` (no launcher, the way the driver runs --gpus 1) must start one process per GPU itself
+    (reference: train_next3d.py:100-103 spawns its own ranks).  The CPU stand-in (--selftest-spawn: gloo, tiny frames) goes
+    through the same self-spawn -> torch.distributed.run -> rendezvous -> AsyncFrameGather path as the GPU benchmark."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--selftest-spawn'], capture_output=True, text=True,
+                       env=env, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['ok'] and out['gathered_last_step'] == [2, 12]

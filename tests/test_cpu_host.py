@@ -39,7 +39,15 @@ def test_generator_module_state_dict_names():
     from next3d_amd import demo, spec
     d = demo.demo_arrays()
     from next3d_amd.generator import TriPlaneGenerator
-    G = TriPlaneGenerator(512, 25, 512, 512, 3, (d['faces'], d['uvs'], d['uvfaces']), rendering_kwargs=dict(demo.RENDERING_KWARGS))
+    from next3d_amd import mesh
+    topo = (d['faces'], d['uvs'], d['uvfaces'])
+    with pytest.raises(RuntimeError, match='uv_face_eye_mask.png not found'):     # as the reference (cv2.imread -> None -> crash): no silent stand-in
+        TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS))
+    with pytest.raises(RuntimeError, match='superresolution_module'):
+        TriPlaneGenerator(512, 25, 512, 512, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
+                          rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybrid4X'))
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask())
+    assert G.sr_conv_clamp is None                                           # sr_num_fp16_res == 0 -> no clamp (superresolution.py:273)
     assert set(G.state_dict()) == set(spec.build_spec())
     params = {n for n, _ in G.named_parameters()}
     assert 'backbone.synthesis.b4.conv1.noise_const' not in params and 'backbone.synthesis.b4.conv1.weight' in params

@@ -58,8 +58,12 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     pts = torch.zeros(N, 1000, 3)
     smp = G.sample_mixed(pts, None, ws, v, noise_mode='const', use_cached_backbone=True)
     assert tuple(smp['rgb'].shape) == (N, 1000, 32) and tuple(smp['sigma'].shape) == (N, 1000, 1) and dry == ['n3d_sample_points']
+    dry.clear()
+    G.synthesis(ws, c, v, neural_rendering_resolution=R)         # noise_mode defaults to 'random' (the reference's default,
+    rnd = Counter(dry)                                           # networks_stylegan2.py:311): noisy layers run sample by sample
+    assert sum(rnd.values()) > n_full if N > 1 else sum(rnd.values()) == n_full
     with pytest.raises(RuntimeError):
-        G.synthesis(ws, c, v, neural_rendering_resolution=R)     # noise_mode defaults to 'random' (training only)
+        G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')

@@ -514,3 +514,24 @@ def test_operator_layer_fp16_and_dtype_errors(dev):
                 lambda: filtered_lrelu.filtered_lrelu(x.to(torch.bfloat16).to(dev))):
         with pytest.raises(RuntimeError):
             bad()
+
+
+@pytest.mark.parametrize('up', [1, 2])
+def test_synthesis_layer_random_noise_mode(dev, monkeypatch, up):
+    """noise_mode='random' (the reference's default, networks_stylegan2.py:318-319: a fresh N(0,1) image per sample): with the
+    draw replaced by the learned noise image it must reproduce noise_mode='const' bit for bit; with real draws the samples of
+    a batch get different noise."""
+    from next3d_amd import layers
+    res, ic, oc, N = 16, 32, 64, 2
+    P = {'L.weight': _gen((oc, ic, 3, 3), 80), 'L.bias': _gen((oc,), 81) * 0.1, 'L.affine.weight': _gen((ic, 512), 82),
+         'L.affine.bias': torch.ones(ic), 'L.noise_const': _gen((res, res), 83), 'L.noise_strength': torch.tensor(0.5)}
+    L = layers.PreparedConv({k: v.to(dev) for k, v in P.items()}, 'L', True)
+    fir = O.setup_filter((1, 3, 3, 1)).to(dev)
+    x = _gen((1, ic, res // up, res // up), 84).to(dev).expand(N, -1, -1, -1)          # identical samples, identical latents
+    w = _gen((1, 512), 85).to(dev).expand(N, -1).contiguous()
+    y_const = layers.synthesis_layer(L, x, w, fir, up=up, noise_mode='const')
+    y_rand = layers.synthesis_layer(L, x, w, fir, up=up, noise_mode='random')
+    assert y_rand.shape == y_const.shape and not torch.equal(y_rand[0], y_rand[1]) and not torch.equal(y_rand, y_const)
+    monkeypatch.setattr(torch, 'randn', lambda shape, **k: L.noise_const.unsqueeze(0).expand(*shape).contiguous())
+    y_fixed = layers.synthesis_layer(L, x, w, fir, up=up, noise_mode='random')
+    assert torch.equal(y_fixed, y_const)
