@@ -21,6 +21,46 @@
 
 #define K_EPS 1e-8f
 
+// Hand-offs BETWEEN the kernels of n3d_rasterize_views (clear -> faces: z-buffer; transform -> faces / resolve: vertices;
+// faces -> resolve: z-buffer) go through agent-scope accesses: write-through (sc1) stores on the producing side, L1-bypassing
+// (sc1) loads on the consuming side.  The z-buffer is updated with device-scope atomics, which execute at the memory side of the
+// (per-XCD, mutually non-coherent) L2s; a plain store of the clear kernel that is still dirty in one XCD's L2 when another
+// XCD's atomicMin lands would later overwrite it.  Kernel boundaries are supposed to order that, and alone on the chip they
+// do; with 8-wave convolution workgroups of ANOTHER stream resident the results were not reproducible (round 1, DESIGN.md
+// §3.3, tools/dbg_race2.py: 12 of 12 runs).  RASTER_VARIANT selects which hand-offs use the agent-scope forms (bisecting with
+// tools/dbg_race3.sh); the shipped value is all of them — they cost nothing on these few hundred KB.
+//   bit 0: z-buffer clear stores   bit 1: vertex (tv) stores   bit 2: vertex loads   bit 3: z-buffer loads in resolve
+//   bit 4: faces / resolve transform their vertices themselves from the INPUT tensor (tv is still written, never read)
+#ifndef RASTER_VARIANT
+#define RASTER_VARIANT 15
+#endif
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+//   bit 5 (probe only): plain single-dword vertex loads the compiler cannot merge into 12-byte dwordx3 loads
+__device__ __forceinline__ float ld_vert(const float* p) {
+    if (RASTER_VARIANT & 4) return ld_agent(p);
+    if (RASTER_VARIANT & 32) { float v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+    return *p;
+}
+struct XfParams { const float* verts; const float* rot; int V, views; float sx, sy, sz, scale; };
+// one transformed vertex (the arithmetic of raster_transform_kernel, operation for operation)
+__device__ __forceinline__ void xf_vertex(const XfParams& q, int nv, int vi, float& ox, float& oy, float& oz) {
+    const int view = nv % q.views, n = nv / q.views;
+    const float* p = q.verts + ((int64_t)n * q.V + vi) * 3;
+    const float* R = q.rot + view * 9;
+    const float x = p[0], y = -p[1], z = p[2];
+    float tx = (x * R[0] + y * R[3] + z * R[6] + q.sx) * q.scale;
+    float ty = (x * R[1] + y * R[4] + z * R[7] + q.sy) * q.scale;
+    float tz = (x * R[2] + y * R[5] + z * R[8] + q.sz) * q.scale;
+    ty = -ty; tz = -tz; tz = tz + 10.f;
+    ox = -tx; oy = -ty; oz = tz;
+}
+__device__ __forceinline__ void get_vertex(const float* vn, const XfParams& q, int nv, int vi, float& x, float& y, float& z) {
+    if (RASTER_VARIANT & 16) { xf_vertex(q, nv, vi, x, y, z); return; }
+    const float* v = vn + 3 * (int64_t)vi;
+    x = ld_vert(v); y = ld_vert(v + 1); z = ld_vert(v + 2);
+}
+
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
@@ -43,8 +83,9 @@ __global__ __launch_bounds__(256) void raster_transform_kernel(const float* __re
         float ty = (x * R[1] + y * R[4] + z * R[7] + sy) * scale;
         float tz = (x * R[2] + y * R[5] + z * R[8] + sz) * scale;
         ty = -ty; tz = -tz; tz = tz + 10.f;
-        float* o = tv + i * 3;
-        o[0] = -tx; o[1] = -ty; o[2] = tz;       // Pytorch3dRasterizer.forward negates x,y (renderer.py:403)
+        float* o = tv + i * 3;                   // Pytorch3dRasterizer.forward negates x,y (renderer.py:403)
+        if (RASTER_VARIANT & 2) { st_agent(o, -tx); st_agent(o + 1, -ty); st_agent(o + 2, tz); }
+        else { o[0] = -tx; o[1] = -ty; o[2] = tz; }
     }
     const int64_t j = i - total;
     if (j >= 0 && j < (int64_t)N * Lm) {
@@ -57,17 +98,17 @@ __global__ __launch_bounds__(256) void raster_transform_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void raster_faces_kernel(const float* __restrict__ tv, const int* __restrict__ faces,
-                                                           unsigned long long* __restrict__ zbuf, int NV, int V, int F, int H, int W) {
+__global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, const int* __restrict__ faces,
+                                                           unsigned long long* zbuf, int NV, int V, int F, int H, int W, XfParams xf) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)NV * F) return;
     const int f = (int)(i % F), nv = (int)(i / F);
     const float* vn = tv + (int64_t)nv * V * 3;
     // the reference rasterises faces[..., [0,2,1]] (triplane_next3d.py:207): `faces` is passed already swapped
-    const float* v0 = vn + 3 * (int64_t)faces[3 * f + 0];
-    const float* v1 = vn + 3 * (int64_t)faces[3 * f + 1];
-    const float* v2 = vn + 3 * (int64_t)faces[3 * f + 2];
-    const float x0 = v0[0], y0 = v0[1], z0 = v0[2], x1 = v1[0], y1 = v1[1], z1 = v1[2], x2 = v2[0], y2 = v2[1], z2 = v2[2];
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    get_vertex(vn, xf, nv, faces[3 * f + 0], x0, y0, z0);
+    get_vertex(vn, xf, nv, faces[3 * f + 1], x1, y1, z1);
+    get_vertex(vn, xf, nv, faces[3 * f + 2], x2, y2, z2);
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
     const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
@@ -140,28 +181,29 @@ __device__ __forceinline__ float bilinear_apply(const BilinearTaps& t, const flo
 
 // per pixel: uv = sum_k bary_k * face_uv[f][k], vis; alpha = grid_sample(uv_face_mask, uv) * vis   (renderer.py:425-437,
 // triplane_next3d.py:211-214).  grid [NV,H,W,2], alpha [NV,H,W]
-__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* __restrict__ tv, const int* __restrict__ faces,
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const float* tv, const int* __restrict__ faces,
                                                              const float* __restrict__ face_uv,   // [F,3,3] (vertex order swapped)
-                                                             const unsigned long long* __restrict__ zbuf,
+                                                             const unsigned long long* zbuf,
                                                              const float* __restrict__ uv_mask, int MH, int MW,
                                                              float* __restrict__ grid, float* __restrict__ alpha, int NV, int V,
-                                                             int F, int H, int W) {
+                                                             int F, int H, int W, XfParams xfp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)NV * H * W) return;
     const int xi = (int)(i % W), yi = (int)((i / W) % H), nv = (int)(i / ((int64_t)H * W));
-    const unsigned long long key = zbuf[i];
+    const unsigned long long key = (RASTER_VARIANT & 8) ? ld_agent(zbuf + i) : zbuf[i];
     float u = 0.f, v = 0.f, vis = 0.f;
     if (key != 0xFFFFFFFFFFFFFFFFull) {
         const int f = (int)(key & 0xFFFFFFFFull);
         const float* vn = tv + (int64_t)nv * V * 3;
-        const float* v0 = vn + 3 * (int64_t)faces[3 * f + 0];
-        const float* v1 = vn + 3 * (int64_t)faces[3 * f + 1];
-        const float* v2 = vn + 3 * (int64_t)faces[3 * f + 2];
+        float ax, ay, az, bx, by, bz, cx, cy, cz;
+        get_vertex(vn, xfp, nv, faces[3 * f + 0], ax, ay, az);
+        get_vertex(vn, xfp, nv, faces[3 * f + 1], bx, by, bz);
+        get_vertex(vn, xfp, nv, faces[3 * f + 2], cx, cy, cz);
         const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
-        const float area = edge_fn(v2[0], v2[1], v0[0], v0[1], v1[0], v1[1]) + K_EPS;
-        const float w0 = edge_fn(xf, yf, v1[0], v1[1], v2[0], v2[1]) / area;
-        const float w1 = edge_fn(xf, yf, v2[0], v2[1], v0[0], v0[1]) / area;
-        const float w2 = edge_fn(xf, yf, v0[0], v0[1], v1[0], v1[1]) / area;
+        const float area = edge_fn(cx, cy, ax, ay, bx, by) + K_EPS;
+        const float w0 = edge_fn(xf, yf, bx, by, cx, cy) / area;
+        const float w1 = edge_fn(xf, yf, cx, cy, ax, ay) / area;
+        const float w2 = edge_fn(xf, yf, ax, ay, bx, by) / area;
         const float* a = face_uv + (int64_t)f * 9;
         u = (w0 * a[0] + w1 * a[3]) + w2 * a[6];
         v = (w0 * a[1] + w1 * a[4]) + w2 * a[7];
@@ -421,7 +463,9 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
 
 __global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long* __restrict__ zbuf, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) zbuf[i] = 0xFFFFFFFFFFFFFFFFull;
+    if (i >= count) return;
+    if (RASTER_VARIANT & 1) st_agent(zbuf + i, 0xFFFFFFFFFFFFFFFFull);
+    else zbuf[i] = 0xFFFFFFFFFFFFFFFFull;
 }
 
 extern "C" {
@@ -446,12 +490,13 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
     hipLaunchKernelGGL(raster_transform_kernel, dim3((unsigned)cdiv64(nt, 256)), dim3(256), 0, stream, verts, lms, rot, tv_ws, lm2d, N,
                        V, Lm, views, shift_x, shift_y, shift_z, scale);
     N3D_LAUNCH_CHECK();
+    const XfParams xf = {verts, rot, V, views, shift_x, shift_y, shift_z, scale};
     hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)cdiv64((int64_t)NV * F, 256)), dim3(256), 0, stream, (const float*)tv_ws,
-                       faces, zbuf_ws, NV, V, F, H, W);
+                       faces, zbuf_ws, NV, V, F, H, W, xf);
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)cdiv64((int64_t)NV * H * W, 256)), dim3(256), 0, stream,
                        (const float*)tv_ws, faces, face_uv, (const unsigned long long*)zbuf_ws, uv_mask, mask_h, mask_w, grid, alpha,
-                       NV, V, F, H, W);
+                       NV, V, F, H, W, xf);
     N3D_LAUNCH_CHECK();
     if (fill) {
         hipLaunchKernelGGL(fill_holes_kernel, dim3(NV), dim3(1024), 0, stream, alpha, H, W, binarize_view, views);
