@@ -1,0 +1,221 @@
+// 3x3 stride-1 convolution on the bf16 matrix cores whose ACTIVATIONS ARRIVE ALREADY SPLIT ("split8" layout, include/n3d.h):
+// the operand split (hi = bf16(x), lo = bf16(x - hi)) and the style modulation were done ONCE by the producer's epilogue
+// (csrc/upfirdn2d.hip: fir4_split8_kernel), so this kernel's K loop contains no staging arithmetic at all.
+//
+//   x  : [N][2 (hi, lo)][I/8][H][W][8] bf16 — one 16-byte unit = 8 consecutive channels of one pixel, already multiplied by
+//        this layer's style (modulation, tat/networks_stylegan2.py:70) by whoever wrote it;
+//   wt : the same split K-major weight tiles as conv2d_bf16x3.hip, shared by the whole batch.
+//
+// Staging is a pure copy done by LDS-DMA (`buffer_load_dwordx4 ... lds`): per 16-channel chunk a workgroup issues 36 weight
+// pieces + 40 patch pieces of 1 KB (64 lanes x 16 B, lane-linear in LDS, per-lane source address = patch pixel; the halo
+// comes from the buffer descriptor's range check) — 9.5 instructions per wave instead of 24 four-byte gathers, ~100 VALU
+// (style multiply, two conversions, a subtraction, packing per value) and 11 ds_write_b128 in conv2d_bf16x3_kernel.  With
+// nothing to convert there are no wave roles: all eight waves issue the next chunk's DMA, multiply the current chunk, wait
+// for their own pieces (s_waitcnt vmcnt(0)) and meet at ONE raw s_barrier per chunk; two LDS buffers (2 x 76 KB).
+// Tile: 64 output channels x (16 x 32) pixels, wave tile 64 x 64 (2 x 2 accumulators of v_mfma_f32_32x32x16_bf16), the same
+// arithmetic and accumulation order per output as conv2d_bf16x3_kernel => bit-identical results for identical operands.
+// Replaces the same reference call sites as conv2d_bf16x3.hip (F.conv2d inside modulated_conv2d, networks_stylegan2.py:34-91).
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct ConvPsParams {
+    const bf16x8* x; const bf16x8* wt16; float* y;
+    int N, I, O, OP64, H, W;
+    int tiles_x, tiles_y, tiles_m;
+    int64_t xbs;                 // 16-byte units between consecutive samples of x (= 2 * I/8 * H * W for a dense tensor)
+    int64_t ybs, yrs;            // floats
+    n3d_epilogue epi;
+};
+
+constexpr int PS_BM = 64, PS_TH = 16, PS_TW = 32, PS_TAPS = 9;
+constexpr int PS_PH = PS_TH + 2, PS_PW = PS_TW + 2, PS_PPIX = PS_PH * PS_PW;          // 18 x 34 = 612 patch pixels
+constexpr int PS_BCH = (PS_PPIX + 63) / 64, PS_BPAD = PS_BCH * 64;                     // 10 DMA pieces = 640 slots per (hi|lo, half)
+constexpr int PS_A_SZ = PS_TAPS * 2 * PS_BM;                                           // 16-byte slots per (buffer, hi|lo): [tap][half][row]
+constexpr int PS_B_SZ = 2 * PS_BPAD;                                                   //                                     [half][pixel]
+constexpr int PS_A_PIECES = PS_TAPS * 2 * 2, PS_B_PIECES = 2 * 2 * PS_BCH, PS_PIECES = PS_A_PIECES + PS_B_PIECES;   // 36 + 40
+constexpr int PS_PER_WAVE = (PS_PIECES + 7) / 8;                                       // 10
+// ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every fragment read of an LDS-DMA pipeline):
+//   [buf 0: A_hi | A_lo | B_hi | B_lo][buf 1: ...]   then 2 x 64 floats of epilogue factors
+constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                                      // 4864 slots = 77,824 B per buffer
+constexpr int PS_LDS_SLOTS = 2 * PS_BUF + 2 * PS_BM * 4 / 16;
+
+__global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[PS_LDS_SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    // XCD-aware 1-D grid, M tile fastest (conv2d_bf16x3.hip): the O/64 workgroups reading one input patch share it in one L2
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int m0 = (lb % p.tiles_m) * PS_BM; lb /= p.tiles_m;
+    const int tile_i = lb % (p.tiles_x * p.tiles_y), n = lb / (p.tiles_x * p.tiles_y);
+    const int y0 = (tile_i / p.tiles_x) * PS_TH, x0 = (tile_i % p.tiles_x) * PS_TW;
+    const int KC = p.I / 16, HW = p.H * p.W;
+
+    // descriptors (range-checked: a lane offset beyond the plane reads as zero -> the halo of the patch)
+    const int plane_bytes = (p.I / 8) * HW * 16;
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
+    const bf16x8* xs = p.x + (int64_t)n * p.xbs;
+    const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_l = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (int64_t)(p.I / 8) * HW), 0, plane_bytes, 0x00020000);
+
+    // this wave's copy pieces (piece = wn + 8 j): the per-lane source offsets do not depend on the chunk — the chunk only moves
+    // the scalar offset
+    int voff[PS_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PS_PER_WAVE; ++j) {
+        const int pc = wn + 8 * j;
+        if (pc < PS_A_PIECES) {
+            voff[j] = (m0 + lane) * 16;                                   // 64 consecutive weight rows (OP64 is padded to 64)
+        } else {
+            const int pp = ((pc - PS_A_PIECES) % PS_BCH) * 64 + lane;     // patch pixel of this lane
+            const int iy = y0 - 1 + pp / PS_PW, ix = x0 - 1 + pp % PS_PW;
+            const bool ok = pp < PS_PPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            voff[j] = ok ? (iy * p.W + ix) * 16 : (int)0x80000000;
+        }
+    }
+    auto copy_chunk = [&](int kc, int buf) {
+        bf16x8* base = smem + buf * PS_BUF;
+#pragma unroll
+        for (int j = 0; j < PS_PER_WAVE; ++j) {
+            const int pc = wn + 8 * j;
+            if (pc >= PS_PIECES) continue;
+            if (pc < PS_A_PIECES) {
+                const int t = pc >> 2, hl = (pc >> 1) & 1, hf = pc & 1;
+                bf16x8* dst = base + hl * PS_A_SZ + (t * 2 + hf) * PS_BM;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)dst, 16, voff[j], ((t * KC + kc) * 4 + hl * 2 + hf) * p.OP64 * 16, 0, 0);
+            } else {
+                const int q = pc - PS_A_PIECES, hl = q / (2 * PS_BCH), hf = (q / PS_BCH) & 1, c = q % PS_BCH;
+                bf16x8* dst = base + 2 * PS_A_SZ + hl * PS_B_SZ + hf * PS_BPAD + c * 64;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(hl ? r_l : r_h, (lds_void*)dst, 16, voff[j], (kc * 2 + hf) * HW * 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const int a_frag = half * PS_BM + l31;                                // + tap*2*BM + mt*32
+    const int b_frag0 = half * PS_BPAD + (wn * 2) * PS_PW + l31;          // + ky*PW + kx (+ PW for the wave's second row)
+    auto mfma_block = [&](int buf) {
+        const bf16x8* A_hi = smem + buf * PS_BUF, *A_lo = A_hi + PS_A_SZ, *B_hi = A_hi + 2 * PS_A_SZ, *B_lo = B_hi + PS_B_SZ;
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        auto fetch = [&](int t, int s) {
+            const int boff = (t / 3) * PS_PW + (t % 3);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { ah[s][mt] = A_hi[t * 2 * PS_BM + a_frag + mt * 32]; al[s][mt] = A_lo[t * 2 * PS_BM + a_frag + mt * 32]; }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) { bh[s][nt] = B_hi[b_frag0 + nt * PS_PW + boff]; bl[s][nt] = B_lo[b_frag0 + nt * PS_PW + boff]; }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < PS_TAPS; ++t) {
+            const int s = t & 1;
+            if (t + 1 < PS_TAPS) fetch(t + 1, s ^ 1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[s][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // per-channel epilogue factors -> LDS (read after the K loop; plain stores, no DMA involved)
+    float* s_rs = reinterpret_cast<float*>(smem + 2 * PS_BUF), *s_bs = s_rs + PS_BM;
+    const n3d_epilogue& E = p.epi;
+    if (tid < PS_BM) {
+        const int o = min(m0 + tid, p.O - 1);
+        s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
+        s_bs[tid] = E.bias ? E.bias[o] : 0.f;
+    }
+
+    copy_chunk(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): this wave's pieces of chunk 0 are in LDS ...
+    __builtin_amdgcn_s_barrier();                                         // ... and after the barrier everybody's are
+    for (int kc = 0; kc < KC; ++kc) {
+        if (kc + 1 < KC) copy_chunk(kc + 1, (kc + 1) & 1);                // the other buffer's last readers passed the previous barrier
+        mfma_block(kc & 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+    const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
+    const int64_t plane = (int64_t)p.H * p.W, yplane = (int64_t)p.H * p.yrs;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int oy = y0 + wn * 2 + nt, ox = x0 + l31;
+        if (oy >= p.H || ox >= p.W) continue;
+        const int64_t po = (int64_t)oy * p.W + ox;
+        const float nz = E.noise ? E.noise[po] * nstr : 0.f;
+        float* d0 = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox + (int64_t)(m0 + 4 * half) * yplane;
+        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po + (int64_t)(m0 + 4 * half) * plane : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);                 // channel within the tile, minus 4*half
+                if (m0 + ol + 4 * half >= p.O) continue;
+                float v = acc[mt][nt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half];
+                v = fmaxf(v, v * alpha_eff) * E.gain;                            // leaky ReLU (0 <= alpha <= 1) or linear
+                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                if (res) v += res[(int64_t)ol * plane];
+                d0[(int64_t)ol * yplane] = v;
+            }
+    }
+}
+
+// Layers this kernel takes (the host asks before it lets a producer write split8): 3x3 stride 1, I % 16 == 0, images of at
+// least 16 x 32 whose 8-wave tiles cover the chip, linear / leaky-ReLU (0 <= alpha <= 1) epilogue.
+extern "C" int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W) {
+    if (I % 16 != 0 || I < 16 || H < 16 || W < 32 || N < 1 || O < 1) return 0;
+    const int64_t blocks = (int64_t)cdiv(W, PS_TW) * cdiv(H, PS_TH) * cdiv(O, PS_BM) * N;
+    if ((int64_t)(I / 8) * H * W * 16 >= (1ll << 31)) return 0;           // 32-bit buffer offsets per plane
+    return blocks >= 256 ? 1 : 0;
+}
+
+int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
+    N3D_CHECK(d->ksize == 3 && d->mode == 0, "conv2d_bf16x3: a split8 input is taken by the 3x3 stride-1 kernel only");
+    N3D_CHECK(d->style == nullptr, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL)");
+    N3D_CHECK(d->ksplit <= 1, "conv2d_bf16x3: no split-K with a split8 input");
+    N3D_CHECK(n3d_conv2d_split8_eligible(d->N, d->I, d->O, d->H, d->W), "conv2d_bf16x3: shape not eligible for the split8 kernel (n3d_conv2d_split8_eligible)");
+    const n3d_epilogue& E = d->epi;
+    N3D_CHECK(E.act == N3D_ACT_LINEAR || (E.act == N3D_ACT_LRELU && E.alpha >= 0.f && E.alpha <= 1.f), "conv2d_bf16x3 (split8): linear or leaky-ReLU epilogue only");
+    N3D_CHECK(!E.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
+    N3D_CHECK(((uintptr_t)d->x & 15) == 0, "conv2d_bf16x3: split8 input must be 16-byte aligned");
+    ConvPsParams p;
+    p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
+    p.tiles_x = cdiv(d->W, PS_TW); p.tiles_y = cdiv(d->H, PS_TH); p.tiles_m = cdiv(d->O, PS_BM);
+    p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;      // x_batch_stride counts fp32-sized elements
+    p.ybs = d->y_batch_stride; p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
+    N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
+    N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.epi = d->epi;
+    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
+    N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
+    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}

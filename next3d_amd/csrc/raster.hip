@@ -21,22 +21,25 @@
 
 #define K_EPS 1e-8f
 
-// Hand-offs BETWEEN the kernels of n3d_rasterize_views (clear -> faces: z-buffer; transform -> faces / resolve: vertices;
-// faces -> resolve: z-buffer) go through agent-scope accesses: write-through (sc1) stores on the producing side, L1-bypassing
-// (sc1) loads on the consuming side.  The z-buffer is updated with device-scope atomics, which execute at the memory side of the
-// (per-XCD, mutually non-coherent) L2s; a plain store of the clear kernel that is still dirty in one XCD's L2 when another
-// XCD's atomicMin lands would later overwrite it.  Kernel boundaries are supposed to order that, and alone on the chip they
-// do; with 8-wave convolution workgroups of ANOTHER stream resident the results were not reproducible (round 1, DESIGN.md
-// §3.3, tools/dbg_race2.py: 12 of 12 runs).  RASTER_VARIANT selects which hand-offs use the agent-scope forms (bisecting with
-// tools/dbg_race3.sh); the shipped value is all of them — they cost nothing on these few hundred KB.
-//   bit 0: z-buffer clear stores   bit 1: vertex (tv) stores   bit 2: vertex loads   bit 3: z-buffer loads in resolve
-//   bit 4: faces / resolve transform their vertices themselves from the INPUT tensor (tv is still written, never read)
+// RASTER_VARIANT — how the rasteriser's kernels read and hand over their small, heavily re-read tables.
+// Round-1 finding: while an 8-wave split-bf16 convolution workgroup of ANOTHER stream is resident on the same
+// CUs, raster_faces / raster_resolve returned different results from run to run (12 of 12 runs).  Round-2 bisection
+// (tools/dbg_race3.py, gpurun_out r2a): the damage is in loads served by the per-CU VECTOR L1 — it persists when the kernels
+// read only IMMUTABLE inputs (variant 16: vertices transformed in place from `verts`, no inter-kernel hand-off left), it
+// persists with un-merged single-dword loads (variant 32), with write-through stores on the producers (1, 2) and with an
+// L1-bypassing z-buffer read (8); it disappears (0 of 12, co-resident stride-1, stride-2 and fill runs) as soon as the vertex
+// loads are agent-scope (sc1: served by L2, bypassing the L1) — variant 4.  So it is not a software coherence bug of this
+// file; the shipped configuration reads every gathered table through sc1 loads and hands the z-buffer / vertices over with
+// write-through stores, which costs nothing on a few hundred KB and is right under any stream schedule.
+//   bit 0: z-buffer clear stores sc1   bit 1: vertex (tv) stores sc1   bit 2: vertex / index / uv-table loads sc1
+//   bit 3: z-buffer loads in resolve sc1   bit 4: (probe) faces / resolve transform their vertices themselves from `verts`
 #ifndef RASTER_VARIANT
 #define RASTER_VARIANT 15
 #endif
 template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 //   bit 5 (probe only): plain single-dword vertex loads the compiler cannot merge into 12-byte dwordx3 loads
+template <typename T> __device__ __forceinline__ T ld_tab(const T* p) { return (RASTER_VARIANT & 4) ? ld_agent(p) : *p; }
 __device__ __forceinline__ float ld_vert(const float* p) {
     if (RASTER_VARIANT & 4) return ld_agent(p);
     if (RASTER_VARIANT & 32) { float v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
     const float* vn = tv + (int64_t)nv * V * 3;
     // the reference rasterises faces[..., [0,2,1]] (triplane_next3d.py:207): `faces` is passed already swapped
     float x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    get_vertex(vn, xf, nv, faces[3 * f + 0], x0, y0, z0);
-    get_vertex(vn, xf, nv, faces[3 * f + 1], x1, y1, z1);
-    get_vertex(vn, xf, nv, faces[3 * f + 2], x2, y2, z2);
+    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 0), x0, y0, z0);
+    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 1), x1, y1, z1);
+    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 2), x2, y2, z2);
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
     const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
@@ -147,10 +150,10 @@ __device__ __forceinline__ float bilinear_1ch(const float* __restrict__ img, int
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
     float acc = 0.f;
-    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc += img[(int64_t)y0 * W + x0] * (wx0 * wy0);
-    if (x0 + 1 >= 0 && x0 + 1 < W && y0 >= 0 && y0 < H) acc += img[(int64_t)y0 * W + x0 + 1] * (wx1 * wy0);
-    if (x0 >= 0 && x0 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += img[(int64_t)(y0 + 1) * W + x0] * (wx0 * wy1);
-    if (x0 + 1 >= 0 && x0 + 1 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += img[(int64_t)(y0 + 1) * W + x0 + 1] * (wx1 * wy1);
+    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc += ld_tab(img + (int64_t)y0 * W + x0) * (wx0 * wy0);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 >= 0 && y0 < H) acc += ld_tab(img + (int64_t)y0 * W + x0 + 1) * (wx1 * wy0);
+    if (x0 >= 0 && x0 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += ld_tab(img + (int64_t)(y0 + 1) * W + x0) * (wx0 * wy1);
+    if (x0 + 1 >= 0 && x0 + 1 < W && y0 + 1 >= 0 && y0 + 1 < H) acc += ld_tab(img + (int64_t)(y0 + 1) * W + x0 + 1) * (wx1 * wy1);
     return acc;
 }
 
@@ -196,17 +199,17 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* tv, co
         const int f = (int)(key & 0xFFFFFFFFull);
         const float* vn = tv + (int64_t)nv * V * 3;
         float ax, ay, az, bx, by, bz, cx, cy, cz;
-        get_vertex(vn, xfp, nv, faces[3 * f + 0], ax, ay, az);
-        get_vertex(vn, xfp, nv, faces[3 * f + 1], bx, by, bz);
-        get_vertex(vn, xfp, nv, faces[3 * f + 2], cx, cy, cz);
+        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 0), ax, ay, az);
+        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 1), bx, by, bz);
+        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 2), cx, cy, cz);
         const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
         const float area = edge_fn(cx, cy, ax, ay, bx, by) + K_EPS;
         const float w0 = edge_fn(xf, yf, bx, by, cx, cy) / area;
         const float w1 = edge_fn(xf, yf, cx, cy, ax, ay) / area;
         const float w2 = edge_fn(xf, yf, ax, ay, bx, by) / area;
         const float* a = face_uv + (int64_t)f * 9;
-        u = (w0 * a[0] + w1 * a[3]) + w2 * a[6];
-        v = (w0 * a[1] + w1 * a[4]) + w2 * a[7];
+        u = (w0 * ld_tab(a + 0) + w1 * ld_tab(a + 3)) + w2 * ld_tab(a + 6);
+        v = (w0 * ld_tab(a + 1) + w1 * ld_tab(a + 4)) + w2 * ld_tab(a + 7);
         vis = 1.f;
     }
     grid[i * 2 + 0] = u; grid[i * 2 + 1] = v;

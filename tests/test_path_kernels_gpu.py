@@ -167,6 +167,37 @@ def test_rasterize_views_fill_mouth(dev, size):
     assert int(((a2 * 255).round() != (a_nofill * 255).round()).sum()) <= 4 and torch.equal(g2, g)
 
 
+def test_rasteriser_reproducible_under_coresident_convolutions(dev):
+    """Round-1 finding: with 8-wave split-bf16 convolution workgroups of ANOTHER stream resident, the rasteriser
+    returned different z-buffers / barycentrics from run to run (tools/dbg_race3.py: 12 of 12 with L1-served table loads).  The
+    shipped kernels read their tables through agent-scope (L2-served) loads: the demo mesh rasterised while stride-1 and
+    stride-2 convolutions run on a side stream must equal the quiet run bit for bit, every time."""
+    import os
+    from next3d_amd import mesh
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'demo_inputs.npz'))
+    c = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'case_r64_s48.npz'))
+    mb = mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces'])
+    faces, face_uv = mb['faces'][0][:, [0, 2, 1]], mb['face_uvcoords'][0][:, [0, 2, 1]].contiguous()
+    v = torch.from_numpy(c['v'])
+    vv, lms = v[:, :5023], v[:, 5023:]
+    mask = F.interpolate(mesh.synthetic_uv_face_mask().float(), [256, 256])[0, 0]
+    quiet = _gpu_views(dev, vv, lms, faces, face_uv, mask, 256, True, 1)
+    x0, x1 = _gen((4, 256, 128, 128), 90).to(dev), _gen((4, 256, 129, 129), 91).to(dev)
+    wt = cg.prep_weight_bf16x3((_gen((256, 256, 3, 3), 92) / 48).to(dev))
+    side = torch.cuda.Stream()
+    for it in range(8):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                cg.conv_launch(x0, wt, 3, 0, 256, bf16x3=True)
+                cg.conv_launch(x1, wt, 3, 1, 256, bf16x3=True)
+        busy = _gpu_views(dev, vv, lms, faces, face_uv, mask, 256, True, 1)
+        torch.cuda.current_stream().wait_stream(side)
+        for a, b, name in zip(busy, quiet, ('grid', 'alpha', 'lm2d')):
+            assert torch.equal(a, b), (it, name, int((a != b).sum()))
+
+
 def test_texture_project_matches_grid_sample(dev):
     """triplane_next3d.py:223-230: F.grid_sample(textures, uv, bilinear, zeros, align_corners=False), the side plane being
     the sum of two views; coordinates beyond [-1,1] exercise the zero padding.  One-plane and three-plane entry points."""
