@@ -23,12 +23,13 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 1
+#define N3D_ABI_VERSION 2
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
        N3D_ACT_ELU = 6, N3D_ACT_SELU = 7, N3D_ACT_SOFTPLUS = 8, N3D_ACT_SWISH = 9 };
 enum { N3D_F32 = 0, N3D_F16 = 1 };
+enum { N3D_LAYOUT_NCHW_F32 = 0, N3D_LAYOUT_SPLIT8 = 1 };   /* activation layouts (split8: see n3d_fir4_split8) */
 
 int n3d_abi_version(void);
 const char* n3d_last_error(void);
@@ -97,6 +98,21 @@ int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
                        int fuh, int fuw, int fdh, int fdw, int up, int down, int px0, int px1, int py0, int py1, float gain,
                        float slope, float clamp, int flip, n3d_stream_t stream);
 
+/* ---- "split8": the activation layout of the pre-split convolution path.  A tensor [N,C,H,W] (C % 8 == 0) is stored as
+ *        bf16  y[N][2 (hi, lo)][C/8][H][W][8]       hi = bf16(v), lo = bf16(v - float(hi))
+ *      — 16-byte units of 8 consecutive channels of one pixel, the same 4 bytes per element as float32.  The PRODUCER of such a
+ *      tensor does the operand split of the bf16x3 arithmetic (n3d_conv2d_bf16x3) and the consumer's style modulation once, in
+ *      its epilogue; the consuming convolution then stages its operands with plain LDS-DMA copies.
+ *      n3d_fir4_split8: the 4x4 FIR behind a transposed convolution (= n3d_upfirdn2d_pitched with up = down = 1, fh = fw = 4,
+ *      padding 1, the layer epilogue `epi` fused: conv2d_resample.py:128-129 + bias_act) writing split8 instead of float32:
+ *      x [N,C,H,W] float32 (row pitch x_row_stride % 4 == 0) -> y split8 [N,C,H-1,W-1] ((W-1) % 4 == 0), each value
+ *      additionally multiplied by out_scale[n*out_scale_stride + c] (the next layer's style; NULL = 1). */
+int n3d_fir4_split8(const float* x, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
+                    int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
+                    int64_t out_scale_stride, n3d_stream_t stream);
+/* 1 when n3d_conv2d_bf16x3 accepts a split8 input for this 3x3 stride-1 shape (x_layout = N3D_LAYOUT_SPLIT8), else 0. */
+int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W);
+
 /* ---- conv2d weight preparation (done once per model): w [O,I,k,k] -> wt [k*k][I][OP] (K-major, the layout
  *      the MFMA kernel streams; OP = O rounded up to a multiple of 4, zero padded, so rows are 16-byte aligned)
  *      and, when wsq != NULL, wsq[o*I+i] = sum_k w[o,i,k]^2 (for demodulation). */
@@ -126,6 +142,9 @@ typedef struct {
     int64_t y_row_stride; /* floats between consecutive output rows (0 = OW).  A multiple of 4 >= OW gives the odd-width
                              (2W+1) transposed-conv output 16-byte-aligned rows for the FIR that follows */
     n3d_epilogue epi;
+    int x_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for n3d_conv2d_bf16x3 with ksize 3 / mode 0 only, N3D_LAYOUT_SPLIT8:
+                             `x` then points to a split8 tensor that already carries the modulation (style must be NULL);
+                             x_batch_stride still counts 4-byte elements (0 = dense) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 

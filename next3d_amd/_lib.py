@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -33,7 +33,7 @@ class Conv2dDesc(ctypes.Structure):
                 ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
-                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue)]
+                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int)]
 
 
 class FcJob(ctypes.Structure):
@@ -56,6 +56,8 @@ _SIGNATURES = {
     'n3d_upfirdn2d_pitched': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_int64, c_int64] + [c_int] * 11 +
                               [c_float, c_int64, c_int64, ctypes.POINTER(Epilogue), c_void_p]),
     'n3d_filtered_lrelu': (c_int, [c_void_p] * 5 + [c_int] * 14 + [c_float] * 3 + [c_int, c_void_p]),
+    'n3d_fir4_split8': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
+    'n3d_conv2d_split8_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_prep_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -128,6 +130,25 @@ def require_device(*tensors):
         if t is not None and t.device.type != 'cuda':
             raise RuntimeError('n3d ops run on a HIP device only (got a %s tensor); the CPU restatement lives in '
                                'oracle/ and is test infrastructure, not a fallback' % t.device.type)
+
+
+class Split8:
+    """A [N,C,H,W] activation in the split8 layout of include/n3d.h — bf16 [N][2 (hi,lo)][C/8][H][W][8], 4 bytes per element —
+    produced by a kernel epilogue (n3d_fir4_split8) for the pre-split 3x3 convolution; the consumer's style modulation is
+    already multiplied in.  `data` is the flat bf16 storage."""
+
+    def __init__(self, n, c, h, w, device):
+        import torch as _t
+        assert c % 8 == 0
+        self.shape = (n, c, h, w)
+        self.data = _t.empty(n * 2 * (c // 8) * h * w * 8, dtype=_t.bfloat16, device=device)
+        self.device = self.data.device
+
+    def to_float(self):
+        """float32 [N,C,H,W] = hi + lo (tests / debugging only)."""
+        n, c, h, w = self.shape
+        t = self.data.reshape(n, 2, c // 8, h, w, 8).float()
+        return (t[:, 0] + t[:, 1]).permute(0, 1, 4, 2, 3).reshape(n, c, h, w)
 
 
 def cast(t, dtype):

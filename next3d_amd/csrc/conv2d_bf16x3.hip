@@ -38,6 +38,7 @@ struct Conv16Params {
 
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
+int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);     // conv2d_ps_bf16x3.hip (split8 input)
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
 
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
@@ -686,6 +687,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
+    N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
+    if (d->x_layout == N3D_LAYOUT_SPLIT8) return conv2d_ps_bf16x3_launch(d, stream);
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     Conv16Params p;

@@ -59,44 +59,45 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
     const int y0 = (tile_i / p.tiles_x) * PS_TH, x0 = (tile_i % p.tiles_x) * PS_TW;
     const int KC = p.I / 16, HW = p.H * p.W;
 
-    // descriptors (range-checked: a lane offset beyond the plane reads as zero -> the halo of the patch)
+    // descriptors (range-checked: a lane offset beyond the buffer reads as zero -> the halo of the patch).  hi and lo planes of
+    // one sample are contiguous, so ONE descriptor covers both and the plane is selected through the scalar offset.
     const int plane_bytes = (p.I / 8) * HW * 16;
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
-    const bf16x8* xs = p.x + (int64_t)n * p.xbs;
-    const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_l = __builtin_amdgcn_make_buffer_rsrc((void*)(xs + (int64_t)(p.I / 8) * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, 2 * plane_bytes, 0x00020000);
 
-    // this wave's copy pieces (piece = wn + 8 j): the per-lane source offsets do not depend on the chunk — the chunk only moves
-    // the scalar offset
-    int voff[PS_PER_WAVE];
+    // This wave's copy pieces, all constants hoisted out of the K loop (the chunk only adds a stride to the scalar offsets):
+    //   weights: pieces pa = wn + 8 j (j < 5, pa < 36) = (tap, hi|lo, half) slabs of 64 rows x 16 B
+    //   patch  : pieces q  = wn + 8 j (j < 5)          = (hi|lo, half, 64-pixel run c) of the 18 x 34 patch
+    constexpr int NA = (PS_A_PIECES + 7) / 8, NB = PS_B_PIECES / 8;       // 5, 5
+    static_assert(PS_B_PIECES % 8 == 0, "patch pieces must divide evenly over the 8 waves");
+    int ldsA[NA], sofA[NA], ldsB[NB], sofB[NB], voffB[NB];
+    const int voffA = (m0 + lane) * 16;                                   // 64 consecutive weight rows (OP64 is padded to 64)
 #pragma unroll
-    for (int j = 0; j < PS_PER_WAVE; ++j) {
-        const int pc = wn + 8 * j;
-        if (pc < PS_A_PIECES) {
-            voff[j] = (m0 + lane) * 16;                                   // 64 consecutive weight rows (OP64 is padded to 64)
-        } else {
-            const int pp = ((pc - PS_A_PIECES) % PS_BCH) * 64 + lane;     // patch pixel of this lane
-            const int iy = y0 - 1 + pp / PS_PW, ix = x0 - 1 + pp % PS_PW;
-            const bool ok = pp < PS_PPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            voff[j] = ok ? (iy * p.W + ix) * 16 : (int)0x80000000;
-        }
+    for (int j = 0; j < NA; ++j) {
+        const int pa = wn + 8 * j, t = pa >> 2, hl = (pa >> 1) & 1, hf = pa & 1;
+        ldsA[j] = hl * PS_A_SZ + (t * 2 + hf) * PS_BM;
+        sofA[j] = ((t * KC) * 4 + hl * 2 + hf) * p.OP64 * 16;
     }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int q = wn + 8 * j, hl = q / (2 * PS_BCH), hf = (q / PS_BCH) & 1, c = q % PS_BCH;
+        ldsB[j] = 2 * PS_A_SZ + hl * PS_B_SZ + hf * PS_BPAD + c * 64;
+        sofB[j] = hl * plane_bytes + hf * HW * 16;
+        const int pp = c * 64 + lane;                                     // patch pixel of this lane
+        const int iy = y0 - 1 + pp / PS_PW, ix = x0 - 1 + pp % PS_PW;
+        const bool ok = pp < PS_PPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        voffB[j] = ok ? (iy * p.W + ix) * 16 : (int)0x80000000;
+    }
+    const int strideA = 4 * p.OP64 * 16, strideB = 2 * HW * 16;           // scalar-offset step per 16-channel chunk
     auto copy_chunk = [&](int kc, int buf) {
         bf16x8* base = smem + buf * PS_BUF;
 #pragma unroll
-        for (int j = 0; j < PS_PER_WAVE; ++j) {
-            const int pc = wn + 8 * j;
-            if (pc >= PS_PIECES) continue;
-            if (pc < PS_A_PIECES) {
-                const int t = pc >> 2, hl = (pc >> 1) & 1, hf = pc & 1;
-                bf16x8* dst = base + hl * PS_A_SZ + (t * 2 + hf) * PS_BM;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)dst, 16, voff[j], ((t * KC + kc) * 4 + hl * 2 + hf) * p.OP64 * 16, 0, 0);
-            } else {
-                const int q = pc - PS_A_PIECES, hl = q / (2 * PS_BCH), hf = (q / PS_BCH) & 1, c = q % PS_BCH;
-                bf16x8* dst = base + 2 * PS_A_SZ + hl * PS_B_SZ + hf * PS_BPAD + c * 64;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(hl ? r_l : r_h, (lds_void*)dst, 16, voff[j], (kc * 2 + hf) * HW * 16, 0, 0);
-            }
-        }
+        for (int j = 0; j < NA; ++j)
+            if (j < NA - 1 || wn + 8 * j < PS_A_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA, sofA[j] + kc * strideA, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + kc * strideB, 0, 0);
     };
 
     f32x16 acc[2][2];

@@ -231,6 +231,141 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
     }
 }
 
+// ---- the same 4x4 FIR (up = down = 1, pad 1: the pass behind a transposed convolution) writing the "split8" layout
+// (include/n3d.h) for the 3x3 convolution that follows: the epilogue (noise, bias, leaky ReLU, gain, clamp) is applied as in
+// fir4_vec_kernel, then the value is multiplied by the NEXT layer's style s[n][c] (modulation, tat/networks_stylegan2.py:70
+// `x * styles`), split into bf16 hi / lo halves and stored as 16-byte units of 8 consecutive channels per pixel:
+//     y[n][hl][c/8][oy][ox][c%8]      hi = bf16(v), lo = bf16(v - hi)
+// — exactly the operands conv2d_bf16x3_kernel builds for itself while staging (same multiply, same two conversions), so the
+// consumer (conv2d_ps_bf16x3.hip) multiplies bit-identical bf16 pairs.  One workgroup = 8 channels x (16 x 64) outputs:
+// the 8 footprints (19 x 72 floats each, aligned 16-byte loads) go to LDS, every work item produces 4 consecutive pixels of
+// one row for all 8 channels and stores 4 + 4 16-byte units (64 contiguous bytes per plane).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct FirSplitParams {
+    const float* x; const float* f; bf16x8_t* y;
+    int N, C, H, W, OH, OW, flip;
+    float gain;
+    int64_t xbs, xrs;
+    const float* out_scale; int64_t out_scale_stride;
+    int has_epi;
+    n3d_epilogue epi;
+    int tiles_x;
+};
+
+__global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
+    constexpr int TW = 64, TH = 16, CG = TW / 4, FW4 = (TW + 8) / 4, FH = TH + 3, CH = 8;
+    __shared__ f32x4 s_x[CH * FH * FW4];
+    const int tile = blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    float f[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) f[ky][kx] = p.flip ? p.f[ky * 4 + kx] : p.f[(3 - ky) * 4 + (3 - kx)];
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c8 * CH * p.H * p.xrs;
+    const int iy_lo = oy0 - 1;                                            // pad 1
+    for (int e = threadIdx.x; e < CH * FH * FW4; e += 256) {
+        const int ch = e / (FH * FW4), r = (e / FW4) % FH, q = e % FW4;
+        const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;                  // LDS column 0 = input column ox0 - 4
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < p.H && col >= 0 && col < p.W) {
+            v = *reinterpret_cast<const f32x4*>(xp + ((int64_t)ch * p.H + iy) * p.xrs + col);
+            if (col + 1 >= p.W) v.y = 0.f;                                // the pitch padding is never used
+            if (col + 2 >= p.W) v.z = 0.f;
+            if (col + 3 >= p.W) v.w = 0.f;
+        }
+        s_x[e] = v;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
+    const int ox = ox0 + 4 * cg, oy = oy0 + rg;
+    if (ox >= p.OW || oy >= p.OH) return;
+    const n3d_epilogue& E = p.epi;
+    const int64_t po = (int64_t)oy * p.OW + ox;
+    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+    if (p.has_epi && E.noise) nz = *reinterpret_cast<const f32x4*>(E.noise + po) * E.noise_strength[0];
+    float val[CH][4];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const f32x4* row = s_x + (ch * FH + rg + ky) * FW4 + cg;
+            const f32x4 a = row[0], b = row[1], d = row[2];
+            const float in[7] = {a.w, b.x, b.y, b.z, b.w, d.x, d.y};      // input columns ox - 1 .. ox + 5
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) acc[i] += in[i + kx] * f[ky][kx];
+        }
+        const int c = c8 * CH + ch;
+        float sc = 1.f, bias = 0.f;
+        if (p.has_epi) {
+            sc = E.const_scale;
+            if (E.row_scale) sc *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + c];
+            if (E.bias) bias = E.bias[c];
+        }
+        const float os = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + c] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[i] * p.gain;
+            if (p.has_epi) {
+                v = v * sc + nz[i] + bias;
+                v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
+                v *= E.gain;
+                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+            }
+            val[ch][i] = v * os;
+        }
+    }
+    const int64_t plane = (int64_t)p.OH * p.OW;                           // 16-byte units per (hl, c8) plane
+    bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane + po;
+    bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane + po;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (ox + i >= p.OW) break;
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            const __bf16 h = (__bf16)val[ch][i];
+            hi[ch] = h;
+            lo[ch] = (__bf16)(val[ch][i] - (float)h);
+        }
+        yh[i] = hi;
+        yl[i] = lo;
+    }
+}
+
+extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
+                               int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
+                               n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && H > 1 && W > 1, "fir4_split8: bad shape (C %% 8 == 0)");
+    const int64_t xrs = x_row_stride ? x_row_stride : W;
+    N3D_CHECK(xrs >= W && (xrs & 3) == 0 && (x_batch_stride & 3) == 0 && ((uintptr_t)x & 15) == 0, "fir4_split8: input rows must be 16-byte aligned (pitch %% 4 == 0)");
+    const int OH = H - 1, OW = W - 1;                                      // 4 taps, padding 1 + 1
+    N3D_CHECK((OW & 3) == 0, "fir4_split8: output width must be a multiple of 4");
+    N3D_CHECK(!epi || (!epi->residual && !epi->residual_up_filter), "fir4_split8: no residual input");
+    N3D_CHECK(!epi || !epi->noise || (epi->noise_strength && ((uintptr_t)epi->noise & 15) == 0), "fir4_split8: noise needs a strength and 16-byte alignment");
+    N3D_CHECK(!epi || (epi->act >= N3D_ACT_LINEAR && epi->act <= N3D_ACT_SWISH), "fir4_split8: unknown activation");
+    if (N == 0) return 0;
+    N3D_CHECK(x && f && y && ((uintptr_t)y & 15) == 0, "fir4_split8: null or misaligned tensor");
+    N3D_CHECK(C / 8 <= 65535 && N <= 65535, "fir4_split8: N and C/8 must be <= 65535");
+    FirSplitParams p;
+    p.x = x; p.f = f; p.y = (bf16x8_t*)y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.flip = flip; p.gain = gain;
+    p.xbs = x_batch_stride ? x_batch_stride : (int64_t)C * H * xrs; p.xrs = xrs;
+    p.out_scale = out_scale; p.out_scale_stride = out_scale_stride ? out_scale_stride : C;
+    p.has_epi = epi != nullptr;
+    if (epi) p.epi = *epi;
+    p.tiles_x = cdiv(OW, 64);
+    N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
+    hipLaunchKernelGGL(fir4_split8_kernel, dim3(p.tiles_x * cdiv(OH, 16), C / 8, N), dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
 static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t xrs, int64_t yrs, int fh, int fw, int upx,
                           int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                           int64_t xbs, int64_t ybs, const n3d_epilogue* epi, n3d_stream_t stream_) {

@@ -30,6 +30,12 @@ _SQRT2 = float(np.sqrt(2))
 PRECISION = os.environ.get('N3D_PRECISION', 'bf16x3')
 
 
+# Pre-split hand-off between an up-sampling layer and the 3x3 convolution behind it (include/n3d.h "split8"): the FIR epilogue
+# writes bf16 hi / lo planes already multiplied by the next layer's style, the convolution stages them by LDS-DMA.
+# N3D_PRESPLIT=0 keeps the float32 hand-off (A/B on one box).
+PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
+
+
 def set_precision(mode):
     global PRECISION
     if mode not in ('bf16x3', 'fp32'):
@@ -74,7 +80,10 @@ class PreparedConv:
 
 
 def _conv3x3(L, x, style=None, epilogue=None, out=None):
-    """3x3 stride-1 convolution on the arithmetic selected by PRECISION."""
+    """3x3 stride-1 convolution on the arithmetic selected by PRECISION.  A `_lib.Split8` input (written by the previous
+    layer's epilogue with THIS layer's style multiplied in) goes to the pre-split kernel; `style` is then ignored."""
+    if isinstance(x, _lib.Split8):
+        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 0):
         return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True)
     return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
@@ -154,12 +163,21 @@ class StyleBank:
         return out
 
 
-def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None):
+def presplit_ok(n, next_layer, h, w):
+    """May the layer in front of `next_layer` (a 3x3 stride-1 PreparedConv running on [n, I, h, w]) hand its output over in
+    the split8 layout?"""
+    return (PRESPLIT and PRECISION == 'bf16x3' and next_layer.wt16 is not None and next_layer.ksize == 3 and
+            cg.split8_eligible(n, next_layer.in_channels, next_layer.out_channels, h, w))
+
+
+def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
+                    split_for=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
     the device generator like the reference) — the kernels' epilogue takes one noise image per launch, so that mode runs
-    the layer sample by sample."""
+    the layer sample by sample.  `split_for` (up = 2 only): the styles [N,O] of the 3x3 layer that consumes this layer's
+    output -> the result is a `_lib.Split8` carrying them (see presplit_ok)."""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
         dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
@@ -168,6 +186,7 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     if noise_mode == 'random' and L.noise_const is not None and _noise is None:
         n = x.shape[0]
         draws = torch.randn([n, *L.noise_const.shape], dtype=torch.float32, device=L.noise_const.device)
+        assert split_for is None
         outs = [synthesis_layer(L, x[i:i + 1], w, fir, up=up, noise_mode='random', conv_clamp=conv_clamp, gain=gain, styles=styles[i:i + 1],
                                 dcoef=dcoef[i:i + 1], out=None if out is None else out[i:i + 1], _noise=draws[i]) for i in range(n)]
         return out if out is not None else torch.cat(outs, 0)
@@ -182,6 +201,8 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
                            row_pitch=True)
     else:
         t = cg.conv_launch(x, L.wt, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), row_pitch=True)
+    if split_for is not None:
+        return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 

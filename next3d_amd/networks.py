@@ -40,7 +40,11 @@ class _Block:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
-            x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv0))
+            # conv0's FIR epilogue may hand its output to conv1 pre-split, with conv1's styles multiplied in (layers.presplit_ok)
+            pre = (noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and
+                   L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
+            x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
+                                  split_for=bank[self.conv1.prefix][0] if pre else None, **sl(self.conv0))
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
         # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.

@@ -67,6 +67,12 @@ def bf16x3_eligible(i, h, w, ksize, mode):
     return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
+def split8_eligible(n, i, o, h, w):
+    """True when the 3x3 stride-1 layer [n,i,h,w] -> o channels is taken by the pre-split kernel (its producer may then write
+    the split8 layout): the library's own rule (n3d_conv2d_split8_eligible)."""
+    return bool(_lib.lib().n3d_conv2d_split8_eligible(n, i, o, h, w))
+
+
 def out_shape(h, w, mode):
     if mode == 0:
         return h, w
@@ -105,7 +111,15 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
     `out` may itself be such a view."""
-    _lib.require_device(x, wt, style, out)
+    split8 = isinstance(x, _lib.Split8)
+    if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
+        if not (bf16x3 and ksize == 3 and mode == 0 and style is None):
+            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 split-bf16 kernel, without a style')
+        n, i, h, w = x.shape
+        xs = x
+        x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only
+        ksplit = 1
+    _lib.require_device(None if split8 else x, wt, style, out)
     n, i, h, w = x.shape
     o = out_channels
     out_dtype = x.dtype
@@ -126,22 +140,23 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     else:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
     pitched_in = bf16x3 and mode == 1 and ksize == 3 and x.stride(3) == 1 and x.stride(2) > w and x.stride(1) == h * x.stride(2)
-    if not pitched_in and x.stride()[1:] != (h * w, w, 1):
+    if not split8 and not pitched_in and x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
     if out is not None:
         y = out
     elif row_pitch:
-        y = torch.empty([n, o, oh, (ow + 3) // 4 * 4], dtype=torch.float32, device=x.device)[..., :ow]
+        y = torch.empty([n, o, oh, (ow + 3) // 4 * 4], dtype=torch.float32, device=wt.device)[..., :ow]
     else:
-        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=x.device)
+        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=wt.device)
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
-    ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
-    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(y), _lib.ptr(ws)
+    d.x_layout = 1 if split8 else 0
     d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)

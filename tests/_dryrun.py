@@ -21,6 +21,10 @@ def _check_conv_desc(name, d):
     assert d.N >= 0 and d.I > 0 and d.O > 0 and d.H > 0 and d.W > 0, (name, d.N, d.I, d.O, d.H, d.W)
     assert d.x and d.wt and d.y, name
     assert d.ksize in (1, 3) and 0 <= d.mode <= 2
+    assert d.x_layout in (0, 1)
+    if d.x_layout == 1:                                  # split8 input: conv2d_ps_bf16x3_launch's preconditions
+        assert bf16x3 and d.ksize == 3 and d.mode == 0 and not d.style and d.ksplit <= 1 and d.epi.act in (1, 3)
+        assert d.I % 16 == 0 and d.H >= 16 and d.W >= 32 and d.x_batch_stride % 4 == 0
     if bf16x3:
         assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)
         assert d.x_row_stride in (0, d.W) or (d.ksize == 3 and d.mode == 1)
@@ -41,7 +45,7 @@ def patches():
     class Recorder:
         def __getattr__(self, name):
             res, argtypes = _lib._SIGNATURES[name]
-            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_abi_version', 'n3d_last_error'):
+            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_abi_version', 'n3d_last_error'):
                 return getattr(real, name)                       # pure host functions: the real ones
 
             def fn(*args):

@@ -535,3 +535,60 @@ def test_synthesis_layer_random_noise_mode(dev, monkeypatch, up):
     monkeypatch.setattr(torch, 'randn', lambda shape, **k: L.noise_const.unsqueeze(0).expand(*shape).contiguous())
     y_fixed = layers.synthesis_layer(L, x, w, fir, up=up, noise_mode='random')
     assert torch.equal(y_fixed, y_const)
+
+
+def _to_split8(x):
+    """float32 [N,C,H,W] -> _lib.Split8 with the kernels' own split (hi = bf16(x), lo = bf16(x - hi)), built with torch."""
+    from next3d_amd import _lib
+    n, c, h, w = x.shape
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    s = _lib.Split8(n, c, h, w, x.device)
+    t = torch.stack([hi, lo], 1).reshape(n, 2, c // 8, 8, h, w).permute(0, 1, 2, 4, 5, 3).contiguous()
+    s.data.copy_(t.reshape(-1))
+    return s
+
+
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 256, 128, 128), (4, 64, 512, 48, 80), (2, 128, 100, 256, 256), (8, 32, 64, 128, 96)])
+def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
+    """conv2d_ps_bf16x3_kernel (split8 input staged by LDS-DMA) against the register-staged split-bf16 kernels on the same
+    operands: same products, same accumulation order per output -> expected bit-identical; ragged sizes exercise the halo
+    coming from the buffer descriptor's range check and the masked stores."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    assert cg.split8_eligible(N, I, OC, H, W)
+    x = _gen((N, I, H, W), 100).to(dev)
+    w = (_gen((OC, I, 3, 3), 101) / np.sqrt(9 * I)).to(dev)
+    wt16 = cg.prep_weight_bf16x3(w)
+    dco, bias, noise = (1 + 0.1 * _gen((N, OC), 102)).to(dev), _gen((OC,), 103).to(dev), _gen((H, W), 104).to(dev)
+    ns = torch.tensor(0.3, device=dev)
+    for kw in (dict(), dict(row_scale=dco, noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=1.4, clamp=2.0)):
+        ref = cg.conv_launch(x, wt16, 3, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True)
+        y = cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True)
+        print('presplit vs plain: max abs diff', float((y - ref).abs().max()), 'bit-identical', bool(torch.equal(y, ref)))
+        _close(y, ref, atol=1e-5, rtol=1e-5)
+    _close(y, O.bias_act(torch.nn.functional.conv2d(x.cpu(), w.cpu(), padding=1) * dco.cpu()[:, :, None, None] + noise.cpu() * 0.3, bias.cpu(),
+                         act='lrelu', gain=1.4, clamp=2.0), atol=2e-4, rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True)      # the split8 input is modulated already
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 32, 16, 32), (1, 64, 64, 64), (3, 16, 40, 24)])
+def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
+    """n3d_fir4_split8 (FIR + layer epilogue + next layer's style + hi/lo split, split8 output) against the float32 FIR path:
+    hi + lo must reproduce style * fir_out to 2^-16 relative (what two bf16 halves carry)."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    f = O.setup_filter((1, 3, 3, 1)).to(dev)
+    z = torch.empty(N, C, 2 * H + 1, (2 * W + 1 + 3) // 4 * 4, device=dev)[..., :2 * W + 1]
+    z.copy_(_gen((N, C, 2 * H + 1, 2 * W + 1), 110).to(dev))
+    bias, noise, ns = _gen((C,), 111).to(dev), _gen((2 * H, 2 * W), 112).to(dev), torch.tensor(0.2, device=dev)
+    style = (1 + 0.2 * _gen((N, C), 113)).to(dev)
+    act = dict(noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=float(np.sqrt(2)), clamp=3.0)
+    ref = uf.upfirdn2d(z, f, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act)) * style[:, :, None, None]
+    s = uf._fir4_split8(z, f, 4, _lib.make_epilogue(**act), style)
+    assert s.shape == (N, C, 2 * H, 2 * W)
+    _close(s.to_float(), ref, atol=1e-6, rtol=2.0 ** -15)
+    t = s.data.reshape(N, 2, C // 8, 2 * H, 2 * W, 8).float()
+    hi_expected = ref.bfloat16().float().reshape(N, C // 8, 8, 2 * H, 2 * W).permute(0, 1, 3, 4, 2)
+    assert float((t[:, 0] - hi_expected).abs().max()) <= float(ref.abs().max()) * 2.0 ** -7      # hi is the bf16 rounding of the value
