@@ -29,6 +29,8 @@ struct ConvPsParams {
     int tiles_x, tiles_y, tiles_m;
     int64_t xbs;                 // 16-byte units between consecutive samples of x (= 2 * I/8 * H * W for a dense tensor)
     int64_t ybs, yrs;            // floats
+    int dbg;                     // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
+                                 // 8 no per-chunk barrier / vmcnt wait (wrong results; timing only)
     n3d_epilogue epi;
 };
 
@@ -149,11 +151,21 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
     copy_chunk(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): this wave's pieces of chunk 0 are in LDS ...
     __builtin_amdgcn_s_barrier();                                         // ... and after the barrier everybody's are
-    for (int kc = 0; kc < KC; ++kc) {
-        if (kc + 1 < KC) copy_chunk(kc + 1, (kc + 1) & 1);                // the other buffer's last readers passed the previous barrier
-        mfma_block(kc & 1);
+    if (p.dbg == 0) {
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc + 1 < KC) copy_chunk(kc + 1, (kc + 1) & 1);            // the other buffer's last readers passed the previous barrier
+            mfma_block(kc & 1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {                                                              // ablations (N3D_CONV_DBG): which part of the loop costs what
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc + 1 < KC && !(p.dbg & 4)) copy_chunk(kc + 1, (kc + 1) & 1);
+            if (!(p.dbg & 2)) mfma_block(kc & 1);
+            if (!(p.dbg & 8)) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_s_barrier(); }
+        }
         __builtin_amdgcn_s_waitcnt(0x0f70);
-        __builtin_amdgcn_s_barrier();
+        if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     }
 
     // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
@@ -211,6 +223,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.epi = d->epi;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;

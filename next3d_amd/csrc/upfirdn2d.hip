@@ -237,9 +237,7 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
 // `x * styles`), split into bf16 hi / lo halves and stored as 16-byte units of 8 consecutive channels per pixel:
 //     y[n][hl][c/8][oy][ox][c%8]      hi = bf16(v), lo = bf16(v - hi)
 // — exactly the operands conv2d_bf16x3_kernel builds for itself while staging (same multiply, same two conversions), so the
-// consumer (conv2d_ps_bf16x3.hip) multiplies bit-identical bf16 pairs.  One workgroup = 8 channels x (16 x 64) outputs:
-// the 8 footprints (19 x 72 floats each, aligned 16-byte loads) go to LDS, every work item produces 4 consecutive pixels of
-// one row for all 8 channels and stores 4 + 4 16-byte units (64 contiguous bytes per plane).
+// consumer (conv2d_ps_bf16x3.hip) multiplies bit-identical bf16 pairs.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct FirSplitParams {
     const float* x; const float* f; bf16x8_t* y;
@@ -253,8 +251,13 @@ struct FirSplitParams {
 };
 
 __global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
-    constexpr int TW = 64, TH = 16, CG = TW / 4, FW4 = (TW + 8) / 4, FH = TH + 3, CH = 8;
-    __shared__ f32x4 s_x[CH * FH * FW4];
+    // 64 x 32 outputs x 8 channels per workgroup; the channels are walked one at a time through a double-buffered LDS footprint
+    // (35 rows x 72 floats = 10 KB each): channel ch+1 is in flight (global -> registers) while channel ch is filtered, every work
+    // item produces 4 pixels x 2 rows per channel (5 footprint rows re-used by both output rows) and keeps its 8 x 2 x 4 results
+    // in registers until all 8 channels of its pixels are there.
+    constexpr int TW = 64, TH = 32, CG = TW / 4, RG = 256 / CG, RPT = TH / RG, FW4 = (TW + 8) / 4, FH = TH + 3, CH = 8;
+    constexpr int FOOT = FH * FW4, LPT = (FOOT + 255) / 256;              // 630 float4 per channel, 3 per work item
+    __shared__ f32x4 s_x[2][FOOT];
     const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -266,39 +269,76 @@ __global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
         for (int kx = 0; kx < 4; ++kx) f[ky][kx] = p.flip ? p.f[ky * 4 + kx] : p.f[(3 - ky) * 4 + (3 - kx)];
     const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c8 * CH * p.H * p.xrs;
     const int iy_lo = oy0 - 1;                                            // pad 1
-    for (int e = threadIdx.x; e < CH * FH * FW4; e += 256) {
-        const int ch = e / (FH * FW4), r = (e / FW4) % FH, q = e % FW4;
+    // this work item's footprint slots (the same for every channel)
+    int goff[LPT];
+    unsigned keep[LPT];                                                   // bit i: column col + i is inside the image
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int r = e / FW4, q = e % FW4;
         const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;                  // LDS column 0 = input column ox0 - 4
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < p.H && col >= 0 && col < p.W) {
-            v = *reinterpret_cast<const f32x4*>(xp + ((int64_t)ch * p.H + iy) * p.xrs + col);
-            if (col + 1 >= p.W) v.y = 0.f;                                // the pitch padding is never used
-            if (col + 2 >= p.W) v.z = 0.f;
-            if (col + 3 >= p.W) v.w = 0.f;
-        }
-        s_x[e] = v;
+        const bool ok = e < FOOT && iy >= 0 && iy < p.H && col >= 0 && col < p.W;
+        goff[j] = ok ? iy * (int)p.xrs + col : -1;
+        keep[j] = ok ? ((col + 1 < p.W ? 2u : 0u) | (col + 2 < p.W ? 4u : 0u) | (col + 3 < p.W ? 8u : 0u) | 1u) : 0u;
     }
-    __syncthreads();
+    f32x4 stage[LPT];
+    auto fetch = [&](int ch) {
+        const float* xc = xp + (int64_t)ch * p.H * p.xrs;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (goff[j] >= 0) v = *reinterpret_cast<const f32x4*>(xc + goff[j]);
+            stage[j] = v;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            if (e >= FOOT) continue;
+            f32x4 v = stage[j];                                           // the pitch padding beyond W is never used
+            if (!(keep[j] & 2u)) v.y = 0.f;
+            if (!(keep[j] & 4u)) v.z = 0.f;
+            if (!(keep[j] & 8u)) v.w = 0.f;
+            s_x[buf][e] = v;
+        }
+    };
     const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
-    const int ox = ox0 + 4 * cg, oy = oy0 + rg;
-    if (ox >= p.OW || oy >= p.OH) return;
+    const int ox = ox0 + 4 * cg, oyb = oy0 + rg * RPT;
+    const bool live = ox < p.OW && oyb < p.OH;
     const n3d_epilogue& E = p.epi;
-    const int64_t po = (int64_t)oy * p.OW + ox;
-    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
-    if (p.has_epi && E.noise) nz = *reinterpret_cast<const f32x4*>(E.noise + po) * E.noise_strength[0];
-    float val[CH][4];
+    f32x4 nz[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        nz[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && p.has_epi && E.noise && oyb + j < p.OH) nz[j] = *reinterpret_cast<const f32x4*>(E.noise + (int64_t)(oyb + j) * p.OW + ox) * E.noise_strength[0];
+    }
+    float val[CH][RPT][4];
+    fetch(0);
+    park(0);
+    __syncthreads();
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ch + 1 < CH) fetch(ch + 1);
+        float acc[RPT][4];
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const f32x4* row = s_x + (ch * FH + rg + ky) * FW4 + cg;
+        for (int j = 0; j < RPT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RPT + 3; ++rr) {
+            const f32x4* row = s_x[ch & 1] + (rg * RPT + rr) * FW4 + cg;
             const f32x4 a = row[0], b = row[1], d = row[2];
             const float in[7] = {a.w, b.x, b.y, b.z, b.w, d.x, d.y};      // input columns ox - 1 .. ox + 5
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < RPT; ++j) {
+                const int ky = rr - j;
+                if (ky < 0 || ky > 3) continue;
 #pragma unroll
-                for (int kx = 0; kx < 4; ++kx) acc[i] += in[i + kx] * f[ky][kx];
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) acc[j][i] += in[i + kx] * f[ky][kx];
+            }
         }
         const int c = c8 * CH + ch;
         float sc = 1.f, bias = 0.f;
@@ -309,32 +349,42 @@ __global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
         }
         const float os = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + c] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = acc[i] * p.gain;
-            if (p.has_epi) {
-                v = v * sc + nz[i] + bias;
-                v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
-                v *= E.gain;
-                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+        for (int j = 0; j < RPT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[j][i] * p.gain;
+                if (p.has_epi) {
+                    v = v * sc + nz[j][i] + bias;
+                    v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
+                    v *= E.gain;
+                    if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+                }
+                val[ch][j][i] = v * os;
             }
-            val[ch][i] = v * os;
-        }
+        if (ch + 1 < CH) park((ch + 1) & 1);
+        __syncthreads();
     }
+    if (!live) return;
     const int64_t plane = (int64_t)p.OH * p.OW;                           // 16-byte units per (hl, c8) plane
-    bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane + po;
-    bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane + po;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (ox + i >= p.OW) break;
-        bf16x8_t hi, lo;
+    for (int j = 0; j < RPT; ++j) {
+        const int oy = oyb + j;
+        if (oy >= p.OH) break;
+        const int64_t po = (int64_t)oy * p.OW + ox;
+        bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane + po;
+        bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane + po;
 #pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            const __bf16 h = (__bf16)val[ch][i];
-            hi[ch] = h;
-            lo[ch] = (__bf16)(val[ch][i] - (float)h);
+        for (int i = 0; i < 4; ++i) {                                     // OW % 4 == 0: all four pixels are inside
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+                const __bf16 h = (__bf16)val[ch][j][i];
+                hi[ch] = h;
+                lo[ch] = (__bf16)(val[ch][j][i] - (float)h);
+            }
+            yh[i] = hi;
+            yl[i] = lo;
         }
-        yh[i] = hi;
-        yl[i] = lo;
     }
 }
 
@@ -361,7 +411,7 @@ extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, i
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, 64);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
-    hipLaunchKernelGGL(fir4_split8_kernel, dim3(p.tiles_x * cdiv(OH, 16), C / 8, N), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fir4_split8_kernel, dim3(p.tiles_x * cdiv(OH, 32), C / 8, N), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }
