@@ -29,7 +29,9 @@ typedef void* n3d_stream_t; /* hipStream_t */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
        N3D_ACT_ELU = 6, N3D_ACT_SELU = 7, N3D_ACT_SOFTPLUS = 8, N3D_ACT_SWISH = 9 };
 enum { N3D_F32 = 0, N3D_F16 = 1 };
-enum { N3D_LAYOUT_NCHW_F32 = 0, N3D_LAYOUT_SPLIT8 = 1 };   /* activation layouts (split8: see n3d_fir4_split8) */
+/* activation layouts: float32 NCHW; split8 (see n3d_fir4_split8); "c8" = float32 [N][C/8][H][row pitch in pixels][8], one
+ * 32-byte unit = 8 consecutive channels of one pixel (what the transposed convolution hands to n3d_fir4_split8) */
+enum { N3D_LAYOUT_NCHW_F32 = 0, N3D_LAYOUT_SPLIT8 = 1, N3D_LAYOUT_C8_F32 = 2 };
 
 int n3d_abi_version(void);
 const char* n3d_last_error(void);
@@ -105,9 +107,10 @@ int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
  *      its epilogue; the consuming convolution then stages its operands with plain LDS-DMA copies.
  *      n3d_fir4_split8: the 4x4 FIR behind a transposed convolution (= n3d_upfirdn2d_pitched with up = down = 1, fh = fw = 4,
  *      padding 1, the layer epilogue `epi` fused: conv2d_resample.py:128-129 + bias_act) writing split8 instead of float32:
- *      x [N,C,H,W] float32 (row pitch x_row_stride % 4 == 0) -> y split8 [N,C,H-1,W-1] ((W-1) % 4 == 0), each value
- *      additionally multiplied by out_scale[n*out_scale_stride + c] (the next layer's style; NULL = 1). */
-int n3d_fir4_split8(const float* x, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
+ *      x [N,C,H,W] float32 in the c8 layout (N3D_LAYOUT_C8_F32, row pitch x_row_stride pixels, 0 = W; batch stride in floats,
+ *      0 = dense) -> y split8 [N,C,H-1,W-1], each value additionally multiplied by out_scale[n*out_scale_stride + c] (the
+ *      next layer's style; NULL = 1). */
+int n3d_fir4_split8(const float* x_c8, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
                     int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
                     int64_t out_scale_stride, n3d_stream_t stream);
 /* 1 when n3d_conv2d_bf16x3 accepts a split8 input for this 3x3 stride-1 shape (x_layout = N3D_LAYOUT_SPLIT8), else 0. */
@@ -145,6 +148,9 @@ typedef struct {
     int x_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for n3d_conv2d_bf16x3 with ksize 3 / mode 0 only, N3D_LAYOUT_SPLIT8:
                              `x` then points to a split8 tensor that already carries the modulation (style must be NULL);
                              x_batch_stride still counts 4-byte elements (0 = dense) */
+    int y_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for the un-split transposed n3d_conv2d_bf16x3 (mode 2, O % 64 == 0,
+                             demodulation-only epilogue), N3D_LAYOUT_C8_F32: y_row_stride then counts PIXELS (0 = OW) and
+                             y_batch_stride floats (= O * OH * pitch) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 

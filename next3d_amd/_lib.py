@@ -33,7 +33,7 @@ class Conv2dDesc(ctypes.Structure):
                 ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
-                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int)]
+                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int)]
 
 
 class FcJob(ctypes.Structure):
@@ -149,6 +149,22 @@ class Split8:
         n, c, h, w = self.shape
         t = self.data.reshape(n, 2, c // 8, h, w, 8).float()
         return (t[:, 0] + t[:, 1]).permute(0, 1, 4, 2, 3).reshape(n, c, h, w)
+
+
+class C8:
+    """A float32 [N,C,H,W] activation in the channel-interleaved "c8" layout of include/n3d.h ([N][C/8][H][W][8]): what the
+    transposed convolution writes for n3d_fir4_split8.  `data` is the dense float32 storage."""
+
+    def __init__(self, n, c, h, w, device):
+        import torch as _t
+        assert c % 8 == 0
+        self.shape = (n, c, h, w)
+        self.data = _t.empty(n, c // 8, h, w, 8, dtype=_t.float32, device=device)
+        self.device = self.data.device
+
+    def to_nchw(self):
+        n, c, h, w = self.shape
+        return self.data.permute(0, 1, 4, 2, 3).reshape(n, c, h, w)
 
 
 def cast(t, dtype):

@@ -31,6 +31,7 @@ struct Conv16Params {
     int N, I, O, OP64, H, W, OH, OW;
     int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
     int tw, th;   // transposed kernel: tile = th rows x tw columns of input-grid positions, flattened over the waves' lanes
+    int y_c8;     // transposed kernel only: write y channel-interleaved, [N][O/8][OH][yrs pixels][8] float32 (N3D_LAYOUT_C8_F32)
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
     int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
     n3d_epilogue epi;
@@ -490,6 +491,33 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     __syncthreads();
     const int gy = y0 + q_row, gx = x0 + q_col;
     if (!q_act || gy >= GH || gx >= GW) return;
+    if (p.y_c8) {
+        // channel-interleaved output for the FIR that follows (fir4_c8_split8_kernel): one 32-byte unit = 8 consecutive channels
+        // of one pixel.  This lane holds, per 32-row tile mt and group g, the 4 consecutive channels 8g + 4*half + (0..3) — half a
+        // unit — for each of its 4 output pixels: 32 16-byte stores per lane (the NCHW form needs 64 8-byte stores).
+        // (demodulation only, like `simple` below: the launch guarantees it)
+        float* yb = p.y + (int64_t)n * p.ybs;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const int oy = 2 * gy + pa;
+            if (oy >= p.OH) continue;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int ox = 2 * gx + pb;
+                if (ox >= p.OW) continue;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c8 = (m0 >> 3) + mt * 4 + g, ol = mt * 32 + 8 * g + 4 * half;
+                        const f32x16& a = acc[mt][pa * 2 + pb];
+                        const f32x4 v = {a[4 * g + 0] * s_rs[ol + 0], a[4 * g + 1] * s_rs[ol + 1], a[4 * g + 2] * s_rs[ol + 2], a[4 * g + 3] * s_rs[ol + 3]};
+                        *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
+                    }
+            }
+        }
+        return;
+    }
     const bool simple = !p.partial && linear && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f && m0 + BM <= p.O;
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
@@ -688,6 +716,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
+    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2 && d->x_layout == N3D_LAYOUT_NCHW_F32),
+              "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
     if (d->x_layout == N3D_LAYOUT_SPLIT8) return conv2d_ps_bf16x3_launch(d, stream);
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
@@ -695,6 +725,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     const bool up = d->mode == 2;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    p.y_c8 = d->y_layout == N3D_LAYOUT_C8_F32;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
@@ -710,6 +741,13 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
     p.ksplit = cdiv(d->I, p.ic_per_split);
     N3D_CHECK(p.ksplit == 1 || d->workspace != nullptr, "conv2d_bf16x3: ksplit > 1 needs a workspace");
+    if (p.y_c8) {
+        const n3d_epilogue& E = d->epi;
+        N3D_CHECK(up && p.ksplit == 1 && d->O % 64 == 0, "conv2d_bf16x3: the channel-interleaved output is written by the un-split transposed kernel with O %% 64 == 0");
+        N3D_CHECK(E.act == N3D_ACT_LINEAR && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f,
+                  "conv2d_bf16x3: the channel-interleaved output takes the demodulation-only epilogue (the layer epilogue runs behind the FIR)");
+        N3D_CHECK(((uintptr_t)d->y & 15) == 0 && (d->y_batch_stride & 3) == 0, "conv2d_bf16x3: channel-interleaved output must be 16-byte aligned");
+    }
     N3D_CHECK(p.ic_per_split <= 1024, "conv2d_bf16x3: more than 1024 input channels per K-split");
     if (p.ksplit == 1) p.partial = nullptr;
     p.tiles_m = cdiv(p.O, 64);

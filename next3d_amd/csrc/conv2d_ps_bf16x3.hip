@@ -223,7 +223,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.epi = d->epi;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    { const char* e = getenv("N3D_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }      // re-read per launch: tools/conv_ps_abl.py flips it in-process
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;

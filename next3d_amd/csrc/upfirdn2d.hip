@@ -231,33 +231,32 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
     }
 }
 
-// ---- the same 4x4 FIR (up = down = 1, pad 1: the pass behind a transposed convolution) writing the "split8" layout
-// (include/n3d.h) for the 3x3 convolution that follows: the epilogue (noise, bias, leaky ReLU, gain, clamp) is applied as in
-// fir4_vec_kernel, then the value is multiplied by the NEXT layer's style s[n][c] (modulation, tat/networks_stylegan2.py:70
-// `x * styles`), split into bf16 hi / lo halves and stored as 16-byte units of 8 consecutive channels per pixel:
-//     y[n][hl][c/8][oy][ox][c%8]      hi = bf16(v), lo = bf16(v - hi)
+// ---- the 4x4 FIR behind a transposed convolution (up = down = 1, pad 1) from the channel-interleaved "c8" layout to the
+// "split8" layout (include/n3d.h) for the 3x3 convolution that follows.  The epilogue (noise, bias, leaky ReLU, gain, clamp) is
+// applied as in fir4_vec_kernel, then the value is multiplied by the NEXT layer's style s[n][c] (modulation,
+// tat/networks_stylegan2.py:70 `x * styles`), split into bf16 hi / lo halves and stored as 16-byte units of 8 consecutive
+// channels per pixel:   y[n][hl][c/8][oy][ox][c%8],  hi = bf16(v), lo = bf16(v - hi)
 // — exactly the operands conv2d_bf16x3_kernel builds for itself while staging (same multiply, same two conversions), so the
 // consumer (conv2d_ps_bf16x3.hip) multiplies bit-identical bf16 pairs.
+// Both layouts keep the 8 channels of a pixel together, so ONE work item owns a pixel column segment with all its channels:
+// lane = pixel on the load side (32 contiguous bytes per lane), in LDS (two conflict-free 16-byte planes) and on the store
+// side (one 16-byte unit per lane and plane, 1 KB contiguous per wave instruction).  Workgroup = 64 x 16 outputs x 8 channels,
+// each work item 4 rows of one column (7 footprint rows shared by its 4 outputs).  HBM-bound: input 4 B + output 4 B per element.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct FirSplitParams {
     const float* x; const float* f; bf16x8_t* y;
     int N, C, H, W, OH, OW, flip;
     float gain;
-    int64_t xbs, xrs;
+    int64_t xbs, xrs;             // batch stride in floats, row pitch in pixels
     const float* out_scale; int64_t out_scale_stride;
     int has_epi;
     n3d_epilogue epi;
     int tiles_x;
 };
 
-__global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
-    // 64 x 32 outputs x 8 channels per workgroup; the channels are walked one at a time through a double-buffered LDS footprint
-    // (35 rows x 72 floats = 10 KB each): channel ch+1 is in flight (global -> registers) while channel ch is filtered, every work
-    // item produces 4 pixels x 2 rows per channel (5 footprint rows re-used by both output rows) and keeps its 8 x 2 x 4 results
-    // in registers until all 8 channels of its pixels are there.
-    constexpr int TW = 64, TH = 32, CG = TW / 4, RG = 256 / CG, RPT = TH / RG, FW4 = (TW + 8) / 4, FH = TH + 3, CH = 8;
-    constexpr int FOOT = FH * FW4, LPT = (FOOT + 255) / 256;              // 630 float4 per channel, 3 per work item
-    __shared__ f32x4 s_x[2][FOOT];
+__global__ __launch_bounds__(256) void fir4_c8_split8_kernel(FirSplitParams p) {
+    constexpr int TW = 64, TH = 16, RPT = 4, FW = TW + 3, FH = TH + 3, CH = 8;
+    __shared__ f32x4 s_a[FH * FW], s_b[FH * FW];                          // channels 0-3 / 4-7 of every footprint pixel
     const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -267,124 +266,82 @@ __global__ __launch_bounds__(256) void fir4_split8_kernel(FirSplitParams p) {
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) f[ky][kx] = p.flip ? p.f[ky * 4 + kx] : p.f[(3 - ky) * 4 + (3 - kx)];
-    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c8 * CH * p.H * p.xrs;
-    const int iy_lo = oy0 - 1;                                            // pad 1
-    // this work item's footprint slots (the same for every channel)
-    int goff[LPT];
-    unsigned keep[LPT];                                                   // bit i: column col + i is inside the image
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        const int r = e / FW4, q = e % FW4;
-        const int iy = iy_lo + r, col = ox0 - 4 + 4 * q;                  // LDS column 0 = input column ox0 - 4
-        const bool ok = e < FOOT && iy >= 0 && iy < p.H && col >= 0 && col < p.W;
-        goff[j] = ok ? iy * (int)p.xrs + col : -1;
-        keep[j] = ok ? ((col + 1 < p.W ? 2u : 0u) | (col + 2 < p.W ? 4u : 0u) | (col + 3 < p.W ? 8u : 0u) | 1u) : 0u;
+    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8;
+    for (int e = threadIdx.x; e < FH * FW * 2; e += 256) {                // 16-byte units, half fastest: lanes read consecutive bytes
+        const int hf = e & 1, q = (e >> 1) % FW, r = (e >> 1) / FW;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;                     // pad 1
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const f32x4*>(xp + ((int64_t)iy * p.xrs + ix) * 8 + 4 * hf);
+        (hf ? s_b : s_a)[r * FW + q] = v;
     }
-    f32x4 stage[LPT];
-    auto fetch = [&](int ch) {
-        const float* xc = xp + (int64_t)ch * p.H * p.xrs;
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (goff[j] >= 0) v = *reinterpret_cast<const f32x4*>(xc + goff[j]);
-            stage[j] = v;
-        }
-    };
-    auto park = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            const int e = threadIdx.x + 256 * j;
-            if (e >= FOOT) continue;
-            f32x4 v = stage[j];                                           // the pitch padding beyond W is never used
-            if (!(keep[j] & 2u)) v.y = 0.f;
-            if (!(keep[j] & 4u)) v.z = 0.f;
-            if (!(keep[j] & 8u)) v.w = 0.f;
-            s_x[buf][e] = v;
-        }
-    };
-    const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
-    const int ox = ox0 + 4 * cg, oyb = oy0 + rg * RPT;
-    const bool live = ox < p.OW && oyb < p.OH;
-    const n3d_epilogue& E = p.epi;
-    f32x4 nz[RPT];
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        nz[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live && p.has_epi && E.noise && oyb + j < p.OH) nz[j] = *reinterpret_cast<const f32x4*>(E.noise + (int64_t)(oyb + j) * p.OW + ox) * E.noise_strength[0];
-    }
-    float val[CH][RPT][4];
-    fetch(0);
-    park(0);
     __syncthreads();
+    const int lx = threadIdx.x % TW, ry = threadIdx.x / TW;
+    const int ox = ox0 + lx, oyb = oy0 + ry * RPT;
+    if (ox >= p.OW || oyb >= p.OH) return;
+    float acc[RPT][CH];
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-        if (ch + 1 < CH) fetch(ch + 1);
-        float acc[RPT][4];
+    for (int j = 0; j < RPT; ++j)
 #pragma unroll
-        for (int j = 0; j < RPT; ++j)
+        for (int c = 0; c < CH; ++c) acc[j][c] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+    for (int rr = 0; rr < RPT + 3; ++rr) {
+        float in[4][CH];
 #pragma unroll
-        for (int rr = 0; rr < RPT + 3; ++rr) {
-            const f32x4* row = s_x[ch & 1] + (rg * RPT + rr) * FW4 + cg;
-            const f32x4 a = row[0], b = row[1], d = row[2];
-            const float in[7] = {a.w, b.x, b.y, b.z, b.w, d.x, d.y};      // input columns ox - 1 .. ox + 5
-#pragma unroll
-            for (int j = 0; j < RPT; ++j) {
-                const int ky = rr - j;
-                if (ky < 0 || ky > 3) continue;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) acc[j][i] += in[i + kx] * f[ky][kx];
-            }
+        for (int kx = 0; kx < 4; ++kx) {
+            const f32x4 a = s_a[(ry * RPT + rr) * FW + lx + kx], b = s_b[(ry * RPT + rr) * FW + lx + kx];
+            in[kx][0] = a.x; in[kx][1] = a.y; in[kx][2] = a.z; in[kx][3] = a.w;
+            in[kx][4] = b.x; in[kx][5] = b.y; in[kx][6] = b.z; in[kx][7] = b.w;
         }
-        const int c = c8 * CH + ch;
-        float sc = 1.f, bias = 0.f;
-        if (p.has_epi) {
-            sc = E.const_scale;
-            if (E.row_scale) sc *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + c];
-            if (E.bias) bias = E.bias[c];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int ky = rr - j;
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) acc[j][c] += in[kx][c] * f[ky][kx];
         }
-        const float os = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + c] : 1.f;
-#pragma unroll
-        for (int j = 0; j < RPT; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = acc[j][i] * p.gain;
-                if (p.has_epi) {
-                    v = v * sc + nz[j][i] + bias;
-                    v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
-                    v *= E.gain;
-                    if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
-                }
-                val[ch][j][i] = v * os;
-            }
-        if (ch + 1 < CH) park((ch + 1) & 1);
-        __syncthreads();
     }
-    if (!live) return;
+    const n3d_epilogue& E = p.epi;
+    float sc[CH], bias[CH], os[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int cc = c8 * CH + c;
+        sc[c] = 1.f; bias[c] = 0.f;
+        if (p.has_epi) {
+            sc[c] = E.const_scale;
+            if (E.row_scale) sc[c] *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + cc];
+            if (E.bias) bias[c] = E.bias[cc];
+        }
+        os[c] = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + cc] : 1.f;
+    }
+    const float nstr = (p.has_epi && E.noise) ? E.noise_strength[0] : 0.f;
     const int64_t plane = (int64_t)p.OH * p.OW;                           // 16-byte units per (hl, c8) plane
+    bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane;
+    bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane;
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         const int oy = oyb + j;
         if (oy >= p.OH) break;
         const int64_t po = (int64_t)oy * p.OW + ox;
-        bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane + po;
-        bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane + po;
+        const float nz = (p.has_epi && E.noise) ? E.noise[po] * nstr : 0.f;
+        bf16x8_t hi, lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                     // OW % 4 == 0: all four pixels are inside
-            bf16x8_t hi, lo;
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) {
-                const __bf16 h = (__bf16)val[ch][j][i];
-                hi[ch] = h;
-                lo[ch] = (__bf16)(val[ch][j][i] - (float)h);
+        for (int c = 0; c < CH; ++c) {
+            float v = acc[j][c] * p.gain;
+            if (p.has_epi) {
+                v = v * sc[c] + nz + bias[c];
+                v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
+                v *= E.gain;
+                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
             }
-            yh[i] = hi;
-            yl[i] = lo;
+            v *= os[c];
+            const __bf16 h = (__bf16)v;
+            hi[c] = h;
+            lo[c] = (__bf16)(v - (float)h);
         }
+        yh[po] = hi;
+        yl[po] = lo;
     }
 }
 
@@ -394,11 +351,10 @@ extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, i
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && H > 1 && W > 1, "fir4_split8: bad shape (C %% 8 == 0)");
     const int64_t xrs = x_row_stride ? x_row_stride : W;
-    N3D_CHECK(xrs >= W && (xrs & 3) == 0 && (x_batch_stride & 3) == 0 && ((uintptr_t)x & 15) == 0, "fir4_split8: input rows must be 16-byte aligned (pitch %% 4 == 0)");
+    N3D_CHECK(xrs >= W && (x_batch_stride & 3) == 0 && ((uintptr_t)x & 15) == 0, "fir4_split8: misaligned c8 input");
     const int OH = H - 1, OW = W - 1;                                      // 4 taps, padding 1 + 1
-    N3D_CHECK((OW & 3) == 0, "fir4_split8: output width must be a multiple of 4");
     N3D_CHECK(!epi || (!epi->residual && !epi->residual_up_filter), "fir4_split8: no residual input");
-    N3D_CHECK(!epi || !epi->noise || (epi->noise_strength && ((uintptr_t)epi->noise & 15) == 0), "fir4_split8: noise needs a strength and 16-byte alignment");
+    N3D_CHECK(!epi || !epi->noise || epi->noise_strength, "fir4_split8: noise without noise_strength");
     N3D_CHECK(!epi || (epi->act >= N3D_ACT_LINEAR && epi->act <= N3D_ACT_SWISH), "fir4_split8: unknown activation");
     if (N == 0) return 0;
     N3D_CHECK(x && f && y && ((uintptr_t)y & 15) == 0, "fir4_split8: null or misaligned tensor");
@@ -411,7 +367,7 @@ extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, i
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, 64);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
-    hipLaunchKernelGGL(fir4_split8_kernel, dim3(p.tiles_x * cdiv(OH, 32), C / 8, N), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fir4_c8_split8_kernel, dim3(p.tiles_x * cdiv(OH, 16), C / 8, N), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

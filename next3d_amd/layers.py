@@ -196,13 +196,14 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     if up == 1:
         return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out)
     assert up == 2 and out is None
+    if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
+        t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
+        return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2):
         t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,
                            row_pitch=True)
     else:
         t = cg.conv_launch(x, L.wt, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), row_pitch=True)
-    if split_for is not None:
-        return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 

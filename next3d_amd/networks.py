@@ -41,7 +41,9 @@ class _Block:
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
             # conv0's FIR epilogue may hand its output to conv1 pre-split, with conv1's styles multiplied in (layers.presplit_ok)
-            pre = (noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and
+            pre = (noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and self.conv0.out_channels % 64 == 0 and
+                   self.conv0.wt16 is not None and L.cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2) and
+                   L.cg.pick_ksplit_bf16x3(n, x.shape[1], self.conv0.out_channels, x.shape[2], x.shape[3], 2) == 1 and
                    L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
                                   split_for=bank[self.conv1.prefix][0] if pre else None, **sl(self.conv0))

@@ -85,12 +85,12 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pit
 
 def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     """The up-sampling layer's FIR (4x4 taps, padding 1 on every side) with its epilogue, writing the split8 layout for the 3x3
-    convolution that follows (n3d_fir4_split8): x float32 [N,C,H,W] with 16-byte-aligned rows -> _lib.Split8 [N,C,H-1,W-1],
-    values multiplied by out_scale [N,C] (the next layer's styles)."""
+    convolution that follows (n3d_fir4_split8): x = the transposed convolution's output as a `_lib.C8` [N,C,H,W] ->
+    `_lib.Split8` [N,C,H-1,W-1], values multiplied by out_scale [N,C] (the next layer's styles)."""
+    assert isinstance(x, _lib.C8) and tuple(f2d.shape) == (4, 4) and out_scale.stride(1) == 1
     n, c, h, w = x.shape
-    assert x.dtype == torch.float32 and _planes_ok(x) and tuple(f2d.shape) == (4, 4) and out_scale.stride(1) == 1
     y = _lib.Split8(n, c, h - 1, w - 1, x.device)
-    _lib.check(_lib.lib().n3d_fir4_split8(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y.data), n, c, h, w, x.stride(2), x.stride(0), 0, float(gain),
+    _lib.check(_lib.lib().n3d_fir4_split8(_lib.ptr(x.data), _lib.ptr(f2d), _lib.ptr(y.data), n, c, h, w, w, 0, 0, float(gain),
                                           epilogue, _lib.ptr(out_scale), out_scale.stride(0), _lib.stream()))
     return y
 

@@ -573,22 +573,40 @@ def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
         cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True)      # the split8 input is modulated already
 
 
-@pytest.mark.parametrize('N,C,H,W', [(2, 32, 16, 32), (1, 64, 64, 64), (3, 16, 40, 24)])
+@pytest.mark.parametrize('N,C,H,W', [(2, 32, 16, 32), (1, 64, 64, 64), (3, 16, 40, 24), (1, 8, 7, 100)])
 def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
-    """n3d_fir4_split8 (FIR + layer epilogue + next layer's style + hi/lo split, split8 output) against the float32 FIR path:
-    hi + lo must reproduce style * fir_out to 2^-16 relative (what two bf16 halves carry)."""
+    """n3d_fir4_split8 (c8 input -> FIR + layer epilogue + next layer's style + hi/lo split, split8 output) against the float32
+    FIR path on the same values: hi + lo must reproduce style * fir_out to 2^-16 relative (what two bf16 halves carry)."""
     from next3d_amd import _lib
     from next3d_amd.torch_utils.ops import upfirdn2d as uf
     f = O.setup_filter((1, 3, 3, 1)).to(dev)
-    z = torch.empty(N, C, 2 * H + 1, (2 * W + 1 + 3) // 4 * 4, device=dev)[..., :2 * W + 1]
-    z.copy_(_gen((N, C, 2 * H + 1, 2 * W + 1), 110).to(dev))
+    zh, zw = 2 * H + 1, 2 * W + 1
+    z = _gen((N, C, zh, zw), 110).to(dev)
+    zc = _lib.C8(N, C, zh, zw, dev)
+    zc.data.copy_(z.reshape(N, C // 8, 8, zh, zw).permute(0, 1, 3, 4, 2))
+    assert torch.equal(zc.to_nchw(), z)
     bias, noise, ns = _gen((C,), 111).to(dev), _gen((2 * H, 2 * W), 112).to(dev), torch.tensor(0.2, device=dev)
     style = (1 + 0.2 * _gen((N, C), 113)).to(dev)
     act = dict(noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=float(np.sqrt(2)), clamp=3.0)
     ref = uf.upfirdn2d(z, f, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act)) * style[:, :, None, None]
-    s = uf._fir4_split8(z, f, 4, _lib.make_epilogue(**act), style)
+    s = uf._fir4_split8(zc, f, 4, _lib.make_epilogue(**act), style)
     assert s.shape == (N, C, 2 * H, 2 * W)
     _close(s.to_float(), ref, atol=1e-6, rtol=2.0 ** -15)
     t = s.data.reshape(N, 2, C // 8, 2 * H, 2 * W, 8).float()
     hi_expected = ref.bfloat16().float().reshape(N, C // 8, 8, 2 * H, 2 * W).permute(0, 1, 3, 4, 2)
     assert float((t[:, 0] - hi_expected).abs().max()) <= float(ref.abs().max()) * 2.0 ** -7      # hi is the bf16 rounding of the value
+
+
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 128, 64, 64), (2, 64, 64, 33, 40), (4, 32, 256, 128, 128)])
+def test_transposed_conv_channel_interleaved_output(dev, N, I, OC, H, W):
+    """The transposed split-bf16 kernel writing the c8 layout (what the FIR of the pre-split path reads) returns the same
+    numbers as its NCHW output, bit for bit."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, style, dco = _gen((N, I, H, W), 120).to(dev), (1 + 0.1 * _gen((N, I), 121)).to(dev), (1 + 0.1 * _gen((N, OC), 122)).to(dev)
+    wt16 = cg.prep_weight_bf16x3((_gen((OC, I, 3, 3), 123) / np.sqrt(9 * I)).to(dev))
+    ref = cg.conv_launch(x, wt16, 3, 2, OC, style=style, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, ksplit=1)
+    c8 = cg.conv_launch(x, wt16, 3, 2, OC, style=style, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
+    assert c8.shape == tuple(ref.shape) and torch.equal(c8.to_nchw(), ref)
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(x, wt16, 3, 2, OC, style=style, epilogue=_lib.make_epilogue(row_scale=dco, bias=dco[0]), bf16x3=True, out_c8=True)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Ablation timing of conv2d_ps_bf16x3_kernel (N3D_CONV_DBG bits: 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
+8 no per-chunk wait / barrier) on the layer shapes of the benchmark, next to the register-staged kernel on the same shape.
+Timing only — the ablated variants compute garbage.  Usage (GPU box): python tools/conv_ps_abl.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from next3d_amd import _lib
+from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+dev = torch.device('cuda', 0)
+
+
+def t_us(fn, iters=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+for (N, I, O, H, W) in [(4, 512, 512, 64, 64), (4, 256, 256, 128, 128), (4, 128, 128, 256, 256), (4, 128, 128, 512, 512)]:
+    x = torch.randn(N, I, H, W, device=dev)
+    wt = cg.prep_weight_bf16x3(torch.randn(O, I, 3, 3, device=dev) / (3 * I ** 0.5))
+    s = _lib.Split8(N, I, H, W, dev)
+    s.data.copy_(torch.randn(s.data.numel(), device=dev).bfloat16())
+    y = torch.empty(N, O, H, W, device=dev)
+    gf = 2.0 * N * O * I * 9 * H * W / 1e9
+    os.environ['N3D_CONV_DBG'] = '0'
+    base = t_us(lambda: cg.conv_launch(x, wt, 3, 0, O, out=y, bf16x3=True))
+    row = [f'N{N} I{I} O{O} {H}x{W} ({gf:.0f} GF): register-staged {base:7.1f} us {gf / base * 1e3:6.1f} TF |']
+    for dbg in (0, 1, 2, 3, 4, 5, 8, 9, 6, 7):
+        os.environ['N3D_CONV_DBG'] = str(dbg)
+        t = t_us(lambda: cg.conv_launch(s, wt, 3, 0, O, out=y, bf16x3=True))
+        row.append(f'dbg{dbg}: {t:6.1f} us ({gf / t * 1e3:5.0f})')
+    os.environ['N3D_CONV_DBG'] = '0'
+    print(' '.join(row), flush=True)
