@@ -12,8 +12,9 @@
 // (style multiply, two conversions, a subtraction, packing per value) and 11 ds_write_b128 in conv2d_bf16x3_kernel.  With
 // nothing to convert there are no wave roles: all eight waves issue the next chunk's DMA, multiply the current chunk, wait
 // for their own pieces (s_waitcnt vmcnt(0)) and meet at ONE raw s_barrier per chunk; two LDS buffers (2 x 76 KB).
-// Tile: 64 output channels x (16 x 32) pixels, wave tile 64 x 64 (2 x 2 accumulators of v_mfma_f32_32x32x16_bf16), the same
-// arithmetic and accumulation order per output as conv2d_bf16x3_kernel => bit-identical results for identical operands.
+// Tile: 64 output channels x (16 x 32) pixels, wave tile 64 x 64 (2 x 2 accumulators of v_mfma_f32_32x32x16_bf16, computed
+// TRANSPOSED — pixels as matrix rows — so that the epilogue writes 16-byte runs of pixels); the same products and the same
+// accumulation order per output as conv2d_bf16x3_kernel => bit-identical results for identical operands.
 // Replaces the same reference call sites as conv2d_bf16x3.hip (F.conv2d inside modulated_conv2d, networks_stylegan2.py:34-91).
 #include <stdlib.h>
 
@@ -131,9 +132,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[s][nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                    // pixels are the matrix ROWS here (first operand), channels the columns: the accumulator then holds, per lane, ONE
+                    // channel and 16 pixels in 4 runs of 4 consecutive x -> the epilogue stores 16 bytes at a time (see below)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][nt], al[s][mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s][nt], ah[s][mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][nt], ah[s][mt], acc[mt][nt], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -168,31 +171,62 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
         if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     }
 
-    // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
+    // epilogue.  C/D layout with the operands as above: col = lane&31 = CHANNEL of the 32-channel group mt, row = (r&3) + 8*(r>>2)
+    // + 4*(lane>>5) = PIXEL of the wave's row nt.  A lane's 16 values per accumulator are 4 runs (g = r>>2) of 4 consecutive
+    // pixels x0 + 8g + 4*half + (0..3): one 16-byte store each — 16 stores per lane instead of 64 four-byte ones (the epilogue of
+    // the channel-per-register form was 10-17 % of the kernel, store-issue bound: tools/conv_ps_abl.py), and the per-channel
+    // factors are two registers per lane instead of 32.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
-    const bool lrelu = E.act == N3D_ACT_LRELU, linear = E.act == N3D_ACT_LINEAR;
+    const bool lrelu = E.act == N3D_ACT_LRELU;
     const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
     const int64_t plane = (int64_t)p.H * p.W, yplane = (int64_t)p.H * p.yrs;
+    const bool vec = ((p.W | p.yrs | p.ybs) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+                     (!E.residual || ((E.residual_batch_stride & 3) == 0 && ((uintptr_t)E.residual & 15) == 0)) && (!E.noise || ((uintptr_t)E.noise & 15) == 0);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int oy = y0 + wn * 2 + nt, ox = x0 + l31;
-        if (oy >= p.H || ox >= p.W) continue;
-        const int64_t po = (int64_t)oy * p.W + ox;
-        const float nz = E.noise ? E.noise[po] * nstr : 0.f;
-        float* d0 = p.y + (int64_t)n * p.ybs + (int64_t)oy * p.yrs + ox + (int64_t)(m0 + 4 * half) * yplane;
-        const float* res = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + po + (int64_t)(m0 + 4 * half) * plane : nullptr;
+    for (int mt = 0; mt < 2; ++mt) {
+        const int o = m0 + mt * 32 + l31;
+        if (o >= p.O) continue;
+        const float rs = s_rs[mt * 32 + l31], bs = s_bs[mt * 32 + l31];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int oy = y0 + wn * 2 + nt;
+            if (oy >= p.H) continue;
+            float* drow = p.y + (int64_t)n * p.ybs + (int64_t)o * yplane + (int64_t)oy * p.yrs;
+            const float* rrow = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)o * plane + (int64_t)oy * p.W : nullptr;
+            const float* nrow = E.noise ? E.noise + (int64_t)oy * p.W : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);                 // channel within the tile, minus 4*half
-                if (m0 + ol + 4 * half >= p.O) continue;
-                float v = acc[mt][nt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half];
-                v = fmaxf(v, v * alpha_eff) * E.gain;                            // leaky ReLU (0 <= alpha <= 1) or linear
-                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
-                if (res) v += res[(int64_t)ol * plane];
-                d0[(int64_t)ol * yplane] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int ox = x0 + 8 * g + 4 * half;
+                if (ox >= p.W) continue;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[mt][nt][4 * g + k];
+                if (vec) {                                                 // W % 4 == 0: the whole run is inside the image
+                    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+                    if (nrow) nz = *reinterpret_cast<const f32x4*>(nrow + ox) * nstr;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = v[k] * rs + nz[k] + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;               // leaky ReLU (0 <= alpha <= 1) or linear
+                        v[k] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                    }
+                    f32x4 out = {v[0], v[1], v[2], v[3]};
+                    if (rrow) out += *reinterpret_cast<const f32x4*>(rrow + ox);
+                    *reinterpret_cast<f32x4*>(drow + ox) = out;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (ox + k >= p.W) break;
+                        float t = v[k] * rs + (nrow ? nrow[ox + k] * nstr : 0.f) + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;
+                        t = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                        if (rrow) t += rrow[ox + k];
+                        drow[ox + k] = t;
+                    }
+                }
             }
+        }
     }
 }
 

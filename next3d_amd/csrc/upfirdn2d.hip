@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void fir4_vec_kernel(UfParams p) {
 // Both layouts keep the 8 channels of a pixel together, so ONE work item owns a pixel column segment with all its channels:
 // lane = pixel on the load side (32 contiguous bytes per lane), in LDS (two conflict-free 16-byte planes) and on the store
 // side (one 16-byte unit per lane and plane, 1 KB contiguous per wave instruction).  Workgroup = 64 x 16 outputs x 8 channels,
-// each work item 4 rows of one column (7 footprint rows shared by its 4 outputs).  HBM-bound: input 4 B + output 4 B per element.
+// 512 work items, each 2 rows of one column (5 footprint rows shared by its 2 outputs), the two channel halves one after the other.  HBM-bound: input 4 B + output 4 B per element.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct FirSplitParams {
     const float* x; const float* f; bf16x8_t* y;
@@ -254,9 +254,12 @@ struct FirSplitParams {
     int tiles_x;
 };
 
-__global__ __launch_bounds__(256) void fir4_c8_split8_kernel(FirSplitParams p) {
-    constexpr int TW = 64, TH = 16, RPT = 4, FW = TW + 3, FH = TH + 3, CH = 8;
-    __shared__ f32x4 s_a[FH * FW], s_b[FH * FW];                          // channels 0-3 / 4-7 of every footprint pixel
+// FAST: linear / leaky-ReLU (0 <= alpha <= 1) epilogues as straight-line code; the generic instantiation carries the full switch
+template <bool FAST>
+__global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p) {
+    constexpr int NT = 512, TW = 64, TH = 16, RPT = 2, FW = TW + 3, FH = TH + 3, CH = 8;
+    __shared__ f32x4 s_ab[2 * FH * FW];                                   // plane 0: channels 0-3, plane 1: channels 4-7 of every footprint pixel
+    f32x4* const s_a = s_ab; f32x4* const s_b = s_ab + FH * FW;
     const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int c8 = blockIdx.y, n = blockIdx.z;
@@ -266,82 +269,105 @@ __global__ __launch_bounds__(256) void fir4_c8_split8_kernel(FirSplitParams p) {
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) f[ky][kx] = p.flip ? p.f[ky * 4 + kx] : p.f[(3 - ky) * 4 + (3 - kx)];
-    const float* xp = p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8;
-    for (int e = threadIdx.x; e < FH * FW * 2; e += 256) {                // 16-byte units, half fastest: lanes read consecutive bytes
-        const int hf = e & 1, q = (e >> 1) % FW, r = (e >> 1) / FW;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;                     // pad 1
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const f32x4*>(xp + ((int64_t)iy * p.xrs + ix) * 8 + 4 * hf);
-        (hf ? s_b : s_a)[r * FW + q] = v;
+    // footprint -> LDS: 16-byte units, channel half fastest (consecutive lanes read consecutive bytes).  Buffer loads with a
+    // 32-bit offset: units outside the image get an offset beyond the descriptor's range and read as zero (the FIR's padding)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8), 0,
+                                                                          (int)(p.H * p.xrs * 32), 0x00020000);
+    constexpr int ROWU = FW * 2, UNITS = FH * ROWU, LPT = (UNITS + NT - 1) / NT;    // 134 units per row, 2546 per tile, 5 per work item
+    f32x4 stage[LPT];
+    int slot[LPT];                                                        // LDS slot (plane-relative) or -1
+    {
+        int r = threadIdx.x / ROWU, cu = threadIdx.x % ROWU;              // this work item's first unit: (row, unit in row)
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {                                   // all loads in flight before the first LDS write
+            const int hf = cu & 1, q = cu >> 1;
+            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;                 // pad 1
+            const bool in_tile = threadIdx.x + NT * j < UNITS;
+            const bool ok = in_tile && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int off = ok ? ((iy * (int)p.xrs + ix) * 8 + 4 * hf) * 4 : (int)0x80000000;
+            stage[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            slot[j] = in_tile ? (hf * FH * FW + r * FW + q) : -1;
+            cu += NT - 3 * ROWU; r += 3;                                  // advance by 512 units = 3 rows + 110 units
+            if (cu >= ROWU) { cu -= ROWU; r += 1; }
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j)
+            if (slot[j] >= 0) s_a[slot[j]] = stage[j];                    // s_b follows s_a (one array, two planes)
     }
     __syncthreads();
     const int lx = threadIdx.x % TW, ry = threadIdx.x / TW;
     const int ox = ox0 + lx, oyb = oy0 + ry * RPT;
     if (ox >= p.OW || oyb >= p.OH) return;
-    float acc[RPT][CH];
+    const n3d_epilogue& E = p.epi;
+    const float nstr = (p.has_epi && E.noise) ? E.noise_strength[0] : 0.f;
+    // the layer epilogue for linear / leaky ReLU (0 <= alpha <= 1): lrelu(v) = max(v, alpha v); no clamp = clamp at infinity
+    const float alpha_eff = (p.has_epi && E.act == N3D_ACT_LRELU) ? E.alpha : 1.f;
+    const float gain_eff = p.has_epi ? E.gain : 1.f, clamp_eff = (p.has_epi && E.clamp >= 0.f) ? E.clamp : INFINITY;
+    float nz[RPT];
 #pragma unroll
-    for (int j = 0; j < RPT; ++j)
+    for (int j = 0; j < RPT; ++j) nz[j] = (p.has_epi && E.noise && oyb + j < p.OH) ? E.noise[(int64_t)(oyb + j) * p.OW + ox] * nstr : 0.f;
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const int64_t plane = (int64_t)p.OH * p.OW;                           // 16-byte units per (hl, c8) plane
+    bf16x4_t* yh = reinterpret_cast<bf16x4_t*>(p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane);
+    bf16x4_t* yl = reinterpret_cast<bf16x4_t*>(p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane);
+    // The two channel halves of a unit one after the other, as a REAL loop: unrolled into one basic block the scheduler hoists
+    // both halves' LDS reads to the top (~250 VGPRs, 2 waves per SIMD, which made the first version latency-bound at 2 TB/s).
+    // Each half is stored as it is finished (8 bytes per lane and plane; the other half of the 16-byte unit follows).
+#pragma unroll 1
+    for (int hf = 0; hf < 2; ++hf) {
+        const f32x4* sp = s_ab + hf * FH * FW;
+        float acc[RPT][4];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) acc[j][c] = 0.f;
+        for (int j = 0; j < RPT; ++j)
 #pragma unroll
-    for (int rr = 0; rr < RPT + 3; ++rr) {
-        float in[4][CH];
+            for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const f32x4 a = s_a[(ry * RPT + rr) * FW + lx + kx], b = s_b[(ry * RPT + rr) * FW + lx + kx];
-            in[kx][0] = a.x; in[kx][1] = a.y; in[kx][2] = a.z; in[kx][3] = a.w;
-            in[kx][4] = b.x; in[kx][5] = b.y; in[kx][6] = b.z; in[kx][7] = b.w;
+        for (int rr = 0; rr < RPT + 3; ++rr) {
+            f32x4 in[4];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) in[kx] = sp[(ry * RPT + rr) * FW + lx + kx];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int ky = rr - j;
+                if (ky < 0 || ky > 3) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) acc[j][c] += in[kx][c] * f[ky][kx];
+            }
+        }
+        bf16x4_t hi[RPT], lo[RPT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cc = c8 * CH + 4 * hf + c;
+            float sc = 1.f, bias = 0.f;
+            if (p.has_epi) {
+                sc = E.const_scale;
+                if (E.row_scale) sc *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + cc];
+                if (E.bias) bias = E.bias[cc];
+            }
+            const float os = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + cc] : 1.f;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                float v = acc[j][c] * p.gain;
+                v = v * sc + nz[j] + bias;
+                v = FAST ? fmaxf(v, v * alpha_eff) : n3d_act(v, p.has_epi ? E.act : N3D_ACT_LINEAR, E.alpha);
+                v *= gain_eff;
+                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                v *= os;
+                const __bf16 h = (__bf16)v;
+                hi[j][c] = h;
+                lo[j][c] = (__bf16)(v - (float)h);
+            }
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int ky = rr - j;
-            if (ky < 0 || ky > 3) continue;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) acc[j][c] += in[kx][c] * f[ky][kx];
+            const int oy = oyb + j;
+            if (oy >= p.OH) break;
+            const int64_t u = ((int64_t)oy * p.OW + ox) * 2 + hf;          // 8-byte half units
+            yh[u] = hi[j];
+            yl[u] = lo[j];
         }
-    }
-    const n3d_epilogue& E = p.epi;
-    float sc[CH], bias[CH], os[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int cc = c8 * CH + c;
-        sc[c] = 1.f; bias[c] = 0.f;
-        if (p.has_epi) {
-            sc[c] = E.const_scale;
-            if (E.row_scale) sc[c] *= E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.C) + cc];
-            if (E.bias) bias[c] = E.bias[cc];
-        }
-        os[c] = p.out_scale ? p.out_scale[(int64_t)n * p.out_scale_stride + cc] : 1.f;
-    }
-    const float nstr = (p.has_epi && E.noise) ? E.noise_strength[0] : 0.f;
-    const int64_t plane = (int64_t)p.OH * p.OW;                           // 16-byte units per (hl, c8) plane
-    bf16x8_t* yh = p.y + (((int64_t)n * 2 + 0) * (p.C / CH) + c8) * plane;
-    bf16x8_t* yl = p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane;
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const int oy = oyb + j;
-        if (oy >= p.OH) break;
-        const int64_t po = (int64_t)oy * p.OW + ox;
-        const float nz = (p.has_epi && E.noise) ? E.noise[po] * nstr : 0.f;
-        bf16x8_t hi, lo;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            float v = acc[j][c] * p.gain;
-            if (p.has_epi) {
-                v = v * sc[c] + nz + bias[c];
-                v = (E.act == N3D_ACT_LRELU) ? (v > 0.f ? v : v * E.alpha) : n3d_act(v, E.act, E.alpha);
-                v *= E.gain;
-                if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
-            }
-            v *= os[c];
-            const __bf16 h = (__bf16)v;
-            hi[c] = h;
-            lo[c] = (__bf16)(v - (float)h);
-        }
-        yh[po] = hi;
-        yl[po] = lo;
     }
 }
 
@@ -367,7 +393,10 @@ extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, i
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, 64);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
-    hipLaunchKernelGGL(fir4_c8_split8_kernel, dim3(p.tiles_x * cdiv(OH, 16), C / 8, N), dim3(256), 0, stream, p);
+    const bool fast = !epi || epi->act == N3D_ACT_LINEAR || (epi->act == N3D_ACT_LRELU && epi->alpha >= 0.f && epi->alpha <= 1.f);
+    const dim3 grid(p.tiles_x * cdiv(OH, 16), C / 8, N);
+    if (fast) hipLaunchKernelGGL(fir4_c8_split8_kernel<true>, grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(fir4_c8_split8_kernel<false>, grid, dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

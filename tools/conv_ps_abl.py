@@ -37,3 +37,17 @@ for (N, I, O, H, W) in [(4, 512, 512, 64, 64), (4, 256, 256, 128, 128), (4, 128,
         row.append(f'dbg{dbg}: {t:6.1f} us ({gf / t * 1e3:5.0f})')
     os.environ['N3D_CONV_DBG'] = '0'
     print(' '.join(row), flush=True)
+
+# ---- the FIR in front of those layers: float32 path (fir4_vec_kernel) vs c8 -> split8 (fir4_c8_split8_kernel), same epilogue
+from next3d_amd.torch_utils.ops import upfirdn2d as uf
+f = uf.setup_filter([1, 3, 3, 1]).to(dev)
+for (N, C, H) in [(4, 512, 64), (4, 256, 128), (4, 128, 256), (4, 128, 512)]:
+    zh = H + 1
+    z = torch.empty(N, C, zh, (zh + 3) // 4 * 4, device=dev)[..., :zh].normal_()
+    zc = _lib.C8(N, C, zh, zh, dev); zc.data.normal_()
+    noise, bias, ns, st = torch.randn(H, H, device=dev), torch.randn(C, device=dev), torch.tensor(0.1, device=dev), torch.rand(N, C, device=dev) + 0.5
+    act = dict(noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=1.414)
+    a = t_us(lambda: uf.upfirdn2d(z, f, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act)))
+    b = t_us(lambda: uf._fir4_split8(zc, f, 4, _lib.make_epilogue(**act), st))
+    gb = 8.0 * N * C * H * H / 1e9
+    print(f'FIR N{N} C{C} -> {H}x{H}: float32 {a:7.1f} us ({gb / a * 1e3:5.2f} TB/s)   c8->split8 {b:7.1f} us ({gb / b * 1e3:5.2f} TB/s)', flush=True)
