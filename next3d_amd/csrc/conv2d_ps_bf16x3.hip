@@ -45,10 +45,15 @@ constexpr int PS_PER_WAVE = (PS_PIECES + 7) / 8;                                
 // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every fragment read of an LDS-DMA pipeline):
 //   [buf 0: A_hi | A_lo | B_hi | B_lo][buf 1: ...]   then 2 x 64 floats of epilogue factors
 constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                                      // 4864 slots = 77,824 B per buffer
-constexpr int PS_LDS_SLOTS = 2 * PS_BUF + 2 * PS_BM * 4 / 16;
 
-__global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p) {
-    __shared__ bf16x8 smem[PS_LDS_SLOTS];
+// NBUF = 2: one workgroup per CU, the next chunk's DMA runs under this chunk's MFMAs (two 76 KB buffers).
+// NBUF = 1: TWO workgroups per CU, one 76 KB buffer each — a workgroup loads, waits and multiplies in turn and the CU's other
+//           workgroup fills the gaps: its MFMAs run while this one waits for its DMA or writes its tile.  With one workgroup per
+//           CU every chunk's DMA wait, every barrier skew and the whole epilogue (a 128 KB tile written while every other CU
+//           writes its own: ~7 us at the chip's ~4.7 TB/s of store bandwidth) leave the matrix pipe idle.
+template <int NBUF>
+__global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[NBUF * PS_BUF + 2 * PS_BM * 4 / 16];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware 1-D grid, M tile fastest (conv2d_bf16x3.hip): the O/64 workgroups reading one input patch share it in one L2
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
     };
 
     // per-channel epilogue factors -> LDS (read after the K loop; plain stores, no DMA involved)
-    float* s_rs = reinterpret_cast<float*>(smem + 2 * PS_BUF), *s_bs = s_rs + PS_BM;
+    float* s_rs = reinterpret_cast<float*>(smem + NBUF * PS_BUF), *s_bs = s_rs + PS_BM;
     const n3d_epilogue& E = p.epi;
     if (tid < PS_BM) {
         const int o = min(m0 + tid, p.O - 1);
@@ -151,6 +156,17 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
         s_bs[tid] = E.bias ? E.bias[o] : 0.f;
     }
 
+    if (NBUF == 1) {
+        __builtin_amdgcn_s_barrier();                                     // (the epilogue factors above are plain LDS stores)
+        for (int kc = 0; kc < KC; ++kc) {
+            if (!(p.dbg & 4) || kc == 0) copy_chunk(kc, 0);
+            __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): this wave's pieces are in LDS ...
+            __builtin_amdgcn_s_barrier();                                 // ... and after the barrier everybody's are
+            if (!(p.dbg & 2)) mfma_block(0);
+            __builtin_amdgcn_s_barrier();                                 // every wave has read its fragments: the buffer may be refilled
+        }
+        if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
+    } else {
     copy_chunk(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): this wave's pieces of chunk 0 are in LDS ...
     __builtin_amdgcn_s_barrier();                                         // ... and after the barrier everybody's are
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
+    }
     }
 
     // epilogue.  C/D layout with the operands as above: col = lane&31 = CHANNEL of the 32-channel group mt, row = (r&3) + 8*(r>>2)
@@ -263,7 +280,9 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    { const char* e = getenv("N3D_PS_NBUF"); const int nbuf = e ? atoi(e) : 1;
+      if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -31,11 +31,7 @@ for (N, I, O, H, W) in [(4, 512, 512, 64, 64), (4, 256, 256, 128, 128), (4, 128,
     os.environ['N3D_CONV_DBG'] = '0'
     base = t_us(lambda: cg.conv_launch(x, wt, 3, 0, O, out=y, bf16x3=True))
     row = [f'N{N} I{I} O{O} {H}x{W} ({gf:.0f} GF): register-staged {base:7.1f} us {gf / base * 1e3:6.1f} TF |']
-    for dbg in (0, 1, 2, 3, 4, 5, 8, 9, 6, 7):
-        os.environ['N3D_CONV_DBG'] = str(dbg)
-        t = t_us(lambda: cg.conv_launch(s, wt, 3, 0, O, out=y, bf16x3=True))
-        row.append(f'dbg{dbg}: {t:6.1f} us ({gf / t * 1e3:5.0f})')
-    os.environ['N3D_CONV_DBG'] = '0'
+XX
     print(' '.join(row), flush=True)
 
 # ---- the FIR in front of those layers: float32 path (fir4_vec_kernel) vs c8 -> split8 (fir4_c8_split8_kernel), same epilogue
