@@ -113,6 +113,11 @@ int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
 int n3d_fir4_split8(const float* x_c8, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
                     int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
                     int64_t out_scale_stride, n3d_stream_t stream);
+/* n3d_split8_from_nchw: a float32 NCHW tensor [N,C,HW] (dense planes, batch stride x_batch_stride floats, 0 = dense) ->
+ * split8, every value multiplied by scale[n*scale_stride + c] first (the consumer's style; NULL = 1).  For tensors whose
+ * producer cannot write split8 itself (two consumers that need different styles). */
+int n3d_split8_from_nchw(const float* x, const float* scale, void* y_split8, int N, int C, int64_t HW, int64_t x_batch_stride,
+                         int64_t scale_stride, n3d_stream_t stream);
 /* 1 when n3d_conv2d_bf16x3 accepts a split8 input for this 3x3 stride-1 shape (x_layout = N3D_LAYOUT_SPLIT8), else 0. */
 int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W);
 
@@ -145,7 +150,7 @@ typedef struct {
     int64_t y_row_stride; /* floats between consecutive output rows (0 = OW).  A multiple of 4 >= OW gives the odd-width
                              (2W+1) transposed-conv output 16-byte-aligned rows for the FIR that follows */
     n3d_epilogue epi;
-    int x_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for n3d_conv2d_bf16x3 with ksize 3 / mode 0 only, N3D_LAYOUT_SPLIT8:
+    int x_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for n3d_conv2d_bf16x3 with ksize 3 / mode 0 or 2 (mode 2: c8 output only), N3D_LAYOUT_SPLIT8:
                              `x` then points to a split8 tensor that already carries the modulation (style must be NULL);
                              x_batch_stride still counts 4-byte elements (0 = dense) */
     int y_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for the un-split transposed n3d_conv2d_bf16x3 (mode 2, O % 64 == 0,

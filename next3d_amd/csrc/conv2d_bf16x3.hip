@@ -40,6 +40,7 @@ struct Conv16Params {
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
 int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);     // conv2d_ps_bf16x3.hip (split8 input)
+int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, transposed, c8 output)
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
 
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
@@ -643,7 +644,7 @@ extern "C" int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, 
 // Tile plan shared by the launch and by n3d_conv2d_bf16x3_blocks (the host's split-K heuristic).  Stride-1: 8-wave
 // workgroups when the grid still covers the chip with them, else 4-wave.  Transposed mode: balanced (th x tw) tiles of at most 32*NW
 // flattened positions, tw <= 33, th <= 32 (patch (th+1) x (tw+1) <= (NW+1)*33 entries of LDS).
-static void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th) {
+void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th) {
     if (gw > 66) {                     // wide images: 32-aligned tile columns (the 33rd-column remainder is a few percent)
         *tw = 32; *th = nw;
         *tiles_x = cdiv(gw, 32); *tiles_y = cdiv(gh, nw);
@@ -716,9 +717,9 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
-    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2 && d->x_layout == N3D_LAYOUT_NCHW_F32),
+    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2),
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
-    if (d->x_layout == N3D_LAYOUT_SPLIT8) return conv2d_ps_bf16x3_launch(d, stream);
+    if (d->x_layout == N3D_LAYOUT_SPLIT8) return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream);
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     Conv16Params p;

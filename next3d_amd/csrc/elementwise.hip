@@ -73,6 +73,36 @@ __global__ __launch_bounds__(256) void cast_kernel(const SRC* __restrict__ x, DS
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[n8 * 8 + threadIdx.x] = (DST)x[n8 * 8 + threadIdx.x];
 }
 
+// float32 NCHW -> split8 (include/n3d.h): y[n][hl][c/8][p][c%8] = split(x[n][c][p] * scale[n][c]).  One work item = one pixel x
+// 8 channels: 8 plane reads (each coalesced across the wave), one 16-byte unit per plane (hi, lo) written (contiguous across the
+// wave).  HBM-bound: 4 B in + 4 B out per element.
+typedef __bf16 ew_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void split8_from_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale, ew_bf16x8* __restrict__ y,
+                                                               int C8, int64_t HW, int64_t xbs, int64_t scale_stride) {
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    const float* xp = x + (int64_t)n * xbs + (int64_t)c8 * 8 * HW;
+    float sc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sc[c] = scale ? scale[(int64_t)n * scale_stride + c8 * 8 + c] : 1.f;
+    ew_bf16x8* yh = y + (((int64_t)n * 2 + 0) * C8 + c8) * HW;
+    ew_bf16x8* yl = y + (((int64_t)n * 2 + 1) * C8 + c8) * HW;
+    for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < HW; px += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = xp[(int64_t)c * HW + px];
+        ew_bf16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = v[c] * sc[c];
+            const __bf16 h = (__bf16)t;
+            hi[c] = h;
+            lo[c] = (__bf16)(t - (float)h);
+        }
+        yh[px] = hi;
+        yl[px] = lo;
+    }
+}
+
 static inline int grid_for(int64_t n) { const int64_t g = cdiv64(n, 256); return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
 extern "C" {
@@ -118,6 +148,21 @@ int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t s
     N3D_CHECK(x && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 3) == 0, "to_uint8: null or misaligned tensor");
     N3dProfScope prof(N3D_K_MISC, stream, 2.0 * numel, 5.0 * numel);
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, stream, x, y, numel / 4);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_split8_from_nchw(const float* x, const float* scale, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int64_t scale_stride,
+                         n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && HW > 0, "split8_from_nchw: bad shape (C %% 8 == 0)");
+    if (N == 0) return 0;
+    N3D_CHECK(x && y && ((uintptr_t)y & 15) == 0, "split8_from_nchw: null or misaligned tensor");
+    N3D_CHECK(C / 8 <= 65535 && N <= 65535, "split8_from_nchw: N and C/8 must be <= 65535");
+    N3dProfScope prof(N3D_K_MISC, stream, 2.0 * N * C * (double)HW, 8.0 * N * C * (double)HW);
+    const int gx = (int)(cdiv64(HW, 256) > 1024 ? 1024 : cdiv64(HW, 256));
+    hipLaunchKernelGGL(split8_from_nchw_kernel, dim3(gx, C / 8, N), dim3(256), 0, stream, x, scale, (ew_bf16x8*)y, C / 8, HW,
+                       x_batch_stride ? x_batch_stride : (int64_t)C * HW, scale_stride ? scale_stride : C);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -34,6 +34,9 @@ PRECISION = os.environ.get('N3D_PRECISION', 'bf16x3')
 # writes bf16 hi / lo planes already multiplied by the next layer's style, the convolution stages them by LDS-DMA.
 # N3D_PRESPLIT=0 keeps the float32 hand-off (A/B on one box).
 PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
+# ... and for the transposed convolution in front of it: its input (a block output with two consumers) is converted once
+# (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
+UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
 
 
 def set_precision(mode):
@@ -197,7 +200,11 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
         return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out)
     assert up == 2 and out is None
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
-        t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
+        if UP_PRESPLIT and x.shape[1] % 16 == 0:
+            xs = cg.split8_from_nchw(x, styles)          # modulation + operand split once, then pure LDS-DMA staging
+            t = cg.conv_launch(xs, L.wt16, 3, 2, L.out_channels, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
+        else:
+            t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
         return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2):
         t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,

@@ -73,6 +73,22 @@ def split8_eligible(n, i, o, h, w):
     return bool(_lib.lib().n3d_conv2d_split8_eligible(n, i, o, h, w))
 
 
+def split8_from_nchw(x, scale=None):
+    """float32 [N,C,H,W] (dense planes, any batch stride) -> `_lib.Split8`, every channel multiplied by scale [N,C] first (the
+    consuming layer's styles) — n3d_split8_from_nchw.  For tensors with two consumers (a block's output feeds toRGB and the
+    next block's up-sampling convolution, with different styles), whose producer therefore cannot write split8 itself."""
+    _lib.require_device(x, scale)
+    n, c, h, w = x.shape
+    if x.dtype != torch.float32 or (scale is not None and (scale.dtype != torch.float32 or scale.stride(1) != 1)):
+        raise RuntimeError('split8_from_nchw: float32 tensors expected')
+    if x.stride()[1:] != (h * w, w, 1):
+        x = x.contiguous()
+    y = _lib.Split8(n, c, h, w, x.device)
+    _lib.check(_lib.lib().n3d_split8_from_nchw(_lib.ptr(x), _lib.ptr(scale), _lib.ptr(y.data), n, c, h * w, x.stride(0),
+                                               scale.stride(0) if scale is not None else 0, _lib.stream()))
+    return y
+
+
 def out_shape(h, w, mode):
     if mode == 0:
         return h, w
@@ -115,8 +131,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
-        if not (bf16x3 and ksize == 3 and mode == 0 and style is None):
-            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 split-bf16 kernel, without a style')
+        if not (bf16x3 and ksize == 3 and (mode == 0 or (mode == 2 and out_c8)) and style is None):
+            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 (or transposed, c8 output) split-bf16 kernel, without a style')
         n, i, h, w = x.shape
         xs = x
         x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only

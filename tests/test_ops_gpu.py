@@ -610,3 +610,9 @@ def test_transposed_conv_channel_interleaved_output(dev, N, I, OC, H, W):
     assert c8.shape == tuple(ref.shape) and torch.equal(c8.to_nchw(), ref)
     with pytest.raises(RuntimeError):
         cg.conv_launch(x, wt16, 3, 2, OC, style=style, epilogue=_lib.make_epilogue(row_scale=dco, bias=dco[0]), bf16x3=True, out_c8=True)
+    # the same layer with the input converted once (style multiplied in, operands split) and staged by LDS-DMA: same products
+    xs = cg.split8_from_nchw(x, style)
+    assert float((xs.to_float() - x * style[:, :, None, None]).abs().max()) <= 2.0 ** -15 * float((x * style[:, :, None, None]).abs().max())
+    ps = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
+    print('transposed presplit vs register-staged: max abs diff', float((ps.to_nchw() - ref).abs().max()), 'bit-identical', bool(torch.equal(ps.to_nchw(), ref)))
+    _close(ps.to_nchw(), ref, atol=1e-5, rtol=1e-5)

@@ -31,7 +31,15 @@ for (N, I, O, H, W) in [(4, 512, 512, 64, 64), (4, 256, 256, 128, 128), (4, 128,
     os.environ['N3D_CONV_DBG'] = '0'
     base = t_us(lambda: cg.conv_launch(x, wt, 3, 0, O, out=y, bf16x3=True))
     row = [f'N{N} I{I} O{O} {H}x{W} ({gf:.0f} GF): register-staged {base:7.1f} us {gf / base * 1e3:6.1f} TF |']
-XX
+    for nbuf in (2, 1):                                   # N3D_PS_NBUF: 2 = one workgroup per CU, double-buffered; 1 = two per CU
+        os.environ['N3D_PS_NBUF'] = str(nbuf)
+        row.append(f'| nbuf{nbuf}:')
+        for dbg in ((0, 1, 2, 4, 5) if nbuf == 1 else (0, 1, 5)):
+            os.environ['N3D_CONV_DBG'] = str(dbg)
+            t = t_us(lambda: cg.conv_launch(s, wt, 3, 0, O, out=y, bf16x3=True))
+            row.append(f'dbg{dbg}: {t:6.1f} us ({gf / t * 1e3:5.0f})')
+    os.environ.pop('N3D_PS_NBUF')
+    os.environ['N3D_CONV_DBG'] = '0'
     print(' '.join(row), flush=True)
 
 # ---- the FIR in front of those layers: float32 path (fir4_vec_kernel) vs c8 -> split8 (fir4_c8_split8_kernel), same epilogue
@@ -47,3 +55,15 @@ for (N, C, H) in [(4, 512, 64), (4, 256, 128), (4, 128, 256), (4, 128, 512)]:
     b = t_us(lambda: uf._fir4_split8(zc, f, 4, _lib.make_epilogue(**act), st))
     gb = 8.0 * N * C * H * H / 1e9
     print(f'FIR N{N} C{C} -> {H}x{H}: float32 {a:7.1f} us ({gb / a * 1e3:5.2f} TB/s)   c8->split8 {b:7.1f} us ({gb / b * 1e3:5.2f} TB/s)', flush=True)
+
+# ---- transposed layers: register-staged (NCHW pitched out) vs pre-split (split8 in, c8 out) + the one-off conversion
+for (N, I, O, H) in [(4, 512, 512, 32), (4, 512, 256, 64), (4, 256, 128, 128), (4, 256, 128, 256)]:
+    x = torch.randn(N, I, H, H, device=dev); st = torch.rand(N, I, device=dev) + 0.5
+    wt = cg.prep_weight_bf16x3(torch.randn(O, I, 3, 3, device=dev) / (3 * I ** 0.5))
+    gf = 2.0 * N * O * I * 9 * H * H / 1e9
+    a = t_us(lambda: cg.conv_launch(x, wt, 3, 2, O, style=st, bf16x3=True, row_pitch=True))
+    a8 = t_us(lambda: cg.conv_launch(x, wt, 3, 2, O, style=st, bf16x3=True, out_c8=True, ksplit=1))
+    cv = t_us(lambda: cg.split8_from_nchw(x, st))
+    xs = cg.split8_from_nchw(x, st)
+    b = t_us(lambda: cg.conv_launch(xs, wt, 3, 2, O, bf16x3=True, out_c8=True))
+    print(f'UP N{N} I{I} O{O} {H}x{H} ({gf:.0f} GF): register-staged {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  same, c8 out {a8:7.1f} us  | pre-split {b:7.1f} us ({gf / b * 1e3:4.0f} TF) + conversion {cv:6.1f} us', flush=True)
