@@ -37,6 +37,7 @@ PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
 # ... and for the transposed convolution in front of it: its input (a block output with two consumers) is converted once
 # (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
 UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
+CONVERT_MAX_BYTES = int(float(os.environ.get('N3D_CONVERT_MAX_MB', '70')) * 1e6)     # see _conv3x3
 
 
 def set_precision(mode):
@@ -87,6 +88,13 @@ def _conv3x3(L, x, style=None, epilogue=None, out=None):
     layer's epilogue with THIS layer's style multiplied in) goes to the pre-split kernel; `style` is then ignored."""
     if isinstance(x, _lib.Split8):
         return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True)
+    n, i, h, w = x.shape
+    if (PRESPLIT and PRECISION == 'bf16x3' and L.wt16 is not None and x.dtype == torch.float32 and 4 * n * i * h * w <= CONVERT_MAX_BYTES and
+            cg.split8_eligible(n, i, L.out_channels, h, w) and (epilogue is None or epilogue.act in (1, 3))):
+        # a float32 input whose producer could not write split8 (1x1 / stride-2 / concatenating producers): one conversion pass
+        # (4 B in + 4 B out per element, with the style) buys the LDS-DMA kernel — worth it while the tensor is small next to
+        # the layer's 9 * O MACs per element (measured: 10 us for 33 MB against ~75 us saved on the 64x64 x 512-channel layers)
+        return cg.conv_launch(cg.split8_from_nchw(x, style), L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 0):
         return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True)
     return cg.conv_launch(x, L.wt, 3, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
