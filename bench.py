@@ -172,7 +172,8 @@ def main():
         if args.serial_gather:
             gatherer.drain()
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-        img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)['image']
+        img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
+                          force_fp32=True)['image']                        # the fp32 path (the one the goldens pin)
         frames = to_frames(img)
         gatherer.submit(frames)          # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
@@ -262,7 +263,7 @@ def main():
 
     extras = {}
     if single and not args.no_extras:
-        kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+        kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
         # ---- strict-fp32 arithmetic (N3D_PRECISION=fp32): the same K steps on v_mfma_f32_32x32x2_f32
         if layers.PRECISION == 'bf16x3':
             layers.set_precision('fp32')

@@ -54,7 +54,7 @@ int n3d_bias_act(const void* x, const void* b, void* y, int64_t numel, int size_
 
 /* Fused per-element epilogue shared by upfirdn2d / conv2d (all optional, applied in this order):
  *   v = v * row_scale[n*O + o] * const_scale;  v += noise[oy*OW+ox] * (*noise_strength);  v += bias[o];
- *   v = act(v) * gain;  clamp;  v += residual[n, o, oy, ox]                                            */
+ *   v = act(v) * gain;  clamp;  [round to float16];  v += residual[n, o, oy, ox]                       */
 typedef struct {
     const float* row_scale;       /* [N,O] (row pitch row_scale_stride; 0 = O) or NULL — demodulation coefficients,
                                      tat/networks_stylegan2.py:72-79                                              */
@@ -72,6 +72,11 @@ typedef struct {
                                         upfirdn2d.upsample2d(residual, f) (up=2, padding (2,1,2,1), gain 4, no flip):
                                         the skip-image path img = upsample2d(img) + toRGB(x) of SynthesisBlock.forward
                                         (tat/networks_stylegan2.py:580-584) without materialising the upsampled image */
+    int round_f16;                /* != 0: the value is rounded to float16 (nearest even) and widened again after the clamp, before
+                                     the residual is added — the storage rounding of the reference's fp16 blocks
+                                     (tat/networks_stylegan2.py:548-552: x.to(float16); every operator of such a block returns
+                                     float16) on float32 arithmetic.  Supported by the pre-split kernels (split8 / c8 layouts),
+                                     the 1x1 kernel and n3d_fir4_split8; other kernels reject it. */
 } n3d_epilogue;
 
 /* ---- upfirdn2d: replaces upfirdn2d_plugin.upfirdn2d (torch_utils/ops/upfirdn2d.cpp:20, kernels

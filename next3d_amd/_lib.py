@@ -25,7 +25,7 @@ class Epilogue(ctypes.Structure):
     _fields_ = [('row_scale', c_void_p), ('noise', c_void_p), ('noise_strength', c_void_p), ('bias', c_void_p),
                 ('residual', c_void_p), ('residual_batch_stride', c_int64), ('row_scale_stride', c_int64),
                 ('const_scale', c_float), ('act', c_int),
-                ('alpha', c_float), ('gain', c_float), ('clamp', c_float), ('residual_up_filter', c_void_p)]
+                ('alpha', c_float), ('gain', c_float), ('clamp', c_float), ('residual_up_filter', c_void_p), ('round_f16', c_int)]
 
 
 class Conv2dDesc(ctypes.Structure):
@@ -185,7 +185,7 @@ def cast(t, dtype):
 
 
 def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, residual=None, const_scale=1.0,
-                  act='linear', alpha=None, gain=None, clamp=None, residual_up_filter=None):
+                  act='linear', alpha=None, gain=None, clamp=None, residual_up_filter=None, round_f16=False):
     """`residual_up_filter` (a [4,4] filter): `residual` is the half-resolution image and is upsampled x2 in the epilogue
     (== upfirdn2d.upsample2d(residual, filter)) instead of being read at full resolution."""
     from .torch_utils.ops.bias_act import activation_funcs
@@ -202,6 +202,7 @@ def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, re
     if residual_up_filter is not None:
         assert residual is not None and residual.is_contiguous() and tuple(residual_up_filter.shape) == (4, 4) and residual_up_filter.is_contiguous()
     e.residual_up_filter = ptr(residual_up_filter)
+    e.round_f16 = 1 if round_f16 else 0
     e._keepalive = (row_scale, noise, noise_strength, bias, residual, residual_up_filter)   # the struct only holds raw pointers
     return e
 

@@ -74,6 +74,8 @@ __device__ __forceinline__ float n3d_up2_apply(const n3d_up2_taps& t, const floa
     return ((plane[t.off[0]] * t.w[0] + plane[t.off[1]] * t.w[1]) + plane[t.off[2]] * t.w[2]) + plane[t.off[3]] * t.w[3];
 }
 
+__device__ __forceinline__ float n3d_round16(float v, int on) { return on ? (float)(_Float16)v : v; }
+
 __device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue& e, int n, int o, int O, int oy, int ox,
                                                     int OH, int OW) {
     float sc = e.const_scale;
@@ -83,6 +85,7 @@ __device__ __forceinline__ float n3d_apply_epilogue(float v, const n3d_epilogue&
     if (e.bias) v += e.bias[o];
     v = n3d_act(v, e.act, e.alpha) * e.gain;
     if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
+    if (e.round_f16) v = (float)(_Float16)v;
     if (e.residual) {
         if (e.residual_up_filter) {
             const int LH = OH >> 1, LW = OW >> 1;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
                 const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
                 float v = acc[mt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half];
                 v = fmaxf(v, v * alpha_eff) * E.gain;
-                d0[(int64_t)ol * yplane] = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                d0[(int64_t)ol * yplane] = n3d_round16(fminf(fmaxf(v, -clamp_eff), clamp_eff), E.round_f16);
             }
         return;
     }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
             for (int r = 0; r < 16; ++r) {
                 const int ol = mt * 32 + (r & 3) + 8 * (r >> 2);
                 float v = (acc[mt][r] * s_rs[ol + 4 * half] + nz + s_bs[ol + 4 * half]) * E.gain;
-                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
+                v = n3d_round16(fminf(fmaxf(v, -clamp_eff), clamp_eff), E.round_f16);
                 d0[(int64_t)ol * yplane] = v + n3d_up2_apply(up2, r0 + (int64_t)ol * lplane);
             }
         return;
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
             else if (!linear) v = conv1_act_generic(v, E.act, E.alpha);
             v *= E.gain;
             if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+            v = n3d_round16(v, E.round_f16);
             if (res_up) v += n3d_up2_apply(up2, res + (int64_t)o * lplane);
             else if (res) v += res[(int64_t)o * p.HW];
             dst[(int64_t)o * yplane] = v;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params 
         v = v * (E.const_scale * (rsp ? rsp[o] : 1.f)) + nz + (E.bias ? E.bias[o] : 0.f);
         v = conv1_act_generic(v, E.act, E.alpha) * E.gain;
         if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+        v = n3d_round16(v, E.round_f16);
         if (res_up) v += n3d_up2_apply(up2, res + (int64_t)o * lplane);
         else if (res) v += res[(int64_t)o * p.HW];
         dst[(int64_t)o * yplane] = v;

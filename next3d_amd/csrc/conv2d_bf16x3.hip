@@ -512,7 +512,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
                     for (int g = 0; g < 4; ++g) {
                         const int c8 = (m0 >> 3) + mt * 4 + g, ol = mt * 32 + 8 * g + 4 * half;
                         const f32x16& a = acc[mt][pa * 2 + pb];
-                        const f32x4 v = {a[4 * g + 0] * s_rs[ol + 0], a[4 * g + 1] * s_rs[ol + 1], a[4 * g + 2] * s_rs[ol + 2], a[4 * g + 3] * s_rs[ol + 3]};
+                        const int rh = E.round_f16;
+                        const f32x4 v = {n3d_round16(a[4 * g + 0] * s_rs[ol + 0], rh), n3d_round16(a[4 * g + 1] * s_rs[ol + 1], rh),
+                                         n3d_round16(a[4 * g + 2] * s_rs[ol + 2], rh), n3d_round16(a[4 * g + 3] * s_rs[ol + 3], rh)};
                         *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
                     }
             }
@@ -721,6 +723,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
     if (d->x_layout == N3D_LAYOUT_SPLIT8) return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream);
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
+    N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     Conv16Params p;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;

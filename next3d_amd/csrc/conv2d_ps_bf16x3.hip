@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
                     for (int k = 0; k < 4; ++k) {
                         float t = v[k] * rs + nz[k] + bs;
                         t = fmaxf(t, t * alpha_eff) * E.gain;               // leaky ReLU (0 <= alpha <= 1) or linear
-                        v[k] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                        v[k] = n3d_round16(fminf(fmaxf(t, -clamp_eff), clamp_eff), E.round_f16);
                     }
                     f32x4 out = {v[0], v[1], v[2], v[3]};
                     if (rrow) out += *reinterpret_cast<const f32x4*>(rrow + ox);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
                         if (ox + k >= p.W) break;
                         float t = v[k] * rs + (nrow ? nrow[ox + k] * nstr : 0.f) + bs;
                         t = fmaxf(t, t * alpha_eff) * E.gain;
-                        t = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                        t = n3d_round16(fminf(fmaxf(t, -clamp_eff), clamp_eff), E.round_f16);
                         if (rrow) t += rrow[ox + k];
                         drow[ox + k] = t;
                     }
@@ -308,6 +308,7 @@ struct ConvUpPsParams {
     int tiles_x, tiles_y, tiles_m, tw, th;
     int64_t xbs, ybs, yrs;       // xbs: 16-byte units; ybs floats; yrs pixels (c8 row pitch)
     const float* row_scale; int64_t row_scale_stride; float const_scale;
+    int round_f16;
 };
 
 __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsParams p) {
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
                 for (int g = 0; g < 4; ++g) {
                     const int c8 = (m0 >> 3) + mt * 4 + g, ol = mt * 32 + 8 * g + 4 * half;
                     const f32x16& a = acc[mt][pa * 2 + pb];
-                    const f32x4 v = {a[4 * g + 0] * s_rs[ol + 0], a[4 * g + 1] * s_rs[ol + 1], a[4 * g + 2] * s_rs[ol + 2], a[4 * g + 3] * s_rs[ol + 3]};
+                    const f32x4 v = {n3d_round16(a[4 * g + 0] * s_rs[ol + 0], p.round_f16), n3d_round16(a[4 * g + 1] * s_rs[ol + 1], p.round_f16),
+                                     n3d_round16(a[4 * g + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * g + 3] * s_rs[ol + 3], p.round_f16)};
                     *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
                 }
         }
@@ -460,6 +462,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.OH * p.yrs;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.row_scale = E.row_scale; p.row_scale_stride = E.row_scale_stride ? E.row_scale_stride : d->O; p.const_scale = E.const_scale;
+    p.round_f16 = E.round_f16;
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;

@@ -353,8 +353,8 @@ __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p
                 v = v * sc + nz[j] + bias;
                 v = FAST ? fmaxf(v, v * alpha_eff) : n3d_act(v, p.has_epi ? E.act : N3D_ACT_LINEAR, E.alpha);
                 v *= gain_eff;
-                v = fminf(fmaxf(v, -clamp_eff), clamp_eff);
-                v *= os;
+                v = n3d_round16(fminf(fmaxf(v, -clamp_eff), clamp_eff), p.has_epi && E.round_f16);      // fp16 block: the activation is stored as float16 ...
+                v *= os;                                                                        // ... and modulated by the next layer afterwards
                 const __bf16 h = (__bf16)v;
                 hi[j][c] = h;
                 lo[j][c] = (__bf16)(v - (float)h);
@@ -422,6 +422,7 @@ static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C
     p.gain = gain; p.xbs = xbs; p.ybs = ybs; p.xrs = xrs; p.yrs = yrs ? yrs : OW;
     N3D_CHECK(p.yrs >= OW, "upfirdn2d: output row pitch smaller than the output width");
     N3D_CHECK(p.yrs == OW || !epi || (!epi->noise && !epi->residual), "upfirdn2d: a pitched output cannot take per-pixel epilogue inputs");
+    N3D_CHECK(!epi || !epi->round_f16, "upfirdn2d: round_f16 is supported by n3d_fir4_split8 only");
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
     p.tiles_x = cdiv(OW, UF_TILE_W); p.tiles_y = cdiv(OH, UF_TILE_H);

@@ -119,6 +119,7 @@ class TriPlaneGenerator(torch.nn.Module):
         if not str(sr_module).endswith('SuperresolutionHybrid8XDC'):
             raise RuntimeError(f'superresolution_module {sr_module!r}: only SuperresolutionHybrid8XDC (512x512) is implemented')
         self.sr_conv_clamp = 256 if sr_num_fp16_res > 0 else None        # (256 if use_fp16 else None); kept under force_fp32
+        self.sr_use_fp16 = sr_num_fp16_res > 0                           # superresolution.py:269: the SR blocks run in fp16 unless force_fp32
         self._drop_derived()
 
     def _drop_derived(self):
@@ -388,7 +389,10 @@ class TriPlaneGenerator(torch.nn.Module):
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
         rgb_image = feature_image[:, :3]
         sr_noise = self.rendering_kwargs.get('superresolution_noise_mode', 'none')     # triplane_next3d.py:182
-        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise)
+        # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is
+        # the float32 path its CPU run takes (networks_stylegan2.py:548) and the one the golden fixtures pin
+        sr_fp16 = self.sr_use_fp16 and not synthesis_kwargs.get('force_fp32', False)
+        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
     def sample_mixed(self, coordinates, directions, ws, v, truncation_psi=1, truncation_cutoff=None, update_emas=False,

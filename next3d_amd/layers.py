@@ -182,13 +182,16 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None):
+                    split_for=None, fp16=False):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
     the device generator like the reference) — the kernels' epilogue takes one noise image per launch, so that mode runs
     the layer sample by sample.  `split_for` (up = 2 only): the styles [N,O] of the 3x3 layer that consumes this layer's
-    output -> the result is a `_lib.Split8` carrying them (see presplit_ok)."""
+    output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  `fp16`: the layer belongs to one of the
+    reference's fp16 blocks — every tensor an operator of such a block returns is float16 (networks_stylegan2.py:548-552); here
+    the arithmetic stays float32 / split-bf16 and the values are rounded to float16 at exactly those points (the transposed
+    convolution's output, the FIR + bias_act output, the convolution + bias_act output: n3d_epilogue.round_f16)."""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
         dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
@@ -203,16 +206,19 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
         return out if out is not None else torch.cat(outs, 0)
     noise = _noise if _noise is not None else (L.noise_const if noise_mode == 'const' else None)
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
-               gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
+               gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain, round_f16=fp16)
+    if fp16 and not (isinstance(x, _lib.Split8) or split_for is not None):
+        raise RuntimeError('the fp16 block mode runs on the pre-split path only (N3D_PRESPLIT=1, eligible layer shapes)')
     if up == 1:
         return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out)
     assert up == 2 and out is None
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
+        zepi = _lib.make_epilogue(row_scale=dcoef, round_f16=fp16)
         if UP_PRESPLIT and x.shape[1] % 16 == 0:
             xs = cg.split8_from_nchw(x, styles)          # modulation + operand split once, then pure LDS-DMA staging
-            t = cg.conv_launch(xs, L.wt16, 3, 2, L.out_channels, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
+            t = cg.conv_launch(xs, L.wt16, 3, 2, L.out_channels, epilogue=zepi, bf16x3=True, out_c8=True)
         else:
-            t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, out_c8=True)
+            t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=zepi, bf16x3=True, out_c8=True)
         return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2):
         t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,
@@ -229,7 +235,7 @@ def _conv1x1(L, x, style=None, epilogue=None, out=None):
     return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
 
 
-def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None):
+def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None, fp16=False):
     """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584).  With
     `residual_up_filter`, `residual` is the PREVIOUS block's half-resolution image and upsample2d (:582) is evaluated
     inside the convolution's epilogue."""
@@ -237,7 +243,7 @@ def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_u
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
     return _conv1x1(L, x, style=styles, epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual,
-                                                                    residual_up_filter=residual_up_filter))
+                                                                    residual_up_filter=residual_up_filter, round_f16=fp16))
 
 
 def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None):

@@ -33,8 +33,10 @@ class _Block:
         out.append((self.torgb, k, 'torgb'))
         return out
 
-    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None):
-        """SynthesisBlock.forward, fp32 / contiguous (the force_fp32 path); `bank` = StyleBank.compute(ws) result."""
+    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None, fp16=False):
+        """SynthesisBlock.forward; `bank` = StyleBank.compute(ws) result.  fp16=True: the reference's fp16 block (use_fp16 and
+        not force_fp32, networks_stylegan2.py:548) — float32 arithmetic with float16 storage rounding (layers.synthesis_layer);
+        the skip image stays float32 as in the reference (:582-585)."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
@@ -46,8 +48,9 @@ class _Block:
                    L.cg.pick_ksplit_bf16x3(n, x.shape[1], self.conv0.out_channels, x.shape[2], x.shape[3], 2) == 1 and
                    L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
-                                  split_for=bank[self.conv1.prefix][0] if pre else None, **sl(self.conv0))
-            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
+                                  split_for=bank[self.conv1.prefix][0] if pre else None, fp16=fp16, **sl(self.conv0))
+            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, fp16=fp16,
+                                  **sl(self.conv1))
         # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
         # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.
         if img_stream is None:
@@ -56,7 +59,7 @@ class _Block:
             if img is not None and up is None:
                 img = uf.upsample2d(img, fir)
             img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0],
-                                residual_up_filter=up)
+                                residual_up_filter=up, fp16=fp16)
         else:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(img_stream):
@@ -211,7 +214,7 @@ class SuperRes8XDC:
         self.input_resolution = 128
         self._banks = {}
 
-    def __call__(self, rgb, x, ws, resize_fn, noise_mode='none'):
+    def __call__(self, rgb, x, ws, resize_fn, noise_mode='none', fp16=False):
         """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286).  Every layer is driven by the
         LAST latent of `ws` (`ws[:, -1:].repeat(1, 3, 1)`, :280): all StyleBank jobs read that one slot."""
         ws = _ws3(ws)
@@ -226,8 +229,11 @@ class SuperRes8XDC:
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side)
-        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side)
+        if fp16:        # block entry: x.to(float16) (networks_stylegan2.py:552); the image stays float32
+            from . import _lib
+            x = _lib.cast(_lib.cast(x.contiguous(), torch.float16), torch.float32)
+        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16)
+        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return rgb

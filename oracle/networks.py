@@ -75,6 +75,46 @@ def torgb_layer(P, prefix, x, w, conv_clamp=None):
     return ops.bias_act(x, P[f'{prefix}.bias'], clamp=conv_clamp)
 
 
+def _q16(t):
+    """float16 storage rounding on float32 values."""
+    return t.half().float()
+
+
+def _modconv_fp16(P, prefix, x, styles, up, demodulate):
+    """modulated_conv2d's float16 branch (tat/networks_stylegan2.py:56-91, fused): weight / style pre-normalisation against
+    overflow (:57-59), per-sample weights `w.to(float16)`, grouped convolution.  Emulated on float32 arithmetic: every tensor
+    the reference holds in float16 is rounded to float16 here (products of two float16 values are exact in float32, the
+    accumulation is float32 as in cuDNN's half kernels)."""
+    weight = P[f'{prefix}.weight']
+    n = x.shape[0]
+    o, i, kh, kw = weight.shape
+    if demodulate:
+        weight = weight * (1 / np.sqrt(i * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    w = weight.unsqueeze(0) * styles.reshape(n, 1, -1, 1, 1)
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, -1, 1, 1, 1)
+    y = ops.conv2d_resample(x.reshape(1, -1, *x.shape[2:]), _q16(w.reshape(-1, i, kh, kw)), f=FIR, up=up, padding=kh // 2, groups=n,
+                            flip_weight=(up == 1), quant=_q16)
+    return y.reshape(n, -1, *y.shape[2:])
+
+
+def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256):
+    """SynthesisBlock.forward with use_fp16 and not force_fp32 (tat/networks_stylegan2.py:548-588), noise_mode='none' (the
+    super-resolution blocks): x is cast to float16 at entry, every layer returns float16, the skip image is float32."""
+    w0, w1, w2 = ws.unbind(dim=1)
+    aff = lambda k, w: ops.fully_connected(w, P[f'{prefix}.{k}.affine.weight'], P[f'{prefix}.{k}.affine.bias'])
+    x = _q16(x)
+    for k, w, up in (('conv0', w0, 2), ('conv1', w1, 1)):
+        x = _modconv_fp16(P, f'{prefix}.{k}', x, aff(k, w), up, True)
+        x = _q16(ops.bias_act(x, _q16(P[f'{prefix}.{k}.bias']), act='lrelu', gain=_LRELU_GAIN, clamp=conv_clamp))
+    wt = P[f'{prefix}.torgb.weight']
+    y = _modconv_fp16(P, f'{prefix}.torgb', x, aff('torgb', w2) * (1.0 / np.sqrt(wt.shape[1] * wt.shape[2] ** 2)), 1, False)
+    y = _q16(ops.bias_act(y, _q16(P[f'{prefix}.torgb.bias']), clamp=conv_clamp))
+    img = ops.upsample2d(img, FIR) + y
+    return x, img
+
+
 def synthesis_block(P, prefix, x, img, ws, in_channels, noise_mode='const', conv_clamp=None):
     """tat/networks_stylegan2.py:544-588 (SynthesisBlock.forward), 'skip' architecture, fp32."""
     w_iter = iter(ws.unbind(dim=1))
@@ -154,13 +194,17 @@ def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, fin
 
 
 def superresolution(P, prefix, rgb, x, ws, force_fp32=True):
-    """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward), fp32 path, noise_mode='none'.
+    """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward), noise_mode='none'; fp32 path (what the reference
+    runs off-GPU and what the goldens pin) or, with force_fp32=False, its fp16 blocks emulated (synthesis_block_fp16).
     conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275)."""
-    assert force_fp32, "the oracle restates the fp32 path only"
     ws = ws[:, -1:, :].repeat(1, 3, 1)
     if x.shape[-1] != 128:
         x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
         rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
+    if not force_fp32:      # the reference's default on a GPU (use_fp16 = sr_num_fp16_res > 0): emulated float16 storage
+        x, rgb = synthesis_block_fp16(P, f'{prefix}.block0', x, rgb, ws)
+        x, rgb = synthesis_block_fp16(P, f'{prefix}.block1', x, rgb, ws)
+        return rgb
     x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, 32, noise_mode='none', conv_clamp=256)
     x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, 256, noise_mode='none', conv_clamp=256)
     return rgb

@@ -31,7 +31,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     G, _ = demo.build_generator(torch.device('cpu'), rendering_kwargs=rk)
     G.overlap_static = False
     z, c, c_cond, v = demo.demo_batch(list(range(N)))
-    kw = dict(neural_rendering_resolution=R, noise_mode='const')
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', force_fp32=True)
     ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
     assert tuple(ws.shape) == (N, 28, 512)
     G.synthesis(ws, c, v, **kw)                                  # first call: also prepares the weights
@@ -63,7 +63,12 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     dry.clear()
     G.synthesis(ws, c, v, neural_rendering_resolution=R)         # noise_mode defaults to 'random' (the reference's default,
     rnd = Counter(dry)                                           # networks_stylegan2.py:311): noisy layers run sample by sample
-    assert sum(rnd.values()) > n_full if N > 1 else sum(rnd.values()) == n_full
+    n_rnd = sum(rnd.values()) - rnd['n3d_cast']                  # (default call: fp16 super-resolution blocks -> 2 casts)
+    assert n_rnd > n_full if N > 1 else n_rnd == n_full
+    dry.clear()
+    G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')      # no force_fp32: the reference's default, fp16
+    half = Counter(dry)                                                          # super-resolution blocks (sr_num_fp16_res = 4)
+    assert half['n3d_cast'] == 2 and sum(half.values()) - half['n3d_split8_from_nchw'] == 153 + (0 if R == 128 else 2) + 2
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
 

@@ -51,7 +51,7 @@ def test_forward_matches_reference_golden(G, dev, case, precision):
     ws = G.mapping(torch.from_numpy(d['z']).to(dev), torch.from_numpy(d['c_cond']).to(dev), truncation_psi=float(d['psi']),
                    truncation_cutoff=int(d['cutoff']))
     out = G.synthesis(ws, torch.from_numpy(d['c']).to(dev), torch.from_numpy(d['v']).to(dev), neural_rendering_resolution=R,
-                      noise_mode='const', depth_jitter=jitter, importance_u=u)
+                      noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)      # the goldens pin the fp32 path
     st = G._debug
     rep = {
         'ws': _md(ws, d['ws']),
@@ -140,7 +140,7 @@ def test_pipelined_steps_are_bitwise_reproducible(G, dev):
     t = lambda k: torch.from_numpy(d[k]).to(dev)
     ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
     c, v = t('c'), t('v')
-    outs = [G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+    outs = [G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
             for _ in range(6)]
     torch.cuda.synchronize()
     for o in outs[1:]:

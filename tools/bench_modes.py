@@ -23,7 +23,7 @@ z, c, c_cond, v = demo.demo_batch(list(range(B)), device=dev)
 g = torch.Generator(device=dev).manual_seed(1)
 jitter = torch.rand((B, R * R, Sc, 1), device=dev, generator=g)
 u = torch.rand((B * R * R, Sf), device=dev, generator=g)
-kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
 ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
 G.synthesis(ws, c, v, cache_backbone=True, cache_identity=True, **kw)
 

@@ -9,7 +9,7 @@ z, c, c_cond, v = demo.demo_batch([0, 1, 2, 3], device=dev)
 jit = torch.rand((4, 4096, 48, 1), device=dev); u = torch.rand((4 * 4096, 48), device=dev)
 def step():
     ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-    return G.synthesis(ws, c, v, neural_rendering_resolution=64, noise_mode='const', depth_jitter=jit, importance_u=u)['image']
+    return G.synthesis(ws, c, v, neural_rendering_resolution=64, noise_mode='const', depth_jitter=jit, importance_u=u, force_fp32=True)['image']
 for _ in range(3): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -52,7 +52,7 @@ def main():
     for it in range(3):
         on[0] = it == 2
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-        G.synthesis(ws, c, v, neural_rendering_resolution=64, noise_mode='const')
+        G.synthesis(ws, c, v, neural_rendering_resolution=64, noise_mode='const', force_fp32=True)
         torch.cuda.synchronize()
     tot = sum(t for _, t in rows)
     for lab, t in rows:
