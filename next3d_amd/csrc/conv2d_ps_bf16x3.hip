@@ -280,7 +280,11 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    { const char* e = getenv("N3D_PS_NBUF"); const int nbuf = e ? atoi(e) : 1;
+    // two workgroups per CU (single LDS buffer each) once the grid holds at least three per CU: with fewer, the in-workgroup
+    // double buffering wins (measured, tools/conv_ps_abl.py: 64x64 x 512 channels = 256 workgroups: 156 us vs 201 us; 512
+    // workgroups: equal; 1024+: 174 vs 182 us, 697 vs 735 us).  Starting every other batch of workgroups late to de-phase the
+    // CUs' store bursts was measured too: no effect.
+    { const char* e = getenv("N3D_PS_NBUF"); const int nbuf = e ? atoi(e) : (nblk >= 768 ? 1 : 2);
       if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
