@@ -129,6 +129,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline_fp32 / config3 / config5')
     ap.add_argument('--serial-gather', action='store_true', help='join the frame gather of step k before step k+1 is enqueued')
+    ap.add_argument('--lanes', type=int, default=2, help='HIP streams the steps are issued on in turn (1 = one stream, in order): '
+                    'consecutive steps are independent batches, so step k+1 may start while step k still runs')
     ap.add_argument('--selftest-spawn', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -168,14 +170,26 @@ def main():
         _lib.check(_lib.lib().n3d_to_uint8(_lib.ptr(img), _lib.ptr(frames), img.numel(), _lib.stream()))
         return frames
 
+    # Consecutive steps are independent batches (different seeds in a real run): they are issued on `--lanes` HIP streams in
+    # turn, so the latency-bound low-resolution layers of step k+1 (a handful of workgroups each) fill the chip while the
+    # MFMA-bound layers of step k run, exactly as a serving loop would pipeline requests.  Every step's whole work is inside
+    # the timed region (all lanes are joined before the clock stops).
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
+    for s_ in lanes:
+        s_.wait_stream(torch.cuda.current_stream())
+    counter, one_lane = [0], [False]
+
     def step():
         if args.serial_gather:
             gatherer.drain()
-        ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-        img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
-                          force_fp32=True)['image']                        # the fp32 path (the one the goldens pin)
-        frames = to_frames(img)
-        gatherer.submit(frames)          # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
+        lane = lanes[counter[0] % (1 if one_lane[0] else len(lanes))]
+        counter[0] += 1
+        with torch.cuda.stream(lane):
+            ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+            img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
+                              force_fp32=True)['image']                    # the fp32 path (the one the goldens pin)
+            frames = to_frames(img)
+            gatherer.submit(frames)      # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
 
     def sync():
@@ -214,7 +228,7 @@ def main():
 
     # the inputs do not change between steps, so pipelined steps must return identical frames: a cheap guard against stream
     # races in exactly the configuration that was timed (tests/test_generator_gpu.py has the per-stage version)
-    fa = step().clone(); fb = step().clone(); fc = step()
+    fa, fb, fc = step(), step(), step()
     sync()
     reproducible = bool(torch.equal(fa, fb) and torch.equal(fb, fc))
 
@@ -222,6 +236,8 @@ def main():
         """`steps` steps with per-launch HIP events on the launch stream (outside the timed region; the static-backbone side
         stream is switched off for this pass so that every kernel's event time is its own duration) -> n3d_prof_read()."""
         overlap, G.overlap_static = G.overlap_static, False
+        one_lane[0] = True                                      # ... and one launch stream
+        torch.cuda.synchronize()
         step(); torch.cuda.synchronize()
         _lib.prof_reset()
         _lib.prof_enable(True)
@@ -229,7 +245,7 @@ def main():
             step()
         torch.cuda.synchronize()
         _lib.prof_enable(False)
-        G.overlap_static = overlap
+        G.overlap_static, one_lane[0] = overlap, False
         prof = _lib.prof_read()
         _lib.prof_reset()
         return prof
@@ -339,6 +355,7 @@ def main():
             'config': {'workload': f'BASELINE.json configs[1]: batch={B} seeds per GPU, 512² output, 64² neural render, '
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,
+                       'streams': f'{len(lanes)} (consecutive steps alternate between them)',
                        'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if world > 1 else 'none',
                        'prewarm_seconds': args.prewarm_seconds},
             'frames_bitwise_reproducible': reproducible, 'roofline': roofline, **extras, 'cpu_baseline': cpu}))

@@ -192,8 +192,7 @@ class TriPlaneGenerator(torch.nn.Module):
         S.face_uv = P['face_uvcoords'][0][:, [0, 2, 1]].contiguous()                       # :208
         S.rot = torch.cat([angle2matrix(a) for a in RENDERING_VIEWS], 0).to(dev).contiguous()
         S.uv_mask = self.uv_face_mask.to(dev)[0, 0].contiguous()
-        S.bounds = torch.empty(2, dtype=torch.float32, device=dev)
-        S.side_stream = torch.cuda.Stream(device=dev)
+        S.side_streams = {}         # launch stream -> its side stream (callers may pipeline calls on several streams)
         S.alpha_views = torch.tensor([0, 1, 3], dtype=torch.int64, device=dev)
         S.tlin = {}
         self._prepared = S
@@ -302,8 +301,11 @@ class TriPlaneGenerator(torch.nn.Module):
         if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
             textures, static = ident
         elif self.overlap_static:
-            S.side_stream.wait_stream(cur)          # ... after the rasterisation
-            with torch.cuda.stream(S.side_stream):
+            sstream = S.side_streams.get(cur.cuda_stream)
+            if sstream is None:
+                sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
+            sstream.wait_stream(cur)                # ... after the rasterisation
+            with torch.cuda.stream(sstream):
                 static = S.static(eg3d_ws, noise_mode)
             static.record_stream(cur)
             textures = S.texture(texture_ws, noise_mode)
@@ -320,7 +322,7 @@ class TriPlaneGenerator(torch.nn.Module):
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
         if ident is None and self.overlap_static:
-            cur.wait_stream(S.side_stream)
+            cur.wait_stream(sstream)
         elif static is None:
             static = S.static(eg3d_ws, noise_mode)
         if cache_identity:
@@ -354,10 +356,11 @@ class TriPlaneGenerator(torch.nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         feat = torch.empty(N, 32, R, R, **f32)
         depth = torch.empty(N, 1, R, R, **f32)
+        bounds = torch.empty(2, **f32)              # scratch of this call (calls may be in flight on several streams)
         _lib.check(_lib.lib().n3d_render_rays(
             _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter),
             _lib.ptr(u), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
-            _lib.ptr(depth), None, _lib.ptr(S.bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
+            _lib.ptr(depth), None, _lib.ptr(bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
             float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
         return feat, depth
 
