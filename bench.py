@@ -12,6 +12,7 @@ configs[1]); inputs are resident in HBM before the timed region.  With N GPUs ev
 rank 0 over RCCL (north_star: "RCCL over xGMI only for the final gather"); the gather of step k runs on RCCL's stream
 while step k+1 computes and is joined before step k+2 is enqueued.
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 only, all measured by this process):
+  single_stream  the same K steps issued in order on ONE stream (`value` pipelines consecutive steps over --lanes streams)
   roofline       the dominant kernel family (3x3 split-bf16 convolutions, bf16 matrix cores) timed with HIP events on the
                  launch stream, against 2500/3 TFLOP/s; `traffic` from the committed rocprofv3 --pmc profile of this build
   roofline_fp32  the same K steps with N3D_PRECISION=fp32 arithmetic (v_mfma_f32_32x32x2_f32 everywhere): frames/s and the
@@ -129,7 +130,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline_fp32 / config3 / config5')
     ap.add_argument('--serial-gather', action='store_true', help='join the frame gather of step k before step k+1 is enqueued')
-    ap.add_argument('--lanes', type=int, default=2, help='HIP streams the steps are issued on in turn (1 = one stream, in order): '
+    ap.add_argument('--lanes', type=int, default=3, help='HIP streams the steps are issued on in turn (1 = one stream, in order): '
                     'consecutive steps are independent batches, so step k+1 may start while step k still runs')
     ap.add_argument('--selftest-spawn', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -251,6 +252,14 @@ def main():
         return prof
 
     single = world == 1
+    single_stream = None
+    if single and len(lanes) > 1 and not args.no_extras:          # the same K steps on ONE stream (in order), for reference
+        one_lane[0] = True
+        step(); torch.cuda.synchronize()
+        t1 = timed(step, args.steps)
+        one_lane[0] = False
+        single_stream = {'value': args.steps * B / t1, 'unit': 'frames/s', 'ms_per_step': 1e3 * t1 / args.steps,
+                         'note': 'steps issued in order on one HIP stream (the static backbone still on its side stream)'}
     roofline = None
     if not args.no_roofline:
         prof = conv_profile(args.steps)
@@ -358,7 +367,8 @@ def main():
                        'streams': f'{len(lanes)} (consecutive steps alternate between them)',
                        'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if world > 1 else 'none',
                        'prewarm_seconds': args.prewarm_seconds},
-            'frames_bitwise_reproducible': reproducible, 'roofline': roofline, **extras, 'cpu_baseline': cpu}))
+            'frames_bitwise_reproducible': reproducible, 'single_stream': single_stream, 'roofline': roofline, **extras,
+            'cpu_baseline': cpu}))
         if not reproducible:
             print('bench.py: pipelined steps returned different frames', file=sys.stderr)
     gatherer.drain()

@@ -1,19 +1,21 @@
 #!/bin/bash
-# GPU box: regenerate the artefacts kept under profiles/ (bench line, rocprofv3 kernel-trace summary, PMC traffic).
-tag=${1:-r01}
+# GPU box: regenerate the artefacts kept under profiles/ for one round: bench line, rocprofv3 kernel-trace summary of the same
+# command, PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and matrix-pipe busy counters of the 3x3 conv family.
+# usage: tools/refresh_profiles.sh r02 [lite]     (lite: no PMC passes)
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/art
-if [ "$2" != "lite" ]; then python bench.py > gpurun_out/art/${tag}_bench.json 2> gpurun_out/art/bench.err; fi
-rocprofv3 --kernel-trace --stats -d gpurun_out/art/kt -o r -- python bench.py --no-cpu-baseline > gpurun_out/art/${tag}_bench_under_rocprofv3.json 2> gpurun_out/art/kt.err
-python tools/rocpd_summary.py $(find gpurun_out/art/kt -name "*.db" | head -1) gpurun_out/art/${tag}_kernel_stats.csv > /dev/null
-if [ "$2" = "lite" ]; then      # kernel trace first, bench line last, no PMC passes (the committed traffic file stays): fits a short GPU slot
-    rm -rf gpurun_out/art/kt
-    python bench.py > gpurun_out/art/${tag}_bench.json 2> gpurun_out/art/bench.err
-    head -c 1500 gpurun_out/art/${tag}_bench.json; echo; head -12 gpurun_out/art/${tag}_kernel_stats.csv
-    exit 0
+out=gpurun_out/art; mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/kt -o r -- python bench.py --no-cpu-baseline --no-extras > $out/${tag}_bench_under_rocprofv3.json 2> $out/kt.err
+python tools/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) $out/${tag}_kernel_stats.csv > /dev/null
+rm -rf $out/kt
+if [ "$2" != "lite" ]; then
+  P="python bench.py --no-cpu-baseline --no-roofline --no-extras --lanes 1 --steps 2 --warmup 1 --prewarm-seconds 0"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pf -o r -- $P > /dev/null 2> $out/pf.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pw -o r -- $P > /dev/null 2> $out/pw.err
+  python tools/traffic_summary.py $(find $out/pf -name "*.db" | head -1) $(find $out/pw -name "*.db" | head -1) $out/${tag}_traffic_pmc.json > /dev/null
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/pm -o r -- $P > /dev/null 2> $out/pm.err
+  python tools/mfma_busy_summary.py $(find $out/pm -name "*.db" | head -1) $out/${tag}_mfma_busy_pmc.json > /dev/null
+  rm -rf $out/pf $out/pw $out/pm
 fi
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/art/pf -o r -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/art/pf.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/art/pw -o r -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/art/pw.err
-python tools/traffic_summary.py $(find gpurun_out/art/pf -name "*.db" | head -1) $(find gpurun_out/art/pw -name "*.db" | head -1) gpurun_out/art/${tag}_traffic_pmc.json > /dev/null
-rm -rf gpurun_out/art/kt gpurun_out/art/pf gpurun_out/art/pw
-head -c 1500 gpurun_out/art/${tag}_bench.json; echo; head -12 gpurun_out/art/${tag}_kernel_stats.csv
+python bench.py > $out/${tag}_bench.json 2> $out/bench.err
+head -c 1200 $out/${tag}_bench.json; echo; head -14 $out/${tag}_kernel_stats.csv; ls -la $out

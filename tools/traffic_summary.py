@@ -17,7 +17,8 @@ def per_kernel(db, counter):
     return agg
 
 
-fam = ('conv2d_bf16x3_kernel', 'conv2d_up_bf16x3_kernel', 'conv2d_s2_bf16x3_kernel')     # bench.py's roofline family (3x3)
+fam = ('conv2d_bf16x3_kernel', 'conv2d_up_bf16x3_kernel', 'conv2d_s2_bf16x3_kernel', 'conv2d_p_bf16x3_kernel', 'conv2d_ps_bf16x3_kernel',
+       'conv2d_up_ps_bf16x3_kernel')     # bench.py's roofline family: every 3x3 split-bf16 kernel
 f, w = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
 sel = lambda d: {k: v for k, v in d.items() if any(s in k for s in fam)}
 f, w = sel(f), sel(w)
@@ -26,7 +27,7 @@ fetch_kb = sum(sum(v) for v in f.values()) / max(nl, 1)
 write_kb = sum(sum(v) for v in w.values()) / max(sum(len(v) for v in w.values()), 1)
 out = {
     'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) on `bench.py --steps 2 --warmup 1`, '
-              'averaged over all launches of the split-bf16 conv family (the roofline kernel family of bench.py)',
+              'averaged over all launches of the 3x3 split-bf16 conv family (the roofline kernel family of bench.py; kernel names below)',
     'per_kernel_avg_KB': {'FETCH_SIZE': {k: sum(v) / len(v) for k, v in f.items()}, 'WRITE_SIZE': {k: sum(v) / len(v) for k, v in w.items()}},
     'launches_counted': nl,
     'fetch_KB_per_launch_raw': fetch_kb, 'write_KB_per_launch': write_kb,
