@@ -41,7 +41,6 @@ constexpr int PS_BCH = (PS_PPIX + 63) / 64, PS_BPAD = PS_BCH * 64;              
 constexpr int PS_A_SZ = PS_TAPS * 2 * PS_BM;                                           // 16-byte slots per (buffer, hi|lo): [tap][half][row]
 constexpr int PS_B_SZ = 2 * PS_BPAD;                                                   //                                     [half][pixel]
 constexpr int PS_A_PIECES = PS_TAPS * 2 * 2, PS_B_PIECES = 2 * 2 * PS_BCH, PS_PIECES = PS_A_PIECES + PS_B_PIECES;   // 36 + 40
-constexpr int PS_PER_WAVE = (PS_PIECES + 7) / 8;                                       // 10
 // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every fragment read of an LDS-DMA pipeline):
 //   [buf 0: A_hi | A_lo | B_hi | B_lo][buf 1: ...]   then 2 x 64 floats of epilogue factors
 constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                                      // 4864 slots = 77,824 B per buffer
@@ -298,12 +297,12 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
 // (ky==2 ? 0 : 1, kx==2 ? 0 : 1); flattened th x tw <= 256 positions over the 8 waves' lanes), channel-interleaved (c8) output
 // for the FIR that follows (fir4_c8_split8_kernel).  The register-staged kernel spends, per 16-channel chunk, the SAME staging work as
 // the stride-1 kernel for half the MFMAs (54 per wave) and waits on memory 56 % of its cycles (round 1); here staging is 7 DMA
-// instructions per wave and chunk.  One workgroup per CU, two LDS buffers (2 x 56 KB).
+// instructions per wave and chunk (NMT = 2), two LDS buffers per workgroup.
 void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th);          // conv2d_bf16x3.hip
 
 constexpr int UP_PPIX = 9 * 33;                                           // patch capacity: (th+1) x (tw+1) <= 297
 constexpr int UP_BCH = (UP_PPIX + 63) / 64, UP_BPAD = UP_BCH * 64;        // 5 pieces = 320 slots per (hi|lo, half)
-constexpr int UP_B_SZ = 2 * UP_BPAD, UP_BUF = 2 * PS_A_SZ + 2 * UP_B_SZ;  // 3584 slots = 57,344 B per buffer
+constexpr int UP_B_SZ = 2 * UP_BPAD;                                      // 640 slots per (hi|lo)
 constexpr int UP_B_PIECES = 2 * 2 * UP_BCH;                               // 20
 
 struct ConvUpPsParams {
@@ -315,8 +314,20 @@ struct ConvUpPsParams {
     int round_f16;
 };
 
-__global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsParams p) {
-    __shared__ bf16x8 smem[2 * UP_BUF + PS_BM * 4 / 16];
+// NMT = 32-channel groups per workgroup.  NMT = 2: 64 channels, one workgroup per CU (167 VGPRs: 128 accumulators).  NMT = 1: 32
+// channels, 64 accumulators, 78 KB of LDS -> TWO workgroups per CU: the transposed kernel writes 4 output pixels per position
+// (a 256 KB tile per 64 channels), and with one workgroup per CU the matrix pipe idles through every tile's stores (pipe busy
+// 0.40 against 0.68 for the stride-1 kernel, profiles/r02_mfma_busy_pmc.json); the second workgroup multiplies meanwhile.
+constexpr int up_ps_buf_slots(int nmt) { return 2 * (PS_TAPS * 2 * 32 * nmt) + 2 * UP_B_SZ; }      // per buffer, 16-byte slots
+constexpr int up_ps_smem_slots(int nmt) { return 2 * up_ps_buf_slots(nmt) + 32 * nmt * 4 / 16; }
+
+// (the body is a __device__ template under two plain kernels: the host pass emits no launch stub for a TEMPLATE kernel whose
+// body uses the LDS-DMA builtin, and says nothing)
+template <int NMT>
+__device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x8* smem) {
+    constexpr int BM = 32 * NMT, A_SZ = PS_TAPS * 2 * BM;                  // 16-byte slots per (buffer, hi|lo): [tap][half][row]
+    constexpr int BUF = up_ps_buf_slots(NMT);                             // NMT = 2: 57,344 B, NMT = 1: 38,912 B per buffer
+    constexpr int A_PIECES = PS_TAPS * 2 * NMT;                            // 64-slot pieces: NMT = 2 (tap, hi|lo, half), NMT = 1 (tap, hi|lo)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int m0 = (lb % p.tiles_m) * PS_BM; lb /= p.tiles_m;
+    const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
     const int tile_i = lb % (p.tiles_x * p.tiles_y), n = lb / (p.tiles_x * p.tiles_y);
     const int y0 = (tile_i / p.tiles_x) * p.th, x0 = (tile_i % p.tiles_x) * p.tw;
     const int PW = p.tw + 1, prows = p.th + 1;
@@ -334,19 +345,21 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
     const int plane_bytes = (p.I / 8) * HW * 16;
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, 2 * plane_bytes, 0x00020000);
-    constexpr int NA = (PS_A_PIECES + 7) / 8, NB = (UP_B_PIECES + 7) / 8;  // 5, 3
+    constexpr int NA = (A_PIECES + 7) / 8, NB = (UP_B_PIECES + 7) / 8;    // 5 (3), 3
     int ldsA[NA], sofA[NA], ldsB[NB], sofB[NB], voffB[NB];
-    const int voffA = (m0 + lane) * 16;
+    // NMT = 2: a piece = 64 consecutive rows of one (tap, hi|lo, half); NMT = 1: the two halves x 32 rows of one (tap, hi|lo)
+    const int voffA = NMT == 2 ? (m0 + lane) * 16 : ((lane >> 5) * p.OP64 + m0 + (lane & 31)) * 16;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int pa = wn + 8 * j, t = pa >> 2, hl = (pa >> 1) & 1, hf = pa & 1;
-        ldsA[j] = hl * PS_A_SZ + (t * 2 + hf) * PS_BM;
+        const int pa = wn + 8 * j;
+        const int t = NMT == 2 ? pa >> 2 : pa >> 1, hl = NMT == 2 ? (pa >> 1) & 1 : pa & 1, hf = NMT == 2 ? pa & 1 : 0;
+        ldsA[j] = hl * A_SZ + (t * 2 + hf) * BM;
         sofA[j] = ((t * KC) * 4 + hl * 2 + hf) * p.OP64 * 16;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int q = wn + 8 * j, hl = q / (2 * UP_BCH), hf = (q / UP_BCH) & 1, c = q % UP_BCH;
-        ldsB[j] = 2 * PS_A_SZ + hl * UP_B_SZ + hf * UP_BPAD + c * 64;
+        ldsB[j] = 2 * A_SZ + hl * UP_B_SZ + hf * UP_BPAD + c * 64;
         sofB[j] = hl * plane_bytes + hf * HW * 16;
         const int pp = c * 64 + lane;                                     // patch pixel of this lane (row-major, run-time pitch PW)
         const int pr = pp / PW, iy = y0 - 1 + pr, ix = x0 - 1 + pp % PW;
@@ -354,69 +367,66 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
         voffB[j] = ok ? (iy * p.W + ix) * 16 : (int)0x80000000;
     }
     const int strideA = 4 * p.OP64 * 16, strideB = 2 * HW * 16;
-    auto copy_chunk = [&](int kc, int buf) {
-        bf16x8* base = smem + buf * UP_BUF;
+    f32x16 acc[NMT][4];
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
-            if (j < NA - 1 || wn + 8 * j < PS_A_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA, sofA[j] + kc * strideA, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (j < NB - 1 || wn + 8 * j < UP_B_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + kc * strideB, 0, 0);
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][ph][r] = 0.f;
-    const int a_frag = half * PS_BM + l31;
+    const int a_frag = half * BM + l31;
     const int q_pos = wn * 32 + l31;                                      // flattened tile position of this lane
     const bool q_act = q_pos < p.th * p.tw;
     const int q_row = q_act ? q_pos / p.tw : 0, q_col = q_act ? q_pos % p.tw : 0;
     const int b_frag = half * UP_BPAD + q_row * PW + q_col;               // + dy*PW + dx
-    auto mfma_block = [&](int buf) {
-        const bf16x8* A_hi = smem + buf * UP_BUF, *A_lo = A_hi + PS_A_SZ, *B_hi = A_hi + 2 * PS_A_SZ, *B_lo = B_hi + UP_B_SZ;
-        __builtin_amdgcn_s_setprio(1);
-        bf16x8 bh[4], bl[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { bh[d] = B_hi[b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[b_frag + (d >> 1) * PW + (d & 1)]; }
-        bf16x8 ah[2][2], al[2][2];
-        auto fetch_a = [&](int t, int s) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { ah[s][mt] = A_hi[t * 2 * PS_BM + a_frag + mt * 32]; al[s][mt] = A_lo[t * 2 * PS_BM + a_frag + mt * 32]; }
-        };
-        fetch_a(0, 0);
-#pragma unroll
-        for (int t = 0; t < PS_TAPS; ++t) {
-            const int ky = t / 3, kx = t % 3, s = t & 1;
-            const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
-            const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
-            if (t + 1 < PS_TAPS) fetch_a(t + 1, s ^ 1);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
-                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[d], acc[mt][ph], 0, 0, 0);
-                acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    float* s_rs = reinterpret_cast<float*>(smem + 2 * UP_BUF);
-    if (tid < PS_BM) {
+    float* s_rs = reinterpret_cast<float*>(smem + 2 * BUF);
+    if (tid < BM) {
         const int o = min(m0 + tid, p.O - 1);
         s_rs[tid] = p.const_scale * (p.row_scale ? p.row_scale[(int64_t)n * p.row_scale_stride + o] : 1.f);
     }
-    copy_chunk(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __builtin_amdgcn_s_barrier();
-    for (int kc = 0; kc < KC; ++kc) {
-        if (kc + 1 < KC) copy_chunk(kc + 1, (kc + 1) & 1);
-        mfma_block(kc & 1);
+    // one loop body holds both the staging of chunk kc + 1 and the multiplies of chunk kc (kc = -1: prologue)
+    for (int kc = -1; kc < KC; ++kc) {
+        if (kc + 1 < KC) {
+            bf16x8* base = smem + ((kc + 1) & 1) * BUF;
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if (j < NA - 1 || wn + 8 * j < A_PIECES)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA, sofA[j] + (kc + 1) * strideA, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < NB - 1 || wn + 8 * j < UP_B_PIECES)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + (kc + 1) * strideB, 0, 0);
+        }
+        if (kc >= 0) {
+            const bf16x8* A_hi = smem + (kc & 1) * BUF, *A_lo = A_hi + A_SZ, *B_hi = A_hi + 2 * A_SZ, *B_lo = B_hi + UP_B_SZ;
+            __builtin_amdgcn_s_setprio(1);
+            bf16x8 bh[4], bl[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { bh[d] = B_hi[b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[b_frag + (d >> 1) * PW + (d & 1)]; }
+            bf16x8 ah[2][NMT], al[2][NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) { ah[0][mt] = A_hi[a_frag + mt * 32]; al[0][mt] = A_lo[a_frag + mt * 32]; }
+#pragma unroll
+            for (int t = 0; t < PS_TAPS; ++t) {
+                const int ky = t / 3, kx = t % 3, s = t & 1;
+                const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+                const int d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+                if (t + 1 < PS_TAPS) {
+#pragma unroll
+                    for (int mt = 0; mt < NMT; ++mt) {
+                        ah[s ^ 1][mt] = A_hi[(t + 1) * 2 * BM + a_frag + mt * 32];
+                        al[s ^ 1][mt] = A_lo[(t + 1) * 2 * BM + a_frag + mt * 32];
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) {
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[d], acc[mt][ph], 0, 0, 0);
+                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __builtin_amdgcn_s_barrier();
     }
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
             const int ox = 2 * gx + pb;
             if (ox >= p.OW) continue;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c8 = (m0 >> 3) + mt * 4 + g, ol = mt * 32 + 8 * g + 4 * half;
@@ -447,10 +457,23 @@ __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsPar
     }
 }
 
+__global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsParams p) {
+    __shared__ bf16x8 smem[up_ps_smem_slots(2)];
+    conv2d_up_ps_body<2>(p, smem);
+}
+__global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsParams p) {
+    __shared__ bf16x8 smem[up_ps_smem_slots(1)];
+    conv2d_up_ps_body<1>(p, smem);
+}
+
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->ksize == 3 && d->mode == 2 && d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: a split8 input to the transposed kernel needs the c8 output layout");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL), no split-K");
     N3D_CHECK(d->I % 16 == 0 && d->O % 64 == 0 && d->H >= 4 && d->W >= 4, "conv2d_bf16x3 (split8, transposed): I %% 16 == 0, O %% 64 == 0");
+    // 32-channel groups per workgroup.  1 (two workgroups per CU) measured 4-22 % faster than 2 on every transposed layer of the
+    // benchmark (profiles/r02_conv_ps_ablation.txt); N3D_UP_PS_MT=2 keeps the 64-channel variant reachable for tuning.
+    int mt = 1;
+    { const char* e = getenv("N3D_UP_PS_MT"); if (e) mt = atoi(e) == 2 ? 2 : 1; }
     N3D_CHECK((int64_t)(d->I / 8) * d->H * d->W * 32 < (1ll << 31), "conv2d_bf16x3: one sample's split8 input exceeds 2 GiB (32-bit buffer offsets)");
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(E.act == N3D_ACT_LINEAR && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f,
@@ -460,7 +483,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
     conv16_up_tiles(d->H + 1, d->W + 1, 8, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
-    p.tiles_m = d->O / 64;
+    p.tiles_m = d->O / (32 * mt);
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.OH * p.yrs;
@@ -472,7 +495,8 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_up_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    if (mt == 1) hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv2d_up_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }
