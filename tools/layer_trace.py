@@ -16,7 +16,7 @@ def main():
     ap.add_argument('--precision', default=None)
     ap.add_argument('--batch', type=int, default=4)
     a = ap.parse_args()
-    from next3d_amd import demo, layers
+    from next3d_amd import demo, layers, _lib
     from next3d_amd.torch_utils.ops import conv2d_gradfix as cg, upfirdn2d as uf
     if a.precision:
         layers.set_precision(a.precision)
@@ -38,17 +38,29 @@ def main():
         n, i, h, w = x.shape
         gh, gw = (h + 1, w + 1) if mode == 2 else cg.out_shape(h, w, mode)
         b16 = kw.get('bf16x3', False)
-        ks = kw.get('ksplit') or (cg.pick_ksplit_bf16x3(n, i, oc, h, w, mode) if b16 else cg.pick_ksplit(n, i, oc, gh, gw, ksize, mode))
+        pre = isinstance(x, _lib.Split8)
+        ks = 1 if pre else (kw.get('ksplit') or (cg.pick_ksplit_bf16x3(n, i, oc, h, w, mode) if b16 else cg.pick_ksplit(n, i, oc, gh, gw, ksize, mode)))
         flops = 2.0 * n * i * oc * ksize * ksize * (h * w if mode != 1 else gh * gw)
-        lab = f'conv k{ksize} mode{mode} {"bf16x3" if b16 else "fp32  "} N{n} I{i:4d} O{oc:4d} {h:3d}x{w:<3d} ksplit{ks} gflop={flops / 1e9:7.2f}'
+        lab = (f'conv k{ksize} mode{mode} {"bf16x3" if b16 else "fp32  "} {"split8" if pre else "nchw  "}->{"c8  " if kw.get("out_c8") else "nchw"} '
+               f'N{n} I{i:4d} O{oc:4d} {h:3d}x{w:<3d} ksplit{ks} gflop={flops / 1e9:7.2f}')
         return timed(lambda: orig_conv(x, wt, ksize, mode, oc, *args, **kw), lab)
 
-    def fir(x, f2d, up, down, padding, flip, gain, epilogue=None):
+    def fir(x, f2d, up, down, padding, *args, **kw):
         n, ch, h, w = x.shape
-        lab = f'fir  up{up[0]} down{down[0]} N{n} C{ch:4d} {h:3d}x{w:<3d} pitch{x.stride(2)} epi={epilogue is not None}'
-        return timed(lambda: orig_fir(x, f2d, up, down, padding, flip, gain, epilogue), lab)
+        lab = f'fir  up{up[0]} down{down[0]} N{n} C{ch:4d} {h:3d}x{w:<3d} pitch{x.stride(2)}'
+        return timed(lambda: orig_fir(x, f2d, up, down, padding, *args, **kw), lab)
 
-    cg.conv_launch, uf._launch = conv, fir
+    orig_fir8, orig_cvt = uf._fir4_split8, cg.split8_from_nchw
+
+    def fir8(x, *args, **kw):
+        n, ch, h, w = x.shape
+        return timed(lambda: orig_fir8(x, *args, **kw), f'fir4 c8->split8 N{n} C{ch:4d} {h:3d}x{w:<3d}')
+
+    def cvt(x, *args, **kw):
+        n, ch, h, w = x.shape
+        return timed(lambda: orig_cvt(x, *args, **kw), f'nchw->split8 N{n} C{ch:4d} {h:3d}x{w:<3d}')
+
+    cg.conv_launch, uf._launch, uf._fir4_split8, cg.split8_from_nchw = conv, fir, fir8, cvt
     for it in range(3):
         on[0] = it == 2
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
