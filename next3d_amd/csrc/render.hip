@@ -129,9 +129,163 @@ __device__ __forceinline__ void decode_point(const RenderParams& p, int n, float
     for (int k = 1; k <= RN_C; ++k) out[k] = sigmoid_f(out[k]) * (1.f + 2.f * 0.001f) - 0.001f;
 }
 
-// LDS layout per ray (one wave per block): all arrays sized for M = Sc + Sf samples
+// ------------------------------------------------------------------------------------------------------------------------------
+// render_rays_kernel: ONE wavefront renders TWO rays.
+//
+// Decoding (the 32 -> 64 softplus -> 33 MLP at every sample) runs on the matrix pipe in fp32 (v_mfma_f32_32x32x2_f32: the same
+// flop rate as packed VALU FMAs, but on a pipe the kernel otherwise leaves idle, and with the weights resident in registers as
+// matrix operands instead of ~130 scalar loads per hidden unit and sample batch).  A decode pass takes 32 samples; a sample is
+// owned by the lane PAIR (s, s + 32): lane half hb = lane >> 5 gathers channels 16 hb .. 16 hb + 15 of the sample's 12 texels, so
+// that the gathered features ARE the B operand (k = hb) of layer 1 with no cross-lane traffic:
+//   layer 1: H[j][s] = sum_c W1[j][c] F[c][s]   M = j (2 blocks of 32), N = s, K = 32 channels as 16 steps (c = 16 hb + kk), + 1 bias step
+//   layer 2: O[o][s] = sum_j W2[o][j] softplus(H[j][s])   M = o (32 colour channels), N = s, K = 64: the accumulator register r of
+//            block jb IS the B operand of K step (jb, r) (rows j = 32 jb + 8 (r / 4) + 4 hb + r % 4), the weights are arranged to match;
+//   sigma  : one more output row, 32 VALU FMAs per lane + one cross-half add.
+// Two rays x 48 samples = 3 passes without idle lanes (one ray per wave left 16 of 64 lanes idle in each of its two passes).
+// The per-ray stages (ray march, importance sampling, merge, composite) run one ray per lane half.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RN_CP 36       // colour row pitch in LDS (floats): 16-byte aligned rows, 36 s mod 64 distinct for 16 consecutive s
+
+// The decoder's matrix operands as an LDS image shared by the workgroup's waves: RN_WROWS rows of 64 floats, row = one MFMA's A
+// operand (lane-indexed), the last row = the sigma weights.  (Resident registers were tried first: 67 operands + the 192 registers of
+// the texels in flight made hipcc spill, and a spill reload waits on vmcnt(0), i.e. on the very loads it was meant to overlap.)
+//   rows  0..33 : layer 1, [hidden block jb][K step kk]: kk < 16 -> W1[32 jb + l31][16 hb + kk], kk = 16 -> bias (half 0) / 0 (half 1)
+//   rows 34..65 : layer 2 colour rows, [jb][r] -> W2[colour l31][hidden 32 jb + 8 (r / 4) + 4 hb + r % 4]
+//   row  66     : layer 2 bias step;   row 67 : sigma row, [hb][jb][r] at lane 32 hb + 16 jb + r
+#define RN_WROWS 68
+__device__ __forceinline__ void stage_decoder(const RenderParams& p, float* wimg, int tid, int nthreads) {
+    for (int e = tid; e < RN_WROWS * 64; e += nthreads) {
+        const int row = e >> 6, l = e & 63, l31 = l & 31, hb = l >> 5;
+        float v;
+        if (row < 34) {
+            const int jb = row / 17, kk = row % 17;
+            v = kk < 16 ? p.w1[(32 * jb + l31) * RN_C + 16 * hb + kk] : (hb == 0 ? p.b1[32 * jb + l31] : 0.f);
+        } else if (row < 66) {
+            const int jb = (row - 34) >> 4, r = (row - 34) & 15;
+            v = p.w2[(32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)) * 34 + 1 + l31];     // output unit 1 + c = colour channel c (unit 0 = sigma, triplane_next3d.py:368-370)
+        } else if (row == 66) {
+            v = hb == 0 ? p.b2[1 + l31] : 0.f;
+        } else {
+            v = p.w2[(32 * ((l >> 4) & 1) + 8 * ((l & 15) >> 2) + 4 * hb + (l & 3)) * 34];
+        }
+        wimg[e] = v;
+    }
+}
+
+// The waves of a workgroup share nothing but the decoder image; inside a wave LDS operations execute in issue order, so the
+// stages of a ray need a compiler-level fence only, not an s_barrier across the workgroup.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// softplus / sigmoid for the matrix-pipe decoder: raw v_exp_f32 / v_log_f32 / v_rcp_f32 (1 + e^x >= 1: no denormal handling needed)
+__device__ __forceinline__ float softplus_raw(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504f);
+    return x > 20.f ? x : __builtin_amdgcn_logf(1.f + e) * 0.693147181f;
+}
+__device__ __forceinline__ float sigmoid_raw(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+
+// One decode pass in two halves, so that the NEXT pass's texel gathers are in flight while this pass runs the decoder (the wave has
+// its SIMD to itself: nothing else hides an L2 round trip).
+struct PassFetch {     // a pass between its two halves: 48 texel quarters in flight + what the second half needs
+    float4 v[3][4][4];
+    const float4* tp[3][4];   // the 12 taps' texels (this lane's half: + 4 hb float4)
+    float tw[3][4];
+    int slot;          // sample slot in the ray's LDS arrays, -1 = idle lane pair
+    int q;             // ray of the wave (0 / 1)
+};
+
+// first half: the sample's position -> 12 tap addresses / weights; the 48 16-byte loads of this lane's 16 channels are issued in
+// four parts of 12 (pass_load) so that the caller can spread them under the previous pass's decoder: four waves share a CU's
+// texture path, a burst of 48 x 64 scattered 16-byte accesses per wave keeps it busy for ~6,000 cycles and a wave that issues
+// them back to back stalls on the full queue instead of multiplying.
+__device__ __forceinline__ void pass_taps(const RenderParams& p, int n, int hb, float px, float py, float pz, PassFetch& F) {
+    const float cx = p.coord_scale * px, cy = p.coord_scale * py, cz = p.coord_scale * pz;
+    const float* base = p.planes + (int64_t)n * 3 * p.PH * p.PW * RN_C + 16 * hb;
+    const int64_t ps = (int64_t)p.PH * p.PW * RN_C;
+    plane_taps(base, p.PH, p.PW, cx, cy, F.tp[0], F.tw[0]);            // plane 0: (x, y)
+    plane_taps(base + ps, p.PH, p.PW, cx, cz, F.tp[1], F.tw[1]);       // plane 1: (x, z)
+    plane_taps(base + 2 * ps, p.PH, p.PW, cz, cy, F.tp[2], F.tw[2]);   // plane 2: (z, y)   (renderer.py:42-44)
+}
+__device__ __forceinline__ void pass_load(PassFetch& F, int part) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int pl = (3 * part + c) >> 2, k = (3 * part + c) & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) F.v[pl][k][q] = F.tp[pl][k][q];
+    }
+}
+
+// second half, part 1: wait for the texels, blend them (the 12 taps' weights, mean over the planes) -> this lane's 16 features
+__device__ __forceinline__ void pass_blend(const PassFetch& F, float (&f)[16]) {
+    f32x2 f2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f2[c] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 w2 = f32x2{F.tw[pl][k], F.tw[pl][k]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f2[2 * q] = __builtin_elementwise_fma(w2, f32x2{F.v[pl][k][q].x, F.v[pl][k][q].y}, f2[2 * q]);
+                f2[2 * q + 1] = __builtin_elementwise_fma(w2, f32x2{F.v[pl][k][q].z, F.v[pl][k][q].w}, f2[2 * q + 1]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { f[2 * c] = f2[c].x * (1.f / 3.f); f[2 * c + 1] = f2[c].y * (1.f / 3.f); }   // mean over the planes (triplane_next3d.py:361)
+}
+
+// second half, part 2: 32 -> 64 softplus -> 33 on the matrix pipe -> rgb[r] = colour channel 8 (r / 4) + 4 hb + r % 4, sigma
+// `mid(part)`, part = 0..3, is called in front of the four quarters of the matrix work (the next pass's loads go there).
+template <typename Mid>
+__device__ __forceinline__ void pass_mlp(const float* wl /* decoder image + lane */, float bsig, int lane, const float (&f)[16], float (&rgb)[16], float& sigma, Mid mid) {
+    const int hb = lane >> 5;
+    const float one0 = hb == 0 ? 1.f : 0.f;
+    // hidden block 0 first, then block 1: block 0's softplus (VALU) runs under block 1's MFMAs, block 1's under layer 2's first half
+    f32x16 h[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        mid(jb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[jb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) h[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 * jb + kk) * 64], f[kk], h[jb], 0, 0, 0);
+        h[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 * jb + 16) * 64], one0, h[jb], 0, 0, 0);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float sp = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        mid(2 + jb);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl - lane + 67 * 64 + hb * 32 + jb * 16 + 4 * r4);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r = 4 * r4 + b;
+                const float hs = softplus_raw(h[jb][r]);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + 16 * jb + r) * 64], hs, o, 0, 0, 0);
+                sp = fmaf(w4[b], hs, sp);
+            }
+        }
+    }
+    o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[66 * 64], one0, o, 0, 0, 0);
+    sigma = sp + __shfl_xor(sp, 32, 64) + bsig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rgb[r] = sigmoid_raw(o[r]) * (1.f + 2.f * 0.001f) - 0.001f;
+}
+
+// LDS of one ray: arrays sized for M = Sc + Sf samples
 struct RayLds {
-    float* col;     // [M][33]  (col[s][0..31] rgb, [32] pad)
+    float* col;     // [M][RN_CP]  colour rows
     float* sig;     // [M]
     float* dep;     // [M]
     float* wgt;     // [M]   march weights
@@ -141,11 +295,75 @@ struct RayLds {
     float* bins;    // [M]
     int* order;     // [M]
 };
+__host__ __device__ constexpr int ray_lds_floats(int M) { return M * (RN_CP + 8); }
 
-// mid-point ray march over `count` samples addressed through idx(i) (ray_marcher.py:28-46); fills wgt[0..count-2]
+// Exclusive prefix product / sum of src[0..n) -> dst[0..n) on the 32 lanes of one ray (n <= 256): every lane folds a contiguous
+// chunk, the chunk totals are scanned across the lanes with five shuffles.  (The order of the floating-point operations differs
+// from a sequential torch.cumprod / cumsum on the CPU exactly as the reference's own parallel scan on the GPU does.)
+template <bool PROD>
+__device__ __forceinline__ void scan_half(const float* src, float* dst, int n, int l31) {
+    const float id = PROD ? 1.f : 0.f;
+    const int C = (n + 31) >> 5, i0 = l31 * C;
+    float v[8], total = id;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v[c] = c < C && i0 + c < n ? src[i0 + c] : id;
+        total = PROD ? total * v[c] : total + v[c];
+    }
+    float inc = total;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const float t = __shfl_up(inc, off, 32);
+        if (l31 >= off) inc = PROD ? t * inc : t + inc;
+    }
+    float run = __shfl_up(inc, 1, 32);
+    if (l31 == 0) run = id;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < C && i0 + c < n) { dst[i0 + c] = run; run = PROD ? run * v[c] : run + v[c]; }
+}
+
+// unify_samples (renderer.py:164-182): stable rank of each of the ray's M samples (<= 32 KP) in the merged depth order ->
+// order[rank] = sample.  Lane l31 ranks samples l31 + 32 m; one broadcast LDS read per compared sample serves all of them.
+template <int KP>
+__device__ __forceinline__ void rank_half(const RayLds& L, int M, int l31) {
+    float d[KP];
+    int lt[KP], le[KP];
+#pragma unroll
+    for (int m = 0; m < KP; ++m) { d[m] = l31 + 32 * m < M ? L.dep[l31 + 32 * m] : INFINITY; lt[m] = 0; le[m] = 0; }
+    for (int q0 = 0; q0 < M; q0 += 16) {                                  // sixteen compared samples per LDS round trip
+        float dq[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dq[k] = q0 + k < M ? L.dep[q0 + k] : INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int m = 0; m < KP; ++m) { lt[m] += dq[k] < d[m] ? 1 : 0; le[m] += dq[k] <= d[m] ? 1 : 0; }      // two compare + add-carry pairs
+    }
+    // no two samples of the ray at the same depth (the normal case): rank = number of smaller depths.  Equal depths are ordered by
+    // sample index (torch.sort is stable there), counted exactly in a second pass only when some lane saw a tie.
+    bool tie = false;
+#pragma unroll
+    for (int m = 0; m < KP; ++m) tie = tie || (l31 + 32 * m < M && le[m] - lt[m] != 1);
+    if (__any(tie)) {
+#pragma unroll
+        for (int m = 0; m < KP; ++m) lt[m] = 0;
+        for (int q = 0; q < M; ++q) {
+            const float dq = L.dep[q];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) lt[m] += (dq < d[m] || (dq == d[m] && q < l31 + 32 * m)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < KP; ++m)
+        if (l31 + 32 * m < M) L.order[lt[m]] = l31 + 32 * m;
+}
+
+// mid-point ray march over `count` samples addressed through idx(i) (ray_marcher.py:28-46); fills wgt[0..count-2].  Every ray
+// of the wave runs this on its own 32 lanes (l31 = lane within the half); the barriers are the wave's.
 template <typename IdxFn>
-__device__ __forceinline__ void march_weights(const RayLds& L, int count, int lane, IdxFn idx) {
-    for (int i = lane; i < count - 1; i += 64) {
+__device__ __forceinline__ void march_weights(const RayLds& L, int count, int l31, IdxFn idx) {
+    for (int i = l31; i < count - 1; i += 32) {
         const int a = idx(i), b = idx(i + 1);
         const float delta = L.dep[b] - L.dep[a];
         const float dm = softplus_f((L.sig[a] + L.sig[b]) / 2.f - 1.f);
@@ -153,137 +371,227 @@ __device__ __forceinline__ void march_weights(const RayLds& L, int count, int la
         L.wgt[i] = alpha;
         L.fac[i] = 1.f - alpha + 1e-10f;
     }
-    __syncthreads();
-    if (lane == 0) {       // sequential exclusive cumprod, same order as torch.cumprod
-        float T = 1.f;
-        for (int i = 0; i < count - 1; ++i) { L.trn[i] = T; T *= L.fac[i]; }
-    }
-    __syncthreads();
-    for (int i = lane; i < count - 1; i += 64) L.wgt[i] = L.wgt[i] * L.trn[i];
-    __syncthreads();
+    wave_sync();
+    scan_half<true>(L.fac, L.trn, count - 1, l31);        // exclusive cumprod (ray_marcher.py:43)
+    wave_sync();
+    for (int i = l31; i < count - 1; i += 32) L.wgt[i] = L.wgt[i] * L.trn[i];
+    wave_sync();
 }
 
-__global__ __launch_bounds__(64) void render_rays_kernel(RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
-    const int ray = blockIdx.x, n = blockIdx.y;
-    const int R = p.R, Sc = p.Sc, Sf = p.Sf, M = Sc + Sf;
-    RayLds L;
-    L.col = smem;
-    L.sig = L.col + M * 33;
-    L.dep = L.sig + M; L.wgt = L.dep + M; L.fac = L.wgt + M; L.trn = L.fac + M; L.cdf = L.trn + M; L.bins = L.cdf + M;
-    L.order = reinterpret_cast<int*>(L.bins + M);
+#ifdef RN_TRACE   // tuning builds only (tools/build_variant.sh trace render.hip -DRN_TRACE): stage time stamps of every wave
+__device__ long long rn_trace_buf[16384 * 16];
+#define RN_STAMP2(k) do { if (g0 == 32 && slot0 == 0) RN_STAMP(k); } while (0)
+#define RN_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 16384) rn_trace_buf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
+    static long long host[16384 * 16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rn_trace_buf), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 15; ++k) {
+        double sum = 0;
+        for (int w = 0; w < nwg; ++w) sum += (double)(host[w * 16 + k] - host[w * 16]);
+        avg[k] = sum / nwg;
+    }
+    return 0;
+}
+#else
+#define RN_STAMP(k)
+#define RN_STAMP2(k)
+#endif
 
-    // ---- ray (ray_sampler.py:33-61); ray index m = i*R + j, x from j, y from i
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hb = lane >> 5;
+    const int n = blockIdx.y;
+    const int R = p.R, RR = R * R, Sc = p.Sc, Sf = p.Sf, M = Sc + Sf;
+    stage_decoder(p, smem, threadIdx.x, blockDim.x);
+    __syncthreads();                                                      // the only workgroup-wide barrier
+    const int ray0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 2;         // this wave's rays: ray0, ray0 + 1 (the second may not exist)
+    if (ray0 >= RR) return;
+    const int nrays = min(2, RR - ray0);
+    RN_STAMP(0);
+    const float* wl = smem + lane;
+    const float bsig = p.b2[0];
+    float* wsm = smem + RN_WROWS * 64 + wave * 2 * ray_lds_floats(M);     // this wave's two rays
+    RayLds Ls[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        RayLds& L = Ls[q];
+        L.col = wsm + q * ray_lds_floats(M);
+        L.sig = L.col + M * RN_CP;
+        L.dep = L.sig + M; L.wgt = L.dep + M; L.fac = L.wgt + M; L.trn = L.fac + M; L.cdf = L.trn + M; L.bins = L.cdf + M;
+        L.order = reinterpret_cast<int*>(L.bins + M);
+    }
+
+    // ---- the two rays (ray_sampler.py:33-61); ray index m = i*R + j, x from j, y from i.  Every lane holds both.
     const float* c2w = p.cam2world + n * 16;
     const float* K = p.intrinsics + n * 9;
     const float fx = K[0], fy = K[4], cxk = K[2], cyk = K[5], sk = K[1];
-    const int ri = ray / R, rj = ray % R;
-    const float inv = (float)(1.0 / (double)R), half = (float)(0.5 / (double)R);
-    const float x_cam = __fadd_rn(__fmul_rn((float)rj, inv), half);
-    const float y_cam = __fadd_rn(__fmul_rn((float)ri, inv), half);
-    const float x_lift = (x_cam - cxk + cyk * sk / fy - sk * y_cam / fy) / fx;
-    const float y_lift = (y_cam - cyk) / fy;
     const float ox = c2w[3], oy = c2w[7], oz = c2w[11];
-    float dx = c2w[0] * x_lift + c2w[1] * y_lift + c2w[2] + c2w[3] - ox;
-    float dy = c2w[4] * x_lift + c2w[5] * y_lift + c2w[6] + c2w[7] - oy;
-    float dz = c2w[8] * x_lift + c2w[9] * y_lift + c2w[10] + c2w[11] - oz;
-    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
-    dx /= nrm; dy /= nrm; dz /= nrm;
-
-    // ---- coarse pass: sample s -> slot s
-    const float* jit = p.jitter + ((int64_t)n * R * R + ray) * Sc;
-    for (int s = lane; s < Sc; s += 64) {
-        const float t = __fadd_rn(p.tlin[s], __fmul_rn(jit[s], p.depth_delta));   // renderer.py:203-205
-        float out[RN_C + 1];
-        decode_point(p, n, __fadd_rn(ox, __fmul_rn(t, dx)), __fadd_rn(oy, __fmul_rn(t, dy)), __fadd_rn(oz, __fmul_rn(t, dz)), out);
-        L.dep[s] = t; L.sig[s] = out[0];
+    float rdx[2], rdy[2], rdz[2];
 #pragma unroll
-        for (int c = 0; c < RN_C; ++c) L.col[s * 33 + c] = out[1 + c];
+    for (int q = 0; q < 2; ++q) {
+        const int ray = min(ray0 + q, RR - 1);
+        const int ri = ray / R, rj = ray % R;
+        const float inv = (float)(1.0 / (double)R), half = (float)(0.5 / (double)R);
+        const float x_cam = __fadd_rn(__fmul_rn((float)rj, inv), half);
+        const float y_cam = __fadd_rn(__fmul_rn((float)ri, inv), half);
+        const float x_lift = (x_cam - cxk + cyk * sk / fy - sk * y_cam / fy) / fx;
+        const float y_lift = (y_cam - cyk) / fy;
+        float dx = c2w[0] * x_lift + c2w[1] * y_lift + c2w[2] + c2w[3] - ox;
+        float dy = c2w[4] * x_lift + c2w[5] * y_lift + c2w[6] + c2w[7] - oy;
+        float dz = c2w[8] * x_lift + c2w[9] * y_lift + c2w[10] + c2w[11] - oz;
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+        rdx[q] = dx / nrm; rdy[q] = dy / nrm; rdz[q] = dz / nrm;
     }
-    __syncthreads();
 
+    // decode `cnt` samples per ray, slots slot0 .. slot0 + cnt - 1, whose depths are in the rays' dep[] arrays.  Passes of 32 samples
+    // over the concatenated sample lists of the wave's rays; pass k + 1's gathers are issued before pass k's decoder runs.
+    auto taps = [&](int g0, int cnt, int slot0, PassFetch& F) {
+        const int g = g0 + l31;
+        const bool live = g < nrays * cnt;
+        F.q = live && g >= cnt ? 1 : 0;
+        const int i = live ? g - F.q * cnt : 0;
+        F.slot = live ? slot0 + i : -1;
+        const float t = (F.q ? Ls[1] : Ls[0]).dep[slot0 + i];
+        const float dx = F.q ? rdx[1] : rdx[0], dy = F.q ? rdy[1] : rdy[0], dz = F.q ? rdz[1] : rdz[0];
+        pass_taps(p, n, hb, __fadd_rn(ox, __fmul_rn(t, dx)), __fadd_rn(oy, __fmul_rn(t, dy)), __fadd_rn(oz, __fmul_rn(t, dz)), F);
+    };
+    auto decode_all = [&](int cnt, int slot0) {
+        const int total = nrays * cnt;
+        PassFetch F;
+        taps(0, cnt, slot0, F);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) pass_load(F, part);
+        for (int g0 = 0; g0 < total; g0 += 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            float f[16];
+            pass_blend(F, f);                                             // waits for this pass's texels ...
+            const int slot = F.slot, q = F.q;
+            __builtin_amdgcn_sched_barrier(0);                            // (... all of them, before ...)
+            RN_STAMP2(10);
+            const bool more = g0 + 32 < total;
+            if (more) taps(g0 + 32, cnt, slot0, F);                       // ... their registers take the next pass's, loaded under the decoder
+            RN_STAMP2(11);
+            float rgb[16], sigma;
+            pass_mlp(wl, bsig, lane, f, rgb, sigma, [&](int part) { RN_STAMP2(12 + part); if (more) pass_load(F, part); });
+            if (slot >= 0) {
+                const RayLds& L = q ? Ls[1] : Ls[0];
+                if (hb == 0) L.sig[slot] = sigma;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    *reinterpret_cast<f32x4*>(L.col + slot * RN_CP + 8 * a + 4 * hb) = f32x4{rgb[4 * a], rgb[4 * a + 1], rgb[4 * a + 2], rgb[4 * a + 3]};
+            }
+            RN_STAMP2(9);
+        }
+    };
+
+    // ---- coarse pass: stratified depths (renderer.py:203-205) -> dep[0 .. Sc), then decode into slots 0 .. Sc
+    RN_STAMP(1);
+    {
+        const float* jit0 = p.jitter + ((int64_t)n * RR + ray0) * Sc;
+        for (int g = lane; g < nrays * Sc; g += 64) {
+            const int q = g >= Sc ? 1 : 0, i = g - q * Sc;
+            (q ? Ls[1] : Ls[0]).dep[i] = __fadd_rn(p.tlin[i], __fmul_rn(jit0[g], p.depth_delta));
+        }
+    }
+    wave_sync();
+    decode_all(Sc, 0);
+    wave_sync();
+    RN_STAMP(2);
+
+    // ---- per-ray stages: lane half hb works on ray hb (a missing second ray repeats the first; its results are not stored)
+    const int myq = hb < nrays ? hb : 0;
+    const RayLds& L = myq ? Ls[1] : Ls[0];
+    const bool store = hb < nrays;
+    const int ray = ray0 + myq;
     int count = Sc;
     if (Sf > 0) {
-        march_weights(L, Sc, lane, [](int i) { return i; });
+        march_weights(L, Sc, l31, [](int i) { return i; });
+        RN_STAMP(3);
         // ---- importance depths (renderer.py:209-268)
         const int Lw = Sc - 1;       // number of march weights
         const int Np = Sc - 3;       // pdf bins (weights[:, 1:-1])
-        for (int i = lane; i < Lw; i += 64) {
+        for (int i = l31; i < Lw; i += 32) {
             const float wl = i > 0 ? L.wgt[i - 1] : -INFINITY, wc = L.wgt[i], wr = i + 1 < Lw ? L.wgt[i + 1] : -INFINITY;
             const float m0 = fmaxf(wl, wc), m1 = fmaxf(wc, wr);       // max_pool1d(2,1,pad=1)
             L.fac[i] = (m0 + m1) / 2.f + 0.01f;                        // avg_pool1d(2,1) + 0.01
             L.bins[i] = 0.5f * (L.dep[i] + L.dep[i + 1]);
         }
-        __syncthreads();
+        wave_sync();
         float part = 0.f;
-        for (int k = lane; k < Np; k += 64) part += L.fac[k + 1] + 1e-5f;
+        for (int k = l31; k < Np; k += 32) part += L.fac[k + 1] + 1e-5f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (lane == 0) {
-            float c = 0.f;
-            L.cdf[0] = 0.f;
-            for (int k = 0; k < Np; ++k) { c += (L.fac[k + 1] + 1e-5f) / part; L.cdf[k + 1] = c; }
-        }
-        __syncthreads();
-        const float* uu = p.u + ((int64_t)n * R * R + ray) * Sf;
-        for (int j = lane; j < Sf; j += 64) {
+        for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        for (int k = l31; k <= Np; k += 32) L.trn[k] = k < Np ? (L.fac[k + 1] + 1e-5f) / part : 0.f;      // pdf (renderer.py:243)
+        wave_sync();
+        scan_half<false>(L.trn, L.cdf, Np + 1, l31);                    // cdf[0] = 0, cdf[k + 1] = pdf[0] + .. + pdf[k] (:244-245)
+        wave_sync();
+        const float* uu = p.u + ((int64_t)n * RR + ray) * Sf;
+        for (int j = l31; j < Sf; j += 32) {
             const float u = uu[j];
             int ind = 0;                                             // searchsorted(cdf, u, right=True)
+#pragma unroll 8
             for (int k = 0; k <= Np; ++k) ind += (L.cdf[k] <= u) ? 1 : 0;
             const int below = max(ind - 1, 0), above = min(ind, Np);
             const float c0 = L.cdf[below], c1 = L.cdf[above], b0 = L.bins[below], b1 = L.bins[above];
             float denom = c1 - c0;
             if (denom < 1e-5f) denom = 1.f;
-            const float t = __fadd_rn(b0, __fmul_rn((u - c0) / denom, (b1 - b0)));
-            float out[RN_C + 1];
-            decode_point(p, n, __fadd_rn(ox, __fmul_rn(t, dx)), __fadd_rn(oy, __fmul_rn(t, dy)), __fadd_rn(oz, __fmul_rn(t, dz)), out);
-            const int s = Sc + j;
-            L.dep[s] = t; L.sig[s] = out[0];
-#pragma unroll
-            for (int c = 0; c < RN_C; ++c) L.col[s * 33 + c] = out[1 + c];
+            L.dep[Sc + j] = __fadd_rn(b0, __fmul_rn((u - c0) / denom, (b1 - b0)));
         }
-        __syncthreads();
+        wave_sync();
+        RN_STAMP(4);
+        // ---- second decode pass at the importance depths -> slots Sc + j
+        decode_all(Sf, Sc);
+        wave_sync();
+        RN_STAMP(5);
         // ---- unify_samples: stable rank of every sample in the merged order (renderer.py:164-182)
-        for (int k = lane; k < M; k += 64) {
-            const float d = L.dep[k];
-            int rank = 0;
-            for (int q = 0; q < M; ++q) {
-                const float dq = L.dep[q];
-                rank += (dq < d || (dq == d && q < k)) ? 1 : 0;
-            }
-            L.order[rank] = k;
-        }
-        __syncthreads();
+        if (M <= 96) rank_half<3>(L, M, l31); else rank_half<8>(L, M, l31);
+        wave_sync();
+        RN_STAMP(6);
         count = M;
         const int* ord = L.order;
-        march_weights(L, M, lane, [ord](int i) { return ord[i]; });
+        march_weights(L, M, l31, [ord](int i) { return ord[i]; });
+        RN_STAMP(7);
     } else {
-        for (int k = lane; k < Sc; k += 64) L.order[k] = k;
-        __syncthreads();
-        march_weights(L, Sc, lane, [](int i) { return i; });
+        for (int k = l31; k < Sc; k += 32) L.order[k] = k;
+        wave_sync();
+        march_weights(L, Sc, l31, [](int i) { return i; });
     }
 
-    // ---- composite (ray_marcher.py:48-59): lanes 0..31 one channel each, lane 32 depth, lane 33 weight total
-    float acc = 0.f;
-    if (lane < RN_C) {
-        for (int i = 0; i < count - 1; ++i) {
-            const int a = L.order[i], b = L.order[i + 1];
-            acc += L.wgt[i] * ((L.col[a * 33 + lane] + L.col[b * 33 + lane]) / 2.f);
+    // ---- composite (ray_marcher.py:48-59): the ray's 32 lanes take one colour channel each; depth and weight total as
+    // lane-strided partial sums
+    float acc = 0.f, dacc = 0.f, wt = 0.f;
+    {
+        float cprev = L.col[L.order[0] * RN_CP + l31];
+        for (int i0 = 0; i0 < count - 1; i0 += 16) {                      // sixteen (weight, next colour) pairs per LDS round trip
+            float w[16], cn[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = min(i0 + k, count - 2);
+                w[k] = L.wgt[i];
+                cn[k] = L.col[L.order[i + 1] * RN_CP + l31];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i0 + k < count - 1) { acc += w[k] * ((cprev + cn[k]) / 2.f); cprev = cn[k]; }
         }
-        p.feat[((int64_t)n * RN_C + lane) * R * R + ray] = acc * 2.f - 1.f;
-    } else if (lane == 32) {
-        float wt = 0.f;
-        for (int i = 0; i < count - 1; ++i) {
-            const int a = L.order[i], b = L.order[i + 1];
-            acc += L.wgt[i] * ((L.dep[a] + L.dep[b]) / 2.f);
-            wt += L.wgt[i];
+    }
+    for (int i = l31; i < count - 1; i += 32) {
+        const int a = L.order[i], b = L.order[i + 1];
+        dacc += L.wgt[i] * ((L.dep[a] + L.dep[b]) / 2.f);
+        wt += L.wgt[i];
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) { dacc += __shfl_xor(dacc, off, 64); wt += __shfl_xor(wt, off, 64); }
+    RN_STAMP(8);
+    if (store) {
+        p.feat[((int64_t)n * RN_C + l31) * RR + ray] = acc * 2.f - 1.f;
+        if (l31 == 0) {
+            float d = dacc / wt;
+            if (isnan(d)) d = INFINITY;                       // nan_to_num(nan=inf)
+            d = fminf(fmaxf(d, p.bounds[0]), p.bounds[1]);
+            p.depth[(int64_t)n * RR + ray] = d;
+            if (p.wsum) p.wsum[(int64_t)n * RR + ray] = wt;
         }
-        float d = acc / wt;
-        if (isnan(d)) d = INFINITY;                       // nan_to_num(nan=inf)
-        d = fminf(fmaxf(d, p.bounds[0]), p.bounds[1]);
-        p.depth[(int64_t)n * R * R + ray] = d;
-        if (p.wsum) p.wsum[(int64_t)n * R * R + ray] = wt;
     }
 }
 
@@ -400,17 +708,25 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.bounds = bounds_ws; p.feat = feat; p.depth = depth; p.wsum = wsum;
     p.N = N; p.R = R; p.Sc = Sc; p.Sf = Sf; p.PH = PH; p.PW = PW; p.depth_delta = depth_delta; p.coord_scale = coord_scale;
     const int M = Sc + Sf;
-    const size_t lds = (size_t)M * (33 + 7) * sizeof(float) + (size_t)M * sizeof(int);
+    // waves per workgroup: as many as the LDS holds beside the shared decoder image (4 at 48 + 48 samples: one per SIMD)
+    const size_t per_wave = (size_t)2 * ray_lds_floats(M) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
+    int wpb = (int)((160 * 1024 - image) / per_wave);
+    wpb = wpb > 4 ? 4 : wpb;
+    N3D_CHECK(wpb >= 1, "render_rays: %d samples per ray do not fit the LDS", M);
+    const size_t lds = image + wpb * per_wave;
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
+    if (lds > 48 * 1024)
+        N3D_CHECK(hipFuncSetAttribute((const void*)render_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                  "render_rays: %zu bytes of LDS refused", lds);
     hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, bounds_ws);
     N3D_LAUNCH_CHECK();
     const int64_t nrays = (int64_t)N * R * R;
     hipLaunchKernelGGL(render_depth_bounds_kernel, dim3((unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256))), dim3(256), 0, stream,
                        tlin, jitter, nrays, Sc, depth_delta, bounds_ws);
     N3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(render_rays_kernel, dim3(R * R, N), dim3(64), lds, stream, p);
+    hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The volume renderer alone at the benchmark's shape (batch 4, 64x64 rays, 48 + 48 samples, 256x256 planes), for timing and for
+PMC passes on render_rays_kernel.  Usage (GPU box): python tools/render_only.py [--iters 20] [--planes random|generator]"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--planes', default='generator')
+    a = ap.parse_args()
+    from next3d_amd import demo
+    dev = torch.device('cuda', 0)
+    G, _ = demo.build_generator(dev)
+    z, c, c_cond, v = demo.demo_batch(list(range(a.batch)), device=dev)
+    if a.planes == 'generator':
+        ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+        planes, _ = G._planes(ws.to(dev), v, 'const', False, False)
+    else:
+        planes = torch.randn(a.batch, 3, 256, 256, 32, device=dev)
+    jit = torch.rand(a.batch, 64 * 64, 48, 1, device=dev)
+    u = torch.rand(a.batch * 64 * 64, 48, device=dev)
+    for _ in range(3):
+        G.render(planes, c, 64, depth_jitter=jit, importance_u=u)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        feat, depth = G.render(planes, c, 64, depth_jitter=jit, importance_u=u)
+    e1.record(); torch.cuda.synchronize()
+    from next3d_amd import _lib
+    import ctypes
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    if hasattr(h, 'n3d_render_trace_dump'):        # tuning build (csrc/render.hip, RN_TRACE): average cycles per stage
+        avg = (ctypes.c_double * 16)()
+        h.n3d_render_trace_dump(avg, 2048)
+        names = ['start', 'decoder regs + rays', 'coarse decode', 'march 1', 'importance depths', 'fine decode', 'rank', 'march 2', 'composite',
+                 'pass 1: decoded + stored', 'pass 1: blended', 'pass 1: next taps', 'pass 1: layer 1 block 0', 'pass 1: layer 1 block 1', 'pass 1: layer 2 half 0', 'pass 1: layer 2 half 1']
+        print('cycles since the wave started, mean over workgroups: ' + ', '.join(f'{n} {avg[i]:.0f}' for i, n in enumerate(names)))
+    print(f'render (bounds + rays) {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us per call, batch {a.batch}; feat mean {feat.mean().item():.6f} depth mean {depth.mean().item():.6f}')
+
+
+if __name__ == '__main__':
+    main()
