@@ -1,13 +1,15 @@
-// Tri-plane volume renderer for gfx950: ONE wavefront renders ONE ray end to end and only the composited
-// [N,32,R,R] feature image and [N,1,R,R] depth ever reach HBM (the reference materialises ~20 tensors of
-// [N, R^2 * S, ...], volumetric_rendering/renderer.py:95-147).
+// Tri-plane volume renderer for gfx950: one wavefront renders TWO rays end to end and only the composited [N,32,R,R] feature
+// image and [N,1,R,R] depth ever reach HBM (the reference materialises ~20 tensors of [N, R^2 * S, ...],
+// volumetric_rendering/renderer.py:95-147).
 //
-//   lane s  : stratified depth t_s -> point -> 3 bilinear tri-plane gathers (channels-last planes: one texel's 32
-//             channels are 128 contiguous bytes = 8 x 16-byte loads) -> mean -> 32->64 softplus ->64->33 MLP
-//             (weights are wave-uniform: scalar loads, no LDS) -> (rgb[32], sigma) parked in LDS
-//   wave    : mid-point ray march (exclusive cumprod), weight smoothing, inverse-CDF importance depths,
-//             second decode pass, rank-merge of the two sample sets, final march + composite.
-// Bound: gather/L2 (604 MB of texel traffic per frame, 25 MB compulsory HBM) + 3.3 GFLOP of fp32 VALU.
+//   decode  : passes of 32 samples over the two rays' sample lists; the lane pair (s, s + 32) owns a sample: stratified /
+//             importance depth -> point -> 3 bilinear tri-plane gathers (channels-last planes: a texel's 32 channels are 128
+//             contiguous bytes; each lane half takes 64 of them = 4 x 16-byte loads per tap) -> mean -> 32 -> 64 softplus -> 33 MLP
+//             on the fp32 matrix pipe (see render_rays_kernel) -> (rgb[32], sigma) parked in LDS
+//   per ray : one ray per lane half: mid-point ray march (exclusive cumprod), weight smoothing, inverse-CDF importance depths,
+//             rank-merge of the two sample sets, final march + composite.
+// Bound: gather/L1 (604 MB of texel traffic per frame through the texture path, 25 MB compulsory HBM) + 3.3 GFLOP of fp32 MFMA.
+// (sample_points_kernel at the end keeps the per-lane VALU decoder: decode_point.)
 //
 // Replaces RaySampler.forward (reference volumetric_rendering/ray_sampler.py:24-63), ImportanceRenderer.forward
 // (renderer.py:95-147), sample_from_planes (:62-72, grid_sampler_2d bilinear/zeros/align_corners=False),
