@@ -118,6 +118,13 @@ int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
 int n3d_fir4_split8(const float* x_c8, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
                     int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
                     int64_t out_scale_stride, n3d_stream_t stream);
+/* n3d_fir4_split8_nchw: the same kernel on a float32 NCHW input (row pitch x_row_stride floats, 0 = W; batch stride in floats, 0 =
+ * dense) with `pad` (1 or 2) zero pixels on every side -> y split8 [N,C,H+2*pad-3,W+2*pad-3].  pad = 2 is the FIR in front of the
+ * stride-2 convolution of Conv2dLayer(down=2) (upfirdn2d with padding [2,2,2,2], conv2d_resample.py:108-111): the down-sampling
+ * layers then run on split8 input like the others. */
+int n3d_fir4_split8_nchw(const float* x, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
+                         int64_t x_batch_stride, int pad, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
+                         int64_t out_scale_stride, n3d_stream_t stream);
 /* n3d_split8_from_nchw: a float32 NCHW tensor [N,C,HW] (dense planes, batch stride x_batch_stride floats, 0 = dense) ->
  * split8, every value multiplied by scale[n*scale_stride + c] first (the consumer's style; NULL = 1).  For tensors whose
  * producer cannot write split8 itself (two consumers that need different styles). */

@@ -41,6 +41,7 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      //
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
 int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);     // conv2d_ps_bf16x3.hip (split8 input)
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, transposed, c8 output)
+int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, stride 2)
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
 
 __device__ __noinline__ float conv16_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
@@ -721,7 +722,9 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
     N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2),
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
-    if (d->x_layout == N3D_LAYOUT_SPLIT8) return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream);
+    N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
+    if (d->x_layout == N3D_LAYOUT_SPLIT8)
+        return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : (d->mode == 1 ? conv2d_s2_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream));
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);

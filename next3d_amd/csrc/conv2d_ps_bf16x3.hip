@@ -17,6 +17,7 @@
 // accumulation order per output as conv2d_bf16x3_kernel => bit-identical results for identical operands.
 // Replaces the same reference call sites as conv2d_bf16x3.hip (F.conv2d inside modulated_conv2d, networks_stylegan2.py:34-91).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -498,5 +499,283 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     if (mt == 1) hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(conv2d_up_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-2 convolution (the down-sampling encoder layers, mode 1) on split8 input.  Same polyphase formulation as
+// conv2d_s2_bf16x3.hip — the K loop runs over (16-channel chunk, phase (py, px)) with 4 / 2 / 2 / 1 taps per phase, one stage =
+// the 17 x 33 patch of ONE phase image + that phase's weights — but the register-staged kernel pays the full staging work of a
+// stride-1 chunk (24 four-byte gathers, style multiply, hi / lo split per work item) for a quarter of its MFMAs per stage and its
+// matrix pipe is busy 23 % of the time (profiles/r02_mfma_busy_pmc.json).  Here a stage is 36 + 4 x taps LDS-DMA pieces: the
+// de-interleave is done by the per-lane SOURCE address (patch pixel (a, b) of phase (py, px) = input pixel (2a + py, 2b + px)), the
+// phase and the chunk move through the scalar offset.  Three LDS buffers of 52 KB: the DMA of stage s + 2 is issued before the
+// MFMAs of stage s and the wait at the end of the iteration is `vmcnt(pieces of stage s + 2)` — stages carry 48 / 24 / 24 / 12
+// MFMAs per wave, a two-deep queue evens that out.  One workgroup per CU, MFMAs transposed (pixels as matrix rows) and the
+// epilogue of conv2d_ps_bf16x3_kernel; optional split-K like the register-staged kernel.
+// Patch pixels beyond the image (only ever feeding outputs beyond OH x OW, which are not stored) read whatever follows in
+// the sample, or zeros beyond its end (descriptor range check).
+constexpr int S2_BM = 64, S2_TH = 16, S2_TW = 32;
+constexpr int S2_PH = S2_TH + 1, S2_PW = S2_TW + 1, S2_PPIX = S2_PH * S2_PW;         // 17 x 33 = 561
+constexpr int S2_BCH = (S2_PPIX + 63) / 64, S2_BPAD = S2_BCH * 64;                    // 9 pieces = 576 slots per (hi|lo, half)
+constexpr int S2_A_SZ = 4 * 2 * S2_BM, S2_B_SZ = 2 * S2_BPAD;                          // per hi|lo: [slot 4][half][row], [half][pixel]
+constexpr int S2_BUF = 2 * S2_A_SZ + 2 * S2_B_SZ;                                      // 3328 slots = 53,248 B
+constexpr int S2_B_PIECES = 2 * 2 * S2_BCH;                                            // 36
+constexpr int S2_NBUF = 3;
+
+struct ConvS2PsParams {
+    const bf16x8* x; const bf16x8* wt16; float* y; float* partial;
+    int N, I, O, OP64, H, W, OH, OW;
+    int tiles_x, tiles_y, tiles_m, ksplit, ic_per_split;
+    int64_t xbs, ybs, yrs;
+    n3d_epilogue epi;
+};
+
+__global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsParams p) {
+    __shared__ bf16x8 smem[S2_NBUF * S2_BUF + 2 * S2_BM * 4 / 16];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int m0 = (lb % p.tiles_m) * S2_BM; lb /= p.tiles_m;
+    const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
+    const int ks = lb % p.ksplit, n = lb / p.ksplit;
+    const int y0 = (tile_i / p.tiles_x) * S2_TH, x0 = (tile_i % p.tiles_x) * S2_TW;
+    const int KC = p.I / 16, HW = p.H * p.W;
+    const int c_begin = ks * (p.ic_per_split / 16), c_end = min(KC, c_begin + p.ic_per_split / 16);
+    const int nstage = (c_end - c_begin) * 4;                             // stage st -> chunk c_begin + (st >> 2), phase st & 3
+
+    const int plane_bytes = (p.I / 8) * HW * 16;
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, 2 * plane_bytes, 0x00020000);
+
+    // This wave's pieces.  Patch: q = wn + 8 j (j < 5, q < 36) = (hi|lo, half, 64-pixel run).  Weights: piece a = wn + 8 j (j < 2,
+    // a < 4 * taps) = (slot, hi|lo, half) slabs of 64 rows.
+    constexpr int NB = (S2_B_PIECES + 7) / 8;                             // 5 (the fifth only for waves 0-3)
+    int ldsB[NB], sofB[NB], voffB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int q = wn + 8 * j, hl = q / (2 * S2_BCH), hf = (q / S2_BCH) & 1, c = q % S2_BCH;
+        ldsB[j] = 2 * S2_A_SZ + hl * S2_B_SZ + hf * S2_BPAD + c * 64;
+        sofB[j] = hl * plane_bytes + hf * HW * 16;
+        const int pp = c * 64 + lane;
+        const int iy = 2 * (y0 + pp / S2_PW), ix = 2 * (x0 + pp % S2_PW);   // phase (0, 0) pixel; the phase adds (py W + px) * 16 to the scalar offset
+        voffB[j] = pp < S2_PPIX && iy < p.H && ix < p.W ? (iy * p.W + ix) * 16 : (int)0x80000000;
+    }
+    const int voffA = (m0 + lane) * 16;
+    const int strideB = 2 * HW * 16, strideA = 4 * p.OP64 * 16;           // scalar-offset step per 16-channel chunk
+    // issue stage st into buffer st % 3; returns nothing — the number of DMA instructions of a (phase, wave) pair is dma_count()
+    auto copy_stage = [&](int st) {
+        const int c = c_begin + (st >> 2), g = st & 3, py = g >> 1, px = g & 1;
+        const int nx = px ? 1 : 2, nt = (py ? 1 : 2) * nx;
+        bf16x8* base = smem + (st % S2_NBUF) * S2_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int a = wn + 8 * j;
+            if (a < 4 * nt) {
+                const int slot = a >> 2, hl = (a >> 1) & 1, hf = a & 1;
+                const int ky = py ? 1 : 2 * (slot / nx), kx = px ? 1 : 2 * (slot % nx);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + hl * S2_A_SZ + (slot * 2 + hf) * S2_BM), 16, voffA,
+                                                         ((((ky * 3 + kx) * KC + c) * 2 + hl) * 2 + hf) * p.OP64 * 16, 0, 0);
+            }
+        }
+        const int sph = (py * p.W + px) * 16 + c * strideB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < NB - 1 || wn + 8 * j < S2_B_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + sph, 0, 0);
+    };
+    // DMA instructions this wave issues for a stage of phase g: patch 5 (waves 0-3) or 4, weights 2 / 1 / 1 / (waves 0-3: 1, else 0)
+    auto dma_count = [&](int g) { return (wn < 4 ? 5 : 4) + (g == 0 ? 2 : (g == 3 ? (wn < 4 ? 1 : 0) : 1)); };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const int a_frag = half * S2_BM + l31;                                // + slot*2*BM + mt*32
+    const int b_frag = half * S2_BPAD + (wn * 2) * S2_PW + l31;           // + nt*PW + dy*PW + dx
+    auto mfma_taps = [&](int st, auto ny_c, auto nx_c) {                  // taps (dy, dx), dy < NY, dx < NX; slot = dy*NX + dx
+        constexpr int NY = decltype(ny_c)::value, NX = decltype(nx_c)::value;
+        const bf16x8* A_hi = smem + (st % S2_NBUF) * S2_BUF, *A_lo = A_hi + S2_A_SZ, *B_hi = A_hi + 2 * S2_A_SZ, *B_lo = B_hi + S2_B_SZ;
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int dy = 0; dy < NY; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < NX; ++dx) {
+                const int slot = dy * NX + dx, boff = dy * S2_PW + dx;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[slot * 2 * S2_BM + a_frag + mt * 32]; al[mt] = A_lo[slot * 2 * S2_BM + a_frag + mt * 32]; }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[b_frag + nt * S2_PW + boff]; bl[nt] = B_lo[b_frag + nt * S2_PW + boff]; }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {                      // pixels = matrix rows, as conv2d_ps_bf16x3_kernel
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    float* s_rs = reinterpret_cast<float*>(smem + S2_NBUF * S2_BUF), *s_bs = s_rs + S2_BM;
+    const n3d_epilogue& E = p.epi;
+    if (tid < S2_BM) {
+        const int o = min(m0 + tid, p.O - 1);
+        s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
+        s_bs[tid] = E.bias ? E.bias[o] : 0.f;
+    }
+
+    if (nstage > 0) copy_stage(0);
+    if (nstage > 1) copy_stage(1);
+    // stage 0 must be complete: at most the pieces of stage 1 may still be in flight (vmcnt counts in order)
+    if (nstage > 1) { if (wn < 4) __builtin_amdgcn_s_waitcnt(0x0f70 | 6); else __builtin_amdgcn_s_waitcnt(0x0f70 | 5); }     // stage 1 = phase 1: 6 / 5 pieces
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+    for (int st = 0; st < nstage; ++st) {
+        const bool more = st + 2 < nstage;
+        if (more) copy_stage(st + 2);                                     // its buffer's last readers passed the barrier of iteration st - 1
+        switch (st & 3) {
+            case 0: mfma_taps(st, I2{}, I2{}); break;
+            case 1: mfma_taps(st, I2{}, I1{}); break;
+            case 2: mfma_taps(st, I1{}, I2{}); break;
+            default: mfma_taps(st, I1{}, I1{}); break;
+        }
+        // stage st + 1 complete = everything but the pieces of stage st + 2 (if issued) has landed
+        switch (more ? dma_count((st + 2) & 3) : 0) {
+            case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+            case 4: __builtin_amdgcn_s_waitcnt(0x0f70 | 4); break;
+            case 5: __builtin_amdgcn_s_waitcnt(0x0f70 | 5); break;
+            case 6: __builtin_amdgcn_s_waitcnt(0x0f70 | 6); break;
+            default: __builtin_amdgcn_s_waitcnt(0x0f70 | 7); break;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // epilogue (conv2d_ps_bf16x3_kernel's): lane = one channel of group mt, 16 pixels of the wave's row nt in 4 runs of 4
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int64_t plane = (int64_t)p.OH * p.OW, yplane = (int64_t)p.OH * p.yrs;
+    if (p.partial) {                                                      // split-K: raw sums, reduced by conv16_splitk_epilogue_kernel
+        const bool vec4 = (p.OW & 3) == 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int o = m0 + mt * 32 + l31;
+            if (o >= p.O) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oy = y0 + wn * 2 + nt;
+                if (oy >= p.OH) continue;
+                float* drow = p.partial + (((int64_t)ks * p.N + n) * p.O + o) * plane + (int64_t)oy * p.OW;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = x0 + 8 * g + 4 * half;
+                    if (ox >= p.OW) continue;
+                    if (vec4) *reinterpret_cast<f32x4*>(drow + ox) = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    else
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (ox + k < p.OW) drow[ox + k] = acc[mt][nt][4 * g + k];
+                }
+            }
+        }
+        return;
+    }
+    const float nstr = E.noise ? E.noise_strength[0] : 0.f;
+    const bool lrelu = E.act == N3D_ACT_LRELU;
+    const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
+    const bool vec = ((p.OW | p.yrs | p.ybs) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+                     (!E.residual || ((E.residual_batch_stride & 3) == 0 && ((uintptr_t)E.residual & 15) == 0)) && (!E.noise || ((uintptr_t)E.noise & 15) == 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int o = m0 + mt * 32 + l31;
+        if (o >= p.O) continue;
+        const float rs = s_rs[mt * 32 + l31], bs = s_bs[mt * 32 + l31];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int oy = y0 + wn * 2 + nt;
+            if (oy >= p.OH) continue;
+            float* drow = p.y + (int64_t)n * p.ybs + (int64_t)o * yplane + (int64_t)oy * p.yrs;
+            const float* rrow = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)o * plane + (int64_t)oy * p.OW : nullptr;
+            const float* nrow = E.noise ? E.noise + (int64_t)oy * p.OW : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ox = x0 + 8 * g + 4 * half;
+                if (ox >= p.OW) continue;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[mt][nt][4 * g + k];
+                if (vec) {
+                    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+                    if (nrow) nz = *reinterpret_cast<const f32x4*>(nrow + ox) * nstr;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = v[k] * rs + nz[k] + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;
+                        v[k] = n3d_round16(fminf(fmaxf(t, -clamp_eff), clamp_eff), E.round_f16);
+                    }
+                    f32x4 out = {v[0], v[1], v[2], v[3]};
+                    if (rrow) out += *reinterpret_cast<const f32x4*>(rrow + ox);
+                    *reinterpret_cast<f32x4*>(drow + ox) = out;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (ox + k >= p.OW) break;
+                        float t = v[k] * rs + (nrow ? nrow[ox + k] * nstr : 0.f) + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;
+                        t = n3d_round16(fminf(fmaxf(t, -clamp_eff), clamp_eff), E.round_f16);
+                        if (rrow) t += rrow[ox + k];
+                        drow[ox + k] = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
+                                  const n3d_epilogue& epi, hipStream_t stream);          // conv2d_bf16x3.hip
+
+int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
+    N3D_CHECK(d->ksize == 3 && d->mode == 1 && d->H >= 3 && d->W >= 3, "conv2d_bf16x3 (split8, stride 2): 3x3 kernel, input of at least 3 x 3");
+    N3D_CHECK(d->style == nullptr, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL)");
+    N3D_CHECK(d->I % 16 == 0 && d->I >= 16, "conv2d_bf16x3 (split8, stride 2): I %% 16 == 0");
+    N3D_CHECK((int64_t)(d->I / 8) * d->H * d->W * 32 < (1ll << 31), "conv2d_bf16x3: one sample's split8 input exceeds 2 GiB (32-bit buffer offsets)");
+    const n3d_epilogue& E = d->epi;
+    N3D_CHECK(E.act == N3D_ACT_LINEAR || (E.act == N3D_ACT_LRELU && E.alpha >= 0.f && E.alpha <= 1.f), "conv2d_bf16x3 (split8): linear or leaky-ReLU epilogue only");
+    N3D_CHECK(!E.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
+    N3D_CHECK(((uintptr_t)d->x & 15) == 0 && d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 input must be 16-byte aligned");
+    ConvS2PsParams p;
+    p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y; p.partial = d->workspace;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
+    p.OH = (d->H - 3) / 2 + 1; p.OW = (d->W - 3) / 2 + 1;
+    p.tiles_x = cdiv(p.OW, S2_TW); p.tiles_y = cdiv(p.OH, S2_TH); p.tiles_m = cdiv(p.O, S2_BM);
+    p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
+    p.ybs = d->y_batch_stride; p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
+    N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    const int max_split = d->I / 16;
+    p.ksplit = d->ksplit < 1 ? 1 : (d->ksplit > max_split ? max_split : d->ksplit);
+    p.ic_per_split = cdiv(cdiv(d->I, p.ksplit), 16) * 16;
+    p.ksplit = cdiv(d->I, p.ic_per_split);
+    N3D_CHECK(p.ksplit == 1 || d->workspace != nullptr, "conv2d_bf16x3: ksplit > 1 needs a workspace");
+    if (p.ksplit == 1) p.partial = nullptr;
+    p.epi = d->epi;
+    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
+    N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.OH * p.OW;
+    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    hipLaunchKernelGGL(conv2d_s2_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi, stream);
     return 0;
 }

@@ -252,10 +252,13 @@ struct FirSplitParams {
     int has_epi;
     n3d_epilogue epi;
     int tiles_x;
+    int pad;                      // zero padding on every side: 1 (behind a transposed convolution) or 2 (in front of a stride-2 one)
 };
 
 // FAST: linear / leaky-ReLU (0 <= alpha <= 1) epilogues as straight-line code; the generic instantiation carries the full switch
-template <bool FAST>
+// NCHW_IN: the input is float32 NCHW (the FIR in front of a stride-2 convolution: n3d_fir4_split8_nchw) instead of c8; only the
+// footprint loads differ (4-byte loads, transposed into the same two LDS planes).
+template <bool FAST, bool NCHW_IN>
 __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p) {
     constexpr int NT = 512, TW = 64, TH = 16, RPT = 2, FW = TW + 3, FH = TH + 3, CH = 8;
     __shared__ f32x4 s_ab[2 * FH * FW];                                   // plane 0: channels 0-3, plane 1: channels 4-7 of every footprint pixel
@@ -273,6 +276,27 @@ __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p
     // 32-bit offset: units outside the image get an offset beyond the descriptor's range and read as zero (the FIR's padding)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8), 0,
                                                                           (int)(p.H * p.xrs * 32), 0x00020000);
+    if (NCHW_IN) {
+        // 8 channel planes of H x xrs floats: element e -> (channel, footprint row, column), column fastest (coalesced rows of 67
+        // floats); written as single floats into the (pixel, channel) slots of the two planes.  All loads first, then the writes.
+        constexpr int ELEMS = CH * FH * FW, EPT = (ELEMS + NT - 1) / NT;  // 10,184 -> 20 per work item
+        float st[EPT];
+        int sl[EPT];
+        float* s_f = reinterpret_cast<float*>(s_ab);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int e = threadIdx.x + NT * j;
+            const int ch = e / (FH * FW), r = (e % (FH * FW)) / FW, q = e % FW;
+            const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + q;
+            const bool ok = e < ELEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int off = ok ? ((ch * p.H + iy) * (int)p.xrs + ix) * 4 : (int)0x80000000;
+            st[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+            sl[j] = e < ELEMS ? (((ch >> 2) * FH * FW + r * FW + q) * 4 + (ch & 3)) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            if (sl[j] >= 0) s_f[sl[j]] = st[j];
+    } else {
     constexpr int ROWU = FW * 2, UNITS = FH * ROWU, LPT = (UNITS + NT - 1) / NT;    // 134 units per row, 2546 per tile, 5 per work item
     f32x4 stage[LPT];
     int slot[LPT];                                                        // LDS slot (plane-relative) or -1
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {                                   // all loads in flight before the first LDS write
             const int hf = cu & 1, q = cu >> 1;
-            const int iy = oy0 - 1 + r, ix = ox0 - 1 + q;                 // pad 1
+            const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + q;
             const bool in_tile = threadIdx.x + NT * j < UNITS;
             const bool ok = in_tile && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int off = ok ? ((iy * (int)p.xrs + ix) * 8 + 4 * hf) * 4 : (int)0x80000000;
@@ -293,6 +317,7 @@ __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p
 #pragma unroll
         for (int j = 0; j < LPT; ++j)
             if (slot[j] >= 0) s_a[slot[j]] = stage[j];                    // s_b follows s_a (one array, two planes)
+    }
     }
     __syncthreads();
     const int lx = threadIdx.x % TW, ry = threadIdx.x / TW;
@@ -371,23 +396,24 @@ __global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p
     }
 }
 
-extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
-                               int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
-                               n3d_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int fir4_split8_impl(const float* x, const float* f, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
+                           int pad, bool nchw_in, int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
+                           hipStream_t stream) {
     N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && H > 1 && W > 1, "fir4_split8: bad shape (C %% 8 == 0)");
+    N3D_CHECK(pad == 1 || pad == 2, "fir4_split8: padding 1 or 2");
     const int64_t xrs = x_row_stride ? x_row_stride : W;
-    N3D_CHECK(xrs >= W && (x_batch_stride & 3) == 0 && ((uintptr_t)x & 15) == 0, "fir4_split8: misaligned c8 input");
-    const int OH = H - 1, OW = W - 1;                                      // 4 taps, padding 1 + 1
+    N3D_CHECK(xrs >= W && (nchw_in || ((x_batch_stride & 3) == 0 && ((uintptr_t)x & 15) == 0)), "fir4_split8: misaligned c8 input");
+    const int OH = H + 2 * pad - 3, OW = W + 2 * pad - 3;                  // 4 taps
     N3D_CHECK(!epi || (!epi->residual && !epi->residual_up_filter), "fir4_split8: no residual input");
     N3D_CHECK(!epi || !epi->noise || epi->noise_strength, "fir4_split8: noise without noise_strength");
     N3D_CHECK(!epi || (epi->act >= N3D_ACT_LINEAR && epi->act <= N3D_ACT_SWISH), "fir4_split8: unknown activation");
     if (N == 0) return 0;
     N3D_CHECK(x && f && y && ((uintptr_t)y & 15) == 0, "fir4_split8: null or misaligned tensor");
     N3D_CHECK(C / 8 <= 65535 && N <= 65535, "fir4_split8: N and C/8 must be <= 65535");
+    N3D_CHECK((int64_t)H * xrs * 32 < (1ll << 31), "fir4_split8: 8 channel planes exceed 2 GiB (32-bit buffer offsets)");
     FirSplitParams p;
     p.x = x; p.f = f; p.y = (bf16x8_t*)y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.flip = flip; p.gain = gain;
-    p.xbs = x_batch_stride ? x_batch_stride : (int64_t)C * H * xrs; p.xrs = xrs;
+    p.xbs = x_batch_stride ? x_batch_stride : (int64_t)C * H * xrs; p.xrs = xrs; p.pad = pad;
     p.out_scale = out_scale; p.out_scale_stride = out_scale_stride ? out_scale_stride : C;
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
@@ -395,10 +421,27 @@ extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, i
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
     const bool fast = !epi || epi->act == N3D_ACT_LINEAR || (epi->act == N3D_ACT_LRELU && epi->alpha >= 0.f && epi->alpha <= 1.f);
     const dim3 grid(p.tiles_x * cdiv(OH, 16), C / 8, N);
-    if (fast) hipLaunchKernelGGL(fir4_c8_split8_kernel<true>, grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(fir4_c8_split8_kernel<false>, grid, dim3(512), 0, stream, p);
+    if (nchw_in) {
+        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, true>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, true>), grid, dim3(512), 0, stream, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, false>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, false>), grid, dim3(512), 0, stream, p);
+    }
     N3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int n3d_fir4_split8(const float* x, const float* f, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
+                               int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
+                               n3d_stream_t stream_) {
+    return fir4_split8_impl(x, f, y, N, C, H, W, x_row_stride, x_batch_stride, 1, false, flip, gain, epi, out_scale, out_scale_stride, (hipStream_t)stream_);
+}
+
+extern "C" int n3d_fir4_split8_nchw(const float* x, const float* f, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
+                                    int pad, int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
+                                    n3d_stream_t stream_) {
+    return fir4_split8_impl(x, f, y, N, C, H, W, x_row_stride, x_batch_stride, pad, true, flip, gain, epi, out_scale, out_scale_stride, (hipStream_t)stream_);
 }
 
 static int upfirdn2d_impl(const float* x, const float* f, float* y, int N, int C, int H, int W, int64_t xrs, int64_t yrs, int fh, int fw, int upx,

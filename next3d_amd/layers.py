@@ -36,6 +36,7 @@ PRECISION = os.environ.get('N3D_PRECISION', 'bf16x3')
 PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
 # ... and for the transposed convolution in front of it: its input (a block output with two consumers) is converted once
 # (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
+S2_PRESPLIT = os.environ.get('N3D_S2_PRESPLIT', '1') != '0'      # stride-2 encoder layers on split8 input (A/B: 0)
 UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
 CONVERT_MAX_BYTES = int(float(os.environ.get('N3D_CONVERT_MAX_MB', '70')) * 1e6)     # see _conv3x3
 
@@ -259,6 +260,11 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3
+    if PRECISION == 'bf16x3' and L.wt16 is not None and S2_PRESPLIT and x.shape[1] % 16 == 0 and x.shape[2] >= 32:
+        # FIR writing split8 -> the LDS-DMA stride-2 kernel (the register-staged one pays a stride-1 chunk's
+        # staging for a quarter of its MFMAs per stage)
+        x = uf._fir4_split8_nchw(x, fir, 2) if x.shape[1] % 8 == 0 and tuple(fir.shape) == (4, 4) else cg.split8_from_nchw(uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2]))
+        return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2] + 1, x.shape[3] + 1, 3, 1):
         # the (W+1)-wide FIR output goes to the stride-2 kernel with rows padded to 16 bytes (aligned float4 FIR stores)
         x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2], _row_pitch=True)

@@ -131,12 +131,13 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
-        if not (bf16x3 and ksize == 3 and (mode == 0 or (mode == 2 and out_c8)) and style is None):
-            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 (or transposed, c8 output) split-bf16 kernel, without a style')
+        if not (bf16x3 and ksize == 3 and (mode in (0, 1) or (mode == 2 and out_c8)) and style is None):
+            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 / stride-2 (or transposed, c8 output) split-bf16 kernel, without a style')
         n, i, h, w = x.shape
         xs = x
         x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only
-        ksplit = 1
+        if mode != 1:
+            ksplit = 1                                                         # (the stride-2 kernel keeps split-K for its small grids)
     _lib.require_device(None if split8 else x, wt, style, out)
     n, i, h, w = x.shape
     o = out_channels

@@ -95,6 +95,20 @@ def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     return y
 
 
+def _fir4_split8_nchw(x, f2d, pad, gain=1.0, epilogue=None, out_scale=None):
+    """The 4x4 FIR with `pad` (1 / 2) zero pixels on every side from a float32 NCHW tensor straight into the split8 layout
+    (n3d_fir4_split8_nchw): the filter in front of a stride-2 convolution (Conv2dLayer(down=2)), whose output is only ever read
+    by that convolution."""
+    assert tuple(f2d.shape) == (4, 4) and x.dtype == torch.float32 and x.ndim == 4
+    if not _planes_ok(x):
+        x = x.contiguous()
+    n, c, h, w = x.shape
+    y = _lib.Split8(n, c, h + 2 * pad - 3, w + 2 * pad - 3, x.device)
+    _lib.check(_lib.lib().n3d_fir4_split8_nchw(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y.data), n, c, h, w, x.stride(2), x.stride(0), pad, 0, float(gain),
+                                               epilogue, _lib.ptr(out_scale), out_scale.stride(0) if out_scale is not None else 0, _lib.stream()))
+    return y
+
+
 def _planes_ok(x):
     """dense planes, or rows with a pitch (a [..., :W] view of a wider buffer: conv_launch(..., row_pitch=True))"""
     return x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)

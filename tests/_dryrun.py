@@ -22,10 +22,11 @@ def _check_conv_desc(name, d):
     assert d.x and d.wt and d.y, name
     assert d.ksize in (1, 3) and 0 <= d.mode <= 2
     assert d.x_layout in (0, 1)
-    if d.x_layout == 1:                                  # split8 input: conv2d_ps_bf16x3_launch's preconditions
-        assert bf16x3 and d.ksize == 3 and d.mode in (0, 2) and not d.style and d.ksplit <= 1 and d.epi.act in (1, 3)
+    if d.x_layout == 1:                                  # split8 input: the pre-split launchers' preconditions (conv2d_ps_bf16x3.hip)
+        assert bf16x3 and d.ksize == 3 and not d.style and d.epi.act in (1, 3)
+        assert d.ksplit <= 1 or d.mode == 1              # only the stride-2 kernel keeps split-K
         assert d.I % 16 == 0 and d.x_batch_stride % 4 == 0
-        assert (d.mode == 0 and d.H >= 16 and d.W >= 32) or (d.mode == 2 and d.y_layout == 2 and d.O % 64 == 0)
+        assert (d.mode == 0 and d.H >= 16 and d.W >= 32) or (d.mode == 2 and d.y_layout == 2 and d.O % 64 == 0) or (d.mode == 1 and d.H >= 3 and d.W >= 3)
     if bf16x3:
         assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)
         assert d.x_row_stride in (0, d.W) or (d.ksize == 3 and d.mode == 1)

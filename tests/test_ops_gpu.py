@@ -573,6 +573,43 @@ def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
         cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True)      # the split8 input is modulated already
 
 
+@pytest.mark.parametrize('N,C,H,W,pad', [(2, 32, 64, 64, 2), (1, 16, 37, 101, 2), (3, 8, 16, 20, 1), (1, 64, 128, 128, 2)])
+def test_fir4_split8_from_nchw_matches_float_fir(dev, N, C, H, W, pad):
+    """n3d_fir4_split8_nchw (the FIR in front of a stride-2 convolution, float32 NCHW in, split8 out) against the float32 FIR of
+    the same library: hi + lo reproduces it to the 16 bits the pair carries."""
+    from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    x = _gen((N, C, H, W), 120).to(dev)
+    f = uf.setup_filter([1, 3, 3, 1]).to(dev)
+    ref = uf.upfirdn2d(x, f, padding=[pad] * 4)
+    y = uf._fir4_split8_nchw(x, f, pad)
+    assert tuple(y.shape) == tuple(ref.shape)
+    print('fir4 nchw -> split8: max |hi + lo - fir|', float((y.to_float() - ref).abs().max()))
+    _close(y.to_float(), ref, atol=1e-6, rtol=2.0 ** -15)                 # hi + lo carries 16 significant bits
+    _close(ref.cpu(), O.upfirdn2d(x.cpu(), f.cpu(), padding=[pad] * 4), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize('N,I,OC,H,W,ks', [(4, 128, 256, 257, 257, 1), (2, 64, 100, 65, 129, 1), (4, 512, 512, 65, 65, 4), (1, 32, 64, 33, 47, 2),
+                                          (3, 16, 64, 40, 36, 1)])
+def test_presplit_stride2_conv_matches_plain_kernel(dev, N, I, OC, H, W, ks):
+    """conv2d_s2_ps_bf16x3_kernel (split8 input, (chunk, phase) stages by LDS-DMA with the de-interleave in the source
+    addresses, three LDS buffers) against the register-staged stride-2 kernel on the same operands and against ATen; odd and
+    even input sizes, ragged tiles, split-K."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x = _gen((N, I, H, W), 110).to(dev)
+    w = (_gen((OC, I, 3, 3), 111) / np.sqrt(9 * I)).to(dev)
+    wt16 = cg.prep_weight_bf16x3(w)
+    bias = _gen((OC,), 113).to(dev)
+    for kw in (dict(), dict(const_scale=0.7, bias=bias, act='lrelu', gain=1.4, clamp=2.0)):
+        ref = cg.conv_launch(x, wt16, 3, 1, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, ksplit=ks)
+        y = cg.conv_launch(_to_split8(x), wt16, 3, 1, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, ksplit=ks)
+        print('stride-2 presplit vs plain: max abs diff', float((y - ref).abs().max()), 'bit-identical', bool(torch.equal(y, ref)))
+        _close(y, ref, atol=1e-5, rtol=1e-5)
+    _close(y, O.bias_act(torch.nn.functional.conv2d(x.cpu(), w.cpu(), stride=2) * 0.7, bias.cpu(), act='lrelu', gain=1.4, clamp=2.0), atol=2e-4, rtol=1e-4)
+    y2 = cg.conv_launch(cg.split8_from_nchw(x), wt16, 3, 1, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, ksplit=ks)
+    assert torch.equal(y2, y)                                             # the library's own conversion pass = the torch-built operand image
+
+
 @pytest.mark.parametrize('N,C,H,W', [(2, 32, 16, 32), (1, 64, 64, 64), (3, 16, 40, 24), (1, 8, 7, 100)])
 def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
     """n3d_fir4_split8 (c8 input -> FIR + layer epilogue + next layer's style + hi/lo split, split8 output) against the float32

@@ -67,3 +67,15 @@ for (N, I, O, H) in [(4, 512, 512, 32), (4, 512, 256, 64), (4, 256, 128, 128), (
     xs = cg.split8_from_nchw(x, st)
     b = t_us(lambda: cg.conv_launch(xs, wt, 3, 2, O, bf16x3=True, out_c8=True))
     print(f'UP N{N} I{I} O{O} {H}x{H} ({gf:.0f} GF): register-staged {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  same, c8 out {a8:7.1f} us  | pre-split {b:7.1f} us ({gf / b * 1e3:4.0f} TF) + conversion {cv:6.1f} us', flush=True)
+
+# ---- stride-2 encoder layers: register-staged vs pre-split (split8 in) + the conversion pass in front
+for (N, I, O, H, ks) in [(4, 128, 256, 257, 1), (4, 256, 512, 129, 1), (4, 512, 512, 65, 4), (4, 512, 512, 65, 2), (4, 512, 512, 65, 1)]:
+    x = torch.randn(N, I, H, H, device=dev)
+    wt = cg.prep_weight_bf16x3(torch.randn(O, I, 3, 3, device=dev) / (3 * I ** 0.5))
+    oh = (H - 3) // 2 + 1
+    gf = 2.0 * N * O * I * 9 * oh * oh / 1e9
+    a = t_us(lambda: cg.conv_launch(x, wt, 3, 1, O, bf16x3=True, ksplit=ks))
+    xs = cg.split8_from_nchw(x)
+    cv = t_us(lambda: cg.split8_from_nchw(x))
+    b = t_us(lambda: cg.conv_launch(xs, wt, 3, 1, O, bf16x3=True, ksplit=ks))
+    print(f'S2 N{N} I{I} O{O} {H}x{H} ksplit{ks} ({gf:.0f} GF): register-staged {a:7.1f} us ({gf / a * 1e3:4.0f} TF) | pre-split {b:7.1f} us ({gf / b * 1e3:4.0f} TF) + conversion {cv:6.1f} us', flush=True)
