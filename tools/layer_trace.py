@@ -50,7 +50,7 @@ def main():
         lab = f'fir  up{up[0]} down{down[0]} N{n} C{ch:4d} {h:3d}x{w:<3d} pitch{x.stride(2)}'
         return timed(lambda: orig_fir(x, f2d, up, down, padding, *args, **kw), lab)
 
-    orig_fir8, orig_cvt = uf._fir4_split8, cg.split8_from_nchw
+    orig_fir8, orig_cvt, orig_firn = uf._fir4_split8, cg.split8_from_nchw, uf._fir4_split8_nchw
 
     def fir8(x, *args, **kw):
         n, ch, h, w = x.shape
@@ -60,7 +60,11 @@ def main():
         n, ch, h, w = x.shape
         return timed(lambda: orig_cvt(x, *args, **kw), f'nchw->split8 N{n} C{ch:4d} {h:3d}x{w:<3d}')
 
-    cg.conv_launch, uf._launch, uf._fir4_split8, cg.split8_from_nchw = conv, fir, fir8, cvt
+    def firn(x, *args, **kw):
+        n, ch, h, w = x.shape
+        return timed(lambda: orig_firn(x, *args, **kw), f'fir4 nchw->split8 N{n} C{ch:4d} {h:3d}x{w:<3d}')
+
+    cg.conv_launch, uf._launch, uf._fir4_split8, cg.split8_from_nchw, uf._fir4_split8_nchw = conv, fir, fir8, cvt, firn
     for it in range(3):
         on[0] = it == 2
         ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
