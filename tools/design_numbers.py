@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Rewrite the 'Round-2 numbers' paragraph of DESIGN.md section 5 from profiles/r02_bench.json (run after tools/refresh_profiles.sh)."""
+import json, os, re
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.load(open(os.path.join(root, 'profiles', 'r02_bench.json')))
+r, r32 = d['roofline'], d['roofline_fp32']
+f = r['family_ms_per_step']
+c3, c5, cpu = d['config3'], d['config5'], d['cpu_baseline']
+traffic = r.get('traffic')
+para = f'''**Round-2 numbers (MI355X, N=1, batch 4, `profiles/r02_bench.json`)**: **{d['value']:.0f} frames/s** ({d['ms_per_step']:.2f} ms per 4-frame step; one stream:
+{d['single_stream']['value']:.0f}; round 1: 307, driver-measured 272), frames bitwise identical across pipelined steps.  3×3 split-bf16 family:
+{r['achieved']:.0f} TFLOP/s fp32-equivalent = **frac {r['frac']:.3f}** of 833 (round 1: 0.365; against the MEASURED random-operand ceiling of the matrix
+pipe, §3.1c, 617-650: ~{r['achieved'] / 633:.2f}), {r['launches_per_step']:.0f} launches, {f['conv2d_bf16x3']:.2f} ms per step, {r['avg_launch_ms'] * 1e3:.0f} µs average (rocprofv3's kernel averages of the
+same command: `profiles/r02_kernel_stats.csv`); per family (`family_ms_per_step`, one stream, events): FIR {f['upfirdn2d']:.2f} ms, 1×1
+{f['conv1x1_bf16x3']:.2f} ms, renderer {f['render']:.2f} ms, rasteriser {f['raster']:.2f} ms, FCs {f['fc']:.2f} ms, conversions / blend / misc {f['misc']:.2f} ms.  History of the
+round: 309.6 (round-1 build, this round's boxes) → 318.7 (pre-split stride-1 + FIR → split8) → 322 (transposed pre-split, c8) → 351
+(three lanes) → 355 (renderer on the matrix pipe, 32-channel transposed workgroups) → 362 (stride-2 layers pre-split).
+`N3D_PRECISION=fp32`: {r32['value']:.0f} frames/s, family {r32['achieved']:.0f} TFLOP/s = {r32['frac']:.2f} of the fp32-MFMA peak.  Other call patterns (`config3` /
+`config5`): orbit with cached planes {c3['cached_planes_images_per_s']:.0f} frames/s (96 + 96 samples: {c3['cached_planes_96+96_images_per_s']:.0f}), reenactment with cached identity
+{c5['cached_identity_frames_per_s']:.0f} frames/s.  CPU baseline (oracle, kind `port`, {cpu['cores']} threads of the box's {cpu.get('host_cores', '?')} logical cores): {cpu['value']:.2f} frames/s.
+PMC traffic (`profiles/r02_traffic_pmc.json`, FETCH_SIZE / WRITE_SIZE in separate passes, 3×3 family): {traffic / 1e6 if traffic else float('nan'):.0f} MB per launch raw
+against {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic.
+
+'''
+p = os.path.join(root, 'DESIGN.md')
+s = open(p).read()
+a = s.index('**Round-2 numbers (MI355X')
+b = s.index('<details><summary>Round-1 numbers</summary>')
+open(p, 'w').write(s[:a] + para + s[b:])
+print(para)
