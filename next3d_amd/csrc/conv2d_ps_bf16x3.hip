@@ -324,8 +324,12 @@ constexpr int up_ps_smem_slots(int nmt) { return 2 * up_ps_buf_slots(nmt) + 32 *
 
 // (the body is a __device__ template under two plain kernels: the host pass emits no launch stub for a TEMPLATE kernel whose
 // body uses the LDS-DMA builtin, and says nothing)
-template <int NMT>
+// NW = waves per workgroup, PG = 32-position groups per wave (NW * PG = 8: the tile is always 256 positions).  <1, 4, 2>: a wave
+// covers 64 positions x 32 channels, so the weight fragments it reads serve twice the MFMAs (34 fragment reads per 54 MFMAs instead
+// of 26 per 27: the <1, 8, 1> form keeps the LDS pipe ~96 % busy at the MFMA rate it reaches).
+template <int NMT, int NW, int PG>
 __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x8* smem) {
+    static_assert(NW * PG == 8, "256 positions per tile");
     constexpr int BM = 32 * NMT, A_SZ = PS_TAPS * 2 * BM;                  // 16-byte slots per (buffer, hi|lo): [tap][half][row]
     constexpr int BUF = up_ps_buf_slots(NMT);                             // NMT = 2: 57,344 B, NMT = 1: 38,912 B per buffer
     constexpr int A_PIECES = PS_TAPS * 2 * NMT;                            // 64-slot pieces: NMT = 2 (tap, hi|lo, half), NMT = 1 (tap, hi|lo)
@@ -346,20 +350,20 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     const int plane_bytes = (p.I / 8) * HW * 16;
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, 2 * plane_bytes, 0x00020000);
-    constexpr int NA = (A_PIECES + 7) / 8, NB = (UP_B_PIECES + 7) / 8;    // 5 (3), 3
+    constexpr int NA = (A_PIECES + NW - 1) / NW, NB = (UP_B_PIECES + NW - 1) / NW;
     int ldsA[NA], sofA[NA], ldsB[NB], sofB[NB], voffB[NB];
     // NMT = 2: a piece = 64 consecutive rows of one (tap, hi|lo, half); NMT = 1: the two halves x 32 rows of one (tap, hi|lo)
     const int voffA = NMT == 2 ? (m0 + lane) * 16 : ((lane >> 5) * p.OP64 + m0 + (lane & 31)) * 16;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int pa = wn + 8 * j;
+        const int pa = wn + NW * j;
         const int t = NMT == 2 ? pa >> 2 : pa >> 1, hl = NMT == 2 ? (pa >> 1) & 1 : pa & 1, hf = NMT == 2 ? pa & 1 : 0;
         ldsA[j] = hl * A_SZ + (t * 2 + hf) * BM;
         sofA[j] = ((t * KC) * 4 + hl * 2 + hf) * p.OP64 * 16;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int q = wn + 8 * j, hl = q / (2 * UP_BCH), hf = (q / UP_BCH) & 1, c = q % UP_BCH;
+        const int q = wn + NW * j, hl = min(q, UP_B_PIECES - 1) / (2 * UP_BCH), hf = (q / UP_BCH) & 1, c = q % UP_BCH;
         ldsB[j] = 2 * A_SZ + hl * UP_B_SZ + hf * UP_BPAD + c * 64;
         sofB[j] = hl * plane_bytes + hf * HW * 16;
         const int pp = c * 64 + lane;                                     // patch pixel of this lane (row-major, run-time pitch PW)
@@ -368,18 +372,25 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
         voffB[j] = ok ? (iy * p.W + ix) * 16 : (int)0x80000000;
     }
     const int strideA = 4 * p.OP64 * 16, strideB = 2 * HW * 16;
-    f32x16 acc[NMT][4];
+    f32x16 acc[NMT][PG][4];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph)
+        for (int g = 0; g < PG; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][ph][r] = 0.f;
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][g][ph][r] = 0.f;
     const int a_frag = half * BM + l31;
-    const int q_pos = wn * 32 + l31;                                      // flattened tile position of this lane
-    const bool q_act = q_pos < p.th * p.tw;
-    const int q_row = q_act ? q_pos / p.tw : 0, q_col = q_act ? q_pos % p.tw : 0;
-    const int b_frag = half * UP_BPAD + q_row * PW + q_col;               // + dy*PW + dx
+    bool q_act[PG];
+    int q_row[PG], q_col[PG], b_frag[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const int q_pos = (wn * PG + g) * 32 + l31;                       // flattened tile position of this lane
+        q_act[g] = q_pos < p.th * p.tw;
+        q_row[g] = q_act[g] ? q_pos / p.tw : 0; q_col[g] = q_act[g] ? q_pos % p.tw : 0;
+        b_frag[g] = half * UP_BPAD + q_row[g] * PW + q_col[g];            // + dy*PW + dx
+    }
     float* s_rs = reinterpret_cast<float*>(smem + 2 * BUF);
     if (tid < BM) {
         const int o = min(m0 + tid, p.O - 1);
@@ -391,19 +402,21 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
             bf16x8* base = smem + ((kc + 1) & 1) * BUF;
 #pragma unroll
             for (int j = 0; j < NA; ++j)
-                if (j < NA - 1 || wn + 8 * j < A_PIECES)
+                if (j < NA - 1 || wn + NW * j < A_PIECES)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA, sofA[j] + (kc + 1) * strideA, 0, 0);
 #pragma unroll
             for (int j = 0; j < NB; ++j)
-                if (j < NB - 1 || wn + 8 * j < UP_B_PIECES)
+                if (j < NB - 1 || wn + NW * j < UP_B_PIECES)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + (kc + 1) * strideB, 0, 0);
         }
         if (kc >= 0) {
             const bf16x8* A_hi = smem + (kc & 1) * BUF, *A_lo = A_hi + A_SZ, *B_hi = A_hi + 2 * A_SZ, *B_lo = B_hi + UP_B_SZ;
             __builtin_amdgcn_s_setprio(1);
-            bf16x8 bh[4], bl[4];
+            bf16x8 bh[PG][4], bl[PG][4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { bh[d] = B_hi[b_frag + (d >> 1) * PW + (d & 1)]; bl[d] = B_lo[b_frag + (d >> 1) * PW + (d & 1)]; }
+            for (int g = 0; g < PG; ++g)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { bh[g][d] = B_hi[b_frag[g] + (d >> 1) * PW + (d & 1)]; bl[g][d] = B_lo[b_frag[g] + (d >> 1) * PW + (d & 1)]; }
             bf16x8 ah[2][NMT], al[2][NMT];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) { ah[0][mt] = A_hi[a_frag + mt * 32]; al[0][mt] = A_lo[a_frag + mt * 32]; }
@@ -420,11 +433,13 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[d], acc[mt][ph], 0, 0, 0);
-                    acc[mt][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[d], acc[mt][ph], 0, 0, 0);
-                }
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < PG; ++g) {
+                        acc[mt][g][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[g][d], acc[mt][g][ph], 0, 0, 0);
+                        acc[mt][g][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[g][d], acc[mt][g][ph], 0, 0, 0);
+                        acc[mt][g][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[g][d], acc[mt][g][ph], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -432,39 +447,46 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
         __builtin_amdgcn_s_barrier();
     }
 
-    // epilogue: channel-interleaved output (see conv2d_up_bf16x3_kernel's c8 path): 32 16-byte stores per lane
-    const int gy = y0 + q_row, gx = x0 + q_col;
-    if (!q_act || gy >= GH || gx >= GW) return;
+    // epilogue: channel-interleaved output (see conv2d_up_bf16x3_kernel's c8 path): 32 16-byte stores per lane and position group
     float* yb = p.y + (int64_t)n * p.ybs;
 #pragma unroll
-    for (int pa = 0; pa < 2; ++pa) {
-        const int oy = 2 * gy + pa;
-        if (oy >= p.OH) continue;
+    for (int g = 0; g < PG; ++g) {
+        const int gy = y0 + q_row[g], gx = x0 + q_col[g];
+        if (!q_act[g] || gy >= GH || gx >= GW) continue;
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const int ox = 2 * gx + pb;
-            if (ox >= p.OW) continue;
+        for (int pa = 0; pa < 2; ++pa) {
+            const int oy = 2 * gy + pa;
+            if (oy >= p.OH) continue;
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt)
+            for (int pb = 0; pb < 2; ++pb) {
+                const int ox = 2 * gx + pb;
+                if (ox >= p.OW) continue;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c8 = (m0 >> 3) + mt * 4 + g, ol = mt * 32 + 8 * g + 4 * half;
-                    const f32x16& a = acc[mt][pa * 2 + pb];
-                    const f32x4 v = {n3d_round16(a[4 * g + 0] * s_rs[ol + 0], p.round_f16), n3d_round16(a[4 * g + 1] * s_rs[ol + 1], p.round_f16),
-                                     n3d_round16(a[4 * g + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * g + 3] * s_rs[ol + 3], p.round_f16)};
-                    *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
-                }
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int c8 = (m0 >> 3) + mt * 4 + gg, ol = mt * 32 + 8 * gg + 4 * half;
+                        const f32x16& a = acc[mt][g][pa * 2 + pb];
+                        const f32x4 v = {n3d_round16(a[4 * gg + 0] * s_rs[ol + 0], p.round_f16), n3d_round16(a[4 * gg + 1] * s_rs[ol + 1], p.round_f16),
+                                         n3d_round16(a[4 * gg + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * gg + 3] * s_rs[ol + 3], p.round_f16)};
+                        *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
+                    }
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsParams p) {
     __shared__ bf16x8 smem[up_ps_smem_slots(2)];
-    conv2d_up_ps_body<2>(p, smem);
+    conv2d_up_ps_body<2, 8, 1>(p, smem);
 }
 __global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsParams p) {
     __shared__ bf16x8 smem[up_ps_smem_slots(1)];
-    conv2d_up_ps_body<1>(p, smem);
+    conv2d_up_ps_body<1, 8, 1>(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void conv2d_up_ps32w_bf16x3_kernel(ConvUpPsParams p) {      // 4 waves x 64 positions x 32 channels
+    __shared__ bf16x8 smem[up_ps_smem_slots(1)];
+    conv2d_up_ps_body<1, 4, 2>(p, smem);
 }
 
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
@@ -474,7 +496,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     // 32-channel groups per workgroup.  1 (two workgroups per CU) measured 4-22 % faster than 2 on every transposed layer of the
     // benchmark (profiles/r02_conv_ps_ablation.txt); N3D_UP_PS_MT=2 keeps the 64-channel variant reachable for tuning.
     int mt = 1;
-    { const char* e = getenv("N3D_UP_PS_MT"); if (e) mt = atoi(e) == 2 ? 2 : 1; }
+    { const char* e = getenv("N3D_UP_PS_MT"); if (e) mt = atoi(e) == 2 ? 2 : (atoi(e) == 3 ? 3 : 1); }       // 3: 32 channels, 4 waves x 64 positions
     N3D_CHECK((int64_t)(d->I / 8) * d->H * d->W * 32 < (1ll << 31), "conv2d_bf16x3: one sample's split8 input exceeds 2 GiB (32-bit buffer offsets)");
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(E.act == N3D_ACT_LINEAR && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f,
@@ -484,7 +506,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
     conv16_up_tiles(d->H + 1, d->W + 1, 8, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
-    p.tiles_m = d->O / (32 * mt);
+    p.tiles_m = d->O / (mt == 2 ? 64 : 32);
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.OH * p.yrs;
@@ -496,7 +518,8 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    if (mt == 1) hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    if (mt == 3) hipLaunchKernelGGL(conv2d_up_ps32w_bf16x3_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    else if (mt == 1) hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(conv2d_up_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
