@@ -16,6 +16,7 @@
 // OSGDecoder.forward (training_avatar_texture/triplane_next3d.py:359-371), MipRayMarcher2 (ray_marcher.py:27-66),
 // sample_importance / sample_pdf / unify_samples (renderer.py:164-268).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -383,7 +384,7 @@ __device__ __forceinline__ void march_weights(const RayLds& L, int count, int l3
 #ifdef RN_TRACE   // tuning builds only (tools/build_variant.sh trace render.hip -DRN_TRACE): stage time stamps of every wave
 __device__ long long rn_trace_buf[16384 * 16];
 #define RN_STAMP2(k) do { if (g0 == 32 && slot0 == 0) RN_STAMP(k); } while (0)
-#define RN_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 16384) rn_trace_buf[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define RN_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 16384) rn_trace_buf[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
     static long long host[16384 * 16];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rn_trace_buf), sizeof(host)) != hipSuccess) return 1;
@@ -399,25 +400,28 @@ extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
 #define RN_STAMP2(k)
 #endif
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// RPW = rays per wave.  2: no idle lanes in the decode passes, but the colours of 2 x (Sc + Sf) samples in LDS leave room for ONE
+// wave per SIMD, which then has nobody to hide its latencies behind.  1: two waves per SIMD (8 per workgroup); a ray's 48 samples
+// take two passes of 32 (the second half empty) and both lane halves run the per-ray stages of the same ray.
+template <int RPW>
+__device__ __forceinline__ void render_rays_body(const RenderParams& p, float* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hb = lane >> 5;
     const int n = blockIdx.y;
     const int R = p.R, RR = R * R, Sc = p.Sc, Sf = p.Sf, M = Sc + Sf;
     stage_decoder(p, smem, threadIdx.x, blockDim.x);
     __syncthreads();                                                      // the only workgroup-wide barrier
-    const int ray0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 2;         // this wave's rays: ray0, ray0 + 1 (the second may not exist)
+    const int ray0 = (blockIdx.x * (blockDim.x >> 6) + wave) * RPW;       // this wave's rays: ray0 (, ray0 + 1: may not exist)
     if (ray0 >= RR) return;
-    const int nrays = min(2, RR - ray0);
+    const int nrays = min(RPW, RR - ray0);
     RN_STAMP(0);
     const float* wl = smem + lane;
     const float bsig = p.b2[0];
-    float* wsm = smem + RN_WROWS * 64 + wave * 2 * ray_lds_floats(M);     // this wave's two rays
+    float* wsm = smem + RN_WROWS * 64 + wave * RPW * ray_lds_floats(M);   // this wave's rays
     RayLds Ls[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         RayLds& L = Ls[q];
-        L.col = wsm + q * ray_lds_floats(M);
+        L.col = wsm + (q < RPW ? q : 0) * ray_lds_floats(M);
         L.sig = L.col + M * RN_CP;
         L.dep = L.sig + M; L.wgt = L.dep + M; L.fac = L.wgt + M; L.trn = L.fac + M; L.cdf = L.trn + M; L.bins = L.cdf + M;
         L.order = reinterpret_cast<int*>(L.bins + M);
@@ -457,8 +461,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float dx = F.q ? rdx[1] : rdx[0], dy = F.q ? rdy[1] : rdy[0], dz = F.q ? rdz[1] : rdz[0];
         pass_taps(p, n, hb, __fadd_rn(ox, __fmul_rn(t, dx)), __fadd_rn(oy, __fmul_rn(t, dy)), __fadd_rn(oz, __fmul_rn(t, dz)), F);
     };
+    auto store_pass = [&](int slot, int q, const float (&rgb)[16], float sigma) {
+        if (slot >= 0) {
+            const RayLds& L = q ? Ls[1] : Ls[0];
+            if (hb == 0) L.sig[slot] = sigma;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                *reinterpret_cast<f32x4*>(L.col + slot * RN_CP + 8 * a + 4 * hb) = f32x4{rgb[4 * a], rgb[4 * a + 1], rgb[4 * a + 2], rgb[4 * a + 3]};
+        }
+    };
     auto decode_all = [&](int cnt, int slot0) {
         const int total = nrays * cnt;
+        if (RPW == 1) {                                                   // two waves per SIMD: the other wave covers this one's loads
+            for (int g0 = 0; g0 < total; g0 += 32) {
+                PassFetch F;
+                taps(g0, cnt, slot0, F);
+#pragma unroll
+                for (int part = 0; part < 4; ++part) pass_load(F, part);
+                float f[16], rgb[16], sigma;
+                pass_blend(F, f);
+                pass_mlp(wl, bsig, lane, f, rgb, sigma, [](int) {});
+                store_pass(F.slot, F.q, rgb, sigma);
+            }
+            return;
+        }
         PassFetch F;
         taps(0, cnt, slot0, F);
 #pragma unroll
@@ -475,13 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             RN_STAMP2(11);
             float rgb[16], sigma;
             pass_mlp(wl, bsig, lane, f, rgb, sigma, [&](int part) { RN_STAMP2(12 + part); if (more) pass_load(F, part); });
-            if (slot >= 0) {
-                const RayLds& L = q ? Ls[1] : Ls[0];
-                if (hb == 0) L.sig[slot] = sigma;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    *reinterpret_cast<f32x4*>(L.col + slot * RN_CP + 8 * a + 4 * hb) = f32x4{rgb[4 * a], rgb[4 * a + 1], rgb[4 * a + 2], rgb[4 * a + 3]};
-            }
+            store_pass(slot, q, rgb, sigma);
             RN_STAMP2(9);
         }
     };
@@ -597,6 +617,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    render_rays_body<2>(p, smem);
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_rays1_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    render_rays_body<1>(p, smem);
+}
+
 // global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
 // block reduces a slice and merges with integer atomics on the float bit patterns (the depths are positive, so the bit
 // patterns order like the values); bounds_ws is initialised by a one-thread launch in front.
@@ -710,25 +739,29 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.bounds = bounds_ws; p.feat = feat; p.depth = depth; p.wsum = wsum;
     p.N = N; p.R = R; p.Sc = Sc; p.Sf = Sf; p.PH = PH; p.PW = PW; p.depth_delta = depth_delta; p.coord_scale = coord_scale;
     const int M = Sc + Sf;
-    // waves per workgroup: as many as the LDS holds beside the shared decoder image (4 at 48 + 48 samples: one per SIMD)
-    const size_t per_wave = (size_t)2 * ray_lds_floats(M) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
+    // rays per wave (see render_rays_body) and waves per workgroup: as many as the LDS holds beside the shared decoder image
+    int rpw = 2;
+    { const char* e = getenv("N3D_RENDER_RPW"); if (e) rpw = atoi(e) == 1 ? 1 : 2; }
+    const size_t per_wave = (size_t)rpw * ray_lds_floats(M) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
+    const int wmax = rpw == 1 ? 8 : 4;
     int wpb = (int)((160 * 1024 - image) / per_wave);
-    wpb = wpb > 4 ? 4 : wpb;
+    wpb = wpb > wmax ? wmax : wpb;
     N3D_CHECK(wpb >= 1, "render_rays: %d samples per ray do not fit the LDS", M);
     const size_t lds = image + wpb * per_wave;
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
     if (lds > 48 * 1024)
-        N3D_CHECK(hipFuncSetAttribute((const void*)render_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                  "render_rays: %zu bytes of LDS refused", lds);
+        N3D_CHECK(hipFuncSetAttribute(rpw == 1 ? (const void*)render_rays1_kernel : (const void*)render_rays_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "render_rays: %zu bytes of LDS refused", lds);
     hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, bounds_ws);
     N3D_LAUNCH_CHECK();
     const int64_t nrays = (int64_t)N * R * R;
     hipLaunchKernelGGL(render_depth_bounds_kernel, dim3((unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256))), dim3(256), 0, stream,
                        tlin, jitter, nrays, Sc, depth_delta, bounds_ws);
     N3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
+    if (rpw == 1) hipLaunchKernelGGL(render_rays1_kernel, dim3(cdiv(R * R, wpb), N), dim3(64 * wpb), lds, stream, p);
+    else hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }
