@@ -9,6 +9,8 @@ accumulation (cuDNN's default for half).  Anything else raises RuntimeError (the
 non-float32 pointer never reaches a float32 kernel."""
 import contextlib
 
+import os
+
 import torch
 
 from ... import _lib
@@ -89,6 +91,9 @@ def split8_from_nchw(x, scale=None):
     return y
 
 
+KSPLIT_MAX = int(os.environ.get('N3D_KSPLIT_MAX', '64'))      # tuning: cap on the split-K factor of the split-bf16 3x3 kernels
+
+
 def out_shape(h, w, mode):
     if mode == 0:
         return h, w
@@ -117,7 +122,7 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
     # faster unsplit); stride-1: smaller 4-wave workgroups, several per CU
     want = 512 if mode == 0 else 160       # modes 1 / 2: 8-wave workgroups, one per CU
     ks = 1
-    while blocks * ks < want and (i // (ks * 2)) >= 64:
+    while blocks * ks < want and (i // (ks * 2)) >= 64 and ks < KSPLIT_MAX:
         ks *= 2
     return ks
 

@@ -16,6 +16,7 @@ if [ "$2" != "lite" ]; then
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/pm -o r -- $P > /dev/null 2> $out/pm.err
   python tools/mfma_busy_summary.py $(find $out/pm -name "*.db" | head -1) $out/${tag}_mfma_busy_pmc.json > /dev/null
   rm -rf $out/pf $out/pw $out/pm
+  cp $out/${tag}_traffic_pmc.json $out/${tag}_mfma_busy_pmc.json profiles/     # the bench line below cites the fresh traffic profile
 fi
 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
 head -c 1200 $out/${tag}_bench.json; echo; head -14 $out/${tag}_kernel_stats.csv; ls -la $out
