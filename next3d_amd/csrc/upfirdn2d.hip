@@ -258,9 +258,13 @@ struct FirSplitParams {
 // FAST: linear / leaky-ReLU (0 <= alpha <= 1) epilogues as straight-line code; the generic instantiation carries the full switch
 // NCHW_IN: the input is float32 NCHW (the FIR in front of a stride-2 convolution: n3d_fir4_split8_nchw) instead of c8; only the
 // footprint loads differ (4-byte loads, transposed into the same two LDS planes).
+#ifndef FIR_TW
+#define FIR_TW 64     // tile width: 64 (512 work items, 40.7 KB of LDS: 3 workgroups per CU) or 32 (256 work items, 21 KB: 7)
+#endif
 template <bool FAST, bool NCHW_IN>
-__global__ __launch_bounds__(512, 4) void fir4_c8_split8_kernel(FirSplitParams p) {
-    constexpr int NT = 512, TW = 64, TH = 16, RPT = 2, FW = TW + 3, FH = TH + 3, CH = 8;
+__global__ __launch_bounds__(FIR_TW * 8, FIR_TW == 64 ? 4 : 8) void fir4_c8_split8_kernel(FirSplitParams p) {
+    constexpr int TW = FIR_TW, NT = TW * 8, TH = 16, RPT = 2, FW = TW + 3, FH = TH + 3, CH = 8;
+    static_assert(NT / (2 * FW) == 3, "the unit cursor below advances by three footprint rows + a remainder per step");
     __shared__ f32x4 s_ab[2 * FH * FW];                                   // plane 0: channels 0-3, plane 1: channels 4-7 of every footprint pixel
     f32x4* const s_a = s_ab; f32x4* const s_b = s_ab + FH * FW;
     const int tile = blockIdx.x;
@@ -417,16 +421,16 @@ static int fir4_split8_impl(const float* x, const float* f, void* y, int N, int 
     p.out_scale = out_scale; p.out_scale_stride = out_scale_stride ? out_scale_stride : C;
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
-    p.tiles_x = cdiv(OW, 64);
+    p.tiles_x = cdiv(OW, FIR_TW);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)OH * OW * 16, 4.0 * N * C * ((double)H * W + (double)OH * OW));
     const bool fast = !epi || epi->act == N3D_ACT_LINEAR || (epi->act == N3D_ACT_LRELU && epi->alpha >= 0.f && epi->alpha <= 1.f);
     const dim3 grid(p.tiles_x * cdiv(OH, 16), C / 8, N);
     if (nchw_in) {
-        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, true>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, true>), grid, dim3(512), 0, stream, p);
+        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, true>), grid, dim3(FIR_TW * 8), 0, stream, p);
+        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, true>), grid, dim3(FIR_TW * 8), 0, stream, p);
     } else {
-        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, false>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, false>), grid, dim3(512), 0, stream, p);
+        if (fast) hipLaunchKernelGGL((fir4_c8_split8_kernel<true, false>), grid, dim3(FIR_TW * 8), 0, stream, p);
+        else hipLaunchKernelGGL((fir4_c8_split8_kernel<false, false>), grid, dim3(FIR_TW * 8), 0, stream, p);
     }
     N3D_LAUNCH_CHECK();
     return 0;
