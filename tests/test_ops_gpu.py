@@ -635,7 +635,7 @@ def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
 
 
 @pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 128, 64, 64), (2, 64, 64, 33, 40), (4, 32, 256, 128, 128)])
-def test_transposed_conv_channel_interleaved_output(dev, N, I, OC, H, W):
+def test_transposed_conv_channel_interleaved_output(dev, monkeypatch, N, I, OC, H, W):
     """The transposed split-bf16 kernel writing the c8 layout (what the FIR of the pre-split path reads) returns the same
     numbers as its NCHW output, bit for bit."""
     from next3d_amd import _lib
@@ -653,3 +653,7 @@ def test_transposed_conv_channel_interleaved_output(dev, N, I, OC, H, W):
     ps = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
     print('transposed presplit vs register-staged: max abs diff', float((ps.to_nchw() - ref).abs().max()), 'bit-identical', bool(torch.equal(ps.to_nchw(), ref)))
     _close(ps.to_nchw(), ref, atol=1e-5, rtol=1e-5)
+    for mt in ('2', '3'):                                                 # the tuning variants of the same kernel body (the launcher reads the switch per call)
+        monkeypatch.setenv('N3D_UP_PS_MT', mt)
+        alt = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
+        assert torch.equal(alt.to_nchw(), ps.to_nchw()), mt

@@ -344,6 +344,26 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
         assert float(e.median()) <= 1e-4
 
 
+def test_render_rays_one_ray_per_wave_variant(dev, monkeypatch):
+    """N3D_RENDER_RPW=1 (one ray per wave, two waves per SIMD, no texel prefetch) renders the same image as the default."""
+    from next3d_amd import _lib, camera_utils
+    N, R, Sc, Sf, PH, PW = 2, 9, 48, 48, 32, 32
+    planes = _gen((N, 3, 32, PH, PW), 70, 2.0)
+    P, (w1, b1, w2t, b2) = _decoder(71)
+    c = torch.cat([camera_utils.demo_camera_params(angle_y=a, angle_p=-0.2)[0] for a in (0.3, -0.25)], 0).float()
+    jitter, u = cases.rng_inputs(N, R, Sc, Sf)
+    t = dict(dtype=torch.float32, device=dev)
+    d = [x.contiguous().to(dev) for x in (_channels_last(planes), c[:, :16], c[:, 16:25], torch.linspace(2.25, 3.3, Sc), jitter, u, w1, b1, w2t, b2)]
+    out = []
+    for rpw in ('2', '1'):
+        monkeypatch.setenv('N3D_RENDER_RPW', rpw)
+        feat, dep, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(2, **t)
+        _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), None, _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
+                                              float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
+        out.append((feat.cpu(), dep.cpu()))
+    assert _md(out[0][0], out[1][0]) <= 1e-5 and _md(out[0][1], out[1][1]) <= 1e-5
+
+
 def test_render_rays_empty_space(dev):
     """Zero density everywhere: all weights are 0, the composite colour is 0 (-> -1 after rgb*2-1), the depth is 0/0 ->
     nan_to_num(inf) -> clamped to the GLOBAL maximum sample depth of the batch (ray_marcher.py:52-54; the kernel's
