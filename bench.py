@@ -122,8 +122,8 @@ def orbit_cameras(frames, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=4, help='seeds per GPU per step (BASELINE.json configs[1]: 4)')
     ap.add_argument('--prewarm-seconds', type=float, default=2.0, help='un-counted steps before the warm-up (clock ramp)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
