@@ -131,8 +131,8 @@ def test_plane_and_identity_caches(G, dev):
 def test_pipelined_steps_are_bitwise_reproducible(G, dev):
     """Six forwards issued back to back WITHOUT host synchronisation (the bench / video-loop pattern, static backbone on its
     side stream) must all return the same bits.  Guards the stream choreography: the atomicMin z-buffer of the rasteriser
-    loses updates when 8-wave split-bf16 conv kernels of another stream are resident (tools/dbg_race2.py), so the
-    rasterisation has to run before the side stream starts."""
+    used to lose updates when 8-wave split-bf16 conv kernels of another stream were resident (the table loads
+    are agent-scope now)."""
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48.npz'))
     N, R, Sc, Sf = d['z'].shape[0], 32, 24, 24
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
@@ -146,6 +146,41 @@ def test_pipelined_steps_are_bitwise_reproducible(G, dev):
     for o in outs[1:]:
         for k in ('image', 'image_raw', 'image_depth'):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch,R', [(3, 64), (1, 128)])
+def test_presplit_pipeline_equals_register_staged_pipeline(G, dev, monkeypatch, batch, R):
+    """The whole forward with every pre-split (LDS-DMA) path switched off — register-staged kernels, float32 NCHW between all
+    layers — against the default pipeline, at a batch size / render resolution the goldens do not cover.  The pre-split kernels
+    multiply bit-identical operands in the same order; the only differences allowed are the FIR variants' accumulation order
+    (c8 / NCHW -> split8 against the float32 FIR), hence a tolerance far below the parity tolerance instead of equality.
+    The reference's default float16 super-resolution mode is run too (finite, close to the float32 mode)."""
+    from next3d_amd import layers
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
+    Sc, Sf = 24, 24
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(batch, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(d[k][:batch]).to(dev)
+    ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+    out = {}
+    for on in (True, False):
+        for name in ('PRESPLIT', 'UP_PRESPLIT', 'S2_PRESPLIT'):
+            monkeypatch.setattr(layers, name, on)
+        out[on] = G.synthesis(ws, t('c'), t('v'), force_fp32=True, **kw)
+    for k in ('image', 'image_raw', 'image_depth'):
+        e = _md(out[True][k], out[False][k])
+        print(f'batch {batch} render {R} {k}: pre-split vs register-staged max abs diff {e:.3e}')
+        assert e <= 2e-4, (k, e)              # (measured 4e-5: rounding-order differences of the FIR variants, amplified by ~30 layers)
+    with pytest.raises(RuntimeError):            # the float16 block mode exists on the pre-split path only, and says so
+        G.synthesis(ws, t('c'), t('v'), **kw)
+    for name in ('PRESPLIT', 'UP_PRESPLIT', 'S2_PRESPLIT'):
+        monkeypatch.setattr(layers, name, True)
+    half = G.synthesis(ws, t('c'), t('v'), **kw)                          # the reference's default: float16 super-resolution blocks
+    e = _md(half['image'], out[True]['image'])
+    print(f'batch {batch} render {R}: fp16-mode image vs fp32-mode image max abs diff {e:.3e}')
+    assert torch.isfinite(half['image']).all() and e <= 2e-2
 
 
 @pytest.mark.gpu
