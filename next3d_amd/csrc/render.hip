@@ -244,41 +244,44 @@ __device__ __forceinline__ void pass_blend(const PassFetch& F, float (&f)[16]) {
     for (int c = 0; c < 8; ++c) { f[2 * c] = f2[c].x * (1.f / 3.f); f[2 * c + 1] = f2[c].y * (1.f / 3.f); }   // mean over the planes (triplane_next3d.py:361)
 }
 
-// second half, part 2: 32 -> 64 softplus -> 33 on the matrix pipe -> rgb[r] = colour channel 8 (r / 4) + 4 hb + r % 4, sigma
-// `mid(part)`, part = 0..3, is called in front of the four quarters of the matrix work (the next pass's loads go there).
-template <typename Mid>
-__device__ __forceinline__ void pass_mlp(const float* wl /* decoder image + lane */, float bsig, int lane, const float (&f)[16], float (&rgb)[16], float& sigma, Mid mid) {
+// second half, part 2: 32 -> 64 softplus -> 33 on the matrix pipe -> rgb[r] = colour channel 8 (r / 4) + 4 hb + r % 4, sigma.
+// Straight-line code, four quarters of 17 / 17 / 16 / 17 dependent MFMAs with the softplus batches between them.  (A pinned
+// sched_group_barrier order that alternates one MFMA with one hidden unit's softplus was measured: no difference — the pass is
+// not bound by the decoder's instruction order.)
+// LOADS: the next pass's 48 texel loads are issued from here (`Fn`), four parts spread over the quarters.
+template <bool LOADS>
+__device__ __forceinline__ void pass_mlp(const float* wl /* decoder image + lane */, float bsig, int lane, const float (&f)[16], float (&rgb)[16], float& sigma,
+                                         PassFetch& Fn) {
     const int hb = lane >> 5;
     const float one0 = hb == 0 ? 1.f : 0.f;
-    // hidden block 0 first, then block 1: block 0's softplus (VALU) runs under block 1's MFMAs, block 1's under layer 2's first half
-    f32x16 h[2];
+    const float* wsig = wl - lane + 67 * 64 + hb * 32;
+    f32x16 h0, h1, o;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-        mid(jb);
+    for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; o[r] = 0.f; }
+    if (LOADS) { pass_load(Fn, 0); pass_load(Fn, 1); }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[jb][r] = 0.f;
+    for (int kk = 0; kk < 16; ++kk) h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[kk * 64], f[kk], h0, 0, 0, 0);
+    h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[16 * 64], one0, h0, 0, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) h[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 * jb + kk) * 64], f[kk], h[jb], 0, 0, 0);
-        h[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 * jb + 16) * 64], one0, h[jb], 0, 0, 0);
-    }
-    f32x16 o;
+    for (int kk = 0; kk < 16; ++kk) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 + kk) * 64], f[kk], h1, 0, 0, 0);
+    h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 + 16) * 64], one0, h1, 0, 0, 0);
+    float hs0[16], hs1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int r = 0; r < 16; ++r) hs0[r] = softplus_raw(h0[r]);
+    if (LOADS) pass_load(Fn, 2);
     float sp = 0.f;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-        mid(2 + jb);
+    for (int r = 0; r < 16; ++r) {
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + r) * 64], hs0[r], o, 0, 0, 0);
+        sp = fmaf(wsig[r], hs0[r], sp);
+    }
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl - lane + 67 * 64 + hb * 32 + jb * 16 + 4 * r4);
+    for (int r = 0; r < 16; ++r) hs1[r] = softplus_raw(h1[r]);
+    if (LOADS) pass_load(Fn, 3);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int r = 4 * r4 + b;
-                const float hs = softplus_raw(h[jb][r]);
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + 16 * jb + r) * 64], hs, o, 0, 0, 0);
-                sp = fmaf(w4[b], hs, sp);
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + 16 + r) * 64], hs1[r], o, 0, 0, 0);
+        sp = fmaf(wsig[16 + r], hs1[r], sp);
     }
     o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[66 * 64], one0, o, 0, 0, 0);
     sigma = sp + __shfl_xor(sp, 32, 64) + bsig;
@@ -480,7 +483,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
                 for (int part = 0; part < 4; ++part) pass_load(F, part);
                 float f[16], rgb[16], sigma;
                 pass_blend(F, f);
-                pass_mlp(wl, bsig, lane, f, rgb, sigma, [](int) {});
+                pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, F);
                 store_pass(F.slot, F.q, rgb, sigma);
             }
             return;
@@ -500,7 +503,8 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             if (more) taps(g0 + 32, cnt, slot0, F);                       // ... their registers take the next pass's, loaded under the decoder
             RN_STAMP2(11);
             float rgb[16], sigma;
-            pass_mlp(wl, bsig, lane, f, rgb, sigma, [&](int part) { RN_STAMP2(12 + part); if (more) pass_load(F, part); });
+            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, F);
+            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, F);
             store_pass(slot, q, rgb, sigma);
             RN_STAMP2(9);
         }
