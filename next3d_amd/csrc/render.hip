@@ -68,7 +68,11 @@ __device__ __forceinline__ void plane_taps(const float* __restrict__ plane, int 
     for (int k = 0; k < 4; ++k) {
         const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
         const bool ok = xx >= 0 && xx < PW && yy >= 0 && yy < PH;
+#if defined(RN_ABL) && RN_ABL == 1      // tuning build: every tap reads texel (0, 0) (cache hits, same instruction stream)
+        tp[k] = reinterpret_cast<const float4*>(plane);
+#else
         tp[k] = reinterpret_cast<const float4*>(plane + (ok ? ((int64_t)yy * PW + xx) * RN_C : 0));
+#endif
         tw[k] = ok ? wgt[k] : 0.f;
     }
 }
