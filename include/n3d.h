@@ -248,6 +248,14 @@ int n3d_render_rays(const float* planes_cl, const float* cam2world, const float*
                     const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
                     int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream);
+/* The same renderer with a colour workspace of n3d_render_rays_workspace_bytes(N, R, Sc, Sf) bytes (16-byte aligned device memory,
+ * contents irrelevant before and after): the samples' decoded colours are parked there instead of in LDS, which lets twice as many
+ * wavefronts share a CU.  workspace == NULL: exactly n3d_render_rays. */
+int64_t n3d_render_rays_workspace_bytes(int N, int R, int Sc, int Sf);
+int n3d_render_rays_ws(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
+                    const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
+                    int Sf, int PH, int PW, float depth_delta, float coord_scale, float* workspace, int64_t workspace_bytes, n3d_stream_t stream);
 
 /* ---- point queries (shape extraction): replaces ImportanceRenderer.run_model (vr/renderer.py:149-155: sample_from_planes +
  *      OSGDecoder) as called by TriPlaneGenerator.sample / sample_mixed (tat/triplane_next3d.py:232-322).

@@ -68,6 +68,8 @@ _SIGNATURES = {
     'n3d_blend_planes': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     'n3d_planes_to_channels_last': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_render_rays': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p]),
+    'n3d_render_rays_ws': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p, c_int64, c_void_p]),
+    'n3d_render_rays_workspace_bytes': (c_int64, [c_int] * 4),
     'n3d_sample_points': (c_int, [c_void_p] * 8 + [c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     'n3d_rasterize_views': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 4 +
                             [c_int, c_int, c_void_p]),

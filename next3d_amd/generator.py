@@ -56,6 +56,9 @@ def _attach(root, dotted, tensor, is_buffer):
         mod.register_parameter(parts[-1], torch.nn.Parameter(tensor, requires_grad=False))
 
 
+RENDER_WORKSPACE = os.environ.get('N3D_RENDER_GCOL', '0') == '1'
+
+
 class TriPlaneGenerator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path, sr_num_fp16_res=0,
                  mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, uv_face_mask=None, **synthesis_kwargs):
@@ -357,11 +360,14 @@ class TriPlaneGenerator(torch.nn.Module):
         feat = torch.empty(N, 32, R, R, **f32)
         depth = torch.empty(N, 1, R, R, **f32)
         bounds = torch.empty(2, **f32)              # scratch of this call (calls may be in flight on several streams)
-        _lib.check(_lib.lib().n3d_render_rays(
+        # N3D_RENDER_GCOL=1: colour workspace variant (eight waves per CU instead of four; measured equal: DESIGN.md 3.2)
+        ws_bytes = _lib.lib().n3d_render_rays_workspace_bytes(N, R, Sc, Sf) if RENDER_WORKSPACE else 0
+        ws = torch.empty(ws_bytes // 4, **f32) if ws_bytes else None
+        _lib.check(_lib.lib().n3d_render_rays_ws(
             _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter),
             _lib.ptr(u), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
             _lib.ptr(depth), None, _lib.ptr(bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
-            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
+            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.ptr(ws), ws_bytes, _lib.stream()))
         return feat, depth
 
     def synthesis(self, ws, c, v, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,

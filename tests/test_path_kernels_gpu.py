@@ -334,6 +334,17 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
                                            u if Sf else torch.zeros(1), w1, b1, w2t, b2)]
     _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
                                           Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
+    # the same call with a colour workspace (n3d_render_rays_ws: colours parked in global memory, eight waves per CU)
+    nbytes = _lib.lib().n3d_render_rays_workspace_bytes(N, R, Sc, Sf)
+    assert nbytes == N * R * R * (Sc + Sf) * 32 * 4
+    work = torch.full((nbytes // 4,), float('nan'), **t)
+    feat2, dep2, ws2 = torch.empty_like(feat), torch.empty_like(dep), torch.empty_like(ws_)
+    _lib.check(_lib.lib().n3d_render_rays_ws(*[_lib.ptr(x) for x in d], _lib.ptr(feat2), _lib.ptr(dep2), _lib.ptr(ws2), _lib.ptr(bounds), N, R, Sc,
+                                             Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.ptr(work), nbytes, _lib.stream()))
+    print(f'workspace variant vs LDS variant: feat {_md(feat2, feat):.2e} depth {_md(dep2, dep):.2e} wsum {_md(ws2, ws_):.2e}')
+    assert _md(feat2, feat) <= 2e-6 and _md(dep2, dep) <= 2e-6 and _md(ws2, ws_) <= 2e-6
+    assert _lib.lib().n3d_render_rays_ws(*[_lib.ptr(x) for x in d], _lib.ptr(feat2), _lib.ptr(dep2), None, _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
+                                         0.1, 2.0, _lib.ptr(work), nbytes - 4, _lib.stream()) != 0            # workspace too small
     e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
     e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
     e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
