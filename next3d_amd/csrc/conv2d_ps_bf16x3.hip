@@ -313,6 +313,7 @@ struct ConvUpPsParams {
     int64_t xbs, ybs, yrs;       // xbs: 16-byte units; ybs floats; yrs pixels (c8 row pitch)
     const float* row_scale; int64_t row_scale_stride; float const_scale;
     int round_f16;
+    int dbg;                     // N3D_CONV_DBG ablation bits (tuning only, wrong results): 1 skip stores, 4 skip the DMA of chunks > 0
 };
 
 // NMT = 32-channel groups per workgroup.  NMT = 2: 64 channels, one workgroup per CU (167 VGPRs: 128 accumulators).  NMT = 1: 32
@@ -398,7 +399,7 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     }
     // one loop body holds both the staging of chunk kc + 1 and the multiplies of chunk kc (kc = -1: prologue)
     for (int kc = -1; kc < KC; ++kc) {
-        if (kc + 1 < KC) {
+        if (kc + 1 < KC && (!(p.dbg & 4) || kc < 0)) {
             bf16x8* base = smem + ((kc + 1) & 1) * BUF;
 #pragma unroll
             for (int j = 0; j < NA; ++j)
@@ -448,6 +449,7 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     }
 
     // epilogue: channel-interleaved output (see conv2d_up_bf16x3_kernel's c8 path): 32 16-byte stores per lane and position group
+    if (p.dbg & 1) { if (acc[0][0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     float* yb = p.y + (int64_t)n * p.ybs;
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
@@ -513,6 +515,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.row_scale = E.row_scale; p.row_scale_stride = E.row_scale_stride ? E.row_scale_stride : d->O; p.const_scale = E.const_scale;
     p.round_f16 = E.round_f16;
+    { const char* e = getenv("N3D_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;

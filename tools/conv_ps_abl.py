@@ -66,7 +66,12 @@ for (N, I, O, H) in [(4, 512, 512, 32), (4, 512, 256, 64), (4, 256, 128, 128), (
     cv = t_us(lambda: cg.split8_from_nchw(x, st))
     xs = cg.split8_from_nchw(x, st)
     b = t_us(lambda: cg.conv_launch(xs, wt, 3, 2, O, bf16x3=True, out_c8=True))
-    print(f'UP N{N} I{I} O{O} {H}x{H} ({gf:.0f} GF): register-staged {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  same, c8 out {a8:7.1f} us  | pre-split {b:7.1f} us ({gf / b * 1e3:4.0f} TF) + conversion {cv:6.1f} us', flush=True)
+    abl = []
+    for dbg in (1, 4, 5):                                 # no stores / no DMA after the first chunk / neither
+        os.environ['N3D_CONV_DBG'] = str(dbg)
+        abl.append(f'dbg{dbg} {t_us(lambda: cg.conv_launch(xs, wt, 3, 2, O, bf16x3=True, out_c8=True)):6.1f} us')
+    os.environ['N3D_CONV_DBG'] = '0'
+    print(f'UP N{N} I{I} O{O} {H}x{H} ({gf:.0f} GF): register-staged {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  same, c8 out {a8:7.1f} us  | pre-split {b:7.1f} us ({gf / b * 1e3:4.0f} TF) + conversion {cv:6.1f} us | ' + ' '.join(abl), flush=True)
 
 # ---- stride-2 encoder layers: register-staged vs pre-split (split8 in) + the conversion pass in front
 for (N, I, O, H, ks) in [(4, 128, 256, 257, 1), (4, 256, 512, 129, 1), (4, 512, 512, 65, 4), (4, 512, 512, 65, 2), (4, 512, 512, 65, 1)]:
