@@ -8,7 +8,7 @@ f = r['family_ms_per_step']
 c3, c5, cpu = d['config3'], d['config5'], d['cpu_baseline']
 traffic = r.get('traffic')
 para = f'''**Round-2 numbers (MI355X, N=1, batch 4, `profiles/r02_bench.json`)**: **{d['value']:.0f} frames/s** ({d['ms_per_step']:.2f} ms per 4-frame step; one stream:
-{d['single_stream']['value']:.0f}; round 1: 307, driver-measured 272), frames bitwise identical across pipelined steps (the pool's boxes differ by ±3 %: 355-362 frames/s and frac 0.43-0.44 for this build).  3×3 split-bf16 family:
+{d['single_stream']['value']:.0f}; round 1: 307, driver-measured 272), frames bitwise identical across pipelined steps (the pool's boxes differ by ±3 %: 355-372 frames/s and frac 0.43-0.44 for this build).  3×3 split-bf16 family:
 {r['achieved']:.0f} TFLOP/s fp32-equivalent = **frac {r['frac']:.3f}** of 833 (round 1: 0.365; against the MEASURED random-operand ceiling of the matrix
 pipe, §3.1c, 617-650: ~{r['achieved'] / 633:.2f}), {r['launches_per_step']:.0f} launches, {f['conv2d_bf16x3']:.2f} ms per step, {r['avg_launch_ms'] * 1e3:.0f} µs average (rocprofv3's kernel averages of the
 same command: `profiles/r02_kernel_stats.csv`); per family (`family_ms_per_step`, one stream, events): FIR {f['upfirdn2d']:.2f} ms, 1×1
