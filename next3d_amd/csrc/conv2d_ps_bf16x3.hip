@@ -1,6 +1,6 @@
 // 3x3 stride-1 convolution on the bf16 matrix cores whose ACTIVATIONS ARRIVE ALREADY SPLIT ("split8" layout, include/n3d.h):
 // the operand split (hi = bf16(x), lo = bf16(x - hi)) and the style modulation were done ONCE by the producer's epilogue
-// (csrc/upfirdn2d.hip: fir4_split8_kernel), so this kernel's K loop contains no staging arithmetic at all.
+// (csrc/upfirdn2d.hip: fir4_c8_split8_kernel, or elementwise.hip: split8_from_nchw_kernel), so this kernel's K loop contains no staging arithmetic at all.
 //
 //   x  : [N][2 (hi, lo)][I/8][H][W][8] bf16 — one 16-byte unit = 8 consecutive channels of one pixel, already multiplied by
 //        this layer's style (modulation, tat/networks_stylegan2.py:70) by whoever wrote it;
@@ -11,7 +11,7 @@
 // comes from the buffer descriptor's range check) — 9.5 instructions per wave instead of 24 four-byte gathers, ~100 VALU
 // (style multiply, two conversions, a subtraction, packing per value) and 11 ds_write_b128 in conv2d_bf16x3_kernel.  With
 // nothing to convert there are no wave roles: all eight waves issue the next chunk's DMA, multiply the current chunk, wait
-// for their own pieces (s_waitcnt vmcnt(0)) and meet at ONE raw s_barrier per chunk; two LDS buffers (2 x 76 KB).
+// for their own pieces (s_waitcnt vmcnt(0)) and meet at ONE raw s_barrier per chunk; two LDS buffers (2 x 76 KB), or one buffer and two workgroups per CU (NBUF).
 // Tile: 64 output channels x (16 x 32) pixels, wave tile 64 x 64 (2 x 2 accumulators of v_mfma_f32_32x32x16_bf16, computed
 // TRANSPOSED — pixels as matrix rows — so that the epilogue writes 16-byte runs of pixels); the same products and the same
 // accumulation order per output as conv2d_bf16x3_kernel => bit-identical results for identical operands.
