@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 on
   roofline_fp32  the same K steps with N3D_PRECISION=fp32 arithmetic (v_mfma_f32_32x32x2_f32 everywhere): frames/s and the
                  conv family against 157.3 TFLOP/s
   config3        gen_videos_next3d.py's 2x2-grid, 120-frame camera orbit over a fixed mesh (BASELINE.json configs[2])
+  sr_fp16_mode   the same K steps with the reference's default float16 super-resolution blocks (no force_fp32)
   config5        reenact_avatar_next3d.py's loop: one identity, a new FLAME mesh per frame (configs[4], synthetic sequence)
   cpu_baseline   the CPU oracle (a port of the reference's fp32 path) timed on the host cores.
 """
@@ -178,7 +179,7 @@ def main():
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
     for s_ in lanes:
         s_.wait_stream(torch.cuda.current_stream())
-    counter, one_lane = [0], [False]
+    counter, one_lane, sr_fp32 = [0], [False], [True]
 
     def step():
         if args.serial_gather:
@@ -188,7 +189,7 @@ def main():
         with torch.cuda.stream(lane):
             ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
             img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
-                              force_fp32=True)['image']                    # the fp32 path (the one the goldens pin)
+                              force_fp32=sr_fp32[0])['image']              # the fp32 path (the one the goldens pin)
             frames = to_frames(img)
             gatherer.submit(frames)      # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
@@ -303,6 +304,16 @@ def main():
                                        'algorithmic_gflop_per_step': p32['flops'] / k32 / 1e9}
             layers.set_precision('bf16x3')
             step(); torch.cuda.synchronize()
+        # ---- the reference's DEFAULT super-resolution mode (sr_num_fp16_res = 4, no force_fp32: float16 storage in the SR blocks,
+        # superresolution.py:210-217) on the same workload
+        sr_fp32[0] = False
+        step(); step(); torch.cuda.synchronize()
+        k16 = max(3, args.steps // 2)
+        t16 = timed(step, k16)
+        extras['sr_fp16_mode'] = {'value': k16 * B / t16, 'unit': 'frames/s', 'ms_per_step': 1e3 * t16 / k16, 'steps': k16,
+                                  'note': 'synthesis(..., force_fp32=False): the scripts\' default route'}
+        sr_fp32[0] = True
+        step(); torch.cuda.synchronize()
         # ---- configs[2]: 2x2 grid (batch 4 = one video frame), 120-frame orbit, fixed mesh (gen_videos_next3d.py:126-158)
         grid_seeds = [10720, 12374, 13393, 17099]                       # README.md:48
         zg, _, cg_cond, vg = demo.demo_batch(grid_seeds[:B], device=dev)

@@ -3,6 +3,7 @@
 import json, os, re
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(root, 'profiles', 'r02_bench.json')))
+d.setdefault('sr_fp16_mode', {'value': float('nan')})
 r, r32 = d['roofline'], d['roofline_fp32']
 f = r['family_ms_per_step']
 c3, c5, cpu = d['config3'], d['config5'], d['cpu_baseline']
@@ -15,6 +16,7 @@ same command: `profiles/r02_kernel_stats.csv`); per family (`family_ms_per_step`
 {f['conv1x1_bf16x3']:.2f} ms, renderer {f['render']:.2f} ms, rasteriser {f['raster']:.2f} ms, FCs {f['fc']:.2f} ms, conversions / blend / misc {f['misc']:.2f} ms.  History of the
 round: 309.6 (round-1 build, this round's boxes) → 318.7 (pre-split stride-1 + FIR → split8) → 322 (transposed pre-split, c8) → 351
 (three lanes) → 355 (renderer on the matrix pipe, 32-channel transposed workgroups) → 362 (stride-2 layers pre-split).
+The reference's default float16 super-resolution mode (`sr_fp16_mode`, no `force_fp32`): {d['sr_fp16_mode']['value']:.0f} frames/s.
 `N3D_PRECISION=fp32`: {r32['value']:.0f} frames/s, family {r32['achieved']:.0f} TFLOP/s = {r32['frac']:.2f} of the fp32-MFMA peak.  Other call patterns (`config3` /
 `config5`): orbit with cached planes {c3['cached_planes_images_per_s']:.0f} frames/s (96 + 96 samples: {c3['cached_planes_96+96_images_per_s']:.0f}), reenactment with cached identity
 {c5['cached_identity_frames_per_s']:.0f} frames/s.  CPU baseline (oracle, kind `port`, {cpu['cores']} threads of the box's {cpu.get('host_cores', '?')} logical cores): {cpu['value']:.2f} frames/s.
