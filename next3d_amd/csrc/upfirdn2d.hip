@@ -280,7 +280,31 @@ __global__ __launch_bounds__(FIR_TW * 8, FIR_TW == 64 ? 4 : 8) void fir4_c8_spli
     // 32-bit offset: units outside the image get an offset beyond the descriptor's range and read as zero (the FIR's padding)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8), 0,
                                                                           (int)(p.H * p.xrs * 32), 0x00020000);
-    if (NCHW_IN) {
+    if (NCHW_IN && p.pad == 2 && ((p.W | p.xrs) & 1) == 0) {
+        // even pad / width / pitch: the footprint rows start on even columns -> 8-byte loads of two neighbouring pixels
+        constexpr int PW2 = (FW + 1) / 2, PAIRS = CH * FH * PW2, PPT = (PAIRS + NT - 1) / NT;      // 34 pairs per row, 5168 -> 11 per work item
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t st[PPT];
+        int sl[PPT];
+        float* s_f = reinterpret_cast<float*>(s_ab);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int e = threadIdx.x + NT * j;
+            const int ch = e / (FH * PW2), r = (e % (FH * PW2)) / PW2, q = 2 * (e % PW2);
+            const int iy = oy0 - 2 + r, ix = ox0 - 2 + q;
+            const bool ok = e < PAIRS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;      // ix even, W even: the pair is inside or outside as a whole
+            const int off = ok ? ((ch * p.H + iy) * (int)p.xrs + ix) * 4 : (int)0x80000000;
+            st[j] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0));
+            sl[j] = e < PAIRS ? (((ch >> 2) * FH * FW + r * FW + q) * 4 + (ch & 3)) | (q + 1 < FW ? 0 : (int)0x40000000) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (sl[j] >= 0) {
+                const int a = sl[j] & 0x3fffffff;
+                s_f[a] = st[j].x;
+                if (!(sl[j] & 0x40000000)) s_f[a + 4] = st[j].y;        // the 68th column of a 67-wide footprint row does not exist
+            }
+    } else if (NCHW_IN) {
         // 8 channel planes of H x xrs floats: element e -> (channel, footprint row, column), column fastest (coalesced rows of 67
         // floats); written as single floats into the (pixel, channel) slots of the two planes.  All loads first, then the writes.
         constexpr int ELEMS = CH * FH * FW, EPT = (ELEMS + NT - 1) / NT;  // 10,184 -> 20 per work item
