@@ -365,7 +365,8 @@ __global__ __launch_bounds__(FIR_TW * 8, FIR_TW == 64 ? 4 : 8) void fir4_c8_spli
     bf16x4_t* yl = reinterpret_cast<bf16x4_t*>(p.y + (((int64_t)n * 2 + 1) * (p.C / CH) + c8) * plane);
     // The two channel halves of a unit one after the other, as a REAL loop: unrolled into one basic block the scheduler hoists
     // both halves' LDS reads to the top (~250 VGPRs, 2 waves per SIMD, which made the first version latency-bound at 2 TB/s).
-    // Each half is stored as it is finished (8 bytes per lane and plane; the other half of the 16-byte unit follows).
+    // The first half's packed results (8 registers) wait for the second: every unit is stored whole, 16 bytes per lane and plane.
+    bf16x4_t hi0[RPT], lo0[RPT];
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
         const f32x4* sp = s_ab + hf * FH * FW;
@@ -413,13 +414,19 @@ __global__ __launch_bounds__(FIR_TW * 8, FIR_TW == 64 ? 4 : 8) void fir4_c8_spli
                 lo[j][c] = (__bf16)(v - (float)h);
             }
         }
+        if (hf == 0) {                                                    // keep the first half; the unit is stored whole (16 bytes) with the second
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int oy = oyb + j;
-            if (oy >= p.OH) break;
-            const int64_t u = ((int64_t)oy * p.OW + ox) * 2 + hf;          // 8-byte half units
-            yh[u] = hi[j];
-            yl[u] = lo[j];
+            for (int j = 0; j < RPT; ++j) { hi0[j] = hi[j]; lo0[j] = lo[j]; }
+        } else {
+            bf16x8_t* yh8 = reinterpret_cast<bf16x8_t*>(yh), *yl8 = reinterpret_cast<bf16x8_t*>(yl);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int oy = oyb + j;
+                if (oy >= p.OH) break;
+                const int64_t u = (int64_t)oy * p.OW + ox;                // 16-byte units
+                yh8[u] = __builtin_shufflevector(hi0[j], hi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+                yl8[u] = __builtin_shufflevector(lo0[j], lo[j], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         }
     }
 }
