@@ -33,13 +33,16 @@ struct C1Params {
 
 __device__ __noinline__ float conv1_act_generic(float v, int act, float alpha) { return n3d_act(v, act, alpha); }
 
-template <int MT>
+// RES (MT = 1, I <= 256: the toRGB layers of the large resolutions): the weights of ALL K steps are staged once (<= 32 KB) and the K
+// loop runs without barriers — with a handful of output channels the per-step barrier, not the arithmetic, paced the activation
+// loads (3.6 TB/s read-only on the 512 x 512 x 128-channel toRGB).
+template <int MT, bool RES>
 __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     constexpr int BM = 32 * MT, NTHR = 512;
     constexpr int KC = MT <= 2 ? 2 : 1;                                   // 16-channel chunks per K step (register budget: 128 VGPRs)
     constexpr int A_ITEMS = KC * 4 * BM;                                  // 16-byte slots per K step: [kc][hl 2][half 2][row BM]
     constexpr int A_PER_T = (A_ITEMS + NTHR - 1) / NTHR;
-    __shared__ bf16x8 A_s[2 * A_ITEMS];
+    __shared__ bf16x8 A_s[(RES ? 8 : 2) * A_ITEMS];
     __shared__ float s_style[1024];
     __shared__ float s_rs[BM], s_bs[BM];                                  // per-channel epilogue factors (no dependent global loads in the store loop)
 
@@ -84,9 +87,11 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     bf16x8 ra[A_PER_T];
     float raw[KC][8];
     auto load_step = [&](int s) {
+        if (!RES) {
 #pragma unroll
-        for (int j = 0; j < A_PER_T; ++j)
-            if (a_ok[j]) ra[j] = a_src[j][s * a_step];
+            for (int j = 0; j < A_PER_T; ++j)
+                if (a_ok[j]) ra[j] = a_src[j][s * a_step];
+        }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -113,9 +118,23 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+    if (RES) {                                                            // every step's weight slab, once
+        for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+            for (int j = 0; j < A_PER_T; ++j) {
+                const int e = tid + j * NTHR;
+                if (e < A_ITEMS) {
+                    bf16x8 z;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) z[c] = (__bf16)0.f;
+                    A_s[st * A_ITEMS + e] = a_ok[j] ? a_src[j][st * a_step] : z;
+                }
+            }
+        }
+    }
     load_step(0);
-    store_a(0);
-    __syncthreads();                                                      // s_style + A(0) visible
+    if (!RES) store_a(0);
+    __syncthreads();                                                      // s_style + A(0) (RES: every A) visible
 
     for (int s = 0; s < nsteps; ++s) {
         bf16x8 bh[KC], bl[KC];
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
             }
         }
         if (s + 1 < nsteps) load_step(s + 1);                             // issue only: consumed after the MFMA block
-        const bf16x8* A = A_s + (s & 1) * A_ITEMS + half * BM + l31;
+        const bf16x8* A = A_s + (RES ? s : (s & 1)) * A_ITEMS + half * BM + l31;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -141,8 +160,10 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[kc], acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[kc], acc[mt], 0, 0, 0);
             }
-        if (s + 1 < nsteps) store_a(s + 1);
-        __syncthreads();
+        if (!RES) {
+            if (s + 1 < nsteps) store_a(s + 1);
+            __syncthreads();
+        }
     }
 
     // epilogue (C/D layout: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel)
@@ -360,10 +381,13 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3dProfScope prof(N3D_K_CONV1X1_BF16X3, stream, flops, bytes);
     const dim3 grid((unsigned)nblk);
     switch (mt) {
-        case 1: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<1>, grid, dim3(512), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<2>, grid, dim3(512), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<3>, grid, dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL(conv1x1_bf16x3_kernel<4>, grid, dim3(512), 0, stream, p); break;
+        case 1:
+            if (d->I <= 256 && d->I % 32 == 0) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, false>), grid, dim3(512), 0, stream, p);
+            break;
+        case 2: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<2, false>), grid, dim3(512), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false>), grid, dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<4, false>), grid, dim3(512), 0, stream, p); break;
     }
     N3D_LAUNCH_CHECK();
     return 0;
