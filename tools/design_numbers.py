@@ -9,13 +9,13 @@ f = r['family_ms_per_step']
 c3, c5, cpu = d['config3'], d['config5'], d['cpu_baseline']
 traffic = r.get('traffic')
 para = f'''**Round-2 numbers (MI355X, N=1, batch 4, `profiles/r02_bench.json`)**: **{d['value']:.0f} frames/s** ({d['ms_per_step']:.2f} ms per 4-frame step; one stream:
-{d['single_stream']['value']:.0f}; round 1: 307, driver-measured 272), frames bitwise identical across pipelined steps (the pool's boxes differ by ±3 %: 355-372 frames/s and frac 0.43-0.44 for this build).  3×3 split-bf16 family:
+{d['single_stream']['value']:.0f}; round 1: 307, driver-measured 272), frames bitwise identical across pipelined steps (the pool's boxes differ by ±3 %: 355-376 frames/s and frac 0.43-0.44 for this build).  3×3 split-bf16 family:
 {r['achieved']:.0f} TFLOP/s fp32-equivalent = **frac {r['frac']:.3f}** of 833 (round 1: 0.365; against the MEASURED random-operand ceiling of the matrix
 pipe, §3.1c, 617-650: ~{r['achieved'] / 633:.2f}), {r['launches_per_step']:.0f} launches, {f['conv2d_bf16x3']:.2f} ms per step, {r['avg_launch_ms'] * 1e3:.0f} µs average (rocprofv3's kernel averages of the
 same command: `profiles/r02_kernel_stats.csv`); per family (`family_ms_per_step`, one stream, events): FIR {f['upfirdn2d']:.2f} ms, 1×1
 {f['conv1x1_bf16x3']:.2f} ms, renderer {f['render']:.2f} ms, rasteriser {f['raster']:.2f} ms, FCs {f['fc']:.2f} ms, conversions / blend / misc {f['misc']:.2f} ms.  History of the
 round: 309.6 (round-1 build, this round's boxes) → 318.7 (pre-split stride-1 + FIR → split8) → 322 (transposed pre-split, c8) → 351
-(three lanes) → 355 (renderer on the matrix pipe, 32-channel transposed workgroups) → 362 (stride-2 layers pre-split).
+(three lanes) → 355 (renderer on the matrix pipe, 32-channel transposed workgroups) → 362 (stride-2 layers pre-split) → 368-376 (30 timed steps instead of 10; FIR and 1×1 store / barrier tweaks).
 The reference's default float16 super-resolution mode (`sr_fp16_mode`, no `force_fp32`): {d['sr_fp16_mode']['value']:.0f} frames/s.
 `N3D_PRECISION=fp32`: {r32['value']:.0f} frames/s, family {r32['achieved']:.0f} TFLOP/s = {r32['frac']:.2f} of the fp32-MFMA peak.  Other call patterns (`config3` /
 `config5`): orbit with cached planes {c3['cached_planes_images_per_s']:.0f} frames/s (96 + 96 samples: {c3['cached_planes_96+96_images_per_s']:.0f}), reenactment with cached identity
