@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 2
+#define N3D_ABI_VERSION 3
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -31,7 +31,8 @@ enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4
 enum { N3D_F32 = 0, N3D_F16 = 1 };
 /* activation layouts: float32 NCHW; split8 (see n3d_fir4_split8); "c8" = float32 [N][C/8][H][row pitch in pixels][8], one
  * 32-byte unit = 8 consecutive channels of one pixel (what the transposed convolution hands to n3d_fir4_split8) */
-enum { N3D_LAYOUT_NCHW_F32 = 0, N3D_LAYOUT_SPLIT8 = 1, N3D_LAYOUT_C8_F32 = 2 };
+enum { N3D_LAYOUT_NCHW_F32 = 0, N3D_LAYOUT_SPLIT8 = 1, N3D_LAYOUT_C8_F32 = 2,
+       N3D_LAYOUT_H8_F16 = 3 /* "h8": float16 [N][C/8][H][W][8], dense — the activations of the reference's float16 blocks (n3d_conv2d_f16) */ };
 
 int n3d_abi_version(void);
 const char* n3d_last_error(void);
@@ -41,7 +42,8 @@ const char* n3d_last_error(void);
  * n3d_prof_read synchronises the recorded events and returns the totals for one family since the last reset. */
 enum { N3D_K_BIAS_ACT = 0, N3D_K_UPFIRDN2D = 1, N3D_K_CONV2D = 2, N3D_K_FC = 3, N3D_K_RENDER = 4, N3D_K_RASTER = 5,
        N3D_K_MISC = 6, N3D_K_CONV2D_BF16X3 = 7 /* 3x3 split-bf16 kernels: MFMA-bound */,
-       N3D_K_CONV1X1_BF16X3 = 8 /* 1x1 split-bf16 kernels: HBM-bound */, N3D_K_COUNT = 9 };
+       N3D_K_CONV1X1_BF16X3 = 8 /* 1x1 split-bf16 kernels (and the float16 toRGB): HBM-bound */,
+       N3D_K_CONV2D_F16 = 9 /* 3x3 float16 kernels of the fp16 blocks (n3d_conv2d_f16): MFMA / HBM */, N3D_K_COUNT = 10 };
 int n3d_prof_enable(int on);
 int n3d_prof_reset(void);
 int n3d_prof_read(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);
@@ -76,7 +78,11 @@ typedef struct {
                                      the residual is added — the storage rounding of the reference's fp16 blocks
                                      (tat/networks_stylegan2.py:548-552: x.to(float16); every operator of such a block returns
                                      float16) on float32 arithmetic.  Supported by the pre-split kernels (split8 / c8 layouts),
-                                     the 1x1 kernel and n3d_fir4_split8; other kernels reject it. */
+                                     the 1x1 kernel and n3d_fir4_split8; other kernels reject it.  The float16-block kernels
+                                     (n3d_conv2d_f16, n3d_fir4_h8) always store float16; for them the value 2 selects the rounding of
+                                     the reference's OFF-GPU bias_act (_bias_act_ref on half tensors, torch_utils/ops/bias_act.py:93-122:
+                                     x + b, leaky_relu, x * gain are separate float16 tensor ops) instead of bias_act.cu's single
+                                     rounding — used to match the reference's own CPU run of its float16 branch. */
 } n3d_epilogue;
 
 /* ---- upfirdn2d: replaces upfirdn2d_plugin.upfirdn2d (torch_utils/ops/upfirdn2d.cpp:20, kernels
@@ -182,6 +188,46 @@ int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 /* Number of workgroups n3d_conv2d_bf16x3 launches for this shape at ksplit = 1 (its tile plan): the host picks a split-K
  * factor from it so that small layers still cover the 256 CUs. */
 int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);
+
+/* ---- the reference's FLOAT16 blocks (super-resolution default route: `sr_num_fp16_res = 4` and no `force_fp32`,
+ *      training/networks_stylegan2.py:417-452, tat/superresolution.py:264-290) on float16 matrix cores.  Activations travel in the
+ *      "h8" layout (N3D_LAYOUT_H8_F16: float16 [N][C/8][H][W][8], C % 8 == 0, dense); every operator computes in float32 on float16
+ *      inputs and rounds once on output, as the reference's half-precision CUDA ops do.
+ *
+ *      n3d_modulate_weights_f16: modulated_conv2d's FUSED branch (training/networks_stylegan2.py:53-66,88): per-sample weights
+ *        w16[n] = half(weight * styles[n] (* dcoefs[n])) with the float16 pre-normalisation of :55-56 when demodulate != 0.
+ *        w [O,I,k,k] float32, styles [N,I] (row pitch styles_stride floats, 0 = I).  Output: ksize 3 (I % 16 == 0) ->
+ *        [N][9][I/16][2][O][8] float16 (the operand tiles n3d_conv2d_f16 streams); ksize 1 -> [N][O][I] (n3d_torgb_h8).
+ *      n3d_conv2d_f16: F.conv2d / F.conv_transpose2d of that branch (conv2d_resample.py:96-136 with groups = N) — same descriptor
+ *        as n3d_conv2d with x_layout = y_layout = N3D_LAYOUT_H8_F16, wt = n3d_modulate_weights_f16's output, style NULL, ksize 3,
+ *        mode 0 (epilogue: [+noise] + bias, lrelu / linear, gain, clamp in the float16 order of SynthesisLayer.forward :320-329) or
+ *        mode 2 (no epilogue: the float16 conv_transpose2d result, OH = 2H+1).  I % 16 == 0, O % 64 == 0, all strides 0 (dense).
+ *      n3d_fir4_h8: upfirdn2d(x, f, padding 1, gain) behind the transposed convolution (conv2d_resample.py:128-129) + the layer's
+ *        [noise] / bias_act (`epi`: bias, noise, act linear | lrelu, gain, clamp): h8 [N,C,H,W] -> h8 [N,C,H-1,W-1].  f [4,4] taps; f1d
+ *        NULL, or 4 device floats with f == outer(f1d, f1d) (the caller's promise): the separable evaluation, same float32 sum.
+ *      n3d_modulate_weights_f16_multi: up to 8 layers in one launch; `jobs` is a HOST array (copied into the kernel arguments),
+ *        job j reads styles_base[n * styles_stride + styles_offset + i].
+ *      n3d_torgb_h8: ToRGBLayer of a float16 block + `img = upsample2d(img) + y.to(float32)` (:446-451): x h8 [N,C,H,W], w16 [N][O][C]
+ *        (n3d_modulate_weights_f16, ksize 1, demodulate 0, styles already times weight_gain), bias [O], img_lo [N,O,H/2,W/2] float32 or
+ *        NULL, up_filter = the 4x4 taps (required with img_lo) -> img [N,O,H,W] float32.  O <= 4, C <= 512; clamp < 0: none.
+ *      n3d_cast_h8: float32 NCHW [N,C,HW] (batch stride x_batch_stride floats, 0 = dense) -> h8 (to_h8 != 0; `x.to(float16)` at the
+ *        block entry, :437) or h8 -> dense float32 NCHW (to_h8 == 0). */
+int n3d_modulate_weights_f16(const float* w, const float* styles, int64_t styles_stride, void* w16, int N, int O, int I, int ksize,
+                             int demodulate, n3d_stream_t stream);
+typedef struct {
+    const float* w;          /* [O,I,k,k] float32 */
+    void* w16;               /* output, layout as n3d_modulate_weights_f16 */
+    int64_t styles_offset;   /* floats from styles_base to this layer's styles of sample 0 */
+    int O, I, ksize, demodulate;
+} n3d_modw_job;
+int n3d_modulate_weights_f16_multi(const n3d_modw_job* jobs, int njobs, const float* styles_base, int64_t styles_stride, int N,
+                                   n3d_stream_t stream);
+int n3d_conv2d_f16(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+int n3d_fir4_h8(const void* x_h8, const float* f, const float* f1d, void* y_h8, int N, int C, int H, int W, int flip, float gain,
+                const n3d_epilogue* epi, n3d_stream_t stream);
+int n3d_torgb_h8(const void* x_h8, const void* w16, const float* bias, const float* img_lo, const float* up_filter, float* img, int N, int C,
+                 int O, int H, int W, float clamp, n3d_stream_t stream);
+int n3d_cast_h8(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, n3d_stream_t stream);
 
 /* ---- fully connected: replaces addmm / matmul+bias_act of FullyConnectedLayer.forward
  *      (tat/networks_stylegan2.py:114-127).  y[n,o] = post(act(sum_i pre(x[n,i]) * w[o,i] * wgain + b[o]*bgain)).

@@ -12,13 +12,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 ACT_IDS = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
 K_BIAS_ACT, K_UPFIRDN2D, K_CONV2D, K_FC, K_RENDER, K_RASTER, K_MISC, K_CONV2D_BF16X3 = range(8)
-FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'misc', 'conv2d_bf16x3', 'conv1x1_bf16x3']
+FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'misc', 'conv2d_bf16x3', 'conv1x1_bf16x3', 'conv2d_f16']
 
 
 class Epilogue(ctypes.Structure):
@@ -34,6 +34,10 @@ class Conv2dDesc(ctypes.Structure):
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
                 ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int)]
+
+
+class ModwJob(ctypes.Structure):
+    _fields_ = [('w', c_void_p), ('w16', c_void_p), ('styles_offset', c_int64), ('O', c_int), ('I', c_int), ('ksize', c_int), ('demodulate', c_int)]
 
 
 class FcJob(ctypes.Structure):
@@ -82,6 +86,12 @@ _SIGNATURES = {
     'n3d_fma': (c_int, [c_void_p] * 4 + [c_int64] * 6 + [c_void_p]),
     'n3d_to_uint8': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'n3d_cast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'n3d_modulate_weights_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'n3d_conv2d_f16': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
+    'n3d_fir4_h8': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p]),
+    'n3d_modulate_weights_f16_multi': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    'n3d_torgb_h8': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
+    'n3d_cast_h8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
     'n3d_fc_multi': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'n3d_fc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
                        c_float, c_int, c_int, c_void_p]),
@@ -171,6 +181,40 @@ class C8:
         return self.data.permute(0, 1, 4, 2, 3).reshape(n, c, h, w)
 
 
+class H8:
+    """A [N,C,H,W] activation of one of the reference's float16 blocks in the "h8" layout of include/n3d.h — float16
+    [N][C/8][H][W][8], 16-byte units of 8 consecutive channels of one pixel, unmodulated (the per-sample float16 weights carry
+    the styles: n3d_modulate_weights_f16).  `data` is the dense float16 storage."""
+
+    def __init__(self, n, c, h, w, device):
+        import torch as _t
+        assert c % 8 == 0
+        self.shape = (n, c, h, w)
+        self.data = _t.empty(n, c // 8, h, w, 8, dtype=_t.float16, device=device)
+        self.device = self.data.device
+
+    def to_float(self):
+        """float32 [N,C,H,W] (tests / debugging only)."""
+        n, c, h, w = self.shape
+        return self.data.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).float()
+
+    @classmethod
+    def from_nchw(cls, x):
+        """`x.to(torch.float16)` of a float32 [N,C,H,W] tensor (dense planes, any batch stride) on libn3d.so (n3d_cast_h8)."""
+        require_device(x)
+        n, c, h, w = x.shape
+        if x.dtype != _torch_f32() or x.stride()[1:] != (h * w, w, 1):
+            x = x.to(_torch_f32()).contiguous()
+        y = cls(n, c, h, w, x.device)
+        check(lib().n3d_cast_h8(ptr(x), ptr(y.data), n, c, h * w, x.stride(0), 1, stream()))
+        y._src = x                               # the source stays referenced until the launch is enqueued behind later work
+        return y
+
+
+def _torch_f32():
+    return torch.float32
+
+
 def cast(t, dtype):
     """float16 <-> float32 conversion on libn3d.so (n3d_cast); a tensor that already has `dtype` is returned as is.  Any other
     dtype raises: the kernels behind the operator layer compute in float32 and store float32 or float16 only."""
@@ -205,7 +249,7 @@ def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, re
     if residual_up_filter is not None:
         assert residual is not None and residual.is_contiguous() and tuple(residual_up_filter.shape) == (4, 4) and residual_up_filter.is_contiguous()
     e.residual_up_filter = ptr(residual_up_filter)
-    e.round_f16 = 1 if round_f16 else 0
+    e.round_f16 = int(round_f16)                 # False / True, or 2 (float16 blocks: the reference's off-GPU bias_act rounding, include/n3d.h)
     e._keepalive = (row_scale, noise, noise_strength, bias, residual, residual_up_filter)   # the struct only holds raw pointers
     return e
 

@@ -75,6 +75,7 @@ class PreparedConv:
             self.wt, self.wsq = cg.prep_weight(w), None
         self.wt16 = cg.prep_weight_bf16x3(w) if ((self.ksize == 3 and self.in_channels % 16 == 0) or
                                                  (self.ksize == 1 and self.in_channels % 32 == 0)) else None
+        self.weight = w                       # the raw parameter: the float16 blocks form per-sample weights from it (modulate_weights_f16)
         self.bias = P.get(f'{prefix}.bias')
         self.weight_gain = 1.0 / np.sqrt(self.in_channels * self.ksize ** 2)
         if modulated:
@@ -271,3 +272,132 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
         return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
     x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
     return cg.conv_launch(x, L.wt, 3, 1, L.out_channels, epilogue=epi, out=out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The reference's float16 blocks (training/networks_stylegan2.py:417-452: `use_fp16 and not force_fp32`) on the f16 matrix cores:
+# h8 activations, per-sample float16 weights (the FUSED modulated_conv2d branch, :53-91), float32 accumulation, one rounding per
+# operator — include/n3d.h "FLOAT16 blocks".
+
+def f16_layer_ok(L, h, w, up):
+    """Can SynthesisLayer `L` on an [*, I, h, w] input run on the float16 kernels?"""
+    return (L.ksize == 3 and L.in_channels % 16 == 0 and L.out_channels % 64 == 0 and L.in_channels * 9 <= 4608 and
+            ((up == 1 and h >= 16 and w >= 32) or (up == 2 and h >= 4 and w >= 4)))
+
+
+def modulate_weights_f16(L, styles, demodulate=True):
+    """Per-sample float16 weights of layer `L` for styles [N,I] (n3d_modulate_weights_f16) -> flat float16 tensor."""
+    n = styles.shape[0]
+    o, i, k = L.out_channels, L.in_channels, L.ksize
+    assert styles.dtype == torch.float32 and styles.stride(1) == 1 and styles.shape[1] == i
+    w = L.weight if L.weight.is_contiguous() else L.weight.contiguous()
+    out = torch.empty(n * o * i * k * k, dtype=torch.float16, device=styles.device)
+    _lib.check(_lib.lib().n3d_modulate_weights_f16(_lib.ptr(w), _lib.ptr(styles), styles.stride(0), _lib.ptr(out), n, o, i, k,
+                                                   1 if demodulate else 0, _lib.stream()))
+    out._keep = (w, styles)
+    return out
+
+
+def conv2d_f16(x, w16, out_channels, mode, epilogue=None):
+    """n3d_conv2d_f16: x `_lib.H8` [N,I,H,W], w16 from modulate_weights_f16 -> `_lib.H8` [N,O,H,W] (mode 0) or [N,O,2H+1,2W+1] (mode 2)."""
+    n, i, h, w = x.shape
+    oh, ow = (h, w) if mode == 0 else (2 * h + 1, 2 * w + 1)
+    y = _lib.H8(n, out_channels, oh, ow, x.device)
+    d = _lib.Conv2dDesc()
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x.data), _lib.ptr(w16), None, _lib.ptr(y.data), None
+    d.N, d.I, d.O, d.H, d.W = n, i, out_channels, h, w
+    d.ksize, d.mode, d.ksplit = 3, mode, 1
+    d.x_layout = d.y_layout = 3
+    d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
+    _lib.check(_lib.lib().n3d_conv2d_f16(d, _lib.stream()))
+    y._keep = (x, w16, d.epi)
+    return y
+
+
+# bias_act rounding of the float16 blocks: False = bias_act.cu (float32 inside, one rounding: what the reference does on a GPU);
+# True = _bias_act_ref on half tensors (what the reference does off-GPU: every step rounds) — only to compare with the reference's
+# own CPU run of its float16 branch (tests/golden/*_fp16sr.npz).
+F16_REF_CPU_ROUNDING = os.environ.get('N3D_F16_REF_CPU_ROUNDING', '0') == '1'
+_FIR1D = {}
+
+
+def fir_factor(fir):
+    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter tensor (a host read at model preparation).
+    The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (upfirdn2d.py:96-116): the separable
+    form of n3d_fir4_h8 evaluates the same float32 sum with half the multiply-adds."""
+    key = (fir.data_ptr(), fir._version, str(fir.device))
+    if key not in _FIR1D:
+        f = fir.detach().to('cpu', torch.float64)
+        a = None
+        if tuple(f.shape) == (4, 4) and float(f.sum()) > 0:
+            v = f.sum(1) / f.sum().sqrt()
+            if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
+                a = v.to(torch.float32).to(fir.device).contiguous()
+        _FIR1D[key] = a
+    return _FIR1D[key]
+
+
+def modulate_weights_f16_multi(entries, styles_base, n):
+    """[(layer, styles view [N,I] into `styles_base` (StyleBank's packed buffer), demodulate)] -> list of flat float16 weight
+    tensors, ONE launch (n3d_modulate_weights_f16_multi)."""
+    import ctypes
+    jobs = (_lib.ModwJob * len(entries))()
+    outs, keep = [], []
+    esz = styles_base.element_size()
+    for j, (L, st, demod) in enumerate(entries):
+        assert st.dtype == torch.float32 and st.stride(1) == 1 and st.stride(0) == styles_base.stride(0) and st.shape == (n, L.in_channels)
+        w = L.weight if L.weight.is_contiguous() else L.weight.contiguous()
+        out = torch.empty(n * L.out_channels * L.in_channels * L.ksize ** 2, dtype=torch.float16, device=styles_base.device)
+        jobs[j].w, jobs[j].w16 = w.data_ptr(), out.data_ptr()
+        jobs[j].styles_offset = (st.data_ptr() - styles_base.data_ptr()) // esz
+        jobs[j].O, jobs[j].I, jobs[j].ksize, jobs[j].demodulate = L.out_channels, L.in_channels, L.ksize, 1 if demod else 0
+        outs.append(out); keep.append(w)
+    _lib.check(_lib.lib().n3d_modulate_weights_f16_multi(ctypes.cast(jobs, ctypes.c_void_p), len(entries), _lib.ptr(styles_base),
+                                                         styles_base.stride(0), n, _lib.stream()))
+    for o in outs:
+        o._keep = (keep, styles_base)
+    return outs
+
+
+def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=None, gain=1.0, w16=None):
+    """SynthesisLayer.forward of a float16 block (training/networks_stylegan2.py:311-330 with x.dtype == float16, fused_modconv):
+    x `_lib.H8` -> `_lib.H8`.  `w16`: the layer's per-sample weights when already formed (modulate_weights_f16_multi)."""
+    if noise_mode not in ('const', 'none'):
+        raise RuntimeError("float16 blocks: noise_mode 'const' or 'none'")
+    noise = L.noise_const if noise_mode == 'const' else None
+    epi = _lib.make_epilogue(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
+                             gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain, round_f16=2 if F16_REF_CPU_ROUNDING else 0)
+    if w16 is None:
+        w16 = modulate_weights_f16(L, styles, demodulate=True)
+    if up == 1:
+        return conv2d_f16(x, w16, L.out_channels, 0, epi)
+    z = conv2d_f16(x, w16, L.out_channels, 2)
+    return fir4_h8(z, fir, epi)
+
+
+def fir4_h8(z, fir, epi, gain=4.0):
+    """upfirdn2d(z, fir, padding=1, gain) + the layer epilogue on h8 tensors (n3d_fir4_h8): [N,C,H,W] -> [N,C,H-1,W-1]."""
+    n, c, h, w = z.shape
+    y = _lib.H8(n, c, h - 1, w - 1, z.device)
+    f1d = fir_factor(fir) if os.environ.get('N3D_FIR_SEP', '1') != '0' else None
+    _lib.check(_lib.lib().n3d_fir4_h8(_lib.ptr(z.data), _lib.ptr(fir), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, 0, float(gain), epi, _lib.stream()))
+    y._keep = (z, epi, f1d)
+    return y
+
+
+def torgb_layer_f16(L, x, styles, fir, conv_clamp=None, img_lo=None, w16=None):
+    """ToRGBLayer.forward of a float16 block + the skip-image update (training/networks_stylegan2.py:353-357, :446-451): x `_lib.H8`,
+    styles [N,I] already multiplied by weight_gain (StyleBank 'torgb'), img_lo the previous block's float32 image or None ->
+    float32 image [N,O,H,W]."""
+    n, c, h, w = x.shape
+    o = L.out_channels
+    if w16 is None:
+        w16 = modulate_weights_f16(L, styles, demodulate=False)
+    img = torch.empty(n, o, h, w, dtype=torch.float32, device=x.device)
+    if img_lo is not None:
+        img_lo = img_lo.contiguous()
+        assert tuple(img_lo.shape) == (n, o, h // 2, w // 2) and tuple(fir.shape) == (4, 4)
+    _lib.check(_lib.lib().n3d_torgb_h8(_lib.ptr(x.data), _lib.ptr(w16), _lib.ptr(L.bias), _lib.ptr(img_lo), _lib.ptr(fir) if img_lo is not None else None,
+                                       _lib.ptr(img), n, c, o, h, w, float(-1 if conv_clamp is None else conv_clamp), _lib.stream()))
+    img._keep = (x, w16, img_lo)
+    return img

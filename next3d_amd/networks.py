@@ -66,7 +66,7 @@ class _Block:
                 img_stream.wait_event(ev)
                 if img is not None:
                     img = uf.upsample2d(img, fir)
-                img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
+                img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0], fp16=fp16)
         return x, img
 
 
@@ -214,6 +214,51 @@ class SuperRes8XDC:
         self.input_resolution = 128
         self._banks = {}
 
+    def _fp16_mode(self, x, noise_mode):
+        """Which implementation runs the reference's float16 blocks: 'native' (f16 matrix cores, conv2d_f16.hip; the default),
+        'emulate' (N3D_SR_FP16=emulate: round 2's storage-rounding emulation on the split-bf16 kernels) or 'fp32' (the float32
+        blocks, with a one-time warning) when the requested one cannot take the configuration — never an error: the reference's
+        default `synthesis(ws, c, v)` call must run under every precision / layout switch."""
+        import os
+        import warnings
+        want = os.environ.get('N3D_SR_FP16', 'native')
+        n, _, h, w = x.shape
+        native_ok = (noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and
+                     all(L.f16_layer_ok(b.conv0, hh, hh, 2) and L.f16_layer_ok(b.conv1, 2 * hh, 2 * hh, 1) and b.torgb.in_channels <= 512
+                         for b, hh in ((self.block0, h), (self.block1, 2 * h))))
+        if want == 'native' and native_ok:
+            return 'native'
+        emulate_ok = (L.PRESPLIT and L.UP_PRESPLIT and L.PRECISION == 'bf16x3' and noise_mode != 'random' and _img_stream(x.device) is None and
+                      all(L.presplit_ok(n, b.conv1, 2 * hh, 2 * hh) and b.conv0.out_channels % 64 == 0 and b.conv0.in_channels % 16 == 0 and
+                          L.cg.pick_ksplit_bf16x3(n, b.conv0.in_channels, b.conv0.out_channels, hh, hh, 2) == 1
+                          for b, hh in ((self.block0, h), (self.block1, 2 * h))))
+        if want in ('native', 'emulate') and emulate_ok:
+            if want == 'native' and not getattr(self, '_warned', False):
+                self._warned = True
+                warnings.warn('float16 super-resolution blocks: configuration not eligible for the f16 kernels, running the storage-rounding emulation')
+            return 'emulate'
+        if not getattr(self, '_warned32', False):
+            self._warned32 = True
+            warnings.warn('float16 super-resolution blocks are not available for this configuration (precision / layout switches, random '
+                          'noise): running them in float32 (the force_fp32=True arithmetic)')
+        return 'fp32'
+
+    def _forward_f16(self, x, rgb, bank, noise_mode):
+        """Both blocks on the f16 kernels (layers.synthesis_layer_f16 / torgb_layer_f16): h8 activations, float32 skip image."""
+        from . import _lib
+        xh = _lib.H8.from_nchw(x)                                   # x.to(float16) at the block entry (networks_stylegan2.py:437)
+        st = lambda layer: bank[layer.prefix][0]
+        layers6 = [(l, st(l), k == 'conv') for blk in (self.block0, self.block1) for (l, _, k) in blk.entries(0)]
+        base = st(self.block0.conv0)
+        base = base._base if base._base is not None else base       # StyleBank's packed [N, total] styles buffer
+        w16 = L.modulate_weights_f16_multi(layers6, base, x.shape[0])           # all six layers' per-sample weights in one launch
+        for bi, blk in enumerate((self.block0, self.block1)):
+            w0, w1, wt = w16[3 * bi:3 * bi + 3]
+            xh = L.synthesis_layer_f16(blk.conv0, xh, None, self.fir, up=2, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w0)
+            xh = L.synthesis_layer_f16(blk.conv1, xh, None, self.fir, up=1, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w1)
+            rgb = L.torgb_layer_f16(blk.torgb, xh, None, self.fir, conv_clamp=blk.conv_clamp, img_lo=rgb, w16=wt)
+        return rgb
+
     def __call__(self, rgb, x, ws, resize_fn, noise_mode='none', fp16=False):
         """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286).  Every layer is driven by the
         LAST latent of `ws` (`ws[:, -1:].repeat(1, 3, 1)`, :280): all StyleBank jobs read that one slot."""
@@ -229,7 +274,12 @@ class SuperRes8XDC:
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-        if fp16:        # block entry: x.to(float16) (networks_stylegan2.py:552); the image stays float32
+        if fp16:
+            mode = self._fp16_mode(x, noise_mode)
+            if mode == 'native':
+                return self._forward_f16(x, rgb, bank, noise_mode)
+            fp16 = mode == 'emulate'
+        if fp16:        # N3D_SR_FP16=emulate: float32 / split-bf16 arithmetic with float16 storage rounding (round 2's route, A/B)
             from . import _lib
             x = _lib.cast(_lib.cast(x.contiguous(), torch.float16), torch.float32)
         x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16)

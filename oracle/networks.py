@@ -75,6 +75,10 @@ def torgb_layer(P, prefix, x, w, conv_clamp=None):
     return ops.bias_act(x, P[f'{prefix}.bias'], clamp=conv_clamp)
 
 
+def _q(t):
+    return t.half().float()
+
+
 def _q16(t):
     """float16 storage rounding on float32 values."""
     return t.half().float()
@@ -99,18 +103,34 @@ def _modconv_fp16(P, prefix, x, styles, up, demodulate):
     return y.reshape(n, -1, *y.shape[2:])
 
 
-def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256):
-    """SynthesisBlock.forward with use_fp16 and not force_fp32 (tat/networks_stylegan2.py:548-588), noise_mode='none' (the
-    super-resolution blocks): x is cast to float16 at entry, every layer returns float16, the skip image is float32."""
+def _bias_act_half_cpu(x, b, act='linear', gain=1.0, clamp=None):
+    """_bias_act_ref applied to float16 tensors (torch_utils/ops/bias_act.py:93-122 — what the reference's float16 blocks run
+    off-GPU): x + b, the activation and x * gain are separate float16 tensor ops, each rounding; emulated on float32 values."""
+    x = _q(x + _q(b).reshape(1, -1, 1, 1))
+    if act == 'lrelu':
+        x = _q(torch.where(x > 0, x, x * 0.2))
+    if gain != 1:
+        x = _q(x * gain)
+    return x.clamp(-clamp, clamp) if clamp is not None else x
+
+
+def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=False):
+    """SynthesisBlock.forward with use_fp16 and not force_fp32 (training/networks_stylegan2.py:417-452), noise_mode='none' (the
+    super-resolution blocks): x is cast to float16 at entry, every layer returns float16, the skip image is float32.
+    bias_act: `cpu_rounding=False` models bias_act.cu (bias_act.cu:19-50: float32 inside, ONE float16 rounding — the reference on a
+    GPU); `cpu_rounding=True` models _bias_act_ref on half tensors (the reference off-GPU).  The latter reproduces the reference's
+    own CPU run of this branch (oracle/pin_against_reference.py --fp16, tests/golden/*_fp16sr.npz) up to the accumulation order
+    inside ATen's half convolutions: the two settings differ in nothing else."""
     w0, w1, w2 = ws.unbind(dim=1)
     aff = lambda k, w: ops.fully_connected(w, P[f'{prefix}.{k}.affine.weight'], P[f'{prefix}.{k}.affine.bias'])
-    x = _q16(x)
+    ba = _bias_act_half_cpu if cpu_rounding else (lambda x, b, **kw: _q(ops.bias_act(x, _q(b), **kw)))
+    x = _q(x)
     for k, w, up in (('conv0', w0, 2), ('conv1', w1, 1)):
         x = _modconv_fp16(P, f'{prefix}.{k}', x, aff(k, w), up, True)
-        x = _q16(ops.bias_act(x, _q16(P[f'{prefix}.{k}.bias']), act='lrelu', gain=_LRELU_GAIN, clamp=conv_clamp))
+        x = ba(x, P[f'{prefix}.{k}.bias'], act='lrelu', gain=_LRELU_GAIN, clamp=conv_clamp)
     wt = P[f'{prefix}.torgb.weight']
     y = _modconv_fp16(P, f'{prefix}.torgb', x, aff('torgb', w2) * (1.0 / np.sqrt(wt.shape[1] * wt.shape[2] ** 2)), 1, False)
-    y = _q16(ops.bias_act(y, _q16(P[f'{prefix}.torgb.bias']), clamp=conv_clamp))
+    y = ba(y, P[f'{prefix}.torgb.bias'], clamp=conv_clamp)
     img = ops.upsample2d(img, FIR) + y
     return x, img
 
@@ -193,7 +213,7 @@ def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, fin
     return img
 
 
-def superresolution(P, prefix, rgb, x, ws, force_fp32=True):
+def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False):
     """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward), noise_mode='none'; fp32 path (what the reference
     runs off-GPU and what the goldens pin) or, with force_fp32=False, its fp16 blocks emulated (synthesis_block_fp16).
     conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275)."""
@@ -202,8 +222,8 @@ def superresolution(P, prefix, rgb, x, ws, force_fp32=True):
         x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
         rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
     if not force_fp32:      # the reference's default on a GPU (use_fp16 = sr_num_fp16_res > 0): emulated float16 storage
-        x, rgb = synthesis_block_fp16(P, f'{prefix}.block0', x, rgb, ws)
-        x, rgb = synthesis_block_fp16(P, f'{prefix}.block1', x, rgb, ws)
+        x, rgb = synthesis_block_fp16(P, f'{prefix}.block0', x, rgb, ws, cpu_rounding=cpu_rounding)
+        x, rgb = synthesis_block_fp16(P, f'{prefix}.block1', x, rgb, ws, cpu_rounding=cpu_rounding)
         return rgb
     x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, 32, noise_mode='none', conv_clamp=256)
     x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, 256, noise_mode='none', conv_clamp=256)

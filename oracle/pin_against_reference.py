@@ -13,8 +13,16 @@ What it does, per case:
   3. runs reference `mapping` + `synthesis` on CPU (fp32 forced off-GPU, networks_stylegan2.py:548),
      capturing stage outputs with forward hooks;
   4. runs the oracle on the same inputs and reports max-abs differences per stage;
-  5. stores inputs + REFERENCE outputs (sub-sampled where large) in tests/golden/case_*.npz.
+  5. stores inputs + REFERENCE outputs (sub-sampled where large) in tests/golden/case_*.npz; the benched case
+     (case_r64_s48_b4) additionally gets its FULL-resolution image in tests/golden/case_r64_s48_b4_image.npz;
+  6. --fp16 (cases in FP16_CASES): runs the reference's OWN float16 super-resolution branch on the CPU — the
+     `if ws.device.type != 'cuda': force_fp32 = True` guard of SynthesisBlock.forward (training/networks_stylegan2.py:421-422) is
+     patched out at run time (the method's source is re-compiled with the guard disabled; nothing is copied into this repo) — on
+     the fp32 run's own (rgb, features, ws) and stores the full-resolution result in tests/golden/<case>_fp16sr.npz;
+  7. writes profiles/r03_cpu_reference.json: seconds of the reference's Python and of the oracle on this container's cores, per case
+     (bench.py cites it next to its own `cpu_baseline`).
 """
+import json
 import os
 import sys
 import time
@@ -54,12 +62,33 @@ CASES = {
 }
 
 
+FP16_CASES = ('case_r32_s24', 'case_r64_s48')      # the float16 reference run costs minutes per sample on the CPU: batch 1 and batch 2
+
+
+def enable_reference_fp16_on_cpu():
+    """Disable SynthesisBlock.forward's off-GPU float32 guard (training/networks_stylegan2.py:421-422) in the imported reference
+    module: the method's own source, with that one condition replaced, is compiled in the module's namespace."""
+    import inspect
+    import textwrap
+    import training.networks_stylegan2 as m
+    fn = m.SynthesisBlock.forward
+    src = textwrap.dedent(inspect.getsource(fn))
+    guard = "if ws.device.type != 'cuda':"
+    assert src.count(guard) == 1, 'reference guard not found'
+    ns = {}
+    exec(compile(src.replace(guard, 'if False:'), '<SynthesisBlock.forward without the off-GPU fp32 guard>', 'exec'), m.__dict__, ns)
+    m.SynthesisBlock.forward = ns['forward']
+    return fn
+
+
 def sub(t, step):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
 def main():
     only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
+    do_fp16 = '--fp16' in sys.argv
+    timings = {}
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     uv_mask = n3d_mesh.synthetic_uv_face_mask()
@@ -104,6 +133,7 @@ def main():
                       ('rendering_stitch', G.neural_blending.synthesis), ('static_plane', G.backbone.synthesis)]:
         hooks.append(mod.register_forward_hook(cap(name)))
     hooks.append(G.renderer.register_forward_hook(lambda m, i, o: stages.__setitem__('renderer', (i[0], o))))
+    hooks.append(G.superresolution.register_forward_hook(lambda m, i, o: stages.__setitem__('sr_in', tuple(t.clone() for t in i[:3]))))
 
     overall_ok = True
     for cname, cfg in CASES.items():
@@ -173,6 +203,8 @@ def main():
         smp_or = ogen.run_model(sd, st['blended_planes'], coords, rk)
         rep['sample_rgb'] = md(smp_ref['rgb'], smp_or['rgb'])
         rep['sample_sigma'] = md(smp_ref['sigma'], smp_or['sigma'])
+        timings[cname] = {'batch': N, 'R': R, 'samples': [Sc, Sf], 'reference_seconds': round(t_ref, 2), 'oracle_seconds': round(t_or, 2),
+                          'reference_frames_per_s': round(N / t_ref, 4), 'oracle_frames_per_s': round(N / t_or, 4)}
         print(f'[{cname}] reference {t_ref:.1f}s oracle {t_or:.1f}s  max-abs(ref-oracle): ' +
               ' '.join(f'{k}={v:.2e}' for k, v in rep.items()))
         ok = all(v <= 1e-4 for v in rep.values())
@@ -195,8 +227,42 @@ def main():
             stage_absmean=np.array([float(stages[k].abs().mean()) for k in
                                     ('textures', 'mouths_plane', 'rendering_stitch', 'static_plane')]),
         )
+        if cname == 'case_r64_s48_b4':       # the benched configuration: every pixel of the reference image
+            np.savez_compressed(os.path.join(GOLDEN, f'{cname}_image.npz'), image=out_ref['image'].numpy())
+        if do_fp16 and cname in FP16_CASES:
+            # the reference's DEFAULT super-resolution route (sr_num_fp16_res = 4, no force_fp32): its own float16 blocks, on the CPU
+            rgb_in, feat_in, ws_in = stages['sr_in']
+            orig_forward = enable_reference_fp16_on_cpu()
+            import training.networks_stylegan2 as ref_sg2
+            try:
+                t0 = time.time()
+                img16 = G.superresolution(rgb_in, feat_in, ws_in, noise_mode=RENDERING_KWARGS['superresolution_noise_mode'])
+                t16 = time.time() - t0
+            finally:
+                ref_sg2.SynthesisBlock.forward = orig_forward
+            assert img16.dtype == torch.float32
+            from oracle import networks as onet
+            or16 = onet.superresolution(sd, 'superresolution', rgb_in, feat_in, ws_in, force_fp32=False)
+            d16 = (img16 - or16).abs()
+            d32 = (img16 - out_ref['image']).abs()
+            print(f'[{cname}] reference float16 SR on CPU {t16:.1f}s: vs oracle fp16 emulation max-abs {float(d16.max()):.3e} mean {float(d16.mean()):.3e}; '
+                  f'vs the float32 route max-abs {float(d32.max()):.3e} mean {float(d32.mean()):.3e}')
+            timings[cname]['reference_fp16_sr_seconds'] = round(t16, 2)
+            timings[cname]['oracle_fp16_vs_reference_fp16_max_abs'] = float(d16.max())
+            timings[cname]['reference_fp16_vs_fp32_max_abs'] = float(d32.max())
+            np.savez_compressed(os.path.join(GOLDEN, f'{cname}_fp16sr.npz'), image=img16.numpy(), rgb_in=rgb_in.numpy(), feat_in=feat_in.numpy(),
+                                ws_in=ws_in.numpy(), oracle_max_abs=float(d16.max()))
     for h in hooks:
         h.remove()
+    if timings:
+        path = os.path.join(REPO, 'profiles', 'r03_cpu_reference.json')
+        prev = json.load(open(path)) if os.path.exists(path) else {}
+        prev.setdefault('cases', {}).update(timings)
+        prev.update({'cores': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'host': 'build container (no GPU)',
+                     'what': "seconds for mapping + synthesis: the reference's own Python (ops -> its _ref implementations, fp32 forced off-GPU; "
+                             'rasteriser / flood fill = oracle/raster_ref.c stand-ins) and the oracle (kind "port") on the same inputs',
+                     'script': 'oracle/pin_against_reference.py'})
+        json.dump(prev, open(path, 'w'), indent=1)
     print('PIN', 'OK' if overall_ok else 'FAILED')
     return 0 if overall_ok else 1
 

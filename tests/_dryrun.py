@@ -39,6 +39,19 @@ def _check_conv_desc(name, d):
     assert 1 <= d.epi.act <= 9
 
 
+def _check_conv_f16_desc(d):
+    """n3d_conv2d_f16's preconditions (conv2d_f16.hip)."""
+    assert d.x and d.wt and d.y and not d.style and d.ksplit <= 1
+    assert d.ksize == 3 and d.mode in (0, 2) and d.x_layout == 3 and d.y_layout == 3
+    assert d.I >= 16 and d.I % 16 == 0 and d.O >= 64 and d.O % 64 == 0
+    assert d.x_batch_stride == 0 and d.y_batch_stride == 0 and d.x_row_stride == 0 and d.y_row_stride == 0
+    assert not d.epi.row_scale and d.epi.const_scale == 1.0 and not d.epi.residual
+    if d.mode == 0:
+        assert d.H >= 16 and d.W >= 32 and d.epi.act in (1, 3)
+    else:
+        assert d.H >= 4 and d.W >= 4 and d.epi.act == 1 and not d.epi.bias and not d.epi.noise and d.epi.clamp < 0 and d.epi.gain == 1.0
+
+
 def patches():
     from next3d_amd import _lib, generator
     real = _lib.lib()                                            # the built library loads without a GPU
@@ -56,6 +69,8 @@ def patches():
                     t.from_param(a)                              # raises exactly where a real ctypes call would
                 if name in ('n3d_conv2d', 'n3d_conv2d_bf16x3'):
                     _check_conv_desc(name, getattr(args[0], '_obj', args[0]))
+                if name == 'n3d_conv2d_f16':
+                    _check_conv_f16_desc(getattr(args[0], '_obj', args[0]))
                 calls.append(name)
                 return 0
             return fn

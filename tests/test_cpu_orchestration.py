@@ -63,12 +63,47 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     dry.clear()
     G.synthesis(ws, c, v, neural_rendering_resolution=R)         # noise_mode defaults to 'random' (the reference's default,
     rnd = Counter(dry)                                           # networks_stylegan2.py:311): noisy layers run sample by sample
-    n_rnd = sum(rnd.values()) - rnd['n3d_cast']                  # (default call: fp16 super-resolution blocks -> 2 casts)
+    # the default call runs the float16 super-resolution blocks on the f16 kernels: 10 launches (cast to h8, one weight
+    # modulation for all six layers, per block transposed conv + FIR + conv + toRGB) instead of the float32 route's 8 (+ 2 conversion passes)
+    sr16 = lambda cnt: (cnt['n3d_cast_h8'], cnt['n3d_modulate_weights_f16_multi'], cnt['n3d_conv2d_f16'], cnt['n3d_fir4_h8'], cnt['n3d_torgb_h8'])
+    assert sr16(rnd) == (1, 1, 4, 2, 2) and sr16(full) == (0, 0, 0, 0, 0)
+    n_rnd = sum(rnd.values()) - 10 + 8 - rnd['n3d_split8_from_nchw'] + full['n3d_split8_from_nchw']
     assert n_rnd > n_full if N > 1 else n_rnd == n_full
     dry.clear()
     G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')      # no force_fp32: the reference's default, fp16
     half = Counter(dry)                                                          # super-resolution blocks (sr_num_fp16_res = 4)
-    assert half['n3d_cast'] == 2 and sum(half.values()) - half['n3d_split8_from_nchw'] == 153 + (0 if R == 128 else 2) + 2
+    assert sr16(half) == (1, 1, 4, 2, 2)
+    assert sum(half.values()) - half['n3d_split8_from_nchw'] == 153 + (0 if R == 128 else 2) - 8 + 10
+    # the switches that used to make the default call raise: strict-fp32 arithmetic, no pre-split hand-off, random
+    # super-resolution noise -> the float16 blocks fall back (f16 kernels -> storage-rounding emulation -> float32), never an error
+    import warnings
+    from next3d_amd import layers
+    for env, attr, val in (('N3D_SR_FP16', None, 'emulate'), (None, 'PRECISION', 'fp32'), (None, 'PRESPLIT', False)):
+        old_env, old_attr = os.environ.get('N3D_SR_FP16'), getattr(layers, attr) if attr else None
+        try:
+            if env:
+                os.environ[env] = val
+            if attr:
+                setattr(layers, attr, val)
+                os.environ['N3D_SR_FP16'] = 'emulate'
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                dry.clear()
+                out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
+            assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry)) == (0, 0, 0, 0, 0)
+        finally:
+            if attr:
+                setattr(layers, attr, old_attr)
+            if old_env is None:
+                os.environ.pop('N3D_SR_FP16', None)
+            else:
+                os.environ['N3D_SR_FP16'] = old_env
+    G.rendering_kwargs['superresolution_noise_mode'] = 'random'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
+    G.rendering_kwargs['superresolution_noise_mode'] = 'none'
+    assert tuple(out['image'].shape) == (N, 3, 512, 512)
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
 
