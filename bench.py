@@ -149,7 +149,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # N3D_BENCH_FORCE_DIST=1 (tests/test_generator_gpu.py::test_bench_multi_gpu_path_on_one_gpu): run the N > 1 code path — RCCL process
+    # group, per-step asynchronous frame gather, barrier — with a single rank, so that it executes on hardware on a 1-GPU box
+    force_dist = os.environ.get('N3D_BENCH_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)        # 'nccl' == RCCL on ROCm
 
@@ -165,7 +169,7 @@ def main():
     u = torch.rand((B * R * R, Sf), device=dev, generator=g)
 
     from next3d_amd.sharding import AsyncFrameGather
-    gatherer = AsyncFrameGather(torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev), dst=0)
+    gatherer = AsyncFrameGather(torch.empty(B, 3, 512, 512, dtype=torch.uint8, device=dev), dst=0, single_rank_collective=force_dist)
 
     def to_frames(img):
         frames = torch.empty(img.shape, dtype=torch.uint8, device=img.device)     # gen_samples_next3d.py:201 (NCHW kept)
@@ -196,7 +200,7 @@ def main():
 
     def sync():
         gatherer.drain()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -223,7 +227,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -322,11 +326,14 @@ def main():
         cam_of = lambda k: cams[k % 120:k % 120 + 1].expand(B, -1).contiguous()
         it = [0]
 
-        def orbit(cached, kw_):
+        def orbit(cached, kw_, graph=False):
             k = it[0]; it[0] += 1
-            to_frames(G.synthesis(wsg, cam_of(k), vg, use_cached_backbone=cached, **kw_)['image'])
+            fn = G.synthesis_graph if graph else G.synthesis
+            to_frames(fn(wsg, cam_of(k), vg, use_cached_backbone=cached, **kw_)['image'])
         G.synthesis(wsg, cam_of(0), vg, cache_backbone=True, **kw); torch.cuda.synchronize()
         t_c = timed(lambda: orbit(True, kw), 120)
+        orbit(True, kw, graph=True); torch.cuda.synchronize()            # capture
+        t_cg = timed(lambda: orbit(True, kw, graph=True), 120)          # the same 120 frames replayed from ONE captured HIP graph
         t_u = timed(lambda: orbit(False, kw), 24)
         G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = 96, 96     # sampling_multiplier 2
         j2 = torch.rand((B, R * R, 96, 1), device=dev, generator=g)
@@ -338,8 +345,23 @@ def main():
         extras['config3'] = {'workload': 'gen_videos_next3d.py: 2x2 grid (batch 4 = one video frame), 120-frame camera orbit, fixed FLAME '
                                          'mesh, uint8 frames; images/s = 4 x video frames/s',
                              'cached_planes_images_per_s': 120 * B / t_c, 'cached_planes_video_fps': 120 / t_c,
+                             'cached_planes_hip_graph_images_per_s': 120 * B / t_cg,
                              'uncached_images_per_s': 24 * B / t_u, 'uncached_video_fps': 24 / t_u,
                              'cached_planes_96+96_images_per_s': 60 * B / t_c2, 'unit': 'frames/s', 'frames_timed': [120, 24, 60]}
+        # ---- configs[0] as a latency figure: batch 1, 32x32 render, 24 + 24 samples, one frame at a time (eager launches vs graph replay)
+        z1, c1, c1_cond, v1 = demo.demo_batch([0], device=dev)
+        ws1 = G.mapping(z1, c1_cond, truncation_psi=0.7, truncation_cutoff=14)
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = 24, 24
+        j1 = torch.rand((1, 32 * 32, 24, 1), device=dev, generator=g)
+        u1 = torch.rand((32 * 32, 24), device=dev, generator=g)
+        kw1 = dict(neural_rendering_resolution=32, noise_mode='const', depth_jitter=j1, importance_u=u1, force_fp32=True)
+        one = lambda fn: to_frames(fn(ws1, c1, v1, **kw1)['image'])
+        one(G.synthesis); one(G.synthesis_graph); torch.cuda.synchronize()
+        t_1e = timed(lambda: one(G.synthesis), 60)
+        t_1g = timed(lambda: one(G.synthesis_graph), 60)
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+        extras['config1'] = {'workload': 'BASELINE.json configs[0] shape on the GPU: batch 1, 512² output, 32² neural render, 24 + 24 samples, frames issued back to back',
+                             'eager_ms_per_frame': 1e3 * t_1e / 60, 'hip_graph_ms_per_frame': 1e3 * t_1g / 60, 'frames_timed': 60}
         # ---- configs[4]: reenactment — one identity (ws), a NEW mesh per frame (reenact_avatar_next3d.py:139-164); data/obama is
         # not in the tree: demo mesh + seeded smooth per-frame perturbation (sigma 1 mm), 4 consecutive frames per step
         zr, cr, cr_cond, vr = demo.demo_batch([0] * B, yaws=[0.0] * B, device=dev)
@@ -356,9 +378,16 @@ def main():
             to_frames(G.synthesis(wsr, cr, meshes[k * B:(k + 1) * B].contiguous(), use_cached_identity=cached, **kw)['image'])
         t_rc = timed(lambda: reenact(True), 32)
         t_ru = timed(lambda: reenact(False), 16)
+
+        def reenact_graph():
+            k = it[0] % (F_ // B); it[0] += 1
+            to_frames(G.synthesis_graph(wsr, cr, meshes[k * B:(k + 1) * B].contiguous(), use_cached_identity=True, **kw)['image'])
+        reenact_graph(); torch.cuda.synchronize()
+        t_rg = timed(reenact_graph, 32)
         extras['config5'] = {'workload': 'reenact_avatar_next3d.py loop: one identity, a new FLAME mesh + landmarks per frame (synthetic '
                                          'smooth sequence; data/obama is not in the tree), 4 consecutive frames per step, camera fixed',
-                             'cached_identity_frames_per_s': 32 * B / t_rc, 'uncached_frames_per_s': 16 * B / t_ru, 'unit': 'frames/s',
+                             'cached_identity_frames_per_s': 32 * B / t_rc, 'cached_identity_hip_graph_frames_per_s': 32 * B / t_rg,
+                             'uncached_frames_per_s': 16 * B / t_ru, 'unit': 'frames/s',
                              'frames_timed': [32 * B, 16 * B]}
 
     cpu = None
@@ -376,14 +405,16 @@ def main():
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,
                        'streams': f'{len(lanes)} (consecutive steps alternate between them)',
-                       'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if world > 1 else 'none',
+                       'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if use_dist else 'none',
                        'prewarm_seconds': args.prewarm_seconds},
             'frames_bitwise_reproducible': reproducible, 'single_stream': single_stream, 'roofline': roofline, **extras,
             'cpu_baseline': cpu}))
         if not reproducible:
             print('bench.py: pipelined steps returned different frames', file=sys.stderr)
     gatherer.drain()
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gatherer.received is not None and args.no_roofline and args.no_extras:       # (the last step submitted was `fc`) what arrived over RCCL is what was rendered
+            assert torch.equal(gatherer.received[0], fc), 'gathered frames differ from the rendered ones'
         dist.barrier()
         dist.destroy_process_group()
 

@@ -324,6 +324,19 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
                         float* grid, float* alpha, float* lm2d, int N, int V, int Lm, int F, int views, int H, int W,
                         float shift_x, float shift_y, float shift_z, float scale, int fill, int binarize_view,
                         n3d_stream_t stream);
+/* ---- the two third-party calls of the rasterisation step under their own names, for reference code that runs UNRELOADED (boundary
+ *      B1: a pickled model executes the reference's Pytorch3dRasterizer.forward / fill_mouth and imports pytorch3d / cv2 from
+ *      next3d_amd/shims/):
+ *      n3d_rasterize_meshes = pytorch3d.renderer.mesh.rasterize_meshes(meshes, image_size, blur_radius = 0, faces_per_pixel = 1,
+ *        perspective_correct = False, cull_backfaces) as called at vr/renderer.py:415-424: verts_ndc [N,V,3] in PyTorch3D NDC, faces
+ *        int32 [F,3] shared (faces_batch_stride 0) or [N,F,3] (stride 3F); zbuf_ws [N*H*W] uint64 scratch ->
+ *        pix_to_face [N,H,W] int64 (packed n*F+f, -1 empty), zbuf [N,H,W] (-1 empty), bary [N,H,W,3] (-1 empty).  Same face kernel as
+ *        n3d_rasterize_views.
+ *      n3d_flood_fill = cv2.floodFill(img, mask, (0,0), new_val, lo_diff, up_diff, FLOODFILL_FIXED_RANGE) (vr/renderer.py:593) on N
+ *        float32 images [N,H,W] (H, W <= 256), in place. */
+int n3d_rasterize_meshes(const float* verts_ndc, const int* faces, int64_t faces_batch_stride, unsigned long long* zbuf_ws, long long* pix_to_face,
+                         float* zbuf, float* bary, int N, int V, int F, int H, int W, int cull_backfaces, n3d_stream_t stream);
+int n3d_flood_fill(float* images, int N, int H, int W, float new_val, float lo_diff, float up_diff, n3d_stream_t stream);
 /* out [N,C,H,W] = grid_sample(textures [N,C,TH,TW], grid[:, view_a]) (+ the same for view_b when view_b >= 0)
  * — bilinear, zeros, align_corners=False, un-masked as in the reference (tat/triplane_next3d.py:218,225). */
 int n3d_texture_project(const float* textures, const float* grid, float* out, int N, int C, int TH, int TW, int H, int W,

@@ -77,6 +77,8 @@ _SIGNATURES = {
     'n3d_sample_points': (c_int, [c_void_p] * 8 + [c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     'n3d_rasterize_views': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 4 +
                             [c_int, c_int, c_void_p]),
+    'n3d_rasterize_meshes': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    'n3d_flood_fill': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
     'n3d_texture_project': (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
     'n3d_texture_project_planes': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     'n3d_mouth_bbox': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

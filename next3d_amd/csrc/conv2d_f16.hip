@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "up_tiles.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -209,7 +210,6 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(C
 // conv2d_up_ps_body (tap (ky, kx) feeds phase (ky == 1, kx == 1) from patch offset (ky == 2 ? 0 : 1, kx == 2 ? 0 : 1); flattened
 // th x tw <= 256 positions of the (H+1) x (W+1) position grid per tile).  The result is the float16 tensor the reference's
 // conv_transpose2d returns: the only epilogue is the rounding.
-void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th);          // conv2d_bf16x3.hip
 
 constexpr int FU_PPIX = 9 * 33;                                           // patch capacity: (th+1) x (tw+1) <= 297
 constexpr int FU_BCH = (FU_PPIX + 63) / 64, FU_BPAD = FU_BCH * 64;        // 5 pieces = 320 slots per k half
@@ -218,7 +218,7 @@ constexpr int FU_B_SZ = 2 * FU_BPAD, FU_B_PIECES = 2 * FU_BCH;            // 640
 struct ConvUpF16Params {
     const f16x8* x; const f16x8* w; f16x8* y;
     int N, I, O, H, W, OH, OW;
-    int tiles_x, tiles_y, tiles_m, tw, th;
+    UpTilePlan plan; int tiles_m;
     int64_t xbs, wbs, ybs;
     int dbg;
 };
@@ -239,9 +239,10 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
     const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
-    const int tile_i = lb % (p.tiles_x * p.tiles_y), n = lb / (p.tiles_x * p.tiles_y);
-    const int y0 = (tile_i / p.tiles_x) * p.th, x0 = (tile_i % p.tiles_x) * p.tw;
-    const int PW = p.tw + 1, prows = p.th + 1;
+    const int tile_i = lb % p.plan.total, n = lb / p.plan.total;
+    int y0, x0, th, tw, end_y, end_x;
+    up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
+    const int PW = tw + 1, prows = th + 1;
     const int KC = p.I / 16, HW = p.H * p.W, GH = p.H + 1, GW = p.W + 1;
 
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)n * p.wbs), 0, F_TAPS * KC * 2 * p.O * 16, 0x00020000);
@@ -282,8 +283,8 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
         const int q_pos = (wn * PG + g) * 32 + l31;                       // flattened tile position of this lane
-        q_act[g] = q_pos < p.th * p.tw;
-        q_row[g] = q_act[g] ? q_pos / p.tw : 0; q_col[g] = q_act[g] ? q_pos % p.tw : 0;
+        q_act[g] = q_pos < th * tw;
+        q_row[g] = q_act[g] ? q_pos / tw : 0; q_col[g] = q_act[g] ? q_pos % tw : 0;
         b_frag[g] = half * FU_BPAD + q_row[g] * PW + q_col[g];            // + dy*PW + dx
     }
     for (int kc = -1; kc < KC; ++kc) {
@@ -335,7 +336,7 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
         const int gy = y0 + q_row[g], gx = x0 + q_col[g];
-        if (!q_act[g] || gy >= GH || gx >= GW) continue;
+        if (!q_act[g] || gy >= end_y || gx >= end_x) continue;
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa) {
             const int oy = 2 * gy + pa;
@@ -418,13 +419,13 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     ConvUpF16Params p;
     p.x = (const f16x8*)d->x; p.w = (const f16x8*)d->wt; p.y = (f16x8*)d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
-    conv16_up_tiles(d->H + 1, d->W + 1, 8, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
+    { const char* e = getenv("N3D_UP_EDGE_TILES"); p.plan = up_tile_plan(d->H, d->W, !(e && atoi(e) == 0)); }
     int variant = 0;                                                      // 0: 4 waves x 64 positions x 32 channels; 1: 8 x 32 x 32; 2: 8 x 32 x 64
     { const char* e = getenv("N3D_F16_UP"); if (e) variant = atoi(e); }
     p.tiles_m = d->O / (variant == 2 ? 64 : 32);
     p.xbs = (int64_t)(d->I / 8) * d->H * d->W; p.wbs = wbs; p.ybs = (int64_t)(d->O / 8) * p.OH * p.OW;
     p.dbg = dbg;
-    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
+    const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_f16: grid too large");
     const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->N * d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_F16, stream, flops, bytes);

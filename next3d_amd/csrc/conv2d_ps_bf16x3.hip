@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "up_tiles.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -299,7 +300,6 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
 // for the FIR that follows (fir4_c8_split8_kernel).  The register-staged kernel spends, per 16-channel chunk, the SAME staging work as
 // the stride-1 kernel for half the MFMAs (54 per wave) and waits on memory 56 % of its cycles (round 1); here staging is 7 DMA
 // instructions per wave and chunk (NMT = 2), two LDS buffers per workgroup.
-void conv16_up_tiles(int gh, int gw, int nw, int* tiles_x, int* tiles_y, int* tw, int* th);          // conv2d_bf16x3.hip
 
 constexpr int UP_PPIX = 9 * 33;                                           // patch capacity: (th+1) x (tw+1) <= 297
 constexpr int UP_BCH = (UP_PPIX + 63) / 64, UP_BPAD = UP_BCH * 64;        // 5 pieces = 320 slots per (hi|lo, half)
@@ -309,7 +309,7 @@ constexpr int UP_B_PIECES = 2 * 2 * UP_BCH;                               // 20
 struct ConvUpPsParams {
     const bf16x8* x; const bf16x8* wt16; float* y;
     int N, I, O, OP64, H, W, OH, OW;
-    int tiles_x, tiles_y, tiles_m, tw, th;
+    UpTilePlan plan; int tiles_m;
     int64_t xbs, ybs, yrs;       // xbs: 16-byte units; ybs floats; yrs pixels (c8 row pitch)
     const float* row_scale; int64_t row_scale_stride; float const_scale;
     int round_f16;
@@ -343,9 +343,10 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
     const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
-    const int tile_i = lb % (p.tiles_x * p.tiles_y), n = lb / (p.tiles_x * p.tiles_y);
-    const int y0 = (tile_i / p.tiles_x) * p.th, x0 = (tile_i % p.tiles_x) * p.tw;
-    const int PW = p.tw + 1, prows = p.th + 1;
+    const int tile_i = lb % p.plan.total, n = lb / p.plan.total;
+    int y0, x0, th, tw, end_y, end_x;
+    up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
+    const int PW = tw + 1, prows = th + 1;
     const int KC = p.I / 16, HW = p.H * p.W, GH = p.H + 1, GW = p.W + 1;
 
     const int plane_bytes = (p.I / 8) * HW * 16;
@@ -388,8 +389,8 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
         const int q_pos = (wn * PG + g) * 32 + l31;                       // flattened tile position of this lane
-        q_act[g] = q_pos < p.th * p.tw;
-        q_row[g] = q_act[g] ? q_pos / p.tw : 0; q_col[g] = q_act[g] ? q_pos % p.tw : 0;
+        q_act[g] = q_pos < th * tw;
+        q_row[g] = q_act[g] ? q_pos / tw : 0; q_col[g] = q_act[g] ? q_pos % tw : 0;
         b_frag[g] = half * UP_BPAD + q_row[g] * PW + q_col[g];            // + dy*PW + dx
     }
     float* s_rs = reinterpret_cast<float*>(smem + 2 * BUF);
@@ -454,7 +455,7 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
 #pragma unroll
     for (int g = 0; g < PG; ++g) {
         const int gy = y0 + q_row[g], gx = x0 + q_col[g];
-        if (!q_act[g] || gy >= GH || gx >= GW) continue;
+        if (!q_act[g] || gy >= end_y || gx >= end_x) continue;
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa) {
             const int oy = 2 * gy + pa;
@@ -507,7 +508,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     ConvUpPsParams p;
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
-    conv16_up_tiles(d->H + 1, d->W + 1, 8, &p.tiles_x, &p.tiles_y, &p.tw, &p.th);
+    { const char* e = getenv("N3D_UP_EDGE_TILES"); p.plan = up_tile_plan(d->H, d->W, !(e && atoi(e) == 0)); }      // 0: the (H+1) x (W+1) grid in uniform tiles (A/B)
     p.tiles_m = d->O / (mt == 2 ? 64 : 32);
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
@@ -516,7 +517,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.row_scale = E.row_scale; p.row_scale_stride = E.row_scale_stride ? E.row_scale_stride : d->O; p.const_scale = E.const_scale;
     p.round_f16 = E.round_f16;
     { const char* e = getenv("N3D_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
-    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
+    const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);

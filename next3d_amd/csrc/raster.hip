@@ -101,11 +101,13 @@ __global__ __launch_bounds__(256) void raster_transform_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, const int* __restrict__ faces,
+// faces_bs: ints between the face tables of consecutive images (0: one shared table); cull: cull_backfaces
+__global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, const int* __restrict__ faces_base, int64_t faces_bs, int cull,
                                                            unsigned long long* zbuf, int NV, int V, int F, int H, int W, XfParams xf) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)NV * F) return;
     const int f = (int)(i % F), nv = (int)(i / F);
+    const int* faces = faces_base + (int64_t)nv * faces_bs;
     const float* vn = tv + (int64_t)nv * V * 3;
     // the reference rasterises faces[..., [0,2,1]] (triplane_next3d.py:207): `faces` is passed already swapped
     float x0, y0, z0, x1, y1, z1, x2, y2, z2;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
     const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
-    if (zmax < 0.0f || face_area < 0.0f || zero_area) return;      // cull_backfaces=True
+    if (zmax < 0.0f || (cull && face_area < 0.0f) || zero_area) return;      // cull_backfaces (renderer.py:397: True)
     const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
     const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
     if (!(xmax >= -2.f && xmin <= 2.f && ymax >= -2.f && ymin <= 2.f)) return;   // far off-screen / NaN
@@ -471,6 +473,91 @@ __global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long* _
     else zbuf[i] = 0xFFFFFFFFFFFFFFFFull;
 }
 
+// pytorch3d.renderer.mesh.rasterize_meshes' outputs from the z-buffer (the B1 shim next3d_amd/shims/pytorch3d: the reference's own
+// Pytorch3dRasterizer.forward, vr/renderer.py:401-440, consumes them): pix_to_face = PACKED index n * F + f (-1 empty), zbuf = the
+// interpolated depth (-1 empty), bary [.,3] (-1 empty) — barycentrics recomputed with the operation order of raster_faces_kernel.
+__global__ __launch_bounds__(256) void raster_meshes_resolve_kernel(const float* tv, const int* __restrict__ faces_base, int64_t faces_bs,
+                                                                    const unsigned long long* zbuf, long long* __restrict__ pix_to_face,
+                                                                    float* __restrict__ zout, float* __restrict__ bary, int N, int V, int F, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * H * W) return;
+    const int xi = (int)(i % W), yi = (int)((i / W) % H), n = (int)(i / ((int64_t)H * W));
+    const unsigned long long key = ld_agent(zbuf + i);
+    long long pf = -1; float z = -1.f, b0 = -1.f, b1 = -1.f, b2 = -1.f;
+    if (key != 0xFFFFFFFFFFFFFFFFull) {
+        const int f = (int)(key & 0xFFFFFFFFull);
+        const int* faces = faces_base + (int64_t)n * faces_bs;
+        const float* vn = tv + (int64_t)n * V * 3;
+        const float* a = vn + 3 * (int64_t)ld_tab(faces + 3 * f + 0), *b = vn + 3 * (int64_t)ld_tab(faces + 3 * f + 1), *c = vn + 3 * (int64_t)ld_tab(faces + 3 * f + 2);
+        const float ax = ld_vert(a), ay = ld_vert(a + 1), bx = ld_vert(b), by = ld_vert(b + 1), cx = ld_vert(c), cy = ld_vert(c + 1);
+        const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
+        const float area = edge_fn(cx, cy, ax, ay, bx, by) + K_EPS;
+        b0 = edge_fn(xf, yf, bx, by, cx, cy) / area;
+        b1 = edge_fn(xf, yf, cx, cy, ax, ay) / area;
+        b2 = edge_fn(xf, yf, ax, ay, bx, by) / area;
+        z = __uint_as_float((unsigned)(key >> 32));
+        pf = (long long)n * F + f;
+    }
+    pix_to_face[i] = pf; zout[i] = z;
+    bary[i * 3 + 0] = b0; bary[i * 3 + 1] = b1; bary[i * 3 + 2] = b2;
+}
+
+// cv2.floodFill(img, mask, seed = (0, 0), new_val, lo, up, FLOODFILL_FIXED_RANGE) on float32 images of up to 256 x 256, in place
+// (the B1 shim next3d_amd/shims/cv2; the reference's call: vr/renderer.py:593): the bit-parallel flood of fill_holes_kernel with the
+// plain cv2 write-back — every pixel 4-connected to the seed through values in [seed - lo, seed + up] becomes new_val.
+__global__ __launch_bounds__(1024) void flood_fill_kernel(float* __restrict__ imgs, int H, int W, float new_val, float lo, float up) {
+    __shared__ unsigned long long s_t[256][FH_WORDS];
+    float* a = imgs + (int64_t)blockIdx.x * H * W;
+    const int tid = threadIdx.x, t = tid & 255, q = tid >> 8;
+    const float seed = a[0];
+    const float vmin = seed - lo, vmax = seed + up;
+    for (int y0 = 0; y0 < 256; y0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int y = y0 + 4 * j + q; v[j] = (y < H && t < W) ? a[(int64_t)y * W + t] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = y0 + 4 * j + q;
+            const unsigned long long word = __ballot(y < H && t < W && v[j] >= vmin && v[j] <= vmax);
+            if ((t & 63) == 0) s_t[y][t >> 6] = word;
+        }
+    }
+    __syncthreads();
+    const bool fl = tid < 256;
+    unsigned long long pr[FH_WORDS] = {0, 0, 0, 0}, pc[FH_WORDS] = {0, 0, 0, 0}, rpr[FH_WORDS], rpc[FH_WORDS];
+    if (fl) {
+#pragma unroll
+        for (int w = 0; w < FH_WORDS; ++w) pr[w] = s_t[t][w];
+        if (t == 0) pr[0] |= 1ull;
+    }
+    __syncthreads();
+    transpose256(pr, pc, s_t, t, fl);
+#pragma unroll
+    for (int w = 0; w < FH_WORDS; ++w) { rpr[w] = pr[w]; rpc[w] = pc[w]; }
+    rev256(rpr); rev256(rpc);
+    unsigned long long rr[FH_WORDS] = {(fl && t == 0) ? 1ull : 0ull, 0, 0, 0};
+    for (int iter = 0; iter < 1024; ++iter) {
+        unsigned long long rc[FH_WORDS] = {0, 0, 0, 0}, back[FH_WORDS] = {0, 0, 0, 0};
+        if (fl) flood_line(pr, rpr, rr);
+        transpose256(rr, rc, s_t, t, fl);
+        if (fl) flood_line(pc, rpc, rc);
+        transpose256(rc, back, s_t, t, fl);
+        bool changed = false;
+#pragma unroll
+        for (int w = 0; w < FH_WORDS; ++w) { changed |= (back[w] & ~rr[w]) != 0; rr[w] |= back[w]; }
+        if (!__syncthreads_or(fl && changed)) break;
+    }
+    if (fl) {
+#pragma unroll
+        for (int w = 0; w < FH_WORDS; ++w) s_t[t][w] = rr[w];
+    }
+    __syncthreads();
+    for (int e = tid; e < H * W; e += 1024) {
+        const int y = e / W, x = e % W;
+        if ((s_t[y][x >> 6] >> (x & 63)) & 1ull) a[e] = new_val;
+    }
+}
+
 extern "C" {
 
 int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, const int* faces, const float* face_uv,
@@ -495,7 +582,7 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
     N3D_LAUNCH_CHECK();
     const XfParams xf = {verts, rot, V, views, shift_x, shift_y, shift_z, scale};
     hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)cdiv64((int64_t)NV * F, 256)), dim3(256), 0, stream, (const float*)tv_ws,
-                       faces, zbuf_ws, NV, V, F, H, W, xf);
+                       faces, (int64_t)0, 1, zbuf_ws, NV, V, F, H, W, xf);
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)cdiv64((int64_t)NV * H * W, 256)), dim3(256), 0, stream,
                        (const float*)tv_ws, faces, face_uv, (const unsigned long long*)zbuf_ws, uv_mask, mask_h, mask_w, grid, alpha,
@@ -505,6 +592,37 @@ int n3d_rasterize_views(const float* verts, const float* lms, const float* rot, 
         hipLaunchKernelGGL(fill_holes_kernel, dim3(NV), dim3(1024), 0, stream, alpha, H, W, binarize_view, views);
         N3D_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int n3d_rasterize_meshes(const float* verts_ndc, const int* faces, int64_t faces_batch_stride, unsigned long long* zbuf_ws, long long* pix_to_face,
+                         float* zbuf, float* bary, int N, int V, int F, int H, int W, int cull_backfaces, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && V > 0 && F > 0 && H > 0 && W > 0 && H == W, "rasterize_meshes: bad shape (square images)");
+    if (N == 0) return 0;
+    N3D_CHECK(verts_ndc && faces && zbuf_ws && pix_to_face && zbuf && bary, "rasterize_meshes: null tensor");
+    N3dProfScope prof(N3D_K_RASTER, stream, 0.0, 4.0 * N * (double)H * W * 8);
+    hipLaunchKernelGGL(raster_clear_kernel, dim3((unsigned)cdiv64((int64_t)N * H * W, 256)), dim3(256), 0, stream, zbuf_ws, (int64_t)N * H * W);
+    N3D_LAUNCH_CHECK();
+    const XfParams xf = {verts_ndc, nullptr, V, 1, 0.f, 0.f, 0.f, 1.f};    // (only read by the RASTER_VARIANT & 16 probe build)
+    hipLaunchKernelGGL(raster_faces_kernel, dim3((unsigned)cdiv64((int64_t)N * F, 256)), dim3(256), 0, stream, verts_ndc, faces, faces_batch_stride,
+                       cull_backfaces ? 1 : 0, zbuf_ws, N, V, F, H, W, xf);
+    N3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_meshes_resolve_kernel, dim3((unsigned)cdiv64((int64_t)N * H * W, 256)), dim3(256), 0, stream, verts_ndc, faces,
+                       faces_batch_stride, (const unsigned long long*)zbuf_ws, pix_to_face, zbuf, bary, N, V, F, H, W);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_flood_fill(float* images, int N, int H, int W, float new_val, float lo_diff, float up_diff, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && H > 0 && W > 0 && H <= 256 && W <= 256, "flood_fill: images of up to 256 x 256");
+    N3D_CHECK(lo_diff >= 0.f && up_diff >= 0.f, "flood_fill: lo_diff / up_diff must be >= 0");
+    if (N == 0) return 0;
+    N3D_CHECK(images, "flood_fill: null tensor");
+    N3dProfScope prof(N3D_K_RASTER, stream, 0.0, 8.0 * N * (double)H * W);
+    hipLaunchKernelGGL(flood_fill_kernel, dim3(N), dim3(1024), 0, stream, images, H, W, new_val, lo_diff, up_diff);
+    N3D_LAUNCH_CHECK();
     return 0;
 }
 

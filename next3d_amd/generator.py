@@ -132,6 +132,7 @@ class TriPlaneGenerator(torch.nn.Module):
         self._last_planes = None
         self._identity_cache = None
         self._param_stamp = None
+        self._graphs = None             # captured HIP graphs (synthesis_graph): they hold pointers into the prepared weights and caches
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -234,7 +235,7 @@ class TriPlaneGenerator(torch.nn.Module):
     def raster_geometry(self, v, lms):
         """The texture-independent half of `rasterize` (reference triplane_next3d.py:190-222): z-buffer the four orthographic
         views of the mesh -> (uv sampling grid [N*4,256,256,2], alpha [N,3,256,256], mouth box [N,4] int32).  It depends only
-        on the vertices; `_planes` runs it first, before any other stream is active."""
+        on the vertices, so `_planes` runs it first."""
         S = self._prep()
         dev, N, V, Lm, F = v.device, v.shape[0], v.shape[1], lms.shape[1], S.faces.shape[0]
         views, H, W = len(RENDERING_VIEWS), 256, 256
@@ -291,10 +292,11 @@ class TriPlaneGenerator(torch.nn.Module):
         N = ws.shape[0]
         nw = S.texture.num_ws
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
-        # The mesh rasterisation depends only on the vertices and runs FIRST, alone: its z-buffer is built with 64-bit
-        # atomicMin, and on this stack those atomics were observed to get lost (whole faces missing, different ones every run)
-        # whenever the 8-wave split-bf16 convolution kernels of ANOTHER stream are resident at the same time — so no other
-        # stream may be active while it runs (tools/dbg_race2.py reproduces it).
+        # The mesh rasterisation depends only on the vertices and runs first.  (Round 1 saw its results change from run to run while
+        # 8-wave split-bf16 convolution workgroups of ANOTHER stream shared the CUs; round 2 bisected that to vector-L1-served gather
+        # loads of the vertex / face tables — not to atomics — and the kernels now read those tables with agent-scope loads, which
+        # made 36 of 36 co-resident runs clean: DESIGN.md §3.3, tests/test_path_kernels_gpu.py::test_rasteriser_reproducible_under_
+        # coresident_convolutions.  No stream rule is needed any more.)
         grid, alpha, bbox = self.raster_geometry(v, lms)
         # The static tri-plane backbone depends only on the latents: it runs on a second HIP stream so that its low-resolution
         # layers (a handful of workgroups each) overlap the texture -> mouth -> blending chain.
@@ -403,6 +405,56 @@ class TriPlaneGenerator(torch.nn.Module):
         sr_fp16 = self.sr_use_fp16 and not synthesis_kwargs.get('force_fp32', False)
         sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
+
+    # ------------------------------------------------------------------ HIP-graph replay of the steady-state loops
+    def synthesis_graph(self, ws, c, v, **synthesis_kwargs):
+        """`synthesis(ws, c, v, **kw)` through a captured HIP graph: the first call with a given signature — tensor shapes, render
+        resolution, sample counts, cache flags, precision switches — runs the forward eagerly twice (prepared weights, job tables,
+        caches), captures it once with static input / scratch / output buffers, and every call (the first included) copies
+        (ws, c, v) [+ depth_jitter / importance_u when given] into the static inputs and REPLAYS the graph: one host call instead of
+        ~155 ctypes launches per frame.  Meant for the loops that call synthesis with a fixed signature — the camera orbit of
+        gen_videos_next3d.py:126-158 (`use_cached_backbone=True`), the reenactment loop of reenact_avatar_next3d.py:139-164
+        (`use_cached_identity=True`), single-frame latency at batch 1.  The returned tensors are the graph's static outputs: consume
+        (or clone) them before the next replay.  `cache_backbone` / `cache_identity` (WRITE flags) are refused — fill the caches with
+        an eager call first; a parameter update drops the graphs (`_drop_derived`)."""
+        if synthesis_kwargs.get('cache_backbone') or synthesis_kwargs.get('cache_identity'):
+            raise RuntimeError('synthesis_graph: fill the caches with an eager synthesis(..., cache_backbone / cache_identity=True) call first')
+        self._check_params()
+        self._prep()
+        rk = self.rendering_kwargs
+        tensors = {k: synthesis_kwargs[k] for k in ('depth_jitter', 'importance_u') if synthesis_kwargs.get(k) is not None}
+        plain = {k: val for k, val in synthesis_kwargs.items() if k not in tensors}
+        sig = (tuple(ws.shape), tuple(c.shape), tuple(v.shape), tuple((k, tuple(t.shape)) for k, t in sorted(tensors.items())),
+               tuple(sorted((k, repr(val)) for k, val in plain.items())), plain.get('neural_rendering_resolution') or self.neural_rendering_resolution,
+               rk['depth_resolution'], rk['depth_resolution_importance'], rk.get('superresolution_noise_mode', 'none'), layers.PRECISION,
+               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, os.environ.get('N3D_SR_FP16', 'native'), self.overlap_static,
+               id(self._last_planes), id(self._identity_cache))
+        if self._graphs is None:
+            self._graphs = {}
+        entry = self._graphs.get(sig)
+        if entry is None:
+            dev = self.device
+            _require_hip(dev)
+            st = dict(ws=ws.to(dev, torch.float32).clone(), c=c.to(dev, torch.float32).clone(), v=v.to(dev, torch.float32).clone())
+            st.update({k: t.to(dev).clone() for k, t in tensors.items()})
+            call = lambda: self.synthesis(st['ws'], st['c'], st['v'], **plain, **{k: st[k] for k in tensors})
+            cur = torch.cuda.current_stream()
+            warm = torch.cuda.Stream(device=dev)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):                  # eager warm-up off the default stream, as graph capture wants it
+                call(); call()
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = call()
+            entry = self._graphs[sig] = (graph, st, out)
+        graph, st, out = entry
+        st['ws'].copy_(ws); st['c'].copy_(c); st['v'].copy_(v)
+        for k, t in tensors.items():
+            st[k].copy_(t)
+        graph.replay()
+        return out
 
     def sample_mixed(self, coordinates, directions, ws, v, truncation_psi=1, truncation_cutoff=None, update_emas=False,
                      cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):

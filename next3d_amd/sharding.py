@@ -38,15 +38,19 @@ class AsyncFrameGather:
     receive buffers on `dst` are never the target of two collectives at once; `drain()` waits for the last one.
     `received` (on dst, after drain / the next submit) = list of the ranks' frame batches of the most recent completed step."""
 
-    def __init__(self, like, dst=0, group=None):
+    def __init__(self, like, dst=0, group=None, single_rank_collective=False):
+        """single_rank_collective: with one rank, still issue the gather when a process group exists (a 1-rank RCCL gather is a
+        valid collective): lets a 1-GPU box execute the N > 1 code path — process-group init, gather on RCCL's stream, drain."""
         self.dst, self.group = dst, group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
-        self.received = [torch.empty_like(like) for _ in range(self.world)] if (self.world > 1 and self.rank == dst) else None
+        init = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if init else 1
+        self.active = init and (self.world > 1 or single_rank_collective)
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.received = [torch.empty_like(like) for _ in range(self.world)] if (self.active and self.rank == dst) else None
         self._pending = None
 
     def submit(self, frames):
-        if self.world == 1:
+        if not self.active:
             return
         self.drain()
         work = dist.gather(frames, self.received, dst=self.dst, group=self.group, async_op=True)

@@ -17,10 +17,29 @@ import torch
 REF = '/root/reference'
 
 
-def install(uv_face_mask_np):
+def install(uv_face_mask_np, third_party=True):
     """Register stub modules and put the reference on sys.path.  `uv_face_mask_np`: [H,W] float in [0,1]
-    returned (as a 3-channel uint8 image) by the stubbed cv2.imread (triplane_next3d.py:91)."""
+    returned (as a 3-channel uint8 image) by the stubbed cv2.imread (triplane_next3d.py:91).
+    third_party=False: leave `cv2` / `pytorch3d` alone (the caller registers next3d_amd.shims for them: the B1 dry run of
+    tests/test_cpu_orchestration.py) and install only the import-time stubs (pydantic.NoneStr, turtle, torchvision, mrcfile, imageio)."""
     from . import raster
+    if not third_party:
+        import pydantic
+        pydantic.__dict__['NoneStr'] = type(None)
+        sys.modules.setdefault('turtle', types.ModuleType('turtle'))
+        sys.modules['turtle'].update = lambda *a, **k: None
+        tv = types.ModuleType('torchvision')
+        tvu = types.ModuleType('torchvision.utils')
+        tvu.save_image = lambda *a, **k: None
+        tvt = types.ModuleType('torchvision.transforms')
+        tv.utils, tv.transforms = tvu, tvt
+        sys.modules.update({'torchvision': tv, 'torchvision.utils': tvu, 'torchvision.transforms': tvt})
+        for name in ('mrcfile', 'imageio'):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        os.chdir(REF)
+        return
 
     import pydantic
     pydantic.__dict__['NoneStr'] = type(None)      # pydantic 2 removed it; dnnlib/util.py:26 imports it

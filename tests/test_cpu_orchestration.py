@@ -185,3 +185,52 @@ def test_operator_layer_dtype_handling_dry_run(dry):
                 lambda: filtered_lrelu.filtered_lrelu(x.to(torch.bfloat16))):
         with pytest.raises(RuntimeError):
             bad()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
+def test_unreloaded_reference_generator_runs_on_op_layer_and_third_party_shims_dry_run():
+    """Boundary B1 end to end: the REFERENCE's own TriPlaneGenerator — constructed, not reloaded — with
+    install_dropin(third_party=True): its `torch_utils.ops.*`, `pytorch3d.{io.load_obj, structures.Meshes, renderer.mesh.rasterize_meshes}`
+    and `cv2.{imread, floodFill}` all resolve to this package, and one full `synthesis` (its Python: rasterize -> Pytorch3dRasterizer.forward
+    -> fill_mouth -> mouth crop / paste -> StyleUNets -> renderer -> super-resolution, float16 blocks included) runs against the
+    recording stand-in of libn3d.so: every call is accepted and marshalled (no arithmetic here; the shims' kernels are checked
+    bit for bit on the GPU, tests/test_path_kernels_gpu.py::test_third_party_shims_*)."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from collections import Counter
+from next3d_amd import mesh, spec, demo
+from oracle import ref_shims
+mask = mesh.synthetic_uv_face_mask()
+ref_shims.install(mask[0, 0].numpy(), third_party=False)
+import next3d_amd
+next3d_amd.install_dropin(third_party=True)
+import cv2, pytorch3d
+assert cv2.__name__ == 'next3d_amd.shims.cv2' and pytorch3d.__name__ == 'next3d_amd.shims.pytorch3d'
+cv2.imread = lambda path, *a: np.stack([(mask[0, 0].numpy() * 255).round().astype(np.uint8)] * 3, -1)     # data/ffhq/uv_face_eye_mask.png is not in the tree
+cv2._device = lambda: torch.device('cpu')
+import _dryrun
+pts, calls = _dryrun.patches()
+for obj, attr, val in pts:
+    setattr(obj, attr, val)
+_empty = torch.empty
+torch.empty = lambda *a, **k: _empty(*a, **k).zero_()          # un-launched kernels leave their outputs untouched: keep gather indices valid
+from oracle.pin_against_reference import RENDERING_KWARGS
+G = ref_shims.build_reference_generator(dict(RENDERING_KWARGS, depth_resolution=12, depth_resolution_importance=12))
+import training_avatar_texture.volumetric_rendering.renderer as vr
+assert vr.rasterize_meshes.__module__.startswith('next3d_amd.shims') and vr.Meshes.__module__.startswith('next3d_amd.shims') and vr.cv2 is cv2
+z, c, c_cond, v = demo.demo_batch([0, 1])
+with torch.no_grad():
+    ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+    calls.clear()
+    out = G.synthesis(ws, c, v, neural_rendering_resolution=32, noise_mode='const')
+cnt = Counter(calls)
+assert tuple(out['image'].shape) == (2, 3, 512, 512) and tuple(out['image_raw'].shape) == (2, 3, 32, 32)
+assert cnt['n3d_rasterize_meshes'] == 4 and cnt['n3d_flood_fill'] == 4 * 2, cnt          # 4 views; fill_mouth loops over the batch
+assert cnt['n3d_conv2d'] + cnt['n3d_conv2d_bf16x3'] > 60 and cnt['n3d_upfirdn2d'] + cnt['n3d_upfirdn2d_pitched'] > 20, cnt
+print('B1_DRY_RUN_OK', sum(cnt.values()))
+""" % (repo, os.path.join(repo, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'B1_DRY_RUN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -40,8 +40,8 @@ def _check_f16(name, got, ref, max_frac=0.02, pre=None, pre_gain=1.0):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     d = (got - ref).abs()
     slack = 2.0 ** -19 * float(ref.abs().max())
-    if pre is not None:
-        slack = slack + pre_gain * _ulp16(_q(pre.detach().cpu().float()))
+    for t in (pre if isinstance(pre, (list, tuple)) else ([] if pre is None else [pre])):     # every intermediate float16 rounding in front of x + b
+        slack = slack + pre_gain * _ulp16(_q(t.detach().cpu().float()))
     ulps = (d - slack).clamp_min(0) / _ulp16(ref)
     frac = float((d > 0).float().mean())
     print(f'{name}: max ulp {float(ulps.max()):.2f}, differing fraction {frac:.2e}, absmax {float(ref.abs().max()):.3g}')
@@ -127,11 +127,11 @@ def test_conv2d_f16_stride1(dev, N, I, O, H, W, nbuf, noise):
         y = layers.conv2d_f16(_lib.H8.from_nchw(x.to(dev)), wt, O, 0, epi)
     finally:
         del os.environ['N3D_F16_NBUF']
-    _check_f16(f'conv2d_f16 stride 1 {N}x{I}->{O} {H}x{W}', y.to_float(), ref, pre=pre, pre_gain=(2 if noise else 1) * float(np.sqrt(2)))
+    _check_f16(f'conv2d_f16 stride 1 {N}x{I}->{O} {H}x{W}', y.to_float(), ref, pre=[pre, _q(pre) + nz * nstr] if noise else pre, pre_gain=float(np.sqrt(2)))
 
 
 @pytest.mark.parametrize('variant', [0, 1, 2])
-@pytest.mark.parametrize('N,I,O,H,W', [(2, 32, 64, 16, 16), (1, 64, 128, 33, 40), (1, 128, 64, 64, 64), (2, 16, 64, 4, 7)])
+@pytest.mark.parametrize('N,I,O,H,W', [(2, 32, 64, 16, 16), (1, 64, 128, 33, 40), (1, 128, 64, 64, 64), (2, 16, 64, 4, 7), (1, 32, 64, 72, 160)])
 def test_conv2d_f16_transposed(dev, variant, N, I, O, H, W):
     x, w, s = _q(_g((N, I, H, W), 8)), _g((O, I, 3, 3), 9), _g((N, I), 10) + 1.0
     w16 = _ref_modulated_weights(w, s, True)
@@ -163,7 +163,7 @@ def test_fir4_h8(dev, N, C, H, W, noise):
             yh = layers.fir4_h8(_lib.H8.from_nchw(z.to(dev)), f_d, epi)
         finally:
             del os.environ['N3D_FIR_SEP']
-        _check_f16(f'fir4_h8 sep={sep} {N}x{C} {H}x{W}', yh.to_float(), ref, pre=y32, pre_gain=(2 if noise else 1) * float(np.sqrt(2)))
+        _check_f16(f'fir4_h8 sep={sep} {N}x{C} {H}x{W}', yh.to_float(), ref, pre=[y32, _q(y32) + nz * nstr] if noise else y32, pre_gain=float(np.sqrt(2)))
 
 
 def test_modulate_weights_f16_multi_equals_single(dev):

@@ -194,9 +194,9 @@ def test_plane_and_identity_caches(G, dev):
 @pytest.mark.gpu
 def test_pipelined_steps_are_bitwise_reproducible(G, dev):
     """Six forwards issued back to back WITHOUT host synchronisation (the bench / video-loop pattern, static backbone on its
-    side stream) must all return the same bits.  Guards the stream choreography: the atomicMin z-buffer of the rasteriser
-    used to lose updates when 8-wave split-bf16 conv kernels of another stream were resident (the table loads
-    are agent-scope now)."""
+    side stream) must all return the same bits.  Guards the stream choreography: the rasteriser used to return different
+    faces from run to run while 8-wave split-bf16 conv kernels of another stream were resident — bisected to L1-served gather
+    loads of its vertex / face tables, which are agent-scope loads now."""
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48.npz'))
     N, R, Sc, Sf = d['z'].shape[0], 32, 24, 24
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
@@ -260,3 +260,70 @@ def test_packed_mesh_sequence_streams_to_device(dev, tmp_path):
     got = [b.clone() for b in seq.batches(3, dev)]
     assert [g.shape[0] for g in got] == [3, 3, 1] and all(g.is_cuda for g in got)
     assert torch.equal(torch.cat(got, 0).cpu(), torch.from_numpy(frames))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_multi_gpu_path_on_one_gpu():
+    """The N > 1 path of bench.py — `torch.distributed.run` launch line of the driver, RCCL ('nccl') process group, the per-step
+    asynchronous uint8 frame gather on RCCL's stream, barrier + max-over-ranks timing — executed on hardware with world size 1
+    (N3D_BENCH_FORCE_DIST=1): the only thing a 1-GPU box cannot show is the scaling number itself."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, N3D_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(repo, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--prewarm-seconds', '0.2', '--no-cpu-baseline', '--no-roofline', '--no-extras']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=repo, timeout=540)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    print(line['value'], line['config']['gather'])
+    assert line['n_gpus'] == 1 and line['config']['gather'].startswith('RCCL') and line['frames_bitwise_reproducible'] and line['value'] > 20
+
+
+@pytest.mark.gpu
+def test_synthesis_graph_replay_is_bit_identical(G, dev):
+    """synthesis_graph (HIP-graph capture + replay) against the eager call on the same inputs: the full forward at
+    batch 2, new inputs through the SAME captured graph, the cached camera orbit (use_cached_backbone) and the reenactment pattern
+    (use_cached_identity, a new mesh per frame) — identical bits every time."""
+    from next3d_amd import layers
+    layers.set_precision('bf16x3')
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48.npz'))
+    N, R, Sc, Sf = d['z'].shape[0], int(d['R']), int(d['Sc']), int(d['Sf'])
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = (t.to(dev) for t in cases.rng_inputs(N, R, Sc, Sf))
+    ws = G.mapping(torch.from_numpy(d['z']).to(dev), torch.from_numpy(d['c_cond']).to(dev), truncation_psi=0.7, truncation_cutoff=14)
+    c, v = torch.from_numpy(d['c']).to(dev), torch.from_numpy(d['v']).to(dev)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+    G.refresh()
+    for force32 in (True, False):                                     # the float32 route and the default float16 super-resolution route
+        eager = {k: t.clone() for k, t in G.synthesis(ws, c, v, force_fp32=force32, **kw).items()}
+        out = G.synthesis_graph(ws, c, v, force_fp32=force32, **kw)
+        assert all(torch.equal(out[k], eager[k]) for k in eager), [k for k in eager if not torch.equal(out[k], eager[k])]
+        c2 = c.flip(0).contiguous()                                   # other cameras, other latents through the same graph
+        ws2 = ws.flip(0).contiguous()
+        eager2 = G.synthesis(ws2, c2, v, force_fp32=force32, **kw)['image'].clone()
+        assert torch.equal(G.synthesis_graph(ws2, c2, v, force_fp32=force32, **kw)['image'], eager2)
+        assert torch.equal(G.synthesis_graph(ws, c, v, force_fp32=force32, **kw)['image'], eager['image'])
+    assert len(G._graphs) == 2
+    # camera orbit on cached planes
+    G.synthesis(ws, c, v, cache_backbone=True, force_fp32=True, **kw)
+    for cam in (c, c2, c):
+        e = G.synthesis(ws, cam, v, use_cached_backbone=True, force_fp32=True, **kw)['image'].clone()
+        assert torch.equal(G.synthesis_graph(ws, cam, v, use_cached_backbone=True, force_fp32=True, **kw)['image'], e)
+    # reenactment: cached identity, a new mesh per frame
+    G.synthesis(ws, c, v, cache_identity=True, force_fp32=True, **kw)
+    gq = torch.Generator(device=dev).manual_seed(3)
+    for k in range(3):
+        vk = v + 2e-4 * torch.randn(v.shape, device=dev, generator=gq)
+        e = G.synthesis(ws, c, vk, use_cached_identity=True, force_fp32=True, **kw)['image'].clone()
+        assert torch.equal(G.synthesis_graph(ws, c, vk, use_cached_identity=True, force_fp32=True, **kw)['image'], e)
+    with pytest.raises(RuntimeError):
+        G.synthesis_graph(ws, c, v, cache_backbone=True, **kw)
+    G.refresh()
+    assert G._graphs is None

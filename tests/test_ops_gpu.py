@@ -634,7 +634,7 @@ def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
     assert float((t[:, 0] - hi_expected).abs().max()) <= float(ref.abs().max()) * 2.0 ** -7      # hi is the bf16 rounding of the value
 
 
-@pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 128, 64, 64), (2, 64, 64, 33, 40), (4, 32, 256, 128, 128)])
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 128, 64, 64), (2, 64, 64, 33, 40), (4, 32, 256, 128, 128), (2, 32, 64, 72, 96)])
 def test_transposed_conv_channel_interleaved_output(dev, monkeypatch, N, I, OC, H, W):
     """The transposed split-bf16 kernel writing the c8 layout (what the FIR of the pre-split path reads) returns the same
     numbers as its NCHW output, bit for bit."""
@@ -657,3 +657,7 @@ def test_transposed_conv_channel_interleaved_output(dev, monkeypatch, N, I, OC, 
         monkeypatch.setenv('N3D_UP_PS_MT', mt)
         alt = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
         assert torch.equal(alt.to_nchw(), ps.to_nchw()), mt
+    monkeypatch.delenv('N3D_UP_PS_MT')
+    monkeypatch.setenv('N3D_UP_EDGE_TILES', '0')                          # the (H+1) x (W+1) position grid in uniform tiles instead of H x W + thin edge tiles
+    alt = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
+    assert torch.equal(alt.to_nchw(), ps.to_nchw())
