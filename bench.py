@@ -109,14 +109,12 @@ def spawn_selftest():
 
 def orbit_cameras(frames, device):
     """gen_videos_next3d.py:133-137: yaw / pitch walk of the camera over `frames` frames -> [frames, 25]."""
-    from next3d_amd import camera_utils
-    piv = torch.tensor([0, 0, 0.2], dtype=torch.float32)
-    K = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]])
+    from next3d_amd import demo
     out = []
     for k in range(frames):
-        cam = camera_utils.LookAtPoseSampler.sample(3.14 / 2 + 0.35 * math.sin(2 * 3.14 * k / (frames // 2)),
-                                                    3.14 / 2 - 0.05 + 0.25 * math.cos(2 * 3.14 * k / (frames // 2)), piv, radius=2.7)
-        out.append(torch.cat([cam.reshape(-1, 16), K.reshape(-1, 9)], 1))
+        az = 3.14 / 2 + 0.35 * math.sin(2 * 3.14 * k / (frames // 2))                 # the script's own 3.14
+        po = 3.14 / 2 - 0.05 + 0.25 * math.cos(2 * 3.14 * k / (frames // 2))
+        out.append(demo.camera_label(az - math.pi / 2, po - math.pi / 2, focal=4.2647))       # gen_videos_next3d.py:97
     return torch.cat(out, 0).to(device)
 
 

@@ -7,6 +7,7 @@ the library is built ahead of time by `python -m next3d_amd.build` and loaded on
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -126,7 +127,14 @@ def lib():
     return _lib
 
 
+_tls = threading.local()
+
+
 def check(rc):
+    """Result check of an entry point — and the end of the keep-alive window of `ptr()` (below): by now the launch is enqueued."""
+    held = getattr(_tls, 'held', None)
+    if held:
+        held.clear()
     if rc != 0:
         raise RuntimeError('libn3d: ' + lib().n3d_last_error().decode())
 
@@ -138,7 +146,19 @@ def stream():
 
 
 def ptr(t):
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device pointer of `t` for a C-ABI call.  Every tensor whose pointer crosses the boundary is HELD until the launch that
+    takes it has been enqueued (`check()` releases the list): a temporary passed straight to an entry point —
+    `fn(ptr(a.contiguous()), ptr(b.contiguous()))` — would otherwise be freed as soon as its pointer is taken, and the NEXT
+    temporary of the same argument list could be carved out of the same block and overwrite it before the kernel is even launched.
+    After the enqueue the caching allocator's stream ordering protects the block (it is only re-used by later work of the same
+    stream).  One mechanism instead of a hand-kept `x = x.contiguous()` discipline at every call site."""
+    if t is None:
+        return None
+    held = getattr(_tls, 'held', None)
+    if held is None:
+        held = _tls.held = []
+    held.append(t)
+    return c_void_p(t.data_ptr())
 
 
 def require_device(*tensors):

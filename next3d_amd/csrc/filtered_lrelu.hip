@@ -35,8 +35,10 @@ __global__ __launch_bounds__(FLR_NT) void filtered_lrelu_kernel(FlrParams p) {
     float* s_fu = s_mid + p.MH * p.MW;                    // [fuh][fuw], stored so that tap t multiplies sample (pos + t)
     float* s_fd = s_fu + p.fuh * p.fuw;
     const int tid = threadIdx.x;
-    const int tx_i = blockIdx.x % p.tiles_x, ty_i = blockIdx.x / p.tiles_x;
-    const int nc = blockIdx.y, c = nc % p.C;
+    // 1-D grid (N * C planes x tiles: no 65535 limit on the plane count)
+    const int tiles = p.tiles_x * p.tiles_y, tile = (int)(blockIdx.x % tiles);
+    const int tx_i = tile % p.tiles_x, ty_i = tile / p.tiles_x;
+    const int nc = (int)(blockIdx.x / tiles), c = nc % p.C;
     const int oy0 = ty_i * FLR_TH, ox0 = tx_i * FLR_TW;
     const int my0 = oy0 * p.down, mx0 = ox0 * p.down;     // top-left intermediate sample of the tile
     const int iy0 = floordiv(my0 - p.py0, p.up), ix0 = floordiv(mx0 - p.px0, p.up);   // first input sample any tap can reach
@@ -96,7 +98,7 @@ extern "C" int n3d_filtered_lrelu(const float* x, const float* fu, const float* 
     p.OH = (mid_h - fdh + down) / down; p.OW = (mid_w - fdw + down) / down;
     if (N == 0) return 0;
     N3D_CHECK(x && y, "filtered_lrelu: null tensor");
-    N3D_CHECK((int64_t)N * C < 65536, "filtered_lrelu: N*C exceeds the grid's y dimension");
+    N3D_CHECK((int64_t)N * C * cdiv(p.OW, FLR_TW) * cdiv(p.OH, FLR_TH) < (1ll << 31), "filtered_lrelu: grid too large");
     p.x = x; p.fu = fu; p.fd = fd; p.b = b; p.y = y;
     p.N = N; p.C = C; p.H = H; p.W = W;
     p.up = up; p.down = down; p.fuh = fuh; p.fuw = fuw; p.fdh = fdh; p.fdw = fdw; p.px0 = px0; p.py0 = py0;
@@ -109,7 +111,7 @@ extern "C" int n3d_filtered_lrelu(const float* x, const float* fu, const float* 
     const double taps = (double)((fuh + up - 1) / up) * ((fuw + up - 1) / up);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * ((double)mid_h * mid_w * taps + (double)p.OH * p.OW * fdh * fdw),
                       4.0 * N * C * ((double)H * W + (double)p.OH * p.OW));
-    hipLaunchKernelGGL(filtered_lrelu_kernel, dim3(p.tiles_x * p.tiles_y, N * C), dim3(FLR_NT), lds, stream, p);
+    hipLaunchKernelGGL(filtered_lrelu_kernel, dim3((unsigned)((int64_t)p.tiles_x * p.tiles_y * N * C)), dim3(FLR_NT), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -100,7 +100,8 @@ def test_filters_padding_and_ksplit():
 
 
 def test_camera_and_mesh_helpers():
-    from next3d_amd import camera_utils, demo, mesh
+    from next3d_amd import demo, mesh
+    camera_utils = demo
     g = np.load(os.path.join(GOLDEN, 'case_r32_s24.npz'))
     c, c_cond = camera_utils.demo_camera_params(angle_y=0.4)
     assert np.abs(c.numpy() - g['c']).max() <= 1e-6 and np.abs(c_cond.numpy() - g['c_cond']).max() <= 1e-6

@@ -318,7 +318,7 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
     on random tri-planes: 48+48 (the headline configuration), 24+24, 96+96 (gen_videos' sampling multiplier 2), coarse only,
     and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star); the importance pass is
     discontinuous in the coarse weights, so at most 1 % of the rays may exceed it."""
-    from next3d_amd import _lib, camera_utils
+    from next3d_amd import _lib, demo as camera_utils
     N = 2
     planes = _gen((N, 3, 32, PH, PW), 60 + R, 2.0)
     P, (w1, b1, w2t, b2) = _decoder(61)
@@ -357,7 +357,7 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
 
 def test_render_rays_one_ray_per_wave_variant(dev, monkeypatch):
     """N3D_RENDER_RPW=1 (one ray per wave, two waves per SIMD, no texel prefetch) renders the same image as the default."""
-    from next3d_amd import _lib, camera_utils
+    from next3d_amd import _lib, demo as camera_utils
     N, R, Sc, Sf, PH, PW = 2, 9, 48, 48, 32, 32
     planes = _gen((N, 3, 32, PH, PW), 70, 2.0)
     P, (w1, b1, w2t, b2) = _decoder(71)
@@ -379,7 +379,7 @@ def test_render_rays_empty_space(dev):
     """Zero density everywhere: all weights are 0, the composite colour is 0 (-> -1 after rgb*2-1), the depth is 0/0 ->
     nan_to_num(inf) -> clamped to the GLOBAL maximum sample depth of the batch (ray_marcher.py:52-54; the kernel's
     depth-bounds pre-pass), identically for every ray."""
-    from next3d_amd import _lib, camera_utils
+    from next3d_amd import _lib, demo as camera_utils
     N, R, Sc, Sf, PH, PW = 3, 16, 48, 48, 8, 8
     planes = torch.zeros(N, 3, 32, PH, PW)
     P, (w1, b1, w2t, b2) = _decoder(62)

@@ -27,16 +27,20 @@ def main():
     ref = forward()
     torch.cuda.synchronize()
     lanes = [torch.cuda.Stream() for _ in range(a.lanes)]
-    bad = torch.zeros(3, dtype=torch.int64, device=dev)
+    # one counter tensor PER LANE: increments issued from different streams on one tensor would race (a lost update could hide a mismatch)
+    bad = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in lanes]
+    for s in lanes:
+        s.wait_stream(torch.cuda.current_stream())
     for k in range(a.steps):
-        s = lanes[k % a.lanes]
-        with torch.cuda.stream(s):
+        lane = k % a.lanes
+        with torch.cuda.stream(lanes[lane]):
             out = forward()
             for i, name in enumerate(('image', 'image_raw', 'image_depth')):
-                bad[i] += (out[name] != ref[name]).any().long()            # (accumulated on the device: no host sync in the loop)
+                bad[lane][i] += (out[name] != ref[name]).any().long()      # (accumulated on the device, in stream order of this lane: no host sync in the loop)
     torch.cuda.synchronize()
-    print(f'{a.steps} pipelined forwards on {a.lanes} streams ({"fp16 SR" if a.fp16 else "fp32"} mode): mismatching image / image_raw / image_depth:', bad.tolist())
-    sys.exit(1 if int(bad.sum()) else 0)
+    total = torch.stack(bad).sum(0)
+    print(f'{a.steps} pipelined forwards on {a.lanes} streams ({"fp16 SR" if a.fp16 else "fp32"} mode): mismatching image / image_raw / image_depth:', total.tolist())
+    sys.exit(1 if int(total.sum()) else 0)
 
 
 if __name__ == '__main__':
