@@ -18,7 +18,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 on
   roofline_fp32  the same K steps with N3D_PRECISION=fp32 arithmetic (v_mfma_f32_32x32x2_f32 everywhere): frames/s and the
                  conv family against 157.3 TFLOP/s
   config3        gen_videos_next3d.py's 2x2-grid, 120-frame camera orbit over a fixed mesh (BASELINE.json configs[2])
-  sr_fp16_mode   the same K steps with the reference's default float16 super-resolution blocks (no force_fp32)
+  sr_fp16_mode   the same K steps with the reference's default float16 super-resolution blocks (no force_fp32): frames/s, speed-up over
+                 the float32 route, `roofline_f16` (the f16 3x3 kernels against the 2.5 PFLOP/s dense f16 peak)
+  config1        BASELINE.json configs[0]'s shape as a latency figure (batch 1), eager launches vs HIP-graph replay
   config5        reenact_avatar_next3d.py's loop: one identity, a new FLAME mesh per frame (configs[4], synthetic sequence)
   cpu_baseline   the CPU oracle (a port of the reference's fp32 path) timed on the host cores.
 """
@@ -38,7 +40,11 @@ sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
-TRAFFIC_PROFILE = os.path.join(REPO, 'profiles', 'r02_traffic_pmc.json')
+TRAFFIC_PROFILE = os.path.join(REPO, 'profiles', 'r03_traffic_pmc.json')
+CPU_REFERENCE_PROFILE = os.path.join(REPO, 'profiles', 'r03_cpu_reference.json')
+# what the bf16 matrix pipe sustains with the kernels' instruction mix and RANDOM operands (tools/mfma_peak.hip, profiles/r02_mfma_peak_probe.txt:
+# 1850-1950 TFLOP/s bf16 = 617-650 fp32-equivalent; the chip power-limits to ~1.8 GHz under this load)
+MEASURED_BF16X3_CEILING_TFLOPS = 633.0
 CONV_FAMILY = ('3x3 split-bf16 conv family: every conv2d*_bf16x3 kernel launched by n3d_conv2d_bf16x3 with ksize 3 '
                '(stride 1 incl. the persistent and pre-split variants, transposed stride 2, stride 2; all launches of the step)')
 
@@ -131,6 +137,8 @@ def main():
     ap.add_argument('--serial-gather', action='store_true', help='join the frame gather of step k before step k+1 is enqueued')
     ap.add_argument('--lanes', type=int, default=3, help='HIP streams the steps are issued on in turn (1 = one stream, in order): '
                     'consecutive steps are independent batches, so step k+1 may start while step k still runs')
+    ap.add_argument('--sr-fp16', action='store_true', help="time the scripts' default route (float16 super-resolution blocks) in the main loop instead of "
+                    'force_fp32=True (SURVEY 8d config 2) — for profiling that route; the headline stays the float32 route')
     ap.add_argument('--selftest-spawn', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -181,7 +189,7 @@ def main():
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
     for s_ in lanes:
         s_.wait_stream(torch.cuda.current_stream())
-    counter, one_lane, sr_fp32 = [0], [False], [True]
+    counter, one_lane, sr_fp32 = [0], [False], [not args.sr_fp16]
 
     def step():
         if args.serial_gather:
@@ -271,14 +279,20 @@ def main():
         if layers.PRECISION != 'bf16x3':
             dom, peak, name = prof['conv2d'], PEAK_FP32_MFMA_TFLOPS, 'conv2d_mfma_kernel family (fp32 MFMA; all launches of the step)'
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-        traffic = traffic_x2 = traffic_src = None   # HBM bytes per launch: PMC passes cannot run inside bench.py -> the committed
+        traffic = traffic_raw = traffic_src = traffic_cal = None   # HBM bytes per launch: PMC passes cannot run inside bench.py -> the committed
         if layers.PRECISION == 'bf16x3' and os.path.exists(TRAFFIC_PROFILE):     # rocprofv3 --pmc result of THIS build is attached
             tj = json.load(open(TRAFFIC_PROFILE))
-            traffic, traffic_x2 = tj['traffic_bytes_per_launch_raw'], tj['traffic_bytes_per_launch_fetch_x2']
+            traffic_raw = tj['traffic_bytes_per_launch_raw']
+            traffic = tj.get('traffic_bytes_per_launch_calibrated', traffic_raw)        # FETCH_SIZE / WRITE_SIZE divided by the factors measured on known byte counts
+            traffic_cal = {k: {'fetch_counter_per_byte': v['fetch_counter_per_byte'], 'write_counter_per_byte': v['write_counter_per_byte']}
+                           for k, v in tj.get('calibration', {}).items()} or None
             traffic_src = 'profiles/' + os.path.basename(TRAFFIC_PROFILE)
         convs = ('conv2d_bf16x3', 'conv2d', 'conv1x1_bf16x3')
-        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                    'traffic_fetch_x2_upper_bound': traffic_x2, 'traffic_source': traffic_src,
+        roofline = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                    'frac_vs_measured_ceiling': (achieved / MEASURED_BF16X3_CEILING_TFLOPS) if layers.PRECISION == 'bf16x3' else None,
+                    'measured_ceiling': {'value': MEASURED_BF16X3_CEILING_TFLOPS, 'unit': 'TFLOP/s fp32-equivalent', 'source': 'profiles/r02_mfma_peak_probe.txt (tools/mfma_peak.hip: '
+                                         'v_mfma_f32_32x32x16_bf16 with random operands and the kernels\' fragment-read mix sustains 1850-1950 TFLOP/s: the chip power-limits to ~1.8 GHz)'},
+                    'traffic': traffic, 'traffic_raw_counters': traffic_raw, 'traffic_calibration': traffic_cal, 'traffic_source': traffic_src,
                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
                     'kernel': name,
                     'note': 'achieved = algorithmic (fp32-equivalent) conv flops / HIP-event time of the family; for bf16x3 the '
@@ -290,6 +304,7 @@ def main():
                     'family_ms_per_step': {k: round(p['ms'] / args.steps, 4) for k, p in prof.items()}}
 
     extras = {}
+    frames_total, elapsed_total = args.steps * B * world, elapsed
     if single and not args.no_extras:
         kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
         # ---- strict-fp32 arithmetic (N3D_PRECISION=fp32): the same K steps on v_mfma_f32_32x32x2_f32
@@ -312,8 +327,19 @@ def main():
         step(); step(); torch.cuda.synchronize()
         k16 = max(3, args.steps // 2)
         t16 = timed(step, k16)
+        p16 = conv_profile(k16)
+        f16 = p16['conv2d_f16']
+        a16 = f16['flops'] / (f16['ms'] * 1e-3) / 1e12 if f16['ms'] > 0 else 0.0
         extras['sr_fp16_mode'] = {'value': k16 * B / t16, 'unit': 'frames/s', 'ms_per_step': 1e3 * t16 / k16, 'steps': k16,
-                                  'note': 'synthesis(..., force_fp32=False): the scripts\' default route'}
+                                  'speedup_vs_fp32_route': (k16 * B / t16) / (frames_total / elapsed_total),
+                                  'note': "synthesis(..., force_fp32=False): the scripts' default route — float16 super-resolution blocks on v_mfma_f32_32x32x16_f16 "
+                                          '(float16 operands, float32 accumulation: the arithmetic of the reference\'s half convolutions)',
+                                  'roofline_f16': {'bound': 'mfma', 'achieved': a16, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': a16 / PEAK_BF16_MFMA_TFLOPS,
+                                                   'kernel': 'conv2d_h8_f16_kernel / conv2d_up_h8_f16_*_kernel (n3d_conv2d_f16: the four 3x3 convolutions of the two float16 blocks)',
+                                                   'launches_per_step': f16['launches'] / k16, 'algorithmic_gflop_per_step': f16['flops'] / k16 / 1e9,
+                                                   'avg_launch_ms': f16['ms'] / max(f16['launches'], 1),
+                                                   'algorithmic_bytes_per_launch': f16['bytes'] / max(f16['launches'], 1)},
+                                  'family_ms_per_step': {k: round(pv['ms'] / k16, 4) for k, pv in p16.items()}}
         sr_fp32[0] = True
         step(); torch.cuda.synchronize()
         # ---- configs[2]: 2x2 grid (batch 4 = one video frame), 120-frame orbit, fixed mesh (gen_videos_next3d.py:126-158)
@@ -391,6 +417,13 @@ def main():
     cpu = None
     if rank == 0 and single and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        if os.path.exists(CPU_REFERENCE_PROFILE):      # the reference's OWN Python beside the port, timed where /root/reference exists (the build container)
+            cr = json.load(open(CPU_REFERENCE_PROFILE))
+            case = cr['cases'].get('case_r64_s48_b4', {})
+            cpu['reference_python'] = {'frames_per_s': case.get('reference_frames_per_s'), 'port_frames_per_s_same_host': case.get('oracle_frames_per_s'),
+                                       'cores': cr.get('cores'), 'sample': 'batch 4, 512²/64²/48+48, fp32: mapping + synthesis of the reference\'s own modules (ops -> its _ref '
+                                       'implementations; rasteriser / flood fill stand-ins) and of the port on the SAME inputs, same container',
+                                       'source': 'profiles/' + os.path.basename(CPU_REFERENCE_PROFILE) + ' (oracle/pin_against_reference.py)'}
 
     if rank == 0:
         precision_dtype = 'bf16x3 (split-bf16 operands, f32 accumulate; f32 elsewhere)' if layers.PRECISION == 'bf16x3' else 'f32'
@@ -399,7 +432,8 @@ def main():
             'metric': 'generator fwd frames/sec at 512² (64³ vol, 96 samples)', 'value': frames / elapsed, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': precision_dtype, 'data': 'synthetic',
-            'config': {'workload': f'BASELINE.json configs[1]: batch={B} seeds per GPU, 512² output, 64² neural render, '
+            'config': {'route': 'default (float16 super-resolution blocks)' if args.sr_fp16 else 'force_fp32=True (SURVEY 8d config 2; the reference-generated goldens pin it)',
+                       'workload': f'BASELINE.json configs[1]: batch={B} seeds per GPU, 512² output, 64² neural render, '
                                    '48 coarse + 48 importance samples, trunc=0.7, demo.obj mesh, mapping+synthesis, '
                                    'seeded synthetic weights (172.8M params)', 'batch_per_gpu': B, 'seed_sharded': True,
                        'streams': f'{len(lanes)} (consecutive steps alternate between them)',

@@ -185,6 +185,12 @@ int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
  *      Requires I % 16 == 0.  Same reference call sites as n3d_conv2d. */
 int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream);
 int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+/* n3d_conv2d_bf16x3(a); n3d_conv2d_bf16x3(b) as ONE launch (+ one split-K reduction launch) when both descriptors select the same
+ * register-staged 3x3 kernel (the <= 32x32 stride-1 and transposed layers): workgroups of both layers share the grid, which doubles
+ * the occupancy of layers that are a handful of workgroups each — the texture and the static tri-plane backbone
+ * (tat/triplane_next3d.py:135-170: two SynthesisNetworks of identical shapes) run in lock step this way.  Any other combination is
+ * executed as the two ordinary launches, in order; results are bit-identical either way. */
+int n3d_conv2d_bf16x3_pair(const n3d_conv2d_desc* a, const n3d_conv2d_desc* b, n3d_stream_t stream);
 /* Number of workgroups n3d_conv2d_bf16x3 launches for this shape at ksplit = 1 (its tile plan): the host picks a split-K
  * factor from it so that small layers still cover the 256 CUs. */
 int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);

@@ -69,6 +69,7 @@ _SIGNATURES = {
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_prep_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d_bf16x3': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
+    'n3d_conv2d_bf16x3_pair': (c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_bf16x3_blocks': (c_int, [c_int] * 5),
     'n3d_blend_planes': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     'n3d_planes_to_channels_last': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -109,6 +110,12 @@ def exported_symbols():
 
 
 def lib():
+    """The library handle (or, inside a `Recording`, the recorder that defers the launches)."""
+    rec = getattr(_tls, 'recorder', None)
+    return rec if rec is not None else _handle()
+
+
+def _handle():
     """Load libn3d.so once.  Raises RuntimeError (never falls back) when it is missing or stale."""
     global _lib
     if _lib is None:
@@ -131,12 +138,75 @@ _tls = threading.local()
 
 
 def check(rc):
-    """Result check of an entry point — and the end of the keep-alive window of `ptr()` (below): by now the launch is enqueued."""
+    """Result check of an entry point — and the end of the keep-alive window of `ptr()` (below): by now the launch is enqueued
+    (inside a `Recording` the launch is only deferred: the tensors move to the recording and live until it has been replayed)."""
     held = getattr(_tls, 'held', None)
     if held:
+        rec = getattr(_tls, 'recorder', None)
+        if rec is not None:
+            rec.keep.extend(held)
         held.clear()
     if rc != 0:
-        raise RuntimeError('libn3d: ' + lib().n3d_last_error().decode())
+        raise RuntimeError('libn3d: ' + _handle().n3d_last_error().decode())
+
+
+_HOST_ONLY = ('n3d_abi_version', 'n3d_last_error', 'n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_render_rays_workspace_bytes',
+              'n3d_prof_enable', 'n3d_prof_reset', 'n3d_prof_read')
+
+
+class Recording:
+    """`with Recording() as r:` — every libn3d.so launch issued inside is DEFERRED: recorded as (entry point, marshalled arguments)
+    instead of being enqueued, and every tensor whose pointer crossed the boundary is kept alive (so the caching allocator cannot
+    hand a recorded buffer to a later allocation).  `replay_paired(ra, rb)` then issues two recordings interleaved, pairing the
+    launches that n3d_conv2d_bf16x3_pair can run as one grid.  Only code whose device work goes through libn3d.so exclusively may
+    run inside (no torch kernels on tensors a deferred launch produces): the StyleGAN2 backbones qualify (networks.SynthesisNet)."""
+
+    def __init__(self):
+        self.entries, self.keep = [], []
+
+    def __getattr__(self, name):
+        if name in _HOST_ONLY:
+            return getattr(_handle(), name)
+        if name not in _SIGNATURES:
+            raise AttributeError(name)
+
+        def deferred(*args):
+            self.entries.append((name, args))
+            return 0
+        return deferred
+
+    def __enter__(self):
+        if getattr(_tls, 'recorder', None) is not None:
+            raise RuntimeError('Recording: already recording')
+        _handle()
+        _tls.recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.recorder = None
+        held = getattr(_tls, 'held', None)
+        if held:
+            self.keep.extend(held)
+            held.clear()
+        return False
+
+
+def replay_paired(ra, rb):
+    """Issue two recordings in lock step: launch i of `ra`, then launch i of `rb` — as ONE launch where both are 3x3 convolutions
+    (n3d_conv2d_bf16x3_pair decides whether the kernels can share a grid; otherwise it runs them one after the other).  Each
+    recording's own order is preserved, so results are those of running the two recordings back to back."""
+    h = _handle()
+    a, b = ra.entries, rb.entries
+    for i in range(max(len(a), len(b))):
+        ea, eb = (a[i] if i < len(a) else None), (b[i] if i < len(b) else None)
+        if ea is not None and eb is not None and ea[0] == eb[0] == 'n3d_conv2d_bf16x3' and ea[1][1].value == eb[1][1].value:
+            check(h.n3d_conv2d_bf16x3_pair(ea[1][0], eb[1][0], ea[1][1]))
+            continue
+        for e in (ea, eb):
+            if e is not None:
+                check(getattr(h, e[0])(*e[1]))
+    ra.entries, rb.entries = [], []
+    ra.keep, rb.keep = [], []
 
 
 def stream():

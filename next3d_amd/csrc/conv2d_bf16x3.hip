@@ -58,7 +58,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 // 3x3, stride 1, padding 1.  NW waves per workgroup, each owning 2 pixel rows: tile = 64 channels x (2 NW x 32) pixels.
 // NW = 8 (512 threads, one workgroup per CU) halves the weight-slab traffic and the per-thread staging work per MFMA.
 template <int NW, bool FLAT>
-__global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params p) {
+__device__ __forceinline__ void conv2d_bf16x3_body(const Conv16Params& p, const int bid, const int nwg) {
     constexpr int NT_ = 64 * NW;                                          // threads
     constexpr int BM = 64, TH = 2 * NW, TW = 32, ICB = 16, TAPS = 9;
     constexpr int PH = TH + 2, PW_C = TW + 2, PPIX = PH * PW_C;           // NW=4: 10 x 34 = 340 patch pixels
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
     // it through that XCD's L2 instead of fetching it O/64 times from HBM / Infinity Cache.
     int lb;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int mt_i = lb % p.tiles_m; lb /= p.tiles_m;
     const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
@@ -308,6 +308,20 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
 }
 
 
+// Two independent launches of one kernel as ONE grid ("pair": n3d_conv2d_bf16x3_pair): workgroups [0, split) run `a`, workgroups
+// [split, gridDim) run `b` (split is a multiple of 8 so that the XCD-aware remap keeps its meaning; the padding workgroups exit).
+// The low-resolution layers of the texture and the static tri-plane backbone have identical shapes and a handful of workgroups
+// each (K = 9 x 512 deep, 4x4 ... 32x32 pixels): run together they fill twice the CUs for the same latency.
+struct Conv16Pair { Conv16Params a, b; int na, split; };
+template <int NW, bool FLAT>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params p) { conv2d_bf16x3_body<NW, FLAT>(p, blockIdx.x, gridDim.x); }
+template <int NW, bool FLAT>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_pair_kernel(Conv16Pair pp) {
+    const bool second = (int)blockIdx.x >= pp.split;
+    if (!second && (int)blockIdx.x >= pp.na) return;
+    conv2d_bf16x3_body<NW, FLAT>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.na);
+}
+
 // Transposed 3x3 stride-2 (the up-sampling layers) on the split-bf16 path: all four output phases from one staged patch,
 // exactly as conv2d_up_mfma_kernel in conv2d.hip (tap (ky,kx) feeds phase (ky==1, kx==1) from patch offset
 // (ky==2 ? 0 : 1, kx==2 ? 0 : 1)).  Workgroup = 64 output channels x (th x tw <= 32*NW) input-grid positions x 4 phases.  The
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params 
 // one piece (a fixed 32-wide tile would need a second, 97 %-empty tile for the last column).  acc[2 row-tiles][4 phases].  Per K=16 chunk: 8 B-fragment reads (4 offsets x hi/lo) are
 // shared by all 9 taps, 36 A-fragment reads, 54 MFMAs.
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) {
+__device__ __forceinline__ void conv2d_up_bf16x3_body(const Conv16Params& p, const int bid, const int nwg) {
     constexpr int NT_ = 64 * NW;
     constexpr int BM = 64, ICB = 16, TAPS = 9;
     constexpr int PPIX = (NW + 1) * 33;                                   // patch capacity: (th+1) x (tw+1) <= PPIX (host plan)
@@ -338,8 +352,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     // it through that XCD's L2 instead of fetching it O/64 times from HBM / Infinity Cache.
     int lb;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int mt_i = lb % p.tiles_m; lb /= p.tiles_m;
     const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
@@ -582,14 +596,27 @@ __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Para
     }
 }
 
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) { conv2d_up_bf16x3_body<NW>(p, blockIdx.x, gridDim.x); }
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_pair_kernel(Conv16Pair pp) {
+    const bool second = (int)blockIdx.x >= pp.split;
+    if (!second && (int)blockIdx.x >= pp.na) return;
+    conv2d_up_bf16x3_body<NW>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.na);
+}
+
 // split-K second pass: sum the partial tiles and apply the epilogue.  VEC: 4 consecutive pixels of one row per thread
 // (OW % 4 == 0, aligned pointers): 16-byte loads/stores and one index decomposition per 4 outputs.
+struct SplitkArgs { const float* partial; float* y; int ksplit, N, O, OH, OW; int64_t ybs, yrs; n3d_epilogue epi; };
 template <bool VEC>
-__global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float* __restrict__ partial, float* __restrict__ y, int ksplit,
-                                                                      int N, int O, int OH, int OW, int64_t ybs, int64_t yrs, n3d_epilogue epi) {
+__device__ __forceinline__ void conv16_splitk_epilogue_body(const SplitkArgs& a, const int bid, const int nwg) {
+    const float* __restrict__ partial = a.partial; float* __restrict__ y = a.y;
+    const int ksplit = a.ksplit, N = a.N, O = a.O, OH = a.OH, OW = a.OW;
+    const int64_t ybs = a.ybs, yrs = a.yrs;
+    const n3d_epilogue& epi = a.epi;
     const int64_t plane = (int64_t)OH * OW, total = (int64_t)N * O * plane;
     constexpr int V = VEC ? 4 : 1;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < total; i += (int64_t)gridDim.x * blockDim.x * V) {
+    for (int64_t i = ((int64_t)bid * blockDim.x + threadIdx.x) * V; i < total; i += (int64_t)nwg * blockDim.x * V) {
         float v[V];
 #pragma unroll
         for (int q = 0; q < V; ++q) v[q] = 0.f;
@@ -611,6 +638,15 @@ __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const float
         if (VEC) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
         else dst[0] = v[0];
     }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(SplitkArgs a) { conv16_splitk_epilogue_body<VEC>(a, blockIdx.x, gridDim.x); }
+struct SplitkPair { SplitkArgs a, b; int split; };
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv16_splitk_epilogue_pair_kernel(SplitkPair pp) {
+    const bool second = (int)blockIdx.x >= pp.split;
+    conv16_splitk_epilogue_body<VEC>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.split);
 }
 
 // w [O,I,k,k] fp32 -> wt16[tap][I/16][hl][half][OP64][8] bf16 (hi / lo split, zero padded rows)
@@ -683,14 +719,20 @@ static void conv16_plan(int N, int O, int H, int W, int mode, bool* big, int* ti
     *tiles_x = cdiv(W, 32); *tiles_y = cdiv(H, *th);
 }
 
+static bool splitk_vec(const float* partial, const float* y, int OW, int64_t ybs, int64_t yrs) {
+    return (OW & 3) == 0 && ((ybs | yrs) & 3) == 0 && (((uintptr_t)partial | (uintptr_t)y) & 15) == 0;
+}
+static int splitk_grid(int64_t total, bool vec) {
+    const int64_t items = vec ? total / 4 : total;
+    return (int)(cdiv64(items, 256) > 4096 ? 4096 : cdiv64(items, 256));
+}
 int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
                                   const n3d_epilogue& epi, hipStream_t stream) {
-    const int64_t total = (int64_t)N * O * OH * OW;
-    const bool vec = (OW & 3) == 0 && ((ybs | yrs) & 3) == 0 && (((uintptr_t)partial | (uintptr_t)y) & 15) == 0;
-    const int64_t items = vec ? total / 4 : total;
-    const int grid = (int)(cdiv64(items, 256) > 4096 ? 4096 : cdiv64(items, 256));
-    if (vec) hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<true>, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
-    else hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<false>, dim3(grid), dim3(256), 0, stream, partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi);
+    const bool vec = splitk_vec(partial, y, OW, ybs, yrs);
+    const int grid = splitk_grid((int64_t)N * O * OH * OW, vec);
+    const SplitkArgs a = {partial, y, ksplit, N, O, OH, OW, ybs, yrs, epi};
+    if (vec) hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(conv16_splitk_epilogue_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
     N3D_LAUNCH_CHECK();
     return 0;
 }
@@ -707,30 +749,11 @@ extern "C" int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode) {
     return b > 0x7fffffff ? 0x7fffffff : (int)b;
 }
 
-extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
-    N3D_CHECK((d->ksize == 3 && d->mode >= 0 && d->mode <= 2) || (d->ksize == 1 && d->mode == 0),
-              "conv2d_bf16x3: 3x3 (stride 1, stride 2, transposed stride 2) or 1x1 stride-1 only");
-    N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
-    N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
-    N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
-    if (d->N == 0) return 0;
-    N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
-    N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
-    N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
-    N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
-    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2),
-              "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
-    N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
-    if (d->x_layout == N3D_LAYOUT_SPLIT8)
-        return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : (d->mode == 1 ? conv2d_s2_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream));
-    if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
-    N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
-    if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
-    Conv16Params p;
-    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
+// Parameters, tile plan and kernel kind of the register-staged 3x3 kernels (stride 1 / transposed) for one descriptor.
+enum { C16_UP8 = 0, C16_BIG8 = 1, C16_FLAT4 = 2, C16_ROW4 = 3 };
+static int conv16_setup(const n3d_conv2d_desc* d, Conv16Params& p, int& kind, int64_t& nblk) {
     const bool up = d->mode == 2;
+    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     p.y_c8 = d->y_layout == N3D_LAYOUT_C8_F32;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
@@ -758,8 +781,38 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(p.ic_per_split <= 1024, "conv2d_bf16x3: more than 1024 input channels per K-split");
     if (p.ksplit == 1) p.partial = nullptr;
     p.tiles_m = cdiv(p.O, 64);
-    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
+    nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
+    kind = up ? C16_UP8 : (big ? C16_BIG8 : (d->W < 32 ? C16_FLAT4 : C16_ROW4));
+    return 0;
+}
+
+extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(d != nullptr, "conv2d_bf16x3: null descriptor");
+    N3D_CHECK((d->ksize == 3 && d->mode >= 0 && d->mode <= 2) || (d->ksize == 1 && d->mode == 0),
+              "conv2d_bf16x3: 3x3 (stride 1, stride 2, transposed stride 2) or 1x1 stride-1 only");
+    N3D_CHECK(d->N >= 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->I % 16 == 0, "conv2d_bf16x3: bad shape (I %% 16 == 0)");
+    N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
+    N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
+    if (d->N == 0) return 0;
+    N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
+    N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
+    N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
+    N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
+    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2),
+              "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
+    N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
+    if (d->x_layout == N3D_LAYOUT_SPLIT8)
+        return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : (d->mode == 1 ? conv2d_s2_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream));
+    if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
+    N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
+    if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
+    Conv16Params p;
+    int kind; int64_t nblk;
+    if (conv16_setup(d, p, kind, nblk) != 0) return -1;
+    const bool up = d->mode == 2;
+    const bool big = kind == C16_BIG8;
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (up ? (double)d->H * d->W : (double)p.OH * p.OW);
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
@@ -774,5 +827,54 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     else hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, false>), grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi, stream);
+    return 0;
+}
+
+// Two layers of identical kind in ONE launch (+ ONE split-K reduction launch): see Conv16Pair.  Anything the pair kernels do not
+// cover — pre-split inputs, 1x1, stride 2, the 8-wave stride-1 kernel of the large layers, different kernel kinds — runs as two
+// ordinary launches, a then b, so the call is always equivalent to n3d_conv2d_bf16x3(a); n3d_conv2d_bf16x3(b).
+extern "C" int n3d_conv2d_bf16x3_pair(const n3d_conv2d_desc* da, const n3d_conv2d_desc* db, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(da && db, "conv2d_bf16x3_pair: null descriptor");
+    auto plain = [&](const n3d_conv2d_desc* d) {
+        return d->N > 0 && d->ksize == 3 && (d->mode == 0 || d->mode == 2) && d->x_layout == N3D_LAYOUT_NCHW_F32 && d->y_layout == N3D_LAYOUT_NCHW_F32 &&
+               d->I > 0 && d->I % 16 == 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->x && d->wt && d->y && !d->epi.round_f16 && !d->epi.residual_up_filter &&
+               d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH && (!d->epi.noise || d->epi.noise_strength) && (d->x_row_stride == 0 || d->x_row_stride == d->W);
+    };
+    Conv16Pair pp;
+    int ka = -1, kb = -2; int64_t na = 0, nb = 0;
+    const char* off = getenv("N3D_CONV_PAIR");
+    bool ok = !(off && atoi(off) == 0) && plain(da) && plain(db) && da->mode == db->mode;
+    if (ok) ok = conv16_setup(da, pp.a, ka, na) == 0 && conv16_setup(db, pp.b, kb, nb) == 0 && ka == kb && ka != C16_BIG8 && pp.a.dbg == 0 &&
+                 (pp.a.ksplit > 1) == (pp.b.ksplit > 1) && na + nb + 8 < (1ll << 31);
+    if (!ok) {
+        if (n3d_conv2d_bf16x3(da, stream_) != 0) return -1;
+        return n3d_conv2d_bf16x3(db, stream_);
+    }
+    pp.na = (int)na; pp.split = (int)((na + 7) / 8 * 8);
+    auto flops = [](const n3d_conv2d_desc* d) { return 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W; };
+    auto bytes = [](const n3d_conv2d_desc* d, const Conv16Params& p) { return 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9); };
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops(da) + flops(db), bytes(da, pp.a) + bytes(db, pp.b));
+    const dim3 grid((unsigned)(pp.split + nb));
+    if (ka == C16_UP8) hipLaunchKernelGGL(conv2d_up_bf16x3_pair_kernel<8>, grid, dim3(512), 0, stream, pp);
+    else if (ka == C16_FLAT4) hipLaunchKernelGGL((conv2d_bf16x3_pair_kernel<4, true>), grid, dim3(256), 0, stream, pp);
+    else hipLaunchKernelGGL((conv2d_bf16x3_pair_kernel<4, false>), grid, dim3(256), 0, stream, pp);
+    N3D_LAUNCH_CHECK();
+    if (pp.a.ksplit > 1) {
+        const Conv16Params& A = pp.a; const Conv16Params& B = pp.b;
+        const bool va = splitk_vec(A.partial, A.y, A.OW, A.ybs, A.yrs), vb = splitk_vec(B.partial, B.y, B.OW, B.ybs, B.yrs);
+        if (va != vb) {
+            if (conv16_splitk_epilogue_launch(A.partial, A.y, A.ksplit, A.N, A.O, A.OH, A.OW, A.ybs, A.yrs, A.epi, stream) != 0) return -1;
+            return conv16_splitk_epilogue_launch(B.partial, B.y, B.ksplit, B.N, B.O, B.OH, B.OW, B.ybs, B.yrs, B.epi, stream);
+        }
+        SplitkPair sp;
+        sp.a = SplitkArgs{A.partial, A.y, A.ksplit, A.N, A.O, A.OH, A.OW, A.ybs, A.yrs, A.epi};
+        sp.b = SplitkArgs{B.partial, B.y, B.ksplit, B.N, B.O, B.OH, B.OW, B.ybs, B.yrs, B.epi};
+        sp.split = splitk_grid((int64_t)A.N * A.O * A.OH * A.OW, va);
+        const int gb = splitk_grid((int64_t)B.N * B.O * B.OH * B.OW, vb);
+        if (va) hipLaunchKernelGGL(conv16_splitk_epilogue_pair_kernel<true>, dim3(sp.split + gb), dim3(256), 0, stream, sp);
+        else hipLaunchKernelGGL(conv16_splitk_epilogue_pair_kernel<false>, dim3(sp.split + gb), dim3(256), 0, stream, sp);
+        N3D_LAUNCH_CHECK();
+    }
     return 0;
 }

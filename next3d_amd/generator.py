@@ -83,6 +83,7 @@ class TriPlaneGenerator(torch.nn.Module):
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
         self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
+        self.pair_backbones = os.environ.get('N3D_PAIR_BACKBONES', '1') != '0'      # texture + static backbone in lock step (_planes)
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -303,8 +304,19 @@ class TriPlaneGenerator(torch.nn.Module):
         cur = torch.cuda.current_stream()
         ident = self._identity_cache if use_cached_identity else None
         static = None
+        paired = False
         if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
             textures, static = ident
+        elif self.pair_backbones and noise_mode != 'random' and networks._img_stream(ws.device) is None:
+            # The texture and the static tri-plane backbone are two StyleGAN2 networks of identical layer shapes on different
+            # latents: their launches are recorded and issued in lock step, the <= 32x32 layers (a handful of workgroups each)
+            # as ONE grid per layer pair (n3d_conv2d_bf16x3_pair), the large ones one after the other.
+            with _lib.Recording() as rec_t:
+                textures = S.texture(texture_ws, noise_mode)
+            with _lib.Recording() as rec_s:
+                static = S.static(eg3d_ws, noise_mode)
+            _lib.replay_paired(rec_t, rec_s)
+            paired = True
         elif self.overlap_static:
             sstream = S.side_streams.get(cur.cuda_stream)
             if sstream is None:
@@ -326,7 +338,7 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch_in = front.clone() if getattr(self, 'keep_stages', False) else front
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
-        if ident is None and self.overlap_static:
+        if ident is None and self.overlap_static and not paired:
             cur.wait_stream(sstream)
         elif static is None:
             static = S.static(eg3d_ws, noise_mode)

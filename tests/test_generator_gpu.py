@@ -237,14 +237,13 @@ def test_presplit_pipeline_equals_register_staged_pipeline(G, dev, monkeypatch, 
         e = _md(out[True][k], out[False][k])
         print(f'batch {batch} render {R} {k}: pre-split vs register-staged max abs diff {e:.3e}')
         assert e <= 2e-4, (k, e)              # (measured 4e-5: rounding-order differences of the FIR variants, amplified by ~30 layers)
-    with pytest.raises(RuntimeError):            # the float16 block mode exists on the pre-split path only, and says so
-        G.synthesis(ws, t('c'), t('v'), **kw)
+    half_off = G.synthesis(ws, t('c'), t('v'), **kw)      # the default call (float16 super-resolution blocks) runs under every layout switch
     for name in ('PRESPLIT', 'UP_PRESPLIT', 'S2_PRESPLIT'):
         monkeypatch.setattr(layers, name, True)
     half = G.synthesis(ws, t('c'), t('v'), **kw)                          # the reference's default: float16 super-resolution blocks
-    e = _md(half['image'], out[True]['image'])
-    print(f'batch {batch} render {R}: fp16-mode image vs fp32-mode image max abs diff {e:.3e}')
-    assert torch.isfinite(half['image']).all() and e <= 2e-2
+    e, e_off = _md(half['image'], out[True]['image']), _md(half_off['image'], half['image'])
+    print(f'batch {batch} render {R}: fp16-mode image vs fp32-mode image max abs diff {e:.3e}; fp16 mode with / without the pre-split hand-off {e_off:.3e}')
+    assert torch.isfinite(half['image']).all() and e <= 2e-2 and e_off <= 2e-2
 
 
 @pytest.mark.gpu
@@ -327,3 +326,32 @@ def test_synthesis_graph_replay_is_bit_identical(G, dev):
         G.synthesis_graph(ws, c, v, cache_backbone=True, **kw)
     G.refresh()
     assert G._graphs is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch', [1, 4])
+def test_paired_backbones_equal_separate_launches(G, dev, batch):
+    """The texture and the static backbone issued in lock step — their <= 32x32 layers as shared grids (n3d_conv2d_bf16x3_pair) —
+    against the two networks run one after the other (and against the static backbone on its side stream): the same kernels on
+    the same operands, so every stage is bit-identical."""
+    from next3d_amd import layers
+    layers.set_precision('bf16x3')
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
+    R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(batch, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(d[k][:batch]).to(dev)
+    ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
+    G.keep_stages = True
+    res = {}
+    try:
+        for mode, (pair, overlap) in {'paired': (True, True), 'serial': (False, False), 'side_stream': (False, True)}.items():
+            G.pair_backbones, G.overlap_static = pair, overlap
+            out = G.synthesis(ws, t('c'), t('v'), **kw)
+            res[mode] = (G._debug['textures'].clone(), G._debug['static'].clone(), out['image'].clone())
+    finally:
+        G.pair_backbones, G.overlap_static, G.keep_stages = True, True, False
+    for mode in ('serial', 'side_stream'):
+        for name, a, b in zip(('textures', 'static', 'image'), res['paired'], res[mode]):
+            assert torch.equal(a, b), (mode, name, _md(a, b))

@@ -8,6 +8,10 @@ out=gpurun_out/art; mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out/kt -o r -- python bench.py --no-cpu-baseline --no-extras > $out/${tag}_bench_under_rocprofv3.json 2> $out/kt.err
 python tools/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) $out/${tag}_kernel_stats.csv > /dev/null
 rm -rf $out/kt
+# the scripts' default route (float16 super-resolution blocks on the f16 matrix cores): kernel trace of the same command with --sr-fp16
+rocprofv3 --kernel-trace --stats -d $out/kt16 -o r -- python bench.py --no-cpu-baseline --no-extras --sr-fp16 > $out/${tag}_bench_sr_fp16_under_rocprofv3.json 2> $out/kt16.err
+python tools/rocpd_summary.py $(find $out/kt16 -name "*.db" | head -1) $out/${tag}_kernel_stats_sr_fp16.csv > /dev/null
+rm -rf $out/kt16
 if [ "$2" != "lite" ]; then
   P="python bench.py --no-cpu-baseline --no-roofline --no-extras --lanes 1 --steps 2 --warmup 1 --prewarm-seconds 0"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pf -o r -- $P > /dev/null 2> $out/pf.err
