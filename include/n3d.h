@@ -124,6 +124,12 @@ int n3d_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
 int n3d_fir4_split8(const float* x_c8, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
                     int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
                     int64_t out_scale_stride, n3d_stream_t stream);
+/* n3d_fir4_split8_sep: n3d_fir4_split8 for a separable filter f = outer(f1d, f1d) (f1d: 4 device floats; the caller's promise) and a
+ * linear / leaky-ReLU epilogue: vertical pass, horizontal pass, 8 instead of 16 multiply-adds per output — the same float32 sum in
+ * another order. */
+int n3d_fir4_split8_sep(const float* x_c8, const float* f1d, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
+                        int64_t x_batch_stride, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
+                        int64_t out_scale_stride, n3d_stream_t stream);
 /* n3d_fir4_split8_nchw: the same kernel on a float32 NCHW input (row pitch x_row_stride floats, 0 = W; batch stride in floats, 0 =
  * dense) with `pad` (1 or 2) zero pixels on every side -> y split8 [N,C,H+2*pad-3,W+2*pad-3].  pad = 2 is the FIR in front of the
  * stride-2 convolution of Conv2dLayer(down=2) (upfirdn2d with padding [2,2,2,2], conv2d_resample.py:108-111): the down-sampling

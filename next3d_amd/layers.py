@@ -318,23 +318,7 @@ def conv2d_f16(x, w16, out_channels, mode, epilogue=None):
 # True = _bias_act_ref on half tensors (what the reference does off-GPU: every step rounds) — only to compare with the reference's
 # own CPU run of its float16 branch (tests/golden/*_fp16sr.npz).
 F16_REF_CPU_ROUNDING = os.environ.get('N3D_F16_REF_CPU_ROUNDING', '0') == '1'
-_FIR1D = {}
-
-
-def fir_factor(fir):
-    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter tensor (a host read at model preparation).
-    The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (upfirdn2d.py:96-116): the separable
-    form of n3d_fir4_h8 evaluates the same float32 sum with half the multiply-adds."""
-    key = (fir.data_ptr(), fir._version, str(fir.device))
-    if key not in _FIR1D:
-        f = fir.detach().to('cpu', torch.float64)
-        a = None
-        if tuple(f.shape) == (4, 4) and float(f.sum()) > 0:
-            v = f.sum(1) / f.sum().sqrt()
-            if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
-                a = v.to(torch.float32).to(fir.device).contiguous()
-        _FIR1D[key] = a
-    return _FIR1D[key]
+fir_factor = uf.fir_factor
 
 
 def modulate_weights_f16_multi(entries, styles_base, n):

@@ -83,6 +83,25 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pit
     return y
 
 
+_FIR1D = {}
+
+
+def fir_factor(fir):
+    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter tensor (a host read at model preparation).
+    The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (:96-116): the separable kernels
+    (n3d_fir4_split8_sep, n3d_fir4_h8) evaluate the same float32 sum with half the multiply-adds."""
+    key = (fir.data_ptr(), fir._version, str(fir.device))
+    if key not in _FIR1D:
+        f = fir.detach().to('cpu', torch.float64)
+        a = None
+        if tuple(f.shape) == (4, 4) and float(f.sum()) > 0:
+            v = f.sum(1) / f.sum().sqrt()
+            if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
+                a = v.to(torch.float32).to(fir.device).contiguous()
+        _FIR1D[key] = a
+    return _FIR1D[key]
+
+
 def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     """The up-sampling layer's FIR (4x4 taps, padding 1 on every side) with its epilogue, writing the split8 layout for the 3x3
     convolution that follows (n3d_fir4_split8): x = the transposed convolution's output as a `_lib.C8` [N,C,H,W] ->
@@ -90,6 +109,12 @@ def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     assert isinstance(x, _lib.C8) and tuple(f2d.shape) == (4, 4) and out_scale.stride(1) == 1
     n, c, h, w = x.shape
     y = _lib.Split8(n, c, h - 1, w - 1, x.device)
+    import os
+    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and (epilogue is None or epilogue.act in (1, 3))) else None
+    if f1d is not None:
+        _lib.check(_lib.lib().n3d_fir4_split8_sep(_lib.ptr(x.data), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, w, 0, 0, float(gain),
+                                                  epilogue, _lib.ptr(out_scale), out_scale.stride(0), _lib.stream()))
+        return y
     _lib.check(_lib.lib().n3d_fir4_split8(_lib.ptr(x.data), _lib.ptr(f2d), _lib.ptr(y.data), n, c, h, w, w, 0, 0, float(gain),
                                           epilogue, _lib.ptr(out_scale), out_scale.stride(0), _lib.stream()))
     return y

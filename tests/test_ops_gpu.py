@@ -610,12 +610,14 @@ def test_presplit_stride2_conv_matches_plain_kernel(dev, N, I, OC, H, W, ks):
     assert torch.equal(y2, y)                                             # the library's own conversion pass = the torch-built operand image
 
 
+@pytest.mark.parametrize('sep', ['1', '0'])
 @pytest.mark.parametrize('N,C,H,W', [(2, 32, 16, 32), (1, 64, 64, 64), (3, 16, 40, 24), (1, 8, 7, 100)])
-def test_fir4_split8_matches_float_fir(dev, N, C, H, W):
+def test_fir4_split8_matches_float_fir(dev, monkeypatch, N, C, H, W, sep):
     """n3d_fir4_split8 (c8 input -> FIR + layer epilogue + next layer's style + hi/lo split, split8 output) against the float32
     FIR path on the same values: hi + lo must reproduce style * fir_out to 2^-16 relative (what two bf16 halves carry)."""
     from next3d_amd import _lib
     from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    monkeypatch.setenv('N3D_FIR_SEP', sep)              # '1': the separable form (n3d_fir4_split8_sep), '0': the 16-tap kernel
     f = O.setup_filter((1, 3, 3, 1)).to(dev)
     zh, zw = 2 * H + 1, 2 * W + 1
     z = _gen((N, C, zh, zw), 110).to(dev)
