@@ -11,9 +11,9 @@ ix = {c: i for i, c in enumerate(cols)}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in con.execute("select * from counters_collection"):
     name = (r[ix['kernel_name']] if 'kernel_name' in ix else r[ix['name']]).split('(')[0]
-    if 'bf16x3' in name and 'conv1x1' not in name and 'prep' not in name and 'splitk' not in name:
+    if (('bf16x3' in name and 'conv1x1' not in name and 'prep' not in name and 'splitk' not in name) or ('h8_f16' in name and name.startswith(('conv2d', 'void conv2d')))):
         agg[name][r[ix['counter_name']]].append(r[ix['value']])
-out = {'source': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --lanes 1 --steps 2 --warmup 1`',
+out = {'source': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on `bench.py --lanes 1 --steps 2 --warmup 1` (+ --sr-fp16 for the float16-block kernels)',
        'note': 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs): fraction of SIMD-cycles the matrix pipe was '
                'busy while the kernel ran; cycles_per_launch = GRBM_GUI_ACTIVE / 8',
        'kernels': {}}

@@ -24,8 +24,10 @@ if [ "$2" != "lite" ]; then
   rm -rf $out/cf $out/cw $out/pmc_calib
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/pm -o r -- $P > /dev/null 2> $out/pm.err
   python tools/mfma_busy_summary.py $(find $out/pm -name "*.db" | head -1) $out/${tag}_mfma_busy_pmc.json > /dev/null
-  rm -rf $out/pf $out/pw $out/pm
-  cp $out/${tag}_traffic_pmc.json $out/${tag}_mfma_busy_pmc.json profiles/     # the bench line below cites the fresh traffic profile
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/pm16 -o r -- $P --sr-fp16 > /dev/null 2> $out/pm16.err
+  python tools/mfma_busy_summary.py $(find $out/pm16 -name "*.db" | head -1) $out/${tag}_mfma_busy_sr_fp16_pmc.json > /dev/null
+  rm -rf $out/pf $out/pw $out/pm $out/pm16
+  cp $out/${tag}_traffic_pmc.json $out/${tag}_mfma_busy_pmc.json $out/${tag}_mfma_busy_sr_fp16_pmc.json profiles/     # the bench line below cites the fresh traffic profile
 fi
 python bench.py > $out/${tag}_bench.json 2> $out/bench.err
 head -c 1200 $out/${tag}_bench.json; echo; head -14 $out/${tag}_kernel_stats.csv; ls -la $out
