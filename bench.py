@@ -270,7 +270,7 @@ def main():
         t1 = timed(step, args.steps)
         one_lane[0] = False
         single_stream = {'value': args.steps * B / t1, 'unit': 'frames/s', 'ms_per_step': 1e3 * t1 / args.steps,
-                         'note': 'steps issued in order on one HIP stream (the static backbone still on its side stream)'}
+                         'note': 'steps issued in order on one HIP stream'}
     roofline = None
     if not args.no_roofline:
         prof = conv_profile(args.steps)
