@@ -115,8 +115,9 @@ def sample_mixed(P, coordinates, ws, v, uv_face_mask, rendering_kwargs, noise_mo
 
 
 def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_rendering_resolution=64,
-              noise_mode='const', return_stages=False):
-    """triplane_next3d.py:117-188 (synthesis).  `jitter`/`u`: see oracle/renderer.py."""
+              noise_mode='const', return_stages=False, force_fp32=True):
+    """triplane_next3d.py:117-188 (synthesis).  `jitter`/`u`: see oracle/renderer.py.  force_fp32=False: the float16
+    super-resolution blocks the reference runs on a GPU by default (oracle/networks.py::synthesis_block_fp16)."""
     st = {}
     N = ws.shape[0]
     cam2world = c[:, :16].view(-1, 4, 4)
@@ -131,6 +132,6 @@ def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_ren
     depth_image = depth.permute(0, 2, 1).reshape(N, 1, R, R)
     rgb = feature_image[:, :3]
     st['feature_image'] = feature_image
-    sr = networks.superresolution(P, 'superresolution', rgb, feature_image, eg3d_ws)
+    sr = networks.superresolution(P, 'superresolution', rgb, feature_image, eg3d_ws, force_fp32=force_fp32)
     out = {'image': sr, 'image_raw': rgb, 'image_depth': depth_image}
     return (out, st) if return_stages else out
