@@ -176,6 +176,9 @@ class Recording:
             return 0
         return deferred
 
+    def release(self):
+        self.entries, self.keep = [], []
+
     def __enter__(self):
         if getattr(_tls, 'recorder', None) is not None:
             raise RuntimeError('Recording: already recording')
@@ -192,23 +195,57 @@ class Recording:
         return False
 
 
-def replay_paired(ra, rb):
+def mark(name):
+    """A named position in the launch sequence (only meaningful inside a `Recording`): networks.SynthesisNet marks where its
+    low-resolution layers end."""
+    rec = getattr(_tls, 'recorder', None)
+    if rec is not None:
+        rec.entries.append(('__mark__', name))
+
+
+def replay_paired(ra, rb, side_stream=None, split_mark='high'):
     """Issue two recordings in lock step: launch i of `ra`, then launch i of `rb` — as ONE launch where both are 3x3 convolutions
     (n3d_conv2d_bf16x3_pair decides whether the kernels can share a grid; otherwise it runs them one after the other).  Each
-    recording's own order is preserved, so results are those of running the two recordings back to back."""
+    recording's own order is preserved, so results are those of running the two recordings back to back.
+    side_stream: from the mark `split_mark` on (the end of the low-resolution layers, whose handful of workgroups gain from
+    sharing a grid) the rest of `rb` — large layers that fill the chip on their own — is issued on `side_stream` (forked from the
+    current stream here) so that it overlaps whatever the caller enqueues next on the current stream; the caller joins
+    (`current.wait_stream(side_stream)`) and only then calls `rb.release()`: the recorded tensors were allocated for the current
+    stream, they must outlive the side stream's work."""
     h = _handle()
     a, b = ra.entries, rb.entries
-    for i in range(max(len(a), len(b))):
+    is_mark = lambda e: e is not None and e[0] == '__mark__'
+    i = 0
+    while i < max(len(a), len(b)):
         ea, eb = (a[i] if i < len(a) else None), (b[i] if i < len(b) else None)
+        if side_stream is not None and is_mark(ea) and is_mark(eb) and ea[1] == eb[1] == split_mark:
+            break
+        i += 1
+        if is_mark(ea) or is_mark(eb):
+            for e in (ea, eb):
+                if e is not None and not is_mark(e):
+                    check(getattr(h, e[0])(*e[1]))
+            continue
         if ea is not None and eb is not None and ea[0] == eb[0] == 'n3d_conv2d_bf16x3' and ea[1][1].value == eb[1][1].value:
             check(h.n3d_conv2d_bf16x3_pair(ea[1][0], eb[1][0], ea[1][1]))
             continue
         for e in (ea, eb):
             if e is not None:
                 check(getattr(h, e[0])(*e[1]))
-    ra.entries, rb.entries = [], []
-    ra.keep, rb.keep = [], []
-
+    if i < max(len(a), len(b)):                         # the marked split: rest of b on the side stream, rest of a here
+        side_stream.wait_stream(torch.cuda.current_stream())
+        sp = c_void_p(side_stream.cuda_stream)
+        for e in b[i:]:
+            if not is_mark(e):
+                check(getattr(h, e[0])(*(e[1][:-1] + (sp,))))          # every entry point takes its stream as the last argument
+        for e in a[i:]:
+            if not is_mark(e):
+                check(getattr(h, e[0])(*e[1]))
+        ra.release()
+        rb.entries = []
+        return
+    ra.release()
+    rb.release()
 
 def stream():
     """The HIP stream kernels are enqueued on = torch's current stream (as the reference plugins do with

@@ -83,7 +83,9 @@ class TriPlaneGenerator(torch.nn.Module):
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
         self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
-        self.pair_backbones = os.environ.get('N3D_PAIR_BACKBONES', '1') != '0'      # texture + static backbone in lock step (_planes)
+        # texture + static backbone in lock step with shared grids for their <= 32x32 layers (_planes): OFF by default — measured no
+        # better than the static backbone on its side stream
+        self.pair_backbones = os.environ.get('N3D_PAIR_BACKBONES', '0') == '1'
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -315,7 +317,16 @@ class TriPlaneGenerator(torch.nn.Module):
                 textures = S.texture(texture_ws, noise_mode)
             with _lib.Recording() as rec_s:
                 static = S.static(eg3d_ws, noise_mode)
-            _lib.replay_paired(rec_t, rec_s)
+            # ... and the static backbone's large layers (64x64 and up) go to a second HIP stream, where they overlap the texture ->
+            # mouth -> blending chain.  Measured on one box, one launch stream: 315 frames/s paired only, 341 paired + side stream,
+            # 347 side stream only (the default): the lock step puts the static backbone's small layers on the critical path of the
+            # texture -> mouth -> blending chain, which costs more than the shared grids save.
+            sstream = None
+            if self.overlap_static:
+                sstream = S.side_streams.get(cur.cuda_stream)
+                if sstream is None:
+                    sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
+            _lib.replay_paired(rec_t, rec_s, side_stream=sstream)
             paired = True
         elif self.overlap_static:
             sstream = S.side_streams.get(cur.cuda_stream)
@@ -338,8 +349,10 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch_in = front.clone() if getattr(self, 'keep_stages', False) else front
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
-        if ident is None and self.overlap_static and not paired:
+        if ident is None and self.overlap_static:
             cur.wait_stream(sstream)
+            if paired:
+                rec_s.release()                     # the recorded tensors outlive the side stream's work
         elif static is None:
             static = S.static(eg3d_ws, noise_mode)
         if cache_identity:

@@ -117,7 +117,10 @@ class SynthesisNet:
             side.wait_stream(torch.cuda.current_stream())
         x = img = None
         keep = []                      # feature maps read by the side stream stay referenced until the join
+        from . import _lib
         for res in self.block_res:
+            if res == 64:
+                _lib.mark('high')              # the layers up to 32x32 are a handful of workgroups each (generator._planes pairs them)
             x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side)
             keep.append(x)
         if side is not None:

@@ -331,9 +331,9 @@ def test_synthesis_graph_replay_is_bit_identical(G, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 4])
 def test_paired_backbones_equal_separate_launches(G, dev, batch):
-    """The texture and the static backbone issued in lock step — their <= 32x32 layers as shared grids (n3d_conv2d_bf16x3_pair) —
-    against the two networks run one after the other (and against the static backbone on its side stream): the same kernels on
-    the same operands, so every stage is bit-identical."""
+    """The texture and the static backbone issued in lock step — their <= 32x32 layers as shared grids (n3d_conv2d_bf16x3_pair), the
+    static backbone's large layers on the side stream (or in line) — against the two networks run one after the other (and against
+    the whole static backbone on its side stream): the same kernels on the same operands, so every stage is bit-identical."""
     from next3d_amd import layers
     layers.set_precision('bf16x3')
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
@@ -346,12 +346,12 @@ def test_paired_backbones_equal_separate_launches(G, dev, batch):
     G.keep_stages = True
     res = {}
     try:
-        for mode, (pair, overlap) in {'paired': (True, True), 'serial': (False, False), 'side_stream': (False, True)}.items():
+        for mode, (pair, overlap) in {'paired': (True, True), 'paired_inline': (True, False), 'serial': (False, False), 'side_stream': (False, True)}.items():
             G.pair_backbones, G.overlap_static = pair, overlap
             out = G.synthesis(ws, t('c'), t('v'), **kw)
             res[mode] = (G._debug['textures'].clone(), G._debug['static'].clone(), out['image'].clone())
     finally:
-        G.pair_backbones, G.overlap_static, G.keep_stages = True, True, False
-    for mode in ('serial', 'side_stream'):
+        G.pair_backbones, G.overlap_static, G.keep_stages = False, True, False
+    for mode in ('paired_inline', 'serial', 'side_stream'):
         for name, a, b in zip(('textures', 'static', 'image'), res['paired'], res[mode]):
             assert torch.equal(a, b), (mode, name, _md(a, b))
