@@ -189,6 +189,15 @@ class TriPlaneGenerator(torch.nn.Module):
         S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64)
         S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256)
         S.sr = networks.SuperRes8XDC(P, 'superresolution', conv_clamp=self.sr_conv_clamp)
+        # every style affine and demodulation coefficient of the five networks in TWO launches per forward (layers.StyleBank over the
+        # full [N, 28, 512] latents: the texture backbone reads slots 14-27, the others 0-13, the super-resolution slot 13)
+        nw = S.texture.num_ws
+        ent = [(l, slot + nw, k) for (l, slot, k) in S.texture.bank.entries]
+        for net in (S.static, S.mouth, S.blend):
+            ent += list(net.bank.entries)
+        ent += S.sr.bank_entries(nw - 1)
+        S.all_bank = layers.StyleBank(ent, dev)
+        S.one_bank = os.environ.get('N3D_ONE_BANK', '1') != '0' 
         lr = float(self.rendering_kwargs.get('decoder_lr_mul', 1))
         S.dec_w1 = (P['decoder.net.0.weight'] * (lr / np.sqrt(32))).contiguous()
         S.dec_b1 = (P['decoder.net.0.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.0.bias']
@@ -281,7 +290,7 @@ class TriPlaneGenerator(torch.nn.Module):
         grid, alpha, bbox = self.raster_geometry(v, lms)
         return self.project_textures(textures, grid), alpha, bbox
 
-    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False):
+    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False, bank=None):
         """Everything up to the blended tri-planes (channels-last [N,3,256,256,32]).  `cache_identity` keeps the two
         latent-only results (neural texture, static tri-planes); `use_cached_identity` re-uses them for a new mesh `v` (the
         reenactment loop, reenact_avatar_next3d.py:139-160: one identity, one mesh per frame)."""
@@ -314,9 +323,9 @@ class TriPlaneGenerator(torch.nn.Module):
             # latents: their launches are recorded and issued in lock step, the <= 32x32 layers (a handful of workgroups each)
             # as ONE grid per layer pair (n3d_conv2d_bf16x3_pair), the large ones one after the other.
             with _lib.Recording() as rec_t:
-                textures = S.texture(texture_ws, noise_mode)
+                textures = S.texture(texture_ws, noise_mode, bank=bank)
             with _lib.Recording() as rec_s:
-                static = S.static(eg3d_ws, noise_mode)
+                static = S.static(eg3d_ws, noise_mode, bank=bank)
             # ... and the static backbone's large layers (64x64 and up) go to a second HIP stream, where they overlap the texture ->
             # mouth -> blending chain.  Measured on one box, one launch stream: 315 frames/s paired only, 341 paired + side stream,
             # 347 side stream only (the default): the lock step puts the static backbone's small layers on the critical path of the
@@ -334,27 +343,27 @@ class TriPlaneGenerator(torch.nn.Module):
                 sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
             sstream.wait_stream(cur)                # ... after the rasterisation
             with torch.cuda.stream(sstream):
-                static = S.static(eg3d_ws, noise_mode)
+                static = S.static(eg3d_ws, noise_mode, bank=bank)
             static.record_stream(cur)
-            textures = S.texture(texture_ws, noise_mode)
+            textures = S.texture(texture_ws, noise_mode, bank=bank)
         else:
-            textures = S.texture(texture_ws, noise_mode)
+            textures = S.texture(texture_ws, noise_mode, bank=bank)
         front, side, top = self.project_textures(textures, grid)
         f32 = dict(dtype=torch.float32, device=ws.device)
         crop = torch.empty(N, 32, 64, 64, **f32)
         _lib.check(L.n3d_resize_aa(_lib.ptr(front), _lib.ptr(crop), _lib.ptr(bbox), None, N, 32, 256, 256, 64, 64, 0, _lib.stream()))
-        mouths = S.mouth(crop, eg3d_ws, noise_mode)
+        mouths = S.mouth(crop, eg3d_ws, noise_mode, bank=bank)
         # the mouth is pasted into the front plane in place (the reference copies it first, :158-160); a copy is kept only
         # when the stage tensors are requested for inspection
         stitch_in = front.clone() if getattr(self, 'keep_stages', False) else front
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
-        stitch = S.blend(stitch_in, eg3d_ws, noise_mode)
+        stitch = S.blend(stitch_in, eg3d_ws, noise_mode, bank=bank)
         if ident is None and self.overlap_static:
             cur.wait_stream(sstream)
             if paired:
                 rec_s.release()                     # the recorded tensors outlive the side stream's work
         elif static is None:
-            static = S.static(eg3d_ws, noise_mode)
+            static = S.static(eg3d_ws, noise_mode, bank=bank)
         if cache_identity:
             self._identity_cache = (textures, static)
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
@@ -416,10 +425,15 @@ class TriPlaneGenerator(torch.nn.Module):
         S = self._prep()
         ws = ws.to(device=self.device, dtype=torch.float32)
         eg3d_ws = ws[:, :S.texture.num_ws]             # always the CURRENT latents (upstream training/triplane.py:67-72 caches planes only)
+        bank = None
+        if S.one_bank and ws.shape[1] == 2 * S.texture.num_ws and ws.shape[2] == 512:
+            if not (ws.stride(2) == 1 and ws.stride(1) == 512):
+                ws = ws.contiguous()
+            bank = S.all_bank.compute(ws)
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity)
+            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank)
         if cache_backbone:
             self._last_planes = planes
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
@@ -428,7 +442,7 @@ class TriPlaneGenerator(torch.nn.Module):
         # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is
         # the float32 path its CPU run takes (networks_stylegan2.py:548) and the one the golden fixtures pin
         sr_fp16 = self.sr_use_fp16 and not synthesis_kwargs.get('force_fp32', False)
-        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16)
+        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16, bank=bank)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
     # ------------------------------------------------------------------ HIP-graph replay of the steady-state loops

@@ -109,9 +109,12 @@ class SynthesisNet:
         slots = _first_slots(self.block_res)
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.block_res), []), self.fir.device)
 
-    def __call__(self, ws, noise_mode='const'):
+    def __call__(self, ws, noise_mode='const', bank=None):
+        """`bank`: this network's styles / demodulation coefficients when the caller computed them already (generator: one
+        StyleBank over all five networks, two launches per forward instead of ten)."""
         ws = _ws3(ws)
-        bank = self.bank.compute(ws)
+        if bank is None:
+            bank = self.bank.compute(ws)
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
@@ -164,9 +167,10 @@ class StyleUNet:
         slots = _first_slots(self.block_res)
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.used_res), []), self.fir.device)
 
-    def __call__(self, x_in, ws, noise_mode='const'):
+    def __call__(self, x_in, ws, noise_mode='const', bank=None):
         ws = _ws3(ws)
-        bank = self.bank.compute(ws)
+        if bank is None:
+            bank = self.bank.compute(ws)
         # The decoder concatenates its feature map with the encoder's condition before every fusion conv (reference
         # networks_stylegan2_styleunet.py:565-567: torch.cat([x, conds[idx]], 1)).  Both halves are WRITTEN IN PLACE into one
         # buffer by the convolutions that produce them (channel-slice views: the kernels take a batch stride), so no
@@ -262,15 +266,19 @@ class SuperRes8XDC:
             rgb = L.torgb_layer_f16(blk.torgb, xh, None, self.fir, conv_clamp=blk.conv_clamp, img_lo=rgb, w16=wt)
         return rgb
 
-    def __call__(self, rgb, x, ws, resize_fn, noise_mode='none', fp16=False):
+    def bank_entries(self, last):
+        """StyleBank entries of both blocks, all reading latent slot `last`."""
+        return [(l, last, k) for blk in (self.block0, self.block1) for (l, _, k) in blk.entries(0)]
+
+    def __call__(self, rgb, x, ws, resize_fn, noise_mode='none', fp16=False, bank=None):
         """`resize_fn(t, size)` = antialiased bilinear resize (superresolution.py:282-286).  Every layer is driven by the
         LAST latent of `ws` (`ws[:, -1:].repeat(1, 3, 1)`, :280): all StyleBank jobs read that one slot."""
         ws = _ws3(ws)
         last = ws.shape[1] - 1
-        if last not in self._banks:
-            ent = [(l, last, k) for blk in (self.block0, self.block1) for (l, _, k) in blk.entries(0)]
-            self._banks[last] = L.StyleBank(ent, self.fir.device)
-        bank = self._banks[last].compute(ws)
+        if bank is None:
+            if last not in self._banks:
+                self._banks[last] = L.StyleBank(self.bank_entries(last), self.fir.device)
+            bank = self._banks[last].compute(ws)
         if x.shape[-1] != self.input_resolution:
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
