@@ -69,6 +69,12 @@ class TriPlaneGenerator(torch.nn.Module):
             raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
         if synthesis_kwargs.get('channel_base', 32768) != 32768 or synthesis_kwargs.get('channel_max', 512) != 512:
             raise RuntimeError('channel_base=32768 / channel_max=512 expected')
+        if synthesis_kwargs.get('num_fp16_res', 0) > 0:
+            # legacy.load_network_pkl(force_fp16=True) (legacy.py:49-59) or a custom config: float16 blocks in the BACKBONES.  The ffhq-512
+            # configuration has none (train_next3d.py: num_fp16_res = 0); they would run in float32 here — a superset in accuracy — so say so
+            import warnings
+            warnings.warn('num_fp16_res > 0: the StyleGAN2 backbones run all their blocks in float32 in this build (only the '
+                          'super-resolution module has float16 blocks: sr_num_fp16_res)')
         self.init_args = (z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path)
         self.init_kwargs = dict(sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs,
                                 rendering_kwargs=rendering_kwargs, sr_kwargs=sr_kwargs, **synthesis_kwargs)

@@ -330,3 +330,88 @@ def test_layout_grid_tiling():
         frames.layout_grid(img, grid_w=4, grid_h=2, float_to_uint8=False)
     with pytest.raises(RuntimeError):
         frames.layout_grid(img.float(), grid_w=3, grid_h=2)          # CPU tensor: no fallback for the conversion
+
+
+def test_ptr_keepalive_window_and_recording():
+    """`_lib.ptr()` holds every tensor whose pointer crosses the C ABI until `check()` (the launch is enqueued by then); inside a
+    `Recording` launches are deferred and the tensors move to the recording; marks are kept in order."""
+    import weakref
+    import torch
+    from next3d_amd import _lib
+    t = torch.zeros(8)
+    r = weakref.ref(t)
+    p = _lib.ptr(t)
+    del t
+    assert r() is not None and p.value == r().data_ptr()          # a temporary survives until the call it was marshalled for
+    _lib.check(0)
+    assert r() is None
+    with pytest.raises(RuntimeError):
+        _lib.check(-1)
+    with _lib.Recording() as rec:
+        x = torch.ones(4)
+        rc = _lib.lib().n3d_fma(_lib.ptr(x), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 4, 0, 1, 0, 1, None)     # deferred: nothing is launched
+        _lib.check(rc)
+        _lib.mark('high')
+        assert _lib.lib().n3d_abi_version() == _lib.ABI_VERSION      # host-only entry points pass through
+        with pytest.raises(RuntimeError):
+            with _lib.Recording():
+                pass
+    assert [e[0] for e in rec.entries] == ['n3d_fma', '__mark__'] and len(rec.keep) == 4
+    assert _lib.lib() is _lib._handle()                              # recording ended
+    rec.release()
+    assert rec.entries == [] and rec.keep == []
+    _lib.replay_paired(_lib.Recording(), _lib.Recording())          # empty recordings: a no-op
+
+
+def test_third_party_shims_host_side():
+    """next3d_amd/shims: module aliasing, the call surface the reference uses, and loud failures for everything else."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import next3d_amd
+for k in [k for k in sys.modules if k == 'cv2' or k.startswith('pytorch3d')]:
+    del sys.modules[k]
+next3d_amd.install_dropin(third_party=True)
+import cv2, pytorch3d
+from pytorch3d.io import load_obj
+from pytorch3d.structures import Meshes
+from pytorch3d.renderer.mesh import rasterize_meshes
+from cv2 import norm                                            # ray_marcher.py:16 imports it (and never calls it)
+assert cv2.__name__ == 'next3d_amd.shims.cv2' and Meshes.__module__ == 'next3d_amd.shims.pytorch3d.structures'
+assert cv2.imread('/nonexistent/uv_face_eye_mask.png') is None  # OpenCV's behaviour
+for bad in (lambda: cv2.resize(None), lambda: norm(1), lambda: cv2.floodFill(np.zeros((4, 4), np.float32), None, (1, 1), 255, 0, 254, cv2.FLOODFILL_FIXED_RANGE),
+            lambda: cv2.floodFill(np.zeros((4, 4), np.float64), None, (0, 0), 255, 0, 254, cv2.FLOODFILL_FIXED_RANGE)):
+    try:
+        bad()
+    except RuntimeError:
+        continue
+    raise AssertionError('expected RuntimeError')
+m = Meshes(verts=torch.zeros(2, 5, 3), faces=torch.zeros(1, 3, 3, dtype=torch.long).expand(2, -1, -1))
+assert len(m) == 2 and m.faces_padded().stride(0) == 0 and tuple(m.faces_packed().shape) == (6, 3)
+for kw in (dict(blur_radius=1e-4, faces_per_pixel=1), dict(blur_radius=0.0, faces_per_pixel=8), dict(blur_radius=0.0, faces_per_pixel=1, perspective_correct=True)):
+    try:
+        rasterize_meshes(m, image_size=64, **kw)
+    except RuntimeError:
+        continue
+    raise AssertionError('expected RuntimeError')
+try:
+    rasterize_meshes(m, image_size=64, blur_radius=0.0, faces_per_pixel=1)      # CPU tensors: no fallback
+except RuntimeError as e:
+    assert 'HIP device' in str(e)
+else:
+    raise AssertionError('expected RuntimeError')
+print('SHIMS_OK')
+""" % REPO
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'SHIMS_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    from next3d_amd import mesh
+    from next3d_amd.shims.pytorch3d.io import load_obj
+    obj = os.path.join(os.path.dirname(__file__), 'golden', '_tiny.obj')
+    with open(obj, 'w') as fh:
+        fh.write('v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\n')
+    try:
+        v, f, aux = load_obj(obj)
+        pv, pf, puv, pft = mesh.parse_obj(obj)
+        assert torch.equal(v, pv) and torch.equal(f.verts_idx, pf) and torch.equal(f.textures_idx, pft) and torch.equal(aux.verts_uvs, puv)
+    finally:
+        os.remove(obj)
