@@ -79,7 +79,7 @@ def test_forward_matches_reference_golden(G, dev, case, precision):
     assert rep['image_depth'] <= 1e-3, rep
 
 
-@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s48_b4'])
 def test_fp16_superresolution_matches_reference_fp16_run(G, dev, case, monkeypatch):
     """The scripts' DEFAULT route (sr_num_fp16_res = 4, no force_fp32) on the f16 kernels against the REFERENCE's own float16
     run of its super-resolution blocks (tests/golden/*_fp16sr.npz, oracle/pin_against_reference.py --fp16), on the reference's
@@ -90,18 +90,19 @@ def test_fp16_superresolution_matches_reference_fp16_run(G, dev, case, monkeypat
     from test_cpu_oracle import FP16_SR_TOL
     g = np.load(os.path.join(GOLDEN, case + '_fp16sr.npz'))
     ref = torch.from_numpy(g['image'])
+    step = int(g['image_step']) if 'image_step' in g else 1          # the batch-4 fixture (the benched configuration) keeps every second pixel
     rgb, feat, ws = (torch.from_numpy(g[k]).to(dev) for k in ('rgb_in', 'feat_in', 'ws_in'))
     sr = G._prep().sr
     for mode in ('cpu', 'cuda'):
         monkeypatch.setattr(layers, 'F16_REF_CPU_ROUNDING', mode == 'cpu')
         assert sr._fp16_mode(generator._resize_aa(feat, 128), 'none') == 'native'
-        out = sr(rgb, feat, ws, generator._resize_aa, noise_mode='none', fp16=True).cpu()
+        out = sr(rgb, feat, ws, generator._resize_aa, noise_mode='none', fp16=True).cpu()[..., ::step, ::step]
         d = (out - ref).abs()
         print(case, mode, f'max {float(d.max()):.3e} mean {float(d.mean()):.3e} (image absmax {float(ref.abs().max()):.2f})')
         assert float(d.max()) <= FP16_SR_TOL[mode][0] and float(d.mean()) <= FP16_SR_TOL[mode][1]
 
 
-@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48', 'case_r64_s48_b4'])
 def test_default_route_end_to_end_against_reference_fp16_run(G, dev, case):
     """The whole forward exactly as the scripts call it (no force_fp32) against the reference's float16-route image: the
     renderer's float32 output differs from the reference's by ~1e-5, which float16 rounding amplifies to single ulps."""
@@ -109,13 +110,14 @@ def test_default_route_end_to_end_against_reference_fp16_run(G, dev, case):
     from test_cpu_oracle import FP16_SR_TOL
     layers.set_precision('bf16x3')
     d = np.load(os.path.join(GOLDEN, case + '.npz'))
-    ref = torch.from_numpy(np.load(os.path.join(GOLDEN, case + '_fp16sr.npz'))['image'])
+    g16 = np.load(os.path.join(GOLDEN, case + '_fp16sr.npz'))
+    ref, step = torch.from_numpy(g16['image']), (int(g16['image_step']) if 'image_step' in g16 else 1)
     N, R, Sc, Sf = d['z'].shape[0], int(d['R']), int(d['Sc']), int(d['Sf'])
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
     jitter, u = cases.rng_inputs(N, R, Sc, Sf)
     ws = G.mapping(torch.from_numpy(d['z']).to(dev), torch.from_numpy(d['c_cond']).to(dev), truncation_psi=float(d['psi']), truncation_cutoff=int(d['cutoff']))
     out = G.synthesis(ws, torch.from_numpy(d['c']).to(dev), torch.from_numpy(d['v']).to(dev), neural_rendering_resolution=R, noise_mode='const',
-                      depth_jitter=jitter, importance_u=u)['image'].cpu()
+                      depth_jitter=jitter, importance_u=u)['image'].cpu()[..., ::step, ::step]
     e = (out - ref).abs()
     print(case, f'default route vs reference fp16 run: max {float(e.max()):.3e} mean {float(e.mean()):.3e}')
     assert float(e.max()) <= FP16_SR_TOL['cuda'][0] and float(e.mean()) <= FP16_SR_TOL['cuda'][1]
