@@ -179,7 +179,9 @@ typedef struct {
                              x_batch_stride still counts 4-byte elements (0 = dense) */
     int y_layout;         /* N3D_LAYOUT_NCHW_F32 (default) or, for the un-split transposed n3d_conv2d_bf16x3 (mode 2, O % 64 == 0,
                              demodulation-only epilogue), N3D_LAYOUT_C8_F32: y_row_stride then counts PIXELS (0 = OW) and
-                             y_batch_stride floats (= O * OH * pitch) */
+                             y_batch_stride floats (= O * OH * pitch); or, for the 1x1 n3d_conv2d_bf16x3 (O % 32 == 0),
+                             N3D_LAYOUT_SPLIT8: y is the dense split8 tensor a following pre-split 3x3 layer reads (that layer's
+                             style is NOT applied — plain Conv2dLayer consumers; y_batch_stride / y_row_stride ignored) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 

@@ -27,6 +27,7 @@ struct C1Params {
     const float* x; const bf16x8* wt16; const float* style; float* y;
     int N, I, O, OP64, H, W, HW;
     int tiles_p, tiles_m;
+    int y_split8;                // y is the split8 layout (bf16 [N][2][O/8][HW][8]) of the following 3x3 layer instead of float32 NCHW
     int64_t xbs, ybs, style_stride, yrs;
     n3d_epilogue epi;
 };
@@ -179,6 +180,40 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     const int64_t lplane = (int64_t)(p.H >> 1) * (p.W >> 1);
     n3d_up2_taps up2;
     if (res_up) up2 = n3d_up2_setup(E.residual_up_filter, oy, ox, p.H >> 1, p.W >> 1);
+    if (p.y_split8) {
+        // single-consumer 1x1 layers in front of a pre-split 3x3 layer (the encoders' fromrgb, networks_stylegan2_styleunet.py:
+        // fromrgb -> + skip -> conv1): the hi / lo bf16 pair goes out directly — lanes 0-31 / 32-63 hold channels 8g..8g+3 /
+        // 8g+4..8g+7 of a pixel, i.e. the two 8-byte halves of one 16-byte split8 unit (a wave store = 512 contiguous bytes).
+        // Same operation order as the generic epilogue below followed by n3d_split8_from_nchw (scale 1) => identical bits.
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const int64_t O8 = p.O >> 3;
+        __bf16* yb = (__bf16*)p.y + (int64_t)n * 2 * O8 * p.HW * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ol = mt * 32 + 8 * g + 4 * half + k;
+                    float v = acc[mt][4 * g + k] * s_rs[ol] + nz + s_bs[ol];
+                    if (lrelu) v = v > 0.f ? v : v * E.alpha;
+                    else if (!linear) v = conv1_act_generic(v, E.act, E.alpha);
+                    v *= E.gain;
+                    if (E.clamp >= 0.f) v = fminf(fmaxf(v, -E.clamp), E.clamp);
+                    v = n3d_round16(v, E.round_f16);
+                    if (res_up) v += n3d_up2_apply(up2, res + (int64_t)(m0 + ol) * lplane);
+                    else if (res) v += res[(int64_t)(m0 + ol) * p.HW];
+                    const __bf16 h = (__bf16)v;
+                    hi[k] = h;
+                    lo[k] = (__bf16)(v - (float)h);
+                }
+                __bf16* u = yb + (((int64_t)((m0 >> 3) + mt * 4 + g)) * p.HW + px) * 8 + 4 * half;
+                *(bf16x4*)u = hi;
+                *(bf16x4*)(u + O8 * p.HW * 8) = lo;
+            }
+        return;
+    }
     if ((linear || (lrelu && E.alpha >= 0.f && E.alpha <= 1.f)) && !E.residual && m0 + BM <= p.O) {
         // the common epilogue as straight-line code: leaky ReLU = max(v, alpha v) (linear: alpha 1), no clamp = clamp at +inf
         const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
@@ -349,11 +384,13 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.y_split8 = d->y_layout == N3D_LAYOUT_SPLIT8;
+    N3D_CHECK(!p.y_split8 || (d->O % 32 == 0 && ((uintptr_t)d->y & 15) == 0), "conv2d_bf16x3: a split8 output of the 1x1 kernel needs O %% 32 == 0 and a 16-byte aligned y");
     N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->H % 2 == 0 && d->W % 2 == 0),
               "conv2d_bf16x3: residual_up_filter needs a residual and an even output size");
     const double flops = 2.0 * d->N * (double)d->O * d->I * p.HW;
     const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.HW + (double)d->O * d->I);
-    if (p.HW <= 4096 && d->I % 128 == 0) {          // few pixels, long K: waves split the input channels (see above)
+    if (p.HW <= 4096 && d->I % 128 == 0 && !p.y_split8) {          // few pixels, long K: waves split the input channels (see above)
         int mt = cdiv(d->O, 32);
         if (mt > 4) mt = 4;
         p.tiles_p = cdiv(p.HW, 32);
@@ -375,6 +412,7 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     int mt = cdiv(d->O, 32);
     if (mt > 4) mt = 4;
     if ((int64_t)p.tiles_p * d->N * cdiv(d->O, 32 * mt) < 128) mt = 1;
+    if (p.y_split8 && d->O % (32 * mt) != 0) mt = 1;                       // the split8 epilogue writes whole tiles
     p.tiles_m = cdiv(d->O, 32 * mt);
     const int64_t nblk = (int64_t)p.tiles_p * p.tiles_m * d->N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");

@@ -800,7 +800,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);
-    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2),
+    N3D_CHECK(d->y_layout == N3D_LAYOUT_NCHW_F32 || (d->y_layout == N3D_LAYOUT_C8_F32 && d->ksize == 3 && d->mode == 2) ||
+              (d->y_layout == N3D_LAYOUT_SPLIT8 && d->ksize == 1 && d->x_layout == N3D_LAYOUT_NCHW_F32),
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
     N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
     if (d->x_layout == N3D_LAYOUT_SPLIT8)

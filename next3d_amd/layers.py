@@ -38,6 +38,7 @@ PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
 # (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
 S2_PRESPLIT = os.environ.get('N3D_S2_PRESPLIT', '1') != '0'      # stride-2 encoder layers on split8 input (A/B: 0)
 UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
+DIRECT_SPLIT8 = os.environ.get('N3D_DIRECT_SPLIT8', '1') != '0'     # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 CONVERT_MAX_BYTES = int(float(os.environ.get('N3D_CONVERT_MAX_MB', '70')) * 1e6)     # see _conv3x3
 
 
@@ -230,10 +231,11 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 
-def _conv1x1(L, x, style=None, epilogue=None, out=None):
-    """1x1 stride-1 convolution on the arithmetic selected by PRECISION."""
+def _conv1x1(L, x, style=None, epilogue=None, out=None, out_split8=False):
+    """1x1 stride-1 convolution on the arithmetic selected by PRECISION.  out_split8: return a `_lib.Split8` (see conv2d_layer)."""
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0):
-        return cg.conv_launch(x, L.wt16, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True)
+        return cg.conv_launch(x, L.wt16, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True, out_split8=out_split8)
+    assert not out_split8
     return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
 
 
@@ -248,8 +250,10 @@ def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_u
                                                                     residual_up_filter=residual_up_filter, round_f16=fp16))
 
 
-def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None):
-    """Conv2dLayer.forward (reference networks_stylegan2.py:173-183), up=1."""
+def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None, sole_consumer=None):
+    """Conv2dLayer.forward (reference networks_stylegan2.py:173-183), up=1.  `sole_consumer`: the un-modulated 3x3 stride-1
+    PreparedConv that is the ONLY reader of this 1x1 layer's result; when that layer runs on the pre-split kernel the result is
+    written as a `_lib.Split8` by this layer's epilogue (no conversion pass, and no CONVERT_MAX_BYTES limit)."""
     from .torch_utils.ops.bias_act import activation_funcs
     epi = _lib.make_epilogue(const_scale=L.weight_gain, bias=L.bias, act=activation,
                              gain=activation_funcs[activation].def_gain * gain,
@@ -257,7 +261,11 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     if down == 1 and L.ksize == 3:
         return _conv3x3(L, x, epilogue=epi, out=out)
     if down == 1 and L.ksize == 1:
-        return _conv1x1(L, x, epilogue=epi, out=out)
+        c = sole_consumer
+        s8 = (DIRECT_SPLIT8 and c is not None and out is None and PRESPLIT and PRECISION == 'bf16x3' and L.wt16 is not None and c.wt16 is not None and c.ksize == 3 and
+              x.dtype == torch.float32 and L.out_channels % 32 == 0 and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0) and
+              cg.split8_eligible(x.shape[0], L.out_channels, c.out_channels, x.shape[2], x.shape[3]))
+        return _conv1x1(L, x, epilogue=epi, out=out, out_split8=bool(s8))
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3

@@ -144,7 +144,7 @@ class _EncoderBlock:
     def __call__(self, inp, skip, fir, out_buf=None):
         if self.downsample:
             inp = uf.downsample2d(inp, fir)
-        out = L.conv2d_layer(self.fromrgb, inp, fir, activation='linear', residual=skip)
+        out = L.conv2d_layer(self.fromrgb, inp, fir, activation='linear', residual=skip, sole_consumer=self.conv1)
         out = L.conv2d_layer(self.conv1, out, fir, activation='lrelu')
         out = L.conv2d_layer(self.conv2, out, fir, activation='lrelu', down=2, out=out_buf)
         return inp, out

@@ -128,12 +128,13 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
 
 
 def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False,
-                out_c8=False):
+                out_c8=False, out_split8=False):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
     `out` may itself be such a view.  out_c8=True (un-split transposed split-bf16 layer, O % 64 == 0, demodulation-only epilogue):
-    the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8."""
+    the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8.  out_split8=True (1x1 split-bf16 layer,
+    O % 32 == 0): the result is a `_lib.Split8` for a following pre-split 3x3 layer without modulation."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
         if not (bf16x3 and ksize == 3 and (mode in (0, 1) or (mode == 2 and out_c8)) and style is None):
@@ -167,12 +168,17 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     if not split8 and not pitched_in and x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
     oh, ow = out_shape(h, w, mode)
-    c8 = None
+    c8 = s8 = None
     if out_c8:
         if not (bf16x3 and mode == 2 and out is None and o % 64 == 0 and out_dtype == torch.float32):
             raise RuntimeError('conv2d: the channel-interleaved output is written by the transposed split-bf16 kernel (O % 64 == 0)')
         c8 = _lib.C8(n, o, oh, ow, wt.device)
         ksplit = 1
+        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')
+    elif out_split8:
+        if not (bf16x3 and ksize == 1 and out is None and o % 32 == 0 and out_dtype == torch.float32 and not split8):
+            raise RuntimeError('conv2d: the split8 output is written by the 1x1 split-bf16 kernel (O % 32 == 0)')
+        s8 = _lib.Split8(n, o, oh, ow, wt.device)
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')
     elif out is not None:
         y = out
@@ -186,8 +192,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
-    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(c8.data if c8 else y), _lib.ptr(ws)
-    d.x_layout, d.y_layout = (1 if split8 else 0), (2 if c8 else 0)
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(c8.data if c8 else (s8.data if s8 else y)), _lib.ptr(ws)
+    d.x_layout, d.y_layout = (1 if split8 else 0), (2 if c8 else (1 if s8 else 0))
     d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
     d.x_batch_stride, d.y_batch_stride = x.stride(0), y.stride(0)
@@ -197,8 +203,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
-    if c8 is not None:
-        return c8
+    if c8 is not None or s8 is not None:
+        return c8 if c8 is not None else s8
     return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)
 
 

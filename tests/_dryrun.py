@@ -21,7 +21,9 @@ def _check_conv_desc(name, d):
     assert d.N >= 0 and d.I > 0 and d.O > 0 and d.H > 0 and d.W > 0, (name, d.N, d.I, d.O, d.H, d.W)
     assert d.x and d.wt and d.y, name
     assert d.ksize in (1, 3) and 0 <= d.mode <= 2
-    assert d.x_layout in (0, 1)
+    assert d.x_layout in (0, 1) and d.y_layout in (0, 1, 2)
+    if d.y_layout == 1:                                  # split8 OUTPUT: the 1x1 split-bf16 kernel in front of an un-modulated 3x3 layer
+        assert bf16x3 and d.ksize == 1 and d.x_layout == 0 and d.O % 32 == 0 and d.ksplit <= 1
     if d.x_layout == 1:                                  # split8 input: the pre-split launchers' preconditions (conv2d_ps_bf16x3.hip)
         assert bf16x3 and d.ksize == 3 and not d.style and d.epi.act in (1, 3)
         assert d.ksplit <= 1 or d.mode == 1              # only the stride-2 kernel keeps split-K

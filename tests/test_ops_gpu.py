@@ -549,6 +549,44 @@ def _to_split8(x):
     return s
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 32, 128, 64, 64), (2, 32, 256, 128, 128), (1, 64, 96, 37, 53), (3, 32, 160, 16, 32), (1, 256, 512, 32, 32),
+                                       (1, 32, 32, 9, 300)])
+def test_conv1x1_split8_output_equals_conversion_pass(dev, monkeypatch, N, I, OC, H, W):
+    """The 1x1 kernel's split8 epilogue (y_layout = N3D_LAYOUT_SPLIT8: the encoders' fromrgb in front of conv1) writes exactly
+    the bits n3d_split8_from_nchw makes of its float32 result — plain, with bias / lrelu / clamp, with the skip residual —
+    and `layers.conv2d_layer(sole_consumer=)` followed by the 3x3 layer is bit-identical with and without it."""
+    from next3d_amd import _lib, layers as L
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x = _gen((N, I, H, W), 140).to(dev)
+    w = (_gen((OC, I, 1, 1), 141) / np.sqrt(I)).to(dev)
+    wt16 = cg.prep_weight_bf16x3(w)
+    b, res = _gen((OC,), 142).to(dev), _gen((N, OC, H, W), 143).to(dev)
+    for kw in (dict(), dict(bias=b, act='lrelu', gain=1.3, clamp=1.5), dict(bias=b, residual=res, const_scale=0.7)):
+        ref = cg.split8_from_nchw(cg.conv_launch(x, wt16, 1, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True))
+        y = cg.conv_launch(x, wt16, 1, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, out_split8=True)
+        assert isinstance(y, _lib.Split8) and y.shape == (N, OC, H, W)
+        if H * W <= 4096 and I % 128 == 0:     # the float32 result of this shape comes from the split-K 1x1 kernel (another summation order)
+            _close(y.to_float(), ref.to_float(), atol=2e-5 * float(ref.to_float().abs().max()), rtol=0)
+        else:
+            assert torch.equal(y.data.view(torch.int16), ref.data.view(torch.int16)), kw.keys()
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(x, cg.prep_weight(w), 1, 0, OC, out_split8=True)                   # only the split-bf16 1x1 kernel writes it
+    if OC % 64 == 0 and cg.split8_eligible(N, OC, OC, H, W):
+        P = {'a.weight': w, 'a.bias': b, 'c.weight': (_gen((OC, OC, 3, 3), 144)).to(dev), 'c.bias': b}
+        A, C = L.PreparedConv(P, 'a', modulated=False), L.PreparedConv(P, 'c', modulated=False)
+        fir = O.setup_filter((1, 3, 3, 1)).to(dev)
+        outs = []
+        for direct in (True, False):
+            monkeypatch.setattr(L, 'DIRECT_SPLIT8', direct)
+            t = L.conv2d_layer(A, x, fir, residual=res, sole_consumer=C)
+            assert isinstance(t, _lib.Split8) == direct
+            outs.append(L.conv2d_layer(C, t, fir, activation='lrelu'))
+        if H * W <= 4096 and I % 128 == 0:
+            _close(outs[0], outs[1], atol=2e-5 * float(outs[1].abs().max()), rtol=0)
+        else:
+            assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 256, 128, 128), (4, 64, 512, 48, 80), (2, 128, 100, 256, 256), (8, 32, 64, 128, 160)])
 def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
     """conv2d_ps_bf16x3_kernel (split8 input staged by LDS-DMA) against the register-staged split-bf16 kernels on the same
