@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 3
+#define N3D_ABI_VERSION 4
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -182,6 +182,12 @@ typedef struct {
                              y_batch_stride floats (= O * OH * pitch); or, for the 1x1 n3d_conv2d_bf16x3 (O % 32 == 0),
                              N3D_LAYOUT_SPLIT8: y is the dense split8 tensor a following pre-split 3x3 layer reads (that layer's
                              style is NOT applied — plain Conv2dLayer consumers; y_batch_stride / y_row_stride ignored) */
+    void* side_split8;    /* NULL, or (1x1 n3d_conv2d_bf16x3 with O <= 128, I % 32 == 0 — the toRGB layers) a second output: the INPUT x
+                             multiplied by side_style [N,I] in the dense split8 layout, i.e. exactly n3d_split8_from_nchw(x, side_style):
+                             a block's feature map has two readers (toRGB, and the next block's transposed convolution with ITS
+                             styles, networks_stylegan2.py:469-475) and is read from HBM once for both */
+    const float* side_style;
+    int64_t side_style_stride; /* floats between samples of side_style (0 = I) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -34,7 +34,8 @@ class Conv2dDesc(ctypes.Structure):
                 ('N', c_int), ('I', c_int), ('O', c_int), ('H', c_int), ('W', c_int),
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
-                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int)]
+                ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int),
+                ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64)]
 
 
 class ModwJob(ctypes.Structure):

@@ -27,6 +27,7 @@ struct C1Params {
     const float* x; const bf16x8* wt16; const float* style; float* y;
     int N, I, O, OP64, H, W, HW;
     int tiles_p, tiles_m;
+    bf16x8* side; const float* side_style; int64_t side_style_stride;    // n3d_conv2d_desc.side_split8 (NULL = none)
     int y_split8;                // y is the split8 layout (bf16 [N][2][O/8][HW][8]) of the following 3x3 layer instead of float32 NCHW
     int64_t xbs, ybs, style_stride, yrs;
     n3d_epilogue epi;
@@ -37,7 +38,7 @@ __device__ __noinline__ float conv1_act_generic(float v, int act, float alpha) {
 // RES (MT = 1, I <= 256: the toRGB layers of the large resolutions): the weights of ALL K steps are staged once (<= 32 KB) and the K
 // loop runs without barriers — with a handful of output channels the per-step barrier, not the arithmetic, paced the activation
 // loads (3.6 TB/s read-only on the 512 x 512 x 128-channel toRGB).
-template <int MT, bool RES>
+template <int MT, bool RES, bool SIDE = false>
 __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     constexpr int BM = 32 * MT, NTHR = 512;
     constexpr int KC = MT <= 2 ? 2 : 1;                                   // 16-channel chunks per K step (register budget: 128 VGPRs)
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     constexpr int A_PER_T = (A_ITEMS + NTHR - 1) / NTHR;
     __shared__ bf16x8 A_s[(RES ? 8 : 2) * A_ITEMS];
     __shared__ float s_style[1024];
+    __shared__ float s_side[SIDE ? 1024 : 1];                            // the side output's styles (the next block's conv0)
     __shared__ float s_rs[BM], s_bs[BM];                                  // per-channel epilogue factors (no dependent global loads in the store loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -62,6 +64,8 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
     const int nsteps = p.I / (16 * KC);
 
     for (int i = tid; i < p.I; i += NTHR) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + i] : 1.f;
+    if (SIDE)
+        for (int i = tid; i < p.I; i += NTHR) s_side[i] = p.side_style[(int64_t)n * p.side_style_stride + i];
     if (tid < BM) {
         const n3d_epilogue& E = p.epi;
         const int o = min(m0 + tid, p.O - 1);
@@ -148,6 +152,27 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
                 const __bf16 h = (__bf16)v;
                 bh[kc][c] = h;
                 bl[kc][c] = (__bf16)(v - (float)h);
+            }
+        }
+        if (SIDE && px_ok) {
+            // second reader of x (the next block's transposed convolution): x * its styles, hi / lo split, one 16-byte unit
+            // per lane — channels (chunk, half) x 8 of this lane's pixel, the unit n3d_split8_from_nchw would write
+            const int64_t C8HW = (int64_t)(p.I >> 3) * p.HW;
+            bf16x8* so = p.side + (int64_t)n * 2 * C8HW + px;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const float* st2 = s_side + s * (16 * KC) + kc * 16 + half * 8;
+                bf16x8 sh, sl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float v = raw[kc][c] * st2[c];
+                    const __bf16 h = (__bf16)v;
+                    sh[c] = h;
+                    sl[c] = (__bf16)(v - (float)h);
+                }
+                const int64_t u = (int64_t)((s * KC + kc) * 2 + half) * p.HW;
+                so[u] = sh;
+                so[C8HW + u] = sl;
             }
         }
         if (s + 1 < nsteps) load_step(s + 1);                             // issue only: consumed after the MFMA block
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
 // issues all loads of its I/8 slice at once (activations by buffer loads, its weight fragments straight from the L2-resident
 // prepared tiles — no LDS staging, no barrier in the loop), and the eight partial accumulators are summed through LDS in a
 // fixed order; wave w then applies the epilogue to rows r = w (mod 8) of the 32 MT x 32 tile.
-template <int MT>
+template <int MT, bool SIDE = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params p) {
     constexpr int BM = 32 * MT;
     constexpr int GS = MT <= 2 ? 4 : 2;                                   // 16-channel chunks in flight per wave
@@ -289,6 +314,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, p.I * p.HW * 4, 0x00020000);
     const int x_voff = ((px_ok ? px : 0) + half * 8 * p.HW) * 4;
     const float* sty = p.style ? p.style + (int64_t)n * p.style_stride : nullptr;
+    const float* sty2 = SIDE ? p.side_style + (int64_t)n * p.side_style_stride : nullptr;     // side output: see conv1x1_bf16x3_kernel
+    const int64_t C8HW = (int64_t)(p.I >> 3) * p.HW;
+    bf16x8* so = SIDE ? p.side + (int64_t)n * 2 * C8HW + px : nullptr;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -325,6 +353,19 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params 
                 const __bf16 h = (__bf16)v;
                 bh[ch] = h;
                 bl[ch] = (__bf16)(v - (float)h);
+            }
+            if (SIDE && px_ok) {
+                bf16x8 sh, sl;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const float v = raw[g][ch] * sty2[c * 16 + half * 8 + ch];
+                    const __bf16 h = (__bf16)v;
+                    sh[ch] = h;
+                    sl[ch] = (__bf16)(v - (float)h);
+                }
+                const int64_t u = (int64_t)(c * 2 + half) * p.HW;
+                so[u] = sh;
+                so[C8HW + u] = sl;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -384,6 +425,10 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.side = (bf16x8*)d->side_split8; p.side_style = d->side_style;
+    p.side_style_stride = d->side_style_stride ? d->side_style_stride : d->I;
+    N3D_CHECK(!d->side_split8 || (d->side_style && d->O <= 128 && d->y_layout == N3D_LAYOUT_NCHW_F32 && ((uintptr_t)d->side_split8 & 15) == 0),
+              "conv2d_bf16x3: side_split8 needs side_style, O <= 128 (one channel tile), a float32 NCHW y and a 16-byte aligned buffer");
     p.y_split8 = d->y_layout == N3D_LAYOUT_SPLIT8;
     N3D_CHECK(!p.y_split8 || (d->O % 32 == 0 && ((uintptr_t)d->y & 15) == 0), "conv2d_bf16x3: a split8 output of the 1x1 kernel needs O %% 32 == 0 and a 16-byte aligned y");
     N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->H % 2 == 0 && d->W % 2 == 0),
@@ -397,7 +442,12 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
         p.tiles_m = cdiv(d->O, 32 * mt);
         N3dProfScope prof(N3D_K_CONV1X1_BF16X3, stream, flops, bytes);
         const dim3 grid((unsigned)(p.tiles_p * p.tiles_m * d->N));
-        switch (mt) {
+        if (p.side) switch (mt) {                                          // O <= 128 -> tiles_m == 1: x is read once
+            case 1: hipLaunchKernelGGL((conv1x1_bf16x3_ksplit_kernel<1, true>), grid, dim3(512), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((conv1x1_bf16x3_ksplit_kernel<2, true>), grid, dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((conv1x1_bf16x3_ksplit_kernel<3, true>), grid, dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((conv1x1_bf16x3_ksplit_kernel<4, true>), grid, dim3(512), 0, stream, p); break;
+        } else switch (mt) {
             case 1: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<1>, grid, dim3(512), 0, stream, p); break;
             case 2: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<2>, grid, dim3(512), 0, stream, p); break;
             case 3: hipLaunchKernelGGL(conv1x1_bf16x3_ksplit_kernel<3>, grid, dim3(512), 0, stream, p); break;
@@ -411,7 +461,7 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     // take 32-channel tiles instead so that more than a handful of CUs work on them (x re-reads hit L2)
     int mt = cdiv(d->O, 32);
     if (mt > 4) mt = 4;
-    if ((int64_t)p.tiles_p * d->N * cdiv(d->O, 32 * mt) < 128) mt = 1;
+    if ((int64_t)p.tiles_p * d->N * cdiv(d->O, 32 * mt) < 128 && !p.side) mt = 1;          // (side output: ONE channel tile, x is read once)
     if (p.y_split8 && d->O % (32 * mt) != 0) mt = 1;                       // the split8 epilogue writes whole tiles
     p.tiles_m = cdiv(d->O, 32 * mt);
     const int64_t nblk = (int64_t)p.tiles_p * p.tiles_m * d->N;
@@ -420,12 +470,24 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const dim3 grid((unsigned)nblk);
     switch (mt) {
         case 1:
-            if (d->I <= 256 && d->I % 32 == 0) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, true>), grid, dim3(512), 0, stream, p);
+            if (p.side) {                                                    // one channel tile (O <= 128): every workgroup sees all channels of its pixels once
+                if (d->I <= 256 && d->I % 32 == 0) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, true, true>), grid, dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, false, true>), grid, dim3(512), 0, stream, p);
+            } else if (d->I <= 256 && d->I % 32 == 0) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, true>), grid, dim3(512), 0, stream, p);
             else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<1, false>), grid, dim3(512), 0, stream, p);
             break;
-        case 2: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<2, false>), grid, dim3(512), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false>), grid, dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL((conv1x1_bf16x3_kernel<4, false>), grid, dim3(512), 0, stream, p); break;
+        case 2:
+            if (p.side) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<2, false, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<2, false>), grid, dim3(512), 0, stream, p);
+            break;
+        case 3:
+            if (p.side) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false>), grid, dim3(512), 0, stream, p);
+            break;
+        default:
+            if (p.side) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<4, false, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<4, false>), grid, dim3(512), 0, stream, p);
+            break;
     }
     N3D_LAUNCH_CHECK();
     return 0;

@@ -595,6 +595,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W, "conv2d: the fp32 kernels take dense input rows");
     N3D_CHECK(!d->epi.round_f16, "conv2d: round_f16 is not supported by the fp32 kernels");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 && d->y_layout == N3D_LAYOUT_NCHW_F32, "conv2d: the fp32 kernels read and write float32 NCHW (x_layout / y_layout 0)");
+    N3D_CHECK(!d->side_split8, "conv2d: side_split8 is written by the split-bf16 1x1 kernel only");
     N3D_CHECK(!d->epi.residual_up_filter || (d->epi.residual && d->mode != 2 && p.OH % 2 == 0 && p.OW % 2 == 0),
               "conv2d: residual_up_filter needs a residual, an even output size and a non-transposed mode");
     N3D_CHECK(d->ksplit <= 1 || d->workspace != nullptr, "conv2d: ksplit > 1 needs a workspace");

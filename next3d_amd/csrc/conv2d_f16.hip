@@ -377,6 +377,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d && d->ksize == 3 && (d->mode == 0 || d->mode == 2), "conv2d_f16: 3x3, stride 1 (mode 0) or transposed stride 2 (mode 2)");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_H8_F16 && d->y_layout == N3D_LAYOUT_H8_F16, "conv2d_f16: input and output in the h8 layout (N3D_LAYOUT_H8_F16)");
+    N3D_CHECK(!d->side_split8, "conv2d_f16: no side output");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_f16: the modulation is part of the per-sample weights (n3d_modulate_weights_f16); no split-K");
     N3D_CHECK(d->N >= 0 && d->I >= 16 && d->I % 16 == 0 && d->O >= 64 && d->O % 64 == 0, "conv2d_f16: I %% 16 == 0, O %% 64 == 0");
     if (d->N == 0) return 0;

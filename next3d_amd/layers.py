@@ -38,6 +38,7 @@ PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
 # (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
 S2_PRESPLIT = os.environ.get('N3D_S2_PRESPLIT', '1') != '0'      # stride-2 encoder layers on split8 input (A/B: 0)
 UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
+TORGB_SIDE = os.environ.get('N3D_TORGB_SIDE', '1') != '0'           # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
 DIRECT_SPLIT8 = os.environ.get('N3D_DIRECT_SPLIT8', '1') != '0'     # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 CONVERT_MAX_BYTES = int(float(os.environ.get('N3D_CONVERT_MAX_MB', '70')) * 1e6)     # see _conv3x3
 
@@ -185,7 +186,7 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, fp16=False):
+                    split_for=None, fp16=False, x_split8=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
@@ -218,7 +219,8 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
         zepi = _lib.make_epilogue(row_scale=dcoef, round_f16=fp16)
         if UP_PRESPLIT and x.shape[1] % 16 == 0:
-            xs = cg.split8_from_nchw(x, styles)          # modulation + operand split once, then pure LDS-DMA staging
+            # modulation + operand split once, then pure LDS-DMA staging; `x_split8`: the previous block's toRGB made it already
+            xs = x_split8 if x_split8 is not None else cg.split8_from_nchw(x, styles)
             t = cg.conv_launch(xs, L.wt16, 3, 2, L.out_channels, epilogue=zepi, bf16x3=True, out_c8=True)
         else:
             t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=zepi, bf16x3=True, out_c8=True)
@@ -231,23 +233,33 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))
 
 
-def _conv1x1(L, x, style=None, epilogue=None, out=None, out_split8=False):
-    """1x1 stride-1 convolution on the arithmetic selected by PRECISION.  out_split8: return a `_lib.Split8` (see conv2d_layer)."""
+def _conv1x1(L, x, style=None, epilogue=None, out=None, out_split8=False, side_style=None):
+    """1x1 stride-1 convolution on the arithmetic selected by PRECISION.  out_split8: return a `_lib.Split8` (see conv2d_layer);
+    side_style: return (y, `_lib.Split8` of x * side_style) (see torgb_layer)."""
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0):
-        return cg.conv_launch(x, L.wt16, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True, out_split8=out_split8)
-    assert not out_split8
+        return cg.conv_launch(x, L.wt16, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out, bf16x3=True, out_split8=out_split8,
+                              side_style=side_style)
+    assert not out_split8 and side_style is None
     return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
 
 
-def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None, fp16=False):
+def torgb_side_ok(L, x):
+    """Can toRGB layer `L` on the float32 feature map `x` also write x's split8 form for the next block (torgb_layer side_style)?"""
+    return (TORGB_SIDE and UP_PRESPLIT and PRECISION == 'bf16x3' and L.wt16 is not None and isinstance(x, torch.Tensor) and x.dtype == torch.float32 and
+            L.out_channels <= 128 and x.shape[1] % 32 == 0 and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0))
+
+
+def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None, fp16=False, side_style=None):
     """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584).  With
     `residual_up_filter`, `residual` is the PREVIOUS block's half-resolution image and upsample2d (:582) is evaluated
-    inside the convolution's epilogue."""
+    inside the convolution's epilogue.  With `side_style` (the styles of the NEXT block's transposed convolution, the other reader
+    of x: SynthesisBlock.forward :469-475) the kernel also writes x * side_style in the split8 layout -> (img, `_lib.Split8`):
+    the feature map is read from HBM once for both readers instead of once by toRGB and once by n3d_split8_from_nchw."""
     g = L.weight_gain
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
     return _conv1x1(L, x, style=styles, epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual,
-                                                                    residual_up_filter=residual_up_filter, round_f16=fp16))
+                                                                    residual_up_filter=residual_up_filter, round_f16=fp16), side_style=side_style)
 
 
 def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None, sole_consumer=None):

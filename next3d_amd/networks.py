@@ -33,22 +33,32 @@ class _Block:
         out.append((self.torgb, k, 'torgb'))
         return out
 
-    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None, fp16=False):
+    def _presplit(self, n, xshape, fir, noise_mode):
+        """conv0's FIR epilogue may hand its output to conv1 pre-split, with conv1's styles multiplied in (layers.presplit_ok)."""
+        return (self.conv0 is not None and noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and self.conv0.out_channels % 64 == 0 and
+                self.conv0.wt16 is not None and L.cg.bf16x3_eligible(xshape[1], xshape[2], xshape[3], 3, 2) and
+                L.cg.pick_ksplit_bf16x3(n, xshape[1], self.conv0.out_channels, xshape[2], xshape[3], 2) == 1 and
+                L.presplit_ok(n, self.conv1, 2 * xshape[2], 2 * xshape[3]))
+
+    def takes_split8(self, n, xshape, fir, noise_mode):
+        """Does conv0 read its [n, I, h, w] input in the split8 layout (layers.synthesis_layer, the transposed pre-split kernel)?"""
+        return bool(L.UP_PRESPLIT and xshape[1] % 16 == 0 and self._presplit(n, xshape, fir, noise_mode))
+
+    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None, fp16=False, x_split8=None, next_block=None):
         """SynthesisBlock.forward; `bank` = StyleBank.compute(ws) result.  fp16=True: the reference's fp16 block (use_fp16 and
         not force_fp32, networks_stylegan2.py:548) — float32 arithmetic with float16 storage rounding (layers.synthesis_layer);
-        the skip image stays float32 as in the reference (:582-585)."""
+        the skip image stays float32 as in the reference (:582-585).  -> (x, img, xs): `next_block` = the block whose conv0 reads
+        THIS block's x unchanged; when it takes split8 input, toRGB writes it on the side (layers.torgb_layer) and `xs` is to be
+        passed to that block as `x_split8` (None otherwise)."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
-            # conv0's FIR epilogue may hand its output to conv1 pre-split, with conv1's styles multiplied in (layers.presplit_ok)
-            pre = (noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and self.conv0.out_channels % 64 == 0 and
-                   self.conv0.wt16 is not None and L.cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2) and
-                   L.cg.pick_ksplit_bf16x3(n, x.shape[1], self.conv0.out_channels, x.shape[2], x.shape[3], 2) == 1 and
-                   L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
+            pre = self._presplit(n, x.shape, fir, noise_mode)
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
-                                  split_for=bank[self.conv1.prefix][0] if pre else None, fp16=fp16, **sl(self.conv0))
+                                  split_for=bank[self.conv1.prefix][0] if pre else None, fp16=fp16, x_split8=x_split8 if pre else None,
+                                  **sl(self.conv0))
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, fp16=fp16,
                                   **sl(self.conv1))
         # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
@@ -58,8 +68,13 @@ class _Block:
             up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
             if img is not None and up is None:
                 img = uf.upsample2d(img, fir)
+            side = (bank[next_block.conv0.prefix][0] if (next_block is not None and L.torgb_side_ok(self.torgb, x) and
+                                                          next_block.takes_split8(n, x.shape, fir, noise_mode)) else None)
             img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0],
-                                residual_up_filter=up, fp16=fp16)
+                                residual_up_filter=up, fp16=fp16, side_style=side)
+            if side is not None:
+                img, xs = img
+                return x, img, xs
         else:
             ev = torch.cuda.current_stream().record_event()
             with torch.cuda.stream(img_stream):
@@ -67,7 +82,7 @@ class _Block:
                 if img is not None:
                     img = uf.upsample2d(img, fir)
                 img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0], fp16=fp16)
-        return x, img
+        return x, img, None
 
 
 _IMG_STREAMS = {}
@@ -121,10 +136,12 @@ class SynthesisNet:
         x = img = None
         keep = []                      # feature maps read by the side stream stay referenced until the join
         from . import _lib
-        for res in self.block_res:
+        xs = None
+        for k, res in enumerate(self.block_res):
             if res == 64:
                 _lib.mark('high')              # the layers up to 32x32 are a handful of workgroups each (generator._planes pairs them)
-            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side)
+            nxt = self.blocks[self.block_res[k + 1]] if k + 1 < len(self.block_res) else None
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_split8=xs, next_block=nxt)
             keep.append(x)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -193,17 +210,20 @@ class StyleUNet:
         side = _img_stream(ws.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-        x = img = None
+        x = img = xs = None
         keep = []
         for idx, res in enumerate(self.used_res):
             if idx < len(self.fusion):
+                xs = None                                             # this block reads the fusion layer's output, not the previous x
                 if idx == 0:
                     x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
                 else:
                     x = L.conv2d_layer(self.fusion[idx], cat[idx] if idx in cat else torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
             nxt = cat.get(idx + 1)
             x_out = nxt[:, :self.cd[res]] if (nxt is not None and nxt.shape[2] == res) else None
-            x, img = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_out=x_out)
+            # the next block reads this x directly unless a fusion layer (or the concatenation buffer's channel-slice view) is in between
+            nb = self.blocks[self.used_res[idx + 1]] if (idx + 1 < len(self.used_res) and idx + 1 >= len(self.fusion) and x_out is None) else None
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_out=x_out, x_split8=xs, next_block=nb)
             if nxt is not None and x_out is None:                 # shapes did not line up: fall back to a copy
                 nxt[:, :self.cd[res]].copy_(x)
             keep.append(x)
@@ -293,8 +313,8 @@ class SuperRes8XDC:
         if fp16:        # N3D_SR_FP16=emulate: float32 / split-bf16 arithmetic with float16 storage rounding (round 2's route, A/B)
             from . import _lib
             x = _lib.cast(_lib.cast(x.contiguous(), torch.float16), torch.float32)
-        x0, rgb = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16)
-        x1, rgb = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16)
+        x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16, next_block=self.block1)
+        x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16, x_split8=xs)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         return rgb

@@ -128,13 +128,14 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
 
 
 def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False,
-                out_c8=False, out_split8=False):
+                out_c8=False, out_split8=False, side_style=None):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
     `out` may itself be such a view.  out_c8=True (un-split transposed split-bf16 layer, O % 64 == 0, demodulation-only epilogue):
     the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8.  out_split8=True (1x1 split-bf16 layer,
-    O % 32 == 0): the result is a `_lib.Split8` for a following pre-split 3x3 layer without modulation."""
+    O % 32 == 0): the result is a `_lib.Split8` for a following pre-split 3x3 layer without modulation.  side_style [N,I] (1x1
+    split-bf16 layer, O <= 128): returns (y, `_lib.Split8` of x * side_style) — n3d_conv2d_desc.side_split8."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
         if not (bf16x3 and ksize == 3 and (mode in (0, 1) or (mode == 2 and out_c8)) and style is None):
@@ -201,8 +202,18 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.y_row_stride = y.stride(2)                         # c8: pitch in pixels (= OW, dense), batch stride O * OH * OW floats
     d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
+    side = None
+    if side_style is not None:
+        if not (bf16x3 and ksize == 1 and not split8 and s8 is None and o <= 128 and i % 32 == 0 and out_dtype == torch.float32 and
+                side_style.dtype == torch.float32 and side_style.stride(1) == 1 and tuple(side_style.shape) == (n, i)):
+            raise RuntimeError('conv2d: the split8 side output is written by the 1x1 split-bf16 kernel (O <= 128, I % 32 == 0, float32 styles [N,I])')
+        _lib.require_device(side_style)
+        side = _lib.Split8(n, i, h, w, wt.device)
+        d.side_split8, d.side_style, d.side_style_stride = _lib.ptr(side.data), _lib.ptr(side_style), side_style.stride(0)
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
+    if side is not None:
+        return (y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)), side
     if c8 is not None or s8 is not None:
         return c8 if c8 is not None else s8
     return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)

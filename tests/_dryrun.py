@@ -29,6 +29,8 @@ def _check_conv_desc(name, d):
         assert d.ksplit <= 1 or d.mode == 1              # only the stride-2 kernel keeps split-K
         assert d.I % 16 == 0 and d.x_batch_stride % 4 == 0
         assert (d.mode == 0 and d.H >= 16 and d.W >= 32) or (d.mode == 2 and d.y_layout == 2 and d.O % 64 == 0) or (d.mode == 1 and d.H >= 3 and d.W >= 3)
+    if d.side_split8:                                    # toRGB's second output: x * the next block's styles as split8
+        assert bf16x3 and d.ksize == 1 and d.x_layout == 0 and d.y_layout == 0 and d.O <= 128 and d.I % 32 == 0 and d.side_style
     if bf16x3:
         assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)
         assert d.x_row_stride in (0, d.W) or (d.ksize == 3 and d.mode == 1)

@@ -357,3 +357,31 @@ def test_paired_backbones_equal_separate_launches(G, dev, batch):
     for mode in ('paired_inline', 'serial', 'side_stream'):
         for name, a, b in zip(('textures', 'static', 'image'), res['paired'], res[mode]):
             assert torch.equal(a, b), (mode, name, _md(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fp16', [False, True])
+def test_fused_layout_handovers_are_bit_identical_to_conversion_passes(G, dev, monkeypatch, fp16):
+    """The two epilogue fusions that replace n3d_split8_from_nchw passes — toRGB writing its input as split8 for the next block's
+    transposed convolution (layers.torgb_layer side_style) and the encoders' fromrgb writing split8 for conv1
+    (layers.conv2d_layer sole_consumer) — against the same forward with both switched off: the same values reach the same
+    kernels, so every output is bit-identical (fp32 route, and the float16-emulating route whose block-0 feature map is
+    rounded to float16 before it is handed over)."""
+    from next3d_amd import layers
+    layers.set_precision('bf16x3')
+    monkeypatch.setenv('N3D_SR_FP16', 'emulate')
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
+    R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(4, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(d[k]).to(dev)
+    ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=not fp16)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(layers, 'TORGB_SIDE', on)
+        monkeypatch.setattr(layers, 'DIRECT_SPLIT8', on)
+        o = G.synthesis(ws, t('c'), t('v'), **kw)
+        outs[on] = {k: o[k].clone() for k in ('image', 'image_raw', 'image_depth')}
+    for k in outs[True]:
+        assert torch.equal(outs[True][k], outs[False][k]), (k, _md(outs[True][k], outs[False][k]))

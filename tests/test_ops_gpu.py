@@ -587,6 +587,36 @@ def test_conv1x1_split8_output_equals_conversion_pass(dev, monkeypatch, N, I, OC
             assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(2, 256, 3, 128, 128), (1, 128, 3, 96, 200), (2, 512, 3, 80, 80), (4, 512, 3, 64, 64), (2, 512, 96, 32, 32),
+                                       (1, 256, 96, 128, 128), (1, 64, 40, 37, 53), (3, 128, 128, 16, 16), (1, 32, 8, 9, 300)])
+def test_conv1x1_side_output_equals_conversion_pass(dev, N, I, OC, H, W):
+    """n3d_conv2d_desc.side_split8 (toRGB also writing x * the next block's styles as split8): the main output is unchanged
+    bit for bit and the side tensor is exactly n3d_split8_from_nchw(x, side_style) — on the pixel-tiled kernels (weights
+    resident / streamed, 1..4 channel tiles) and the split-K kernel of the <= 64 x 64 layers, with the fused skip upsample."""
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x = _gen((N, I, H, W), 150).to(dev)
+    wt16 = cg.prep_weight_bf16x3((_gen((OC, I, 1, 1), 151) / np.sqrt(I)).to(dev))
+    st, st2, b = _gen((N, I), 152).to(dev), _gen((N, I + 5), 153).to(dev)[:, 2:I + 2], _gen((OC,), 154).to(dev)      # st2: strided rows
+    low, f = _gen((N, OC, H // 2, W // 2), 155).to(dev), O.setup_filter((1, 3, 3, 1)).to(dev)
+    kws = [dict(bias=b, clamp=0.8)]
+    if H % 2 == 0 and W % 2 == 0:
+        kws.append(dict(bias=b, clamp=0.8, residual=low, residual_up_filter=f))
+    for kw in kws:
+        ref = cg.conv_launch(x, wt16, 1, 0, OC, style=st, epilogue=_lib.make_epilogue(**kw), bf16x3=True)
+        y, side = cg.conv_launch(x, wt16, 1, 0, OC, style=st, epilogue=_lib.make_epilogue(**kw), bf16x3=True, side_style=st2)
+        assert torch.equal(y, ref)
+        want = cg.split8_from_nchw(x, st2)
+        assert side.shape == (N, I, H, W) and torch.equal(side.data.view(torch.int16), want.data.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(x, wt16, 1, 0, OC, style=st, bf16x3=True, side_style=st2.double())
+    if OC <= 128:
+        xv = torch.empty(N, I + 32, H, W, device=dev)[:, 32:]          # a channel-slice view (batch stride > I*H*W), as in the U-Net's buffers
+        xv.copy_(x)
+        y, side = cg.conv_launch(xv, wt16, 1, 0, OC, style=st, bf16x3=True, side_style=st2)
+        assert torch.equal(side.data.view(torch.int16), cg.split8_from_nchw(x, st2).data.view(torch.int16))
+
+
 @pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 256, 128, 128), (4, 64, 512, 48, 80), (2, 128, 100, 256, 256), (8, 32, 64, 128, 160)])
 def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
     """conv2d_ps_bf16x3_kernel (split8 input staged by LDS-DMA) against the register-staged split-bf16 kernels on the same
