@@ -137,6 +137,11 @@ int n3d_fir4_split8_sep(const float* x_c8, const float* f1d, void* y_split8, int
 int n3d_fir4_split8_nchw(const float* x, const float* f, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
                          int64_t x_batch_stride, int pad, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
                          int64_t out_scale_stride, n3d_stream_t stream);
+/* n3d_fir4_split8_nchw_sep: n3d_fir4_split8_nchw for a separable filter f = outer(f1d, f1d) and a linear / leaky-ReLU epilogue (the
+ * NCHW twin of n3d_fir4_split8_sep: column sums from the 8 channel planes, LDS, row pass). */
+int n3d_fir4_split8_nchw_sep(const float* x, const float* f1d, void* y_split8, int N, int C, int H, int W, int64_t x_row_stride,
+                             int64_t x_batch_stride, int pad, int flip, float gain, const n3d_epilogue* epi, const float* out_scale,
+                             int64_t out_scale_stride, n3d_stream_t stream);
 /* n3d_split8_from_nchw: a float32 NCHW tensor [N,C,HW] (dense planes, batch stride x_batch_stride floats, 0 = dense) ->
  * split8, every value multiplied by scale[n*scale_stride + c] first (the consumer's style; NULL = 1).  For tensors whose
  * producer cannot write split8 itself (two consumers that need different styles). */

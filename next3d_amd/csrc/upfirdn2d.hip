@@ -438,15 +438,18 @@ __global__ __launch_bounds__(FIR_TW * 8, FIR_TW == 64 ? 4 : 8) void fir4_c8_spli
 // evaluated in another order than the 16-tap form — differences of a float32 ulp.  Tile: 61 x 16 outputs, 256 work items.
 struct FirSplitSepParams {
     const float* x; const float* f1d; bf16x8_t* y;
-    int N, C, H, W, OH, OW, flip, tiles_x;
+    int N, C, H, W, OH, OW, flip, tiles_x, pad;
     float gain;
     int64_t xbs, xrs;
     const float* out_scale; int64_t out_scale_stride;
     int has_epi;
     n3d_epilogue epi;
 };
-__global__ __launch_bounds__(256) void fir4_c8_split8_sep_kernel(FirSplitSepParams p) {
-    constexpr int SW = 61, COLS = 64, TH = 16, RPT = 4;
+// NCHW_IN: the same from 8 float32 channel planes (padding p.pad = 1 or 2): the filter in front of a stride-2 convolution — the
+// 16-tap form staged 10,184 single floats per tile through LDS and ran at 2.2 TB/s.
+template <bool NCHW_IN, int RPT = 4>
+__global__ __launch_bounds__(256) void fir4_split8_sep_kernel(FirSplitSepParams p) {
+    constexpr int SW = 61, COLS = 64, TH = 4 * RPT;
     __shared__ f32x4 s_v[2 * TH * COLS];                                  // [channel half][row][column]
     const int lx = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
@@ -458,15 +461,25 @@ __global__ __launch_bounds__(256) void fir4_c8_split8_sep_kernel(FirSplitSepPara
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs + (int64_t)c8 * p.H * p.xrs * 8), 0,
                                                                           (int)(p.H * p.xrs * 32), 0x00020000);
     {
-        const int ix = ox0 - 1 + lx;
+        const int ix = ox0 - p.pad + lx;
         f32x4 lo4[RPT + 3], hi4[RPT + 3];
 #pragma unroll
         for (int r = 0; r < RPT + 3; ++r) {
-            const int iy = oy0 - 1 + RPT * g + r;
+            const int iy = oy0 - p.pad + RPT * g + r;
             const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int off = ok ? (iy * (int)p.xrs + ix) * 32 : (int)0x80000000;
-            lo4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-            hi4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+            if (NCHW_IN) {                                                // 8 planes of H x xrs floats; a wave reads 256 contiguous bytes per (channel, row)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int o0 = ok ? ((ch * p.H + iy) * (int)p.xrs + ix) * 4 : (int)0x80000000;
+                    const int o1 = ok ? (((ch + 4) * p.H + iy) * (int)p.xrs + ix) * 4 : (int)0x80000000;
+                    lo4[r][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o0, 0, 0));
+                    hi4[r][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o1, 0, 0));
+                }
+            } else {
+                const int off = ok ? (iy * (int)p.xrs + ix) * 32 : (int)0x80000000;
+                lo4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                hi4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+            }
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -587,9 +600,37 @@ extern "C" int n3d_fir4_split8_sep(const float* x, const float* f1d, void* y, in
     p.out_scale = out_scale; p.out_scale_stride = out_scale_stride ? out_scale_stride : C;
     p.has_epi = epi != nullptr;
     if (epi) p.epi = *epi;
+    p.tiles_x = cdiv(p.OW, 61); p.pad = 1;
+    N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)p.OH * p.OW * 8, 4.0 * N * C * ((double)H * W + (double)p.OH * p.OW));
+    // (8 rows per work item — 11 input rows for 8 outputs instead of 7 for 4, 64 KB of LDS — measured 8-12 % slower: 2 workgroups per CU)
+    hipLaunchKernelGGL((fir4_split8_sep_kernel<false, 4>), dim3(p.tiles_x * cdiv(p.OH, 16), C / 8, N), dim3(256), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int n3d_fir4_split8_nchw_sep(const float* x, const float* f1d, void* y, int N, int C, int H, int W, int64_t x_row_stride, int64_t x_batch_stride,
+                                        int pad, int flip, float gain, const n3d_epilogue* epi, const float* out_scale, int64_t out_scale_stride,
+                                        n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && H > 1 && W > 1, "fir4_split8_nchw_sep: bad shape (C %% 8 == 0)");
+    N3D_CHECK(pad == 1 || pad == 2, "fir4_split8_nchw_sep: padding 1 or 2");
+    const int64_t xrs = x_row_stride ? x_row_stride : W;
+    N3D_CHECK(xrs >= W, "fir4_split8_nchw_sep: row stride smaller than the width");
+    N3D_CHECK(!epi || (!epi->residual && !epi->residual_up_filter), "fir4_split8_nchw_sep: no residual input");
+    N3D_CHECK(!epi || !epi->noise || epi->noise_strength, "fir4_split8_nchw_sep: noise without noise_strength");
+    N3D_CHECK(!epi || epi->act == N3D_ACT_LINEAR || (epi->act == N3D_ACT_LRELU && epi->alpha >= 0.f && epi->alpha <= 1.f), "fir4_split8_nchw_sep: linear or leaky-ReLU epilogue only");
+    if (N == 0) return 0;
+    N3D_CHECK(x && f1d && y && ((uintptr_t)y & 15) == 0, "fir4_split8_nchw_sep: null or misaligned tensor");
+    N3D_CHECK(C / 8 <= 65535 && N <= 65535 && (int64_t)H * xrs * 32 < (1ll << 31), "fir4_split8_nchw_sep: tensor too large");
+    FirSplitSepParams p;
+    p.x = x; p.f1d = f1d; p.y = (bf16x8_t*)y; p.N = N; p.C = C; p.H = H; p.W = W; p.OH = H + 2 * pad - 3; p.OW = W + 2 * pad - 3; p.flip = flip; p.gain = gain;
+    p.xbs = x_batch_stride ? x_batch_stride : (int64_t)C * H * xrs; p.xrs = xrs; p.pad = pad;
+    p.out_scale = out_scale; p.out_scale_stride = out_scale_stride ? out_scale_stride : C;
+    p.has_epi = epi != nullptr;
+    if (epi) p.epi = *epi;
     p.tiles_x = cdiv(p.OW, 61);
     N3dProfScope prof(N3D_K_UPFIRDN2D, stream, 2.0 * N * C * (double)p.OH * p.OW * 8, 4.0 * N * C * ((double)H * W + (double)p.OH * p.OW));
-    hipLaunchKernelGGL(fir4_c8_split8_sep_kernel, dim3(p.tiles_x * cdiv(p.OH, 16), C / 8, N), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fir4_split8_sep_kernel<true, 4>), dim3(p.tiles_x * cdiv(p.OH, 16), C / 8, N), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -110,7 +110,9 @@ def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     n, c, h, w = x.shape
     y = _lib.Split8(n, c, h - 1, w - 1, x.device)
     import os
-    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and (epilogue is None or epilogue.act in (1, 3))) else None
+    # (64 x 64 outputs: the 16-tap kernel's staged tile is the faster one, 21 vs 24 us — profiles/r03_fir_bench.txt)
+    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and (epilogue is None or epilogue.act in (1, 3)) and
+                              (h > 100 or os.environ.get('N3D_FIR_SEP') == '1')) else None
     if f1d is not None:
         _lib.check(_lib.lib().n3d_fir4_split8_sep(_lib.ptr(x.data), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, w, 0, 0, float(gain),
                                                   epilogue, _lib.ptr(out_scale), out_scale.stride(0), _lib.stream()))
@@ -129,6 +131,14 @@ def _fir4_split8_nchw(x, f2d, pad, gain=1.0, epilogue=None, out_scale=None):
         x = x.contiguous()
     n, c, h, w = x.shape
     y = _lib.Split8(n, c, h + 2 * pad - 3, w + 2 * pad - 3, x.device)
+    import os
+    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and os.environ.get('N3D_FIR_SEP_NCHW', '1') != '0' and
+                              (epilogue is None or epilogue.act in (1, 3))) else None
+    if f1d is not None and h * x.stride(2) * 32 < 2 ** 31:
+        _lib.check(_lib.lib().n3d_fir4_split8_nchw_sep(_lib.ptr(x), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, x.stride(2), x.stride(0), pad, 0,
+                                                       float(gain), epilogue, _lib.ptr(out_scale), out_scale.stride(0) if out_scale is not None else 0,
+                                                       _lib.stream()))
+        return y
     _lib.check(_lib.lib().n3d_fir4_split8_nchw(_lib.ptr(x), _lib.ptr(f2d), _lib.ptr(y.data), n, c, h, w, x.stride(2), x.stride(0), pad, 0, float(gain),
                                                epilogue, _lib.ptr(out_scale), out_scale.stride(0) if out_scale is not None else 0, _lib.stream()))
     return y

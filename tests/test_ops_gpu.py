@@ -642,10 +642,14 @@ def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
 
 
 @pytest.mark.parametrize('N,C,H,W,pad', [(2, 32, 64, 64, 2), (1, 16, 37, 101, 2), (3, 8, 16, 20, 1), (1, 64, 128, 128, 2)])
-def test_fir4_split8_from_nchw_matches_float_fir(dev, N, C, H, W, pad):
-    """n3d_fir4_split8_nchw (the FIR in front of a stride-2 convolution, float32 NCHW in, split8 out) against the float32 FIR of
-    the same library: hi + lo reproduces it to the 16 bits the pair carries."""
+@pytest.mark.parametrize('sep', ['1', '0'])
+def test_fir4_split8_from_nchw_matches_float_fir(dev, monkeypatch, N, C, H, W, pad, sep):
+    """n3d_fir4_split8_nchw / n3d_fir4_split8_nchw_sep (the FIR in front of a stride-2 convolution, float32 NCHW in, split8 out;
+    sep '1': the separable kernel, '0': the 16-tap one) against the float32 FIR of the same library: hi + lo reproduces it to the
+    16 bits the pair carries — dense input, a row-pitched batch-strided view, and with an epilogue + the next layer's styles."""
+    from next3d_amd import _lib
     from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    monkeypatch.setenv('N3D_FIR_SEP', sep)
     x = _gen((N, C, H, W), 120).to(dev)
     f = uf.setup_filter([1, 3, 3, 1]).to(dev)
     ref = uf.upfirdn2d(x, f, padding=[pad] * 4)
@@ -654,6 +658,13 @@ def test_fir4_split8_from_nchw_matches_float_fir(dev, N, C, H, W, pad):
     print('fir4 nchw -> split8: max |hi + lo - fir|', float((y.to_float() - ref).abs().max()))
     _close(y.to_float(), ref, atol=1e-6, rtol=2.0 ** -15)                 # hi + lo carries 16 significant bits
     _close(ref.cpu(), O.upfirdn2d(x.cpu(), f.cpu(), padding=[pad] * 4), atol=1e-6, rtol=1e-6)
+    xv = torch.zeros(N, C + 8, H, W + 3, device=dev)[:, 8:, :, :W]        # pitched rows, batch stride > C*H*pitch
+    xv.copy_(x)
+    _close(uf._fir4_split8_nchw(xv, f, pad).to_float(), ref, atol=1e-6, rtol=2.0 ** -15)
+    bias, style = _gen((C,), 121).to(dev), (1 + 0.2 * _gen((N, C), 122)).to(dev)
+    act = dict(bias=bias, act='lrelu', gain=float(np.sqrt(2)), clamp=1.5)
+    ref2 = uf.upfirdn2d(x, f, padding=[pad] * 4, gain=2, _epilogue=_lib.make_epilogue(**act)) * style[:, :, None, None]
+    _close(uf._fir4_split8_nchw(x, f, pad, gain=2, epilogue=_lib.make_epilogue(**act), out_scale=style).to_float(), ref2, atol=1e-6, rtol=2.0 ** -15)
 
 
 @pytest.mark.parametrize('N,I,OC,H,W,ks', [(4, 128, 256, 257, 257, 1), (2, 64, 100, 65, 129, 1), (4, 512, 512, 65, 65, 4), (1, 32, 64, 33, 47, 2),
