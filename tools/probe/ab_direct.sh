@@ -1,10 +1,13 @@
 #!/bin/bash
-# FIR kernel A/B: isolated launches (tools/fir_bench.py, both row counts of the c8 kernel), the FIR tests, bench with the NCHW separable kernel on / off
+# env-switch A/B on the whole bench (interleaved repetitions): transposed kernel shapes
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_ops_gpu.py -q -m gpu -k "fir4 or stride2" 2>&1 | tail -4
-timeout 120 python tools/fir_bench.py 2>&1 | tee gpurun_out/fir_bench.txt
-N3D_FIR_SEP_RPT=8 timeout 120 python tools/fir_bench.py 2>&1 | head -8 | tee -a gpurun_out/fir_bench.txt
-for v in 1 0 1 0; do
-  N3D_FIR_SEP_NCHW=$v timeout 200 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/ab_fir_$v.json
-  python -c "import json; d=json.load(open('gpurun_out/ab_fir_$v.json')); print('fir_sep_nchw=$v', d['value'], d['ms_per_step'], d.get('sr_fp16_mode',{}).get('value'))"
+for rep in 1 2 3 4 5; do
+  for cfg in "N3D_UP_PS_MT=1" "N3D_UP_PS_MT=3"; do
+    env $cfg timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/ab_tmp.json
+    python -c "import json; d=json.load(open('gpurun_out/ab_tmp.json')); print('$cfg', round(d['value'],1), round(d['ms_per_step'],3))"
+  done
+done
+for cfg in "N3D_UP_PS_MT=1" "N3D_UP_PS_MT=3"; do
+  env $cfg timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras --sr-fp16 2>/dev/null | tail -1 > gpurun_out/ab_tmp.json
+  python -c "import json; d=json.load(open('gpurun_out/ab_tmp.json')); print('sr-fp16 $cfg', round(d['value'],1), round(d['ms_per_step'],3))"
 done
