@@ -481,6 +481,8 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
             else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<2, false>), grid, dim3(512), 0, stream, p);
             break;
         case 3:
+            // (all 8 K steps' weights resident in LDS, the MT = 1 kernels' barrier-free loop, was measured for the 96-channel tri-plane
+            // toRGB: 65.2 against 63.6 us — profiles/r03_c1_bench.txt — so the staged loop stays)
             if (p.side) hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false, true>), grid, dim3(512), 0, stream, p);
             else hipLaunchKernelGGL((conv1x1_bf16x3_kernel<3, false>), grid, dim3(512), 0, stream, p);
             break;

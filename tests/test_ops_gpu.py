@@ -367,7 +367,7 @@ def test_upfirdn2d_pad2_pitched_output(dev, shape):
 
 @pytest.mark.parametrize('bf16x3', [False, True])
 @pytest.mark.parametrize('N,I,OC,H,W', [(2, 128, 96, 32, 32), (1, 32, 512, 16, 16), (2, 512, 3, 8, 8), (1, 64, 40, 6, 10), (1, 256, 130, 20, 12),
-                                       (4, 512, 96, 4, 4), (1, 128, 32, 64, 48)])
+                                       (4, 512, 96, 4, 4), (1, 128, 32, 64, 48), (1, 128, 96, 72, 80), (2, 64, 70, 66, 68)])
 def test_conv1x1_and_fused_skip_upsample(dev, bf16x3, N, I, OC, H, W):
     """1x1 conv (toRGB / fromRGB): fp32-MFMA and split-bf16 kernels vs F.conv2d, with style, bias, clamp, a dense residual,
     and the fused skip path  img = upsample2d(img_lowres) + toRGB(x)  (n3d_epilogue.residual_up_filter)."""
