@@ -8,7 +8,6 @@ itself is a different program: every arithmetic step runs in libn3d.so HIP kerne
 device->host round trips (the reference has 4N+1 per frame: fill_mouth and gen_mouth_mask) and no
 dynamic shapes (the mouth box lives in device memory).
 """
-import math
 import os
 
 import numpy as np

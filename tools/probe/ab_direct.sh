@@ -1,6 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
-{ timeout 300 python tools/soak.py --steps 600 2>&1 | tail -1
-  timeout 300 python tools/soak.py --steps 600 --fp16 2>&1 | tail -1
-  N3D_PAIR_BACKBONES=1 timeout 300 python tools/soak.py --steps 300 2>&1 | tail -1
-  echo "(third run: N3D_PAIR_BACKBONES=1; final round-3 build: toRGB split8 side outputs, fromrgb split8 results, separable NCHW FIR)"; } | tee gpurun_out/soak.txt
+for rep in 1 2; do
+for k in 64 8 4 2 1; do
+  N3D_KSPLIT_MAX=$k timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > gpurun_out/ab_tmp.json
+  python -c "import json; d=json.load(open('gpurun_out/ab_tmp.json')); print('ksplit_max=$k', round(d['value'],1), round(d['ms_per_step'],3))"
+done
+done
