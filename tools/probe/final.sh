@@ -1,6 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 > gpurun_out/final_gpu_tests.txt
-cat gpurun_out/final_gpu_tests.txt
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
-timeout 900 bash tools/refresh_profiles.sh r03 2>&1 | tail -30
+for i in 1 2 3; do timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -1; done | tee gpurun_out/final_gpu_tests_x3.txt
+timeout 300 python tools/soak.py --steps 3000 2>&1 | tail -1 | tee gpurun_out/soak_long.txt
+timeout 300 python tools/soak.py --steps 3000 --fp16 2>&1 | tail -1 | tee -a gpurun_out/soak_long.txt
