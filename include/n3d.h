@@ -147,6 +147,9 @@ int n3d_fir4_split8_nchw_sep(const float* x, const float* f1d, void* y_split8, i
  * producer cannot write split8 itself (two consumers that need different styles). */
 int n3d_split8_from_nchw(const float* x, const float* scale, void* y_split8, int N, int C, int64_t HW, int64_t x_batch_stride,
                          int64_t scale_stride, n3d_stream_t stream);
+/* 1 when n3d_conv2d_bf16x3 runs this 3x3 stride-1 float32-NCHW layer on the few-pixel kernel (conv2d_sk_bf16x3.hip: the whole K inside
+ * one workgroup, one launch): ksplit / workspace are then ignored, the caller need not allocate one.  (N3D_CONV_SK=0: never.) */
+int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W);
 /* 1 when n3d_conv2d_bf16x3 accepts a split8 input for this 3x3 stride-1 shape (x_layout = N3D_LAYOUT_SPLIT8), else 0. */
 int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W);
 

@@ -66,6 +66,7 @@ _SIGNATURES = {
     'n3d_fir4_split8_sep': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
     'n3d_fir4_split8_nchw_sep': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
     'n3d_fir4_split8_nchw': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
+    'n3d_conv2d_sk_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_split8_eligible': (c_int, [c_int] * 5),
     'n3d_split8_from_nchw': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -153,7 +154,7 @@ def check(rc):
         raise RuntimeError('libn3d: ' + _handle().n3d_last_error().decode())
 
 
-_HOST_ONLY = ('n3d_abi_version', 'n3d_last_error', 'n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_render_rays_workspace_bytes',
+_HOST_ONLY = ('n3d_abi_version', 'n3d_last_error', 'n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_sk_eligible', 'n3d_render_rays_workspace_bytes',
               'n3d_prof_enable', 'n3d_prof_reset', 'n3d_prof_read')
 
 

@@ -40,6 +40,8 @@ struct Conv16Params {
 int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);      // conv1x1_bf16x3.hip
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    // conv2d_s2_bf16x3.hip
 int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);     // conv2d_ps_bf16x3.hip (split8 input)
+int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_sk_bf16x3.hip (few-pixel layers; 1 = not its layer)
+extern "C" int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W);
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, transposed, c8 output)
 int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, stride 2)
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
@@ -810,6 +812,10 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
+    if (d->mode == 0) {                                                    // few-pixel layers: K split inside the workgroup, one launch
+        const int r = conv2d_sk_bf16x3_try_launch(d, stream);
+        if (r <= 0) return r;
+    }
     Conv16Params p;
     int kind; int64_t nblk;
     if (conv16_setup(d, p, kind, nblk) != 0) return -1;
@@ -847,6 +853,8 @@ extern "C" int n3d_conv2d_bf16x3_pair(const n3d_conv2d_desc* da, const n3d_conv2
     int ka = -1, kb = -2; int64_t na = 0, nb = 0;
     const char* off = getenv("N3D_CONV_PAIR");
     bool ok = !(off && atoi(off) == 0) && plain(da) && plain(db) && da->mode == db->mode;
+    // (the few-pixel stride-1 layers have their own one-launch kernel: two of those instead of a shared split-K grid + shared reduce pass)
+    if (ok && da->mode == 0 && (n3d_conv2d_sk_eligible(da->N, da->I, da->O, da->H, da->W) || n3d_conv2d_sk_eligible(db->N, db->I, db->O, db->H, db->W))) ok = false;
     if (ok) ok = conv16_setup(da, pp.a, ka, na) == 0 && conv16_setup(db, pp.b, kb, nb) == 0 && ka == kb && ka != C16_BIG8 && pp.a.dbg == 0 &&
                  (pp.a.ksplit > 1) == (pp.b.ksplit > 1) && na + nb + 8 < (1ll << 31);
     if (!ok) {

@@ -1,0 +1,239 @@
+// conv2d_sk_bf16x3.hip — the 3x3 stride-1 split-bf16 convolution of the FEW-PIXEL layers (4 x 4 .. 16 x 16 at batch 4, up to 32 x 32 at
+// batch 1: at most 2048 output pixels in the whole batch) in ONE launch.  Same arithmetic as conv2d_bf16x3.hip (three
+// v_mfma_f32_32x32x16_bf16 per 16-channel chunk and tap on hi / lo operand halves, float32 accumulation); replaces the same reference call
+// sites (F.conv2d inside modulated_conv2d, tat/networks_stylegan2.py:34-91, and Conv2dLayer :173-183).
+//
+// Why a separate kernel: these layers are K-deep (9 x 512..1024) on a handful of pixels.  conv2d_bf16x3_kernel fills the chip by splitting K
+// over 8-16 WORKGROUPS, which costs a partial-sum round trip through HBM plus a second launch (conv16_splitk_epilogue_kernel), and every
+// workgroup's K loop pays the register-staging latency per chunk: 25-32 us per layer launch to launch for ~1-5 us of matrix work
+// (profiles/r03_small_layer_sweep.txt).  Here the 8 waves of a workgroup split K INSIDE the workgroup (the scheme of
+// conv1x1_bf16x3_ksplit_kernel): a workgroup owns 32 output channels x 32 or 64 pixels for the whole K; wave w takes the chunks
+// [w * KC/8, (w+1) * KC/8) and, per chunk,
+//   * loads its weight fragments (9 taps x hi|lo) straight from the L2-resident prepared tiles — no LDS staging, no barrier,
+//   * stages the 16 channels of the tile's pixel patch (tile rows + one halo row / column on every side, <= 128 patch pixels) ONCE: two
+//     pixels per lane, style multiply + hi / lo split, into a PRIVATE 8 KB LDS region of the wave (in-order LDS: no barrier either),
+//   * reads the 9 shifted pixel fragments back and issues 27 MFMAs per 32-pixel group;
+// the eight partial accumulators are summed through LDS in a fixed order (deterministic) and wave w applies the epilogue to rows r = w (mod 8).
+// The grid is XCD-aware the other way round from the large kernels: a 32-channel weight tile (9 * I * 32 * 4 B = 0.6 MB at I = 512) is
+// re-read by every pixel tile, so all workgroups of one channel tile sit on ONE XCD and its 4 MB L2 holds the two or so tiles it serves.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct SkParams {
+    const float* x; const bf16x8* wt16; const float* style; float* y;
+    int N, I, O, OP64, H, W, HW;
+    int R, NS, PR, PW, nslots, tps;      // tile rows per sample, samples per tile, patch rows / pitch, patch pixels, tiles per sample (NS == 1)
+    int tiles_p, tiles_m;
+    int x_bytes;                          // size of the whole input tensor (buffer descriptor range)
+    int64_t xbs, ybs, yrs, style_stride;
+    n3d_epilogue epi;
+};
+
+constexpr int SK_SLOTS = 128;                                              // patch pixels per wave region
+constexpr int SK_WAVE_SLOTS = 2 * 2 * SK_SLOTS;                            // [hi|lo][half][pixel] 16-byte slots = 8 KB
+
+template <int PT>                                                          // 32-pixel groups per workgroup tile
+__global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
+    __shared__ bf16x8 smem[8 * SK_WAVE_SLOTS];                             // 64 KB: the waves' patch regions; afterwards the partial sums
+    __shared__ float s_style[2 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    int mt_i, tile;
+    {
+        const int b = blockIdx.x;
+        if ((p.tiles_m & 7) == 0) {                                        // one channel tile's workgroups share an XCD (= blockIdx % 8)
+            const int per = p.tiles_m >> 3, q = b >> 3;
+            mt_i = (b & 7) + 8 * (q % per); tile = q / per;
+        } else { mt_i = b % p.tiles_m; tile = b / p.tiles_m; }
+    }
+    const int m0 = mt_i * 32;
+    const int n0 = p.NS == 1 ? tile / p.tps : tile * p.NS;
+    const int y0 = p.NS == 1 ? (tile % p.tps) * p.R : 0;
+    const int KC = p.I / 16, nc = KC / 8, c_begin = wn * nc;
+    const int PRW = p.PR * p.PW;
+
+    for (int i = tid; i < p.NS * p.I; i += 512) {
+        const int s = i / p.I, ch = i - s * p.I;
+        s_style[i] = (p.style && n0 + s < p.N) ? p.style[(int64_t)(n0 + s) * p.style_stride + ch] : 1.f;
+    }
+
+    // this lane's two patch pixels: byte offset of (sample, channel 0, y, x) in x, or out of range (halo, beyond the batch)
+    int voff[2], srow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = lane + 64 * j;
+        const int s = pp / PRW, rem = pp - s * PRW, pr = rem / p.PW, pc = rem - pr * p.PW;
+        const int n = n0 + s, yy = y0 - 1 + pr, xx = pc - 1;
+        const bool ok = pp < p.nslots && n < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        voff[j] = ok ? (int)(((int64_t)n * p.xbs + yy * p.W + xx) * 4) : (int)0x80000000;
+        srow[j] = min(s, p.NS - 1) * p.I;
+    }
+    // this lane's output pixels (one per 32-pixel group) and the patch slot of their centre tap
+    int centre[PT], on[PT], oy[PT], ox[PT];
+#pragma unroll
+    for (int g = 0; g < PT; ++g) {
+        const int q = g * 32 + l31;
+        const int s = p.NS == 1 ? 0 : q / p.HW, rem = q - s * p.HW, ry = rem / p.W, x = rem - ry * p.W;
+        centre[g] = s * PRW + (ry + 1) * p.PW + (x + 1);
+        on[g] = n0 + s; oy[g] = y0 + ry; ox[g] = x;
+    }
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    bf16x8* Bw = smem + wn * SK_WAVE_SLOTS;                                // this wave's patch region
+
+    // several accumulators per pixel group — one per product of the operand split (lo*hi, hi*lo, hi*hi; PT = 2: the two cross terms share
+    // one, register budget) — so that consecutive MFMAs do not wait for each other's results (27 dependent MFMAs per chunk otherwise);
+    // they are added once, cross terms first
+    constexpr int NA = PT == 1 ? 3 : 2;
+    f32x16 acc[PT][NA];
+#pragma unroll
+    for (int g = 0; g < PT; ++g)
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][k][r] = 0.f;
+    __syncthreads();                                                       // s_style
+
+    // software pipeline over the wave's chunks: the activations of chunk c + 1 are requested as soon as chunk c's are converted, and every
+    // tap's weight fragments are re-requested for chunk c + 1 right after the MFMAs that consumed them (same registers)
+    float raw[2][16];
+    bf16x8 ah[9], al[9];
+    auto load_raw = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch)
+                raw[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[j], (c * 16 + ch) * p.HW * 4, 0));
+    };
+    const bf16x8* a0 = p.wt16 + (int64_t)half * p.OP64 + m0 + l31;
+    const int64_t a_tap = (int64_t)KC * 4 * p.OP64, a_chunk = (int64_t)4 * p.OP64;
+    load_raw(c_begin);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { ah[t] = a0[t * a_tap + c_begin * a_chunk]; al[t] = a0[t * a_tap + c_begin * a_chunk + 2 * p.OP64]; }
+
+    for (int c = c_begin; c < c_begin + nc; ++c) {
+        const bool more = c + 1 < c_begin + nc;
+        // modulation + operand split, once per patch pixel, into the wave's own region (2 patch pixels x 16 channels per lane)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* st = s_style + srow[j] + c * 16;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = raw[j][hf * 8 + k] * st[hf * 8 + k];
+                    const __bf16 h = (__bf16)v;
+                    hi[k] = h;
+                    lo[k] = (__bf16)(v - (float)h);
+                }
+                Bw[(0 * 2 + hf) * SK_SLOTS + lane + 64 * j] = hi;
+                Bw[(1 * 2 + hf) * SK_SLOTS + lane + 64 * j] = lo;
+            }
+        }
+        if (more) load_raw(c + 1);
+        // 9 taps: shifted pixel fragments from the patch (LDS operations of one wave complete in order: no barrier)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = (t / 3 - 1) * p.PW + (t % 3 - 1);
+#pragma unroll
+            for (int g = 0; g < PT; ++g) {
+                const bf16x8 bh = Bw[(0 * 2 + half) * SK_SLOTS + centre[g] + off];
+                const bf16x8 bl = Bw[(1 * 2 + half) * SK_SLOTS + centre[g] + off];
+                acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[g][0], 0, 0, 0);
+                acc[g][NA - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[g][NA - 2], 0, 0, 0);
+                acc[g][NA - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[g][NA - 1], 0, 0, 0);
+            }
+            if (more) { ah[t] = a0[t * a_tap + (c + 1) * a_chunk]; al[t] = a0[t * a_tap + (c + 1) * a_chunk + 2 * p.OP64]; }
+        }
+    }
+
+    // the eight partial sums through LDS, summed in wave order (C/D layout: col = lane & 31 = pixel, row = (r&3) + 8*(r>>2) + 4*half = channel)
+    __syncthreads();                                                       // every wave is done with its patch region
+    float* red = reinterpret_cast<float*>(smem);                           // [wave][group][r][lane]: PT x 32 KB
+#pragma unroll
+    for (int g = 0; g < PT; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wn * PT + g) * 16 + r) * 64 + lane] = NA == 3 ? (acc[g][0][r] + acc[g][1][r]) + acc[g][NA - 1][r] : acc[g][0][r] + acc[g][NA - 1][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT * 2; ++q) {
+        const int item = q * 8 + wn, g = item >> 4, r = item & 15;
+        const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[((w * PT + g) * 16 + r) * 64 + lane];
+        int n_, oy_, ox_;                                                  // (g is a run-time value here: select instead of indexing registers)
+        n_ = on[0]; oy_ = oy[0]; ox_ = ox[0];
+#pragma unroll
+        for (int gg = 1; gg < PT; ++gg)
+            if (g == gg) { n_ = on[gg]; oy_ = oy[gg]; ox_ = ox[gg]; }
+        if (n_ >= p.N || o >= p.O) continue;
+        v = n3d_apply_epilogue(v, p.epi, n_, o, p.O, oy_, ox_, p.H, p.W);
+        p.y[(int64_t)n_ * p.ybs + ((int64_t)o * p.H + oy_) * p.yrs + ox_] = v;
+    }
+}
+
+// tile plan; false when the layer is not this kernel's
+static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_out) {
+    static const bool enabled = !(getenv("N3D_CONV_SK") && atoi(getenv("N3D_CONV_SK")) == 0);
+    if (!enabled) return false;
+    if (N < 1 || I % 128 != 0 || I > 1024 || O % 32 != 0 || O < 32 || H < 2 || W < 2 || W > 32) return false;
+    const int HW = H * W;
+    const int64_t px = (int64_t)N * HW;
+    if (px > 2048 || HW > 1024) return false;                              // every pixel tile re-reads the layer's weights from L2
+    if (I > 512 && px > 256) return false;                                 // (measured: 61 against 45 us at I = 1024, 16 x 16 x 4: 8 chunks per wave in sequence)
+    int best = 0;
+    SkParams bp;
+    for (int pt = 2; pt >= 1; --pt) {
+        const int TP = 32 * pt;
+        SkParams q;
+        if (HW >= TP) { if (TP % W != 0 || HW % TP != 0) continue; q.NS = 1; q.R = TP / W; q.tps = HW / TP; q.tiles_p = N * q.tps; }
+        else { if (TP % HW != 0) continue; q.NS = TP / HW; q.R = H; q.tps = 1; q.tiles_p = (N + q.NS - 1) / q.NS; }
+        if (q.NS > 2) continue;                                            // s_style holds two samples' styles
+        q.PR = q.R + 2; q.PW = W + 2; q.nslots = q.NS * q.PR * q.PW;
+        if (q.nslots > SK_SLOTS) continue;
+        // 64-pixel tiles (every weight fragment feeds two pixel groups) once they still give the chip a workgroup per CU
+        if (pt == 2 && (int64_t)q.tiles_p * (O / 32) < 256) continue;
+        best = pt; bp = q;
+        break;
+    }
+    if (!best) return false;
+    if (out) { out->NS = bp.NS; out->R = bp.R; out->tps = bp.tps; out->tiles_p = bp.tiles_p; out->PR = bp.PR; out->PW = bp.PW; out->nslots = bp.nslots; }
+    if (pt_out) *pt_out = best;
+    return true;
+}
+
+extern "C" int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W) { return sk_plan(N, I, O, H, W, nullptr, nullptr) ? 1 : 0; }
+
+// called by n3d_conv2d_bf16x3 for ksize 3 / mode 0 / float32 NCHW in and out (common fields validated there); returns 1 when the layer is
+// not this kernel's (the caller goes on to the general kernels), 0 after a launch, -1 on error
+int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
+    SkParams p;
+    int pt;
+    if (d->epi.round_f16 || d->epi.residual_up_filter || d->side_split8 || d->y_layout != N3D_LAYOUT_NCHW_F32) return 1;
+    if (!sk_plan(d->N, d->I, d->O, d->H, d->W, &p, &pt)) return 1;
+    const int64_t xbs = d->x_batch_stride;                                 // taken literally, like the other float32-input kernels: 0 = one image for the whole batch (the learned constant, expand()ed)
+    const int64_t x_bytes = ((int64_t)(d->N - 1) * xbs + (int64_t)d->I * d->H * d->W) * 4;
+    if (x_bytes >= (1ll << 31)) return 1;
+    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.HW = d->H * d->W;
+    p.tiles_m = d->O / 32;
+    p.x_bytes = (int)x_bytes;
+    p.xbs = xbs; p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * d->H * d->W;
+    p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
+    N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.style_stride = d->style_stride ? d->style_stride : d->I;
+    p.epi = d->epi;
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
+    const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.HW + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    const dim3 grid((unsigned)(p.tiles_p * p.tiles_m));
+    if (pt == 2) hipLaunchKernelGGL(conv2d_sk_bf16x3_kernel<2>, grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv2d_sk_bf16x3_kernel<1>, grid, dim3(512), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -189,6 +189,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=wt.device)
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
+    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and _lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w):
+        ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None

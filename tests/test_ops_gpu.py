@@ -229,6 +229,41 @@ def test_conv2d_bf16x3(dev, N, I, OC, H, W):
     assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 512, 512, 4, 4), (4, 512, 512, 8, 8), (4, 512, 512, 16, 16), (4, 1024, 512, 8, 8), (1, 512, 512, 32, 32),
+                                       (3, 128, 64, 4, 4), (2, 256, 96, 16, 16), (1, 128, 32, 8, 8), (2, 128, 64, 8, 16), (8, 128, 256, 16, 16), (5, 128, 32, 4, 8)])
+def test_conv2d_bf16x3_few_pixel_kernel(dev, N, I, OC, H, W):
+    """conv2d_sk_bf16x3_kernel (few-pixel layers: the whole K inside one workgroup, 8 waves splitting the input channels, patch staged per
+    wave, LDS reduction, epilogue in the same launch) against the float32 oracle: 32- and 64-pixel tiles, two samples per tile (4 x 4
+    images, odd batch), channel-tile counts that do / do not divide by the 8 XCDs, non-square images, a batch-strided input view and
+    output view, the full layer epilogue with a residual, run-to-run bitwise equality."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    assert _lib.lib().n3d_conv2d_sk_eligible(N, I, OC, H, W) == 1
+    x, w = _gen((N, I, H, W), 160), _gen((OC, I, 3, 3), 161) / np.sqrt(I * 9)
+    s, d, b = _gen((N, I), 162), _gen((N, OC), 163).abs() + 0.5, _gen((OC,), 164)
+    noise, ns, res = _gen((H, W), 165), torch.tensor(0.4), _gen((N, OC, H, W), 166)
+    ref_plain = F.conv2d(x, w, padding=1)
+    ref_full = O.bias_act(F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None] * 0.8 + noise * ns, b, act='lrelu', gain=1.2, clamp=1.5) + res
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    y = cg.conv_launch(t(x), wt16, 3, 0, OC, bf16x3=True)
+    err = float((y.cpu() - ref_plain).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_plain.abs().max())), err
+    epi = _lib.make_epilogue(row_scale=t(d), noise=t(noise), noise_strength=t(ns), bias=t(b), const_scale=0.8, act='lrelu', gain=1.2, clamp=1.5, residual=t(res))
+    xv = torch.zeros(N, I + 16, H, W, device=dev)[:, 16:]                 # batch stride > I * H * W (the U-Net's concatenation buffers)
+    xv.copy_(t(x))
+    out = torch.zeros(N, OC + 8, H, W, device=dev)[:, :OC]
+    y = cg.conv_launch(xv, wt16, 3, 0, OC, style=t(s), epilogue=epi, bf16x3=True, out=out)
+    err = float((y.cpu() - ref_full).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
+    assert torch.equal(y, cg.conv_launch(t(x), wt16, 3, 0, OC, style=t(s), epilogue=epi, bf16x3=True))       # other views, same bits; run to run
+    # batch stride 0: one image for the whole batch (SynthesisBlock's learned constant, `const.unsqueeze(0).expand(n, ...)`, networks_stylegan2.py:463-465)
+    xe = t(x)[:1].expand(N, -1, -1, -1)
+    ye = cg.conv_launch(xe, wt16, 3, 0, OC, style=t(s), bf16x3=True)
+    assert torch.equal(ye, cg.conv_launch(xe.contiguous(), wt16, 3, 0, OC, style=t(s), bf16x3=True))
+
+
 @pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 256, 256), (3, 48, 256, 144, 160), (3, 32, 128, 250, 200), (1, 128, 128, 512, 512),
                                        (4, 512, 256, 128, 128)])
 def test_conv2d_bf16x3_persistent(dev, N, I, OC, H, W):
