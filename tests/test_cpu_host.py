@@ -99,6 +99,22 @@ def test_filters_padding_and_ksplit():
     assert cg.pick_ksplit(4, 512, 512, 4, 4, 3) == 16 and cg.pick_ksplit(4, 128, 128, 256, 256, 3) == 1
 
 
+def test_few_pixel_kernel_eligibility_plan(built_lib):
+    """n3d_conv2d_sk_eligible (host-only): which stride-1 3x3 layers run on the one-launch few-pixel kernel — the generator's 4x4 .. 16x16
+    layers at batch 1 / 4 / 8 and 32x32 at batch 1 and 2; not the layers with more than 2048 output pixels, the deep fusion layer at 16x16
+    (8 chunks per wave), channel counts the tile plan does not take, or image shapes whose rows do not tile 32 / 64 pixels."""
+    from next3d_amd import _lib
+    e = lambda *a: _lib.lib().n3d_conv2d_sk_eligible(*a)
+    for n in (1, 2, 4, 8):
+        for hw in (4, 8, 16):
+            assert e(n, 512, 512, hw, hw) == 1, (n, hw)
+    assert e(1, 512, 512, 32, 32) == 1 and e(2, 512, 512, 32, 32) == 1 and e(4, 512, 512, 32, 32) == 0     # <= 2048 pixels in the batch
+    assert e(4, 1024, 512, 8, 8) == 1 and e(4, 1024, 512, 16, 16) == 0 and e(1, 1024, 512, 16, 16) == 1     # I > 512: <= 256 pixels
+    assert e(4, 64, 64, 4, 4) == 0 and e(4, 2048, 512, 4, 4) == 0 and e(4, 512, 70, 8, 8) == 0              # I % 128, I <= 1024, O % 32
+    assert e(4, 512, 512, 64, 64) == 0 and e(1, 128, 32, 6, 6) == 0 and e(1, 128, 32, 5, 40) == 0          # large images; rows that do not tile
+    assert e(3, 128, 64, 4, 4) == 1 and e(2, 128, 64, 8, 16) == 1 and e(5, 128, 32, 4, 8) == 1             # odd batches, non-square
+
+
 def test_camera_and_mesh_helpers():
     from next3d_amd import demo, mesh
     camera_utils = demo
