@@ -207,12 +207,6 @@ int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
  *      Requires I % 16 == 0.  Same reference call sites as n3d_conv2d. */
 int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream);
 int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
-/* n3d_conv2d_bf16x3(a); n3d_conv2d_bf16x3(b) as ONE launch (+ one split-K reduction launch) when both descriptors select the same
- * register-staged 3x3 kernel (the <= 32x32 stride-1 and transposed layers): workgroups of both layers share the grid, which doubles
- * the occupancy of layers that are a handful of workgroups each — the texture and the static tri-plane backbone
- * (tat/triplane_next3d.py:135-170: two SynthesisNetworks of identical shapes) run in lock step this way.  Any other combination is
- * executed as the two ordinary launches, in order; results are bit-identical either way. */
-int n3d_conv2d_bf16x3_pair(const n3d_conv2d_desc* a, const n3d_conv2d_desc* b, n3d_stream_t stream);
 /* Number of workgroups n3d_conv2d_bf16x3 launches for this shape at ksplit = 1 (its tile plan): the host picks a split-K
  * factor from it so that small layers still cover the 256 CUs. */
 int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);
@@ -322,15 +316,6 @@ int n3d_render_rays(const float* planes_cl, const float* cam2world, const float*
                     const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
                     int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream);
-/* The same renderer with a colour workspace of n3d_render_rays_workspace_bytes(N, R, Sc, Sf) bytes (16-byte aligned device memory,
- * contents irrelevant before and after): the samples' decoded colours are parked there instead of in LDS, which lets twice as many
- * wavefronts share a CU.  workspace == NULL: exactly n3d_render_rays. */
-int64_t n3d_render_rays_workspace_bytes(int N, int R, int Sc, int Sf);
-int n3d_render_rays_ws(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
-                    const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
-                    const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
-                    int Sf, int PH, int PW, float depth_delta, float coord_scale, float* workspace, int64_t workspace_bytes, n3d_stream_t stream);
-
 /* ---- point queries (shape extraction): replaces ImportanceRenderer.run_model (vr/renderer.py:149-155: sample_from_planes +
  *      OSGDecoder) as called by TriPlaneGenerator.sample / sample_mixed (tat/triplane_next3d.py:232-322).
  *      coords [N,M,3] world coordinates -> rgb [N,M,32], sigma [N,M,1]; coord_scale = 2 / box_warp; decoder weights as in

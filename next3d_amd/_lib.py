@@ -73,13 +73,10 @@ _SIGNATURES = {
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_prep_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d_bf16x3': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
-    'n3d_conv2d_bf16x3_pair': (c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_bf16x3_blocks': (c_int, [c_int] * 5),
     'n3d_blend_planes': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     'n3d_planes_to_channels_last': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_render_rays': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p]),
-    'n3d_render_rays_ws': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p, c_int64, c_void_p]),
-    'n3d_render_rays_workspace_bytes': (c_int64, [c_int] * 4),
     'n3d_sample_points': (c_int, [c_void_p] * 8 + [c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     'n3d_rasterize_views': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 4 +
                             [c_int, c_int, c_void_p]),
@@ -114,9 +111,8 @@ def exported_symbols():
 
 
 def lib():
-    """The library handle (or, inside a `Recording`, the recorder that defers the launches)."""
-    rec = getattr(_tls, 'recorder', None)
-    return rec if rec is not None else _handle()
+    """The library handle."""
+    return _handle()
 
 
 def _handle():
@@ -142,113 +138,13 @@ _tls = threading.local()
 
 
 def check(rc):
-    """Result check of an entry point — and the end of the keep-alive window of `ptr()` (below): by now the launch is enqueued
-    (inside a `Recording` the launch is only deferred: the tensors move to the recording and live until it has been replayed)."""
+    """Result check of an entry point — and the end of the keep-alive window of `ptr()` (below): by now the launch is enqueued."""
     held = getattr(_tls, 'held', None)
     if held:
-        rec = getattr(_tls, 'recorder', None)
-        if rec is not None:
-            rec.keep.extend(held)
         held.clear()
     if rc != 0:
         raise RuntimeError('libn3d: ' + _handle().n3d_last_error().decode())
 
-
-_HOST_ONLY = ('n3d_abi_version', 'n3d_last_error', 'n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_sk_eligible', 'n3d_render_rays_workspace_bytes',
-              'n3d_prof_enable', 'n3d_prof_reset', 'n3d_prof_read')
-
-
-class Recording:
-    """`with Recording() as r:` — every libn3d.so launch issued inside is DEFERRED: recorded as (entry point, marshalled arguments)
-    instead of being enqueued, and every tensor whose pointer crossed the boundary is kept alive (so the caching allocator cannot
-    hand a recorded buffer to a later allocation).  `replay_paired(ra, rb)` then issues two recordings interleaved, pairing the
-    launches that n3d_conv2d_bf16x3_pair can run as one grid.  Only code whose device work goes through libn3d.so exclusively may
-    run inside (no torch kernels on tensors a deferred launch produces): the StyleGAN2 backbones qualify (networks.SynthesisNet)."""
-
-    def __init__(self):
-        self.entries, self.keep = [], []
-
-    def __getattr__(self, name):
-        if name in _HOST_ONLY:
-            return getattr(_handle(), name)
-        if name not in _SIGNATURES:
-            raise AttributeError(name)
-
-        def deferred(*args):
-            self.entries.append((name, args))
-            return 0
-        return deferred
-
-    def release(self):
-        self.entries, self.keep = [], []
-
-    def __enter__(self):
-        if getattr(_tls, 'recorder', None) is not None:
-            raise RuntimeError('Recording: already recording')
-        _handle()
-        _tls.recorder = self
-        return self
-
-    def __exit__(self, *exc):
-        _tls.recorder = None
-        held = getattr(_tls, 'held', None)
-        if held:
-            self.keep.extend(held)
-            held.clear()
-        return False
-
-
-def mark(name):
-    """A named position in the launch sequence (only meaningful inside a `Recording`): networks.SynthesisNet marks where its
-    low-resolution layers end."""
-    rec = getattr(_tls, 'recorder', None)
-    if rec is not None:
-        rec.entries.append(('__mark__', name))
-
-
-def replay_paired(ra, rb, side_stream=None, split_mark='high'):
-    """Issue two recordings in lock step: launch i of `ra`, then launch i of `rb` — as ONE launch where both are 3x3 convolutions
-    (n3d_conv2d_bf16x3_pair decides whether the kernels can share a grid; otherwise it runs them one after the other).  Each
-    recording's own order is preserved, so results are those of running the two recordings back to back.
-    side_stream: from the mark `split_mark` on (the end of the low-resolution layers, whose handful of workgroups gain from
-    sharing a grid) the rest of `rb` — large layers that fill the chip on their own — is issued on `side_stream` (forked from the
-    current stream here) so that it overlaps whatever the caller enqueues next on the current stream; the caller joins
-    (`current.wait_stream(side_stream)`) and only then calls `rb.release()`: the recorded tensors were allocated for the current
-    stream, they must outlive the side stream's work."""
-    h = _handle()
-    a, b = ra.entries, rb.entries
-    is_mark = lambda e: e is not None and e[0] == '__mark__'
-    i = 0
-    while i < max(len(a), len(b)):
-        ea, eb = (a[i] if i < len(a) else None), (b[i] if i < len(b) else None)
-        if side_stream is not None and is_mark(ea) and is_mark(eb) and ea[1] == eb[1] == split_mark:
-            break
-        i += 1
-        if is_mark(ea) or is_mark(eb):
-            for e in (ea, eb):
-                if e is not None and not is_mark(e):
-                    check(getattr(h, e[0])(*e[1]))
-            continue
-        if ea is not None and eb is not None and ea[0] == eb[0] == 'n3d_conv2d_bf16x3' and ea[1][1].value == eb[1][1].value:
-            check(h.n3d_conv2d_bf16x3_pair(ea[1][0], eb[1][0], ea[1][1]))
-            continue
-        for e in (ea, eb):
-            if e is not None:
-                check(getattr(h, e[0])(*e[1]))
-    if i < max(len(a), len(b)):                         # the marked split: rest of b on the side stream, rest of a here
-        side_stream.wait_stream(torch.cuda.current_stream())
-        sp = c_void_p(side_stream.cuda_stream)
-        for e in b[i:]:
-            if not is_mark(e):
-                check(getattr(h, e[0])(*(e[1][:-1] + (sp,))))          # every entry point takes its stream as the last argument
-        for e in a[i:]:
-            if not is_mark(e):
-                check(getattr(h, e[0])(*e[1]))
-        ra.release()
-        rb.entries = []
-        return
-    ra.release()
-    rb.release()
 
 def stream():
     """The HIP stream kernels are enqueued on = torch's current stream (as the reference plugins do with
@@ -336,8 +232,8 @@ class H8:
         """`x.to(torch.float16)` of a float32 [N,C,H,W] tensor (dense planes, any batch stride) on libn3d.so (n3d_cast_h8)."""
         require_device(x)
         n, c, h, w = x.shape
-        if x.dtype != _torch_f32() or x.stride()[1:] != (h * w, w, 1):
-            x = x.to(_torch_f32()).contiguous()
+        if x.dtype != _torch_f32() or x.stride()[1:] != (h * w, w, 1) or (x.stride(0) == 0 and n > 1):
+            x = x.to(_torch_f32()).contiguous()      # (n3d_cast_h8 reads a batch stride of 0 as "dense": an expand()ed batch is materialised)
         y = cls(n, c, h, w, x.device)
         check(lib().n3d_cast_h8(ptr(x), ptr(y.data), n, c, h * w, x.stride(0), 1, stream()))
         y._src = x                               # the source stays referenced until the launch is enqueued behind later work

@@ -6,6 +6,10 @@
 
 #include "../../include/n3d.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libn3d.so kernels are written for gfx950 only (160 KB of LDS per workgroup, v_mfma_f32_32x32x16_bf16 / _f16): build with --offload-arch=gfx950"
+#endif
+
 // ---- host-side error + profiling plumbing (runtime.hip)
 int n3d_set_error(const char* fmt, ...);
 struct N3dProfScope {          // brackets the launches of one entry point with events on the launch stream
@@ -25,6 +29,15 @@ struct N3dProfScope {          // brackets the launches of one entry point with 
         hipError_t e_ = hipGetLastError();                                              \
         if (e_ != hipSuccess) return n3d_set_error("HIP launch failed: %s", hipGetErrorString(e_)); \
     } while (0)
+
+// Tuning switches (ablation bits, kernel-variant selectors) exist in tuning builds only (tools/build_variant.sh <tag> <file> -DN3D_TUNING):
+// the shipped library reads no environment variable on its launch paths.
+#ifdef N3D_TUNING
+#include <stdlib.h>
+static inline int n3d_tune(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int n3d_tune(const char*, int dflt) { return dflt; }
+#endif
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -584,7 +584,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.nphase = 1;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    p.dbg = n3d_tune("N3D_CONV_DBG", 0);
     if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }
     else if (d->mode == 1) {
         N3D_CHECK(d->H >= 3 && d->W >= 3, "conv2d: input too small for stride-2 3x3");

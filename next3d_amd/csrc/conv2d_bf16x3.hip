@@ -310,19 +310,8 @@ __device__ __forceinline__ void conv2d_bf16x3_body(const Conv16Params& p, const 
 }
 
 
-// Two independent launches of one kernel as ONE grid ("pair": n3d_conv2d_bf16x3_pair): workgroups [0, split) run `a`, workgroups
-// [split, gridDim) run `b` (split is a multiple of 8 so that the XCD-aware remap keeps its meaning; the padding workgroups exit).
-// The low-resolution layers of the texture and the static tri-plane backbone have identical shapes and a handful of workgroups
-// each (K = 9 x 512 deep, 4x4 ... 32x32 pixels): run together they fill twice the CUs for the same latency.
-struct Conv16Pair { Conv16Params a, b; int na, split; };
 template <int NW, bool FLAT>
 __global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_kernel(Conv16Params p) { conv2d_bf16x3_body<NW, FLAT>(p, blockIdx.x, gridDim.x); }
-template <int NW, bool FLAT>
-__global__ __launch_bounds__(64 * NW, 2) void conv2d_bf16x3_pair_kernel(Conv16Pair pp) {
-    const bool second = (int)blockIdx.x >= pp.split;
-    if (!second && (int)blockIdx.x >= pp.na) return;
-    conv2d_bf16x3_body<NW, FLAT>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.na);
-}
 
 // Transposed 3x3 stride-2 (the up-sampling layers) on the split-bf16 path: all four output phases from one staged patch,
 // exactly as conv2d_up_mfma_kernel in conv2d.hip (tap (ky,kx) feeds phase (ky==1, kx==1) from patch offset
@@ -600,12 +589,6 @@ __device__ __forceinline__ void conv2d_up_bf16x3_body(const Conv16Params& p, con
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_kernel(Conv16Params p) { conv2d_up_bf16x3_body<NW>(p, blockIdx.x, gridDim.x); }
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void conv2d_up_bf16x3_pair_kernel(Conv16Pair pp) {
-    const bool second = (int)blockIdx.x >= pp.split;
-    if (!second && (int)blockIdx.x >= pp.na) return;
-    conv2d_up_bf16x3_body<NW>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.na);
-}
 
 // split-K second pass: sum the partial tiles and apply the epilogue.  VEC: 4 consecutive pixels of one row per thread
 // (OW % 4 == 0, aligned pointers): 16-byte loads/stores and one index decomposition per 4 outputs.
@@ -644,12 +627,6 @@ __device__ __forceinline__ void conv16_splitk_epilogue_body(const SplitkArgs& a,
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(SplitkArgs a) { conv16_splitk_epilogue_body<VEC>(a, blockIdx.x, gridDim.x); }
-struct SplitkPair { SplitkArgs a, b; int split; };
-template <bool VEC>
-__global__ __launch_bounds__(256) void conv16_splitk_epilogue_pair_kernel(SplitkPair pp) {
-    const bool second = (int)blockIdx.x >= pp.split;
-    conv16_splitk_epilogue_body<VEC>(second ? pp.b : pp.a, second ? blockIdx.x - pp.split : blockIdx.x, second ? gridDim.x - pp.split : pp.split);
-}
 
 // w [O,I,k,k] fp32 -> wt16[tap][I/16][hl][half][OP64][8] bf16 (hi / lo split, zero padded rows)
 __global__ __launch_bounds__(256) void conv16_prep_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ wt16, int O, int I, int KK,
@@ -756,7 +733,7 @@ enum { C16_UP8 = 0, C16_BIG8 = 1, C16_FLAT4 = 2, C16_ROW4 = 3 };
 static int conv16_setup(const n3d_conv2d_desc* d, Conv16Params& p, int& kind, int64_t& nblk) {
     const bool up = d->mode == 2;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    p.dbg = n3d_tune("N3D_CONV_DBG", 0);
     p.y_c8 = d->y_layout == N3D_LAYOUT_C8_F32;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
@@ -835,56 +812,5 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     else hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, false>), grid, dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi, stream);
-    return 0;
-}
-
-// Two layers of identical kind in ONE launch (+ ONE split-K reduction launch): see Conv16Pair.  Anything the pair kernels do not
-// cover — pre-split inputs, 1x1, stride 2, the 8-wave stride-1 kernel of the large layers, different kernel kinds — runs as two
-// ordinary launches, a then b, so the call is always equivalent to n3d_conv2d_bf16x3(a); n3d_conv2d_bf16x3(b).
-extern "C" int n3d_conv2d_bf16x3_pair(const n3d_conv2d_desc* da, const n3d_conv2d_desc* db, n3d_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    N3D_CHECK(da && db, "conv2d_bf16x3_pair: null descriptor");
-    auto plain = [&](const n3d_conv2d_desc* d) {
-        return d->N > 0 && d->ksize == 3 && (d->mode == 0 || d->mode == 2) && d->x_layout == N3D_LAYOUT_NCHW_F32 && d->y_layout == N3D_LAYOUT_NCHW_F32 &&
-               d->I > 0 && d->I % 16 == 0 && d->O > 0 && d->H > 0 && d->W > 0 && d->x && d->wt && d->y && !d->epi.round_f16 && !d->epi.residual_up_filter &&
-               d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH && (!d->epi.noise || d->epi.noise_strength) && (d->x_row_stride == 0 || d->x_row_stride == d->W);
-    };
-    Conv16Pair pp;
-    int ka = -1, kb = -2; int64_t na = 0, nb = 0;
-    const char* off = getenv("N3D_CONV_PAIR");
-    bool ok = !(off && atoi(off) == 0) && plain(da) && plain(db) && da->mode == db->mode;
-    // (the few-pixel stride-1 layers have their own one-launch kernel: two of those instead of a shared split-K grid + shared reduce pass)
-    if (ok && da->mode == 0 && (n3d_conv2d_sk_eligible(da->N, da->I, da->O, da->H, da->W) || n3d_conv2d_sk_eligible(db->N, db->I, db->O, db->H, db->W))) ok = false;
-    if (ok) ok = conv16_setup(da, pp.a, ka, na) == 0 && conv16_setup(db, pp.b, kb, nb) == 0 && ka == kb && ka != C16_BIG8 && pp.a.dbg == 0 &&
-                 (pp.a.ksplit > 1) == (pp.b.ksplit > 1) && na + nb + 8 < (1ll << 31);
-    if (!ok) {
-        if (n3d_conv2d_bf16x3(da, stream_) != 0) return -1;
-        return n3d_conv2d_bf16x3(db, stream_);
-    }
-    pp.na = (int)na; pp.split = (int)((na + 7) / 8 * 8);
-    auto flops = [](const n3d_conv2d_desc* d) { return 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W; };
-    auto bytes = [](const n3d_conv2d_desc* d, const Conv16Params& p) { return 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9); };
-    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops(da) + flops(db), bytes(da, pp.a) + bytes(db, pp.b));
-    const dim3 grid((unsigned)(pp.split + nb));
-    if (ka == C16_UP8) hipLaunchKernelGGL(conv2d_up_bf16x3_pair_kernel<8>, grid, dim3(512), 0, stream, pp);
-    else if (ka == C16_FLAT4) hipLaunchKernelGGL((conv2d_bf16x3_pair_kernel<4, true>), grid, dim3(256), 0, stream, pp);
-    else hipLaunchKernelGGL((conv2d_bf16x3_pair_kernel<4, false>), grid, dim3(256), 0, stream, pp);
-    N3D_LAUNCH_CHECK();
-    if (pp.a.ksplit > 1) {
-        const Conv16Params& A = pp.a; const Conv16Params& B = pp.b;
-        const bool va = splitk_vec(A.partial, A.y, A.OW, A.ybs, A.yrs), vb = splitk_vec(B.partial, B.y, B.OW, B.ybs, B.yrs);
-        if (va != vb) {
-            if (conv16_splitk_epilogue_launch(A.partial, A.y, A.ksplit, A.N, A.O, A.OH, A.OW, A.ybs, A.yrs, A.epi, stream) != 0) return -1;
-            return conv16_splitk_epilogue_launch(B.partial, B.y, B.ksplit, B.N, B.O, B.OH, B.OW, B.ybs, B.yrs, B.epi, stream);
-        }
-        SplitkPair sp;
-        sp.a = SplitkArgs{A.partial, A.y, A.ksplit, A.N, A.O, A.OH, A.OW, A.ybs, A.yrs, A.epi};
-        sp.b = SplitkArgs{B.partial, B.y, B.ksplit, B.N, B.O, B.OH, B.OW, B.ybs, B.yrs, B.epi};
-        sp.split = splitk_grid((int64_t)A.N * A.O * A.OH * A.OW, va);
-        const int gb = splitk_grid((int64_t)B.N * B.O * B.OH * B.OW, vb);
-        if (va) hipLaunchKernelGGL(conv16_splitk_epilogue_pair_kernel<true>, dim3(sp.split + gb), dim3(256), 0, stream, sp);
-        else hipLaunchKernelGGL(conv16_splitk_epilogue_pair_kernel<false>, dim3(sp.split + gb), dim3(256), 0, stream, sp);
-        N3D_LAUNCH_CHECK();
-    }
     return 0;
 }

@@ -363,14 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_h8_f16_w64_kernel(ConvUpF16P
     __shared__ f16x8 smem[2 * fu_buf_slots(1)];
     conv2d_up_f16_body<1, 4, 2>(p, smem);
 }
-__global__ __launch_bounds__(512, 4) void conv2d_up_h8_f16_kernel(ConvUpF16Params p) {           // 8 waves x 32 positions x 32 channels
-    __shared__ f16x8 smem[2 * fu_buf_slots(1)];
-    conv2d_up_f16_body<1, 8, 1>(p, smem);
-}
-__global__ __launch_bounds__(512, 2) void conv2d_up_h8_f16_m64_kernel(ConvUpF16Params p) {       // 8 waves x 32 positions x 64 channels
-    __shared__ f16x8 smem[2 * fu_buf_slots(2)];
-    conv2d_up_f16_body<2, 8, 1>(p, smem);
-}
+// (the 8 waves x 32 positions x 32 / 64 channel forms of the body measured 16-19 % slower in round 3 and are not instantiated)
 
 // ------------------------------------------------------------------------------------------------------------------------------
 extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
@@ -386,8 +379,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     N3D_CHECK(d->x_batch_stride == 0 && d->y_batch_stride == 0 && d->x_row_stride == 0 && d->y_row_stride == 0, "conv2d_f16: dense h8 tensors only (strides 0)");
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(!E.row_scale && E.const_scale == 1.f && !E.residual && !E.residual_up_filter, "conv2d_f16: no row scale / residual (the demodulation is in the weights)");
-    int dbg = 0;
-    { const char* e = getenv("N3D_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    const int dbg = n3d_tune("N3D_CONV_DBG", 0);
     const int KC = d->I / 16;
     const int64_t wbs = (int64_t)F_TAPS * KC * 2 * d->O;
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
@@ -407,8 +399,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         N3D_CHECK(nblk < (1ll << 31), "conv2d_f16: grid too large");
         const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->N * d->O * d->I * 9);
         N3dProfScope prof(N3D_K_CONV2D_F16, stream, flops, bytes);
-        const char* e = getenv("N3D_F16_NBUF");
-        const int nbuf = e ? atoi(e) : 2;      // measured (tools/f16_bench.py, 1024 / 2048 workgroups): two buffers 263 / 285 us, one buffer + two workgroups per CU 285 / 317 us
+        const int nbuf = n3d_tune("N3D_F16_NBUF", 2);     // measured (tools/f16_bench.py, 1024 / 2048 workgroups): two buffers 263 / 285 us, one buffer + two workgroups per CU 285 / 317 us
         if (nbuf == 2) hipLaunchKernelGGL(conv2d_h8_f16_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL(conv2d_h8_f16_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         N3D_LAUNCH_CHECK();
@@ -420,19 +411,15 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     ConvUpF16Params p;
     p.x = (const f16x8*)d->x; p.w = (const f16x8*)d->wt; p.y = (f16x8*)d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
-    { const char* e = getenv("N3D_UP_EDGE_TILES"); p.plan = up_tile_plan(d->H, d->W, !(e && atoi(e) == 0)); }
-    int variant = 0;                                                      // 0: 4 waves x 64 positions x 32 channels; 1: 8 x 32 x 32; 2: 8 x 32 x 64
-    { const char* e = getenv("N3D_F16_UP"); if (e) variant = atoi(e); }
-    p.tiles_m = d->O / (variant == 2 ? 64 : 32);
+    p.plan = up_tile_plan(d->H, d->W, true);
+    p.tiles_m = d->O / 32;
     p.xbs = (int64_t)(d->I / 8) * d->H * d->W; p.wbs = wbs; p.ybs = (int64_t)(d->O / 8) * p.OH * p.OW;
     p.dbg = dbg;
     const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_f16: grid too large");
     const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->N * d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_F16, stream, flops, bytes);
-    if (variant == 2) hipLaunchKernelGGL(conv2d_up_h8_f16_m64_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-    else if (variant == 1) hipLaunchKernelGGL(conv2d_up_h8_f16_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(conv2d_up_h8_f16_w64_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(conv2d_up_h8_f16_w64_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -318,7 +318,7 @@ static int conv_p_num_cus() {
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched) {
     *launched = 0;
     static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("N3D_CONV_PERSIST"); enabled = e ? atoi(e) : 1; }
+    if (enabled < 0) enabled = n3d_tune("N3D_CONV_PERSIST", 1);
     const n3d_epilogue& E = d->epi;
     const bool act_ok = E.act == N3D_ACT_LINEAR || (E.act == N3D_ACT_LRELU && E.alpha >= 0.f && E.alpha <= 1.f);
     const int tiles_m = d->O / 64;

@@ -275,7 +275,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.epi = d->epi;
-    { const char* e = getenv("N3D_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }      // re-read per launch: tools/conv_ps_abl.py flips it in-process
+    p.dbg = n3d_tune("N3D_CONV_DBG", 0);                                  // tuning builds re-read it per launch: tools/conv_ps_abl.py flips it in-process
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
@@ -285,7 +285,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     // double buffering wins (measured, tools/conv_ps_abl.py: 64x64 x 512 channels = 256 workgroups: 156 us vs 201 us; 512
     // workgroups: equal; 1024+: 174 vs 182 us, 697 vs 735 us).  Starting every other batch of workgroups late to de-phase the
     // CUs' store bursts was measured too: no effect.
-    { const char* e = getenv("N3D_PS_NBUF"); const int nbuf = e ? atoi(e) : (nblk >= 768 ? 1 : 2);
+    { const int nbuf = n3d_tune("N3D_PS_NBUF", nblk >= 768 ? 1 : 2);
       if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
@@ -479,27 +479,17 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     }
 }
 
-__global__ __launch_bounds__(512, 2) void conv2d_up_ps_bf16x3_kernel(ConvUpPsParams p) {
-    __shared__ bf16x8 smem[up_ps_smem_slots(2)];
-    conv2d_up_ps_body<2, 8, 1>(p, smem);
-}
 __global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsParams p) {
     __shared__ bf16x8 smem[up_ps_smem_slots(1)];
     conv2d_up_ps_body<1, 8, 1>(p, smem);
-}
-__global__ __launch_bounds__(256, 2) void conv2d_up_ps32w_bf16x3_kernel(ConvUpPsParams p) {      // 4 waves x 64 positions x 32 channels
-    __shared__ bf16x8 smem[up_ps_smem_slots(1)];
-    conv2d_up_ps_body<1, 4, 2>(p, smem);
 }
 
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->ksize == 3 && d->mode == 2 && d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: a split8 input to the transposed kernel needs the c8 output layout");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL), no split-K");
     N3D_CHECK(d->I % 16 == 0 && d->O % 64 == 0 && d->H >= 4 && d->W >= 4, "conv2d_bf16x3 (split8, transposed): I %% 16 == 0, O %% 64 == 0");
-    // 32-channel groups per workgroup.  1 (two workgroups per CU) measured 4-22 % faster than 2 on every transposed layer of the
-    // benchmark (profiles/r02_conv_ps_ablation.txt); N3D_UP_PS_MT=2 keeps the 64-channel variant reachable for tuning.
-    int mt = 1;
-    { const char* e = getenv("N3D_UP_PS_MT"); if (e) mt = atoi(e) == 2 ? 2 : (atoi(e) == 3 ? 3 : 1); }       // 3: 32 channels, 4 waves x 64 positions
+    // 32-channel workgroups, two per CU: measured 4-22 % faster than 64-channel ones on every transposed layer of the benchmark
+    // (profiles/r02_conv_ps_ablation.txt); the 4-wave x 64-position form gained 0.3 % (round 3) — neither is instantiated any more.
     N3D_CHECK((int64_t)(d->I / 8) * d->H * d->W * 32 < (1ll << 31), "conv2d_bf16x3: one sample's split8 input exceeds 2 GiB (32-bit buffer offsets)");
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(E.act == N3D_ACT_LINEAR && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f,
@@ -508,23 +498,21 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     ConvUpPsParams p;
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
-    { const char* e = getenv("N3D_UP_EDGE_TILES"); p.plan = up_tile_plan(d->H, d->W, !(e && atoi(e) == 0)); }      // 0: the (H+1) x (W+1) grid in uniform tiles (A/B)
-    p.tiles_m = d->O / (mt == 2 ? 64 : 32);
+    p.plan = up_tile_plan(d->H, d->W, true);
+    p.tiles_m = d->O / 32;
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.OH * p.yrs;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.row_scale = E.row_scale; p.row_scale_stride = E.row_scale_stride ? E.row_scale_stride : d->O; p.const_scale = E.const_scale;
     p.round_f16 = E.round_f16;
-    { const char* e = getenv("N3D_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = n3d_tune("N3D_CONV_DBG", 0);
     const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    if (mt == 3) hipLaunchKernelGGL(conv2d_up_ps32w_bf16x3_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
-    else if (mt == 1) hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(conv2d_up_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
 
 // tile plan; false when the layer is not this kernel's
 static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_out) {
-    static const bool enabled = !(getenv("N3D_CONV_SK") && atoi(getenv("N3D_CONV_SK")) == 0);
+    static const bool enabled = n3d_tune("N3D_CONV_SK", 1) != 0;
     if (!enabled) return false;
     if (N < 1 || I % 128 != 0 || I > 1024 || O % 32 != 0 || O < 32 || H < 2 || W < 2 || W > 32) return false;
     const int HW = H * W;

@@ -41,7 +41,6 @@ struct RenderParams {
     float* feat;              // [N,32,R,R]
     float* depth;             // [N,1,R,R]
     float* wsum;              // [N,R*R] or NULL
-    float* col_ws;            // colour workspace [N,R*R,Sc+Sf,32] (render_rays_g_kernel) or NULL
     int N, R, Sc, Sf, PH, PW;
     float depth_delta, coord_scale;
 };
@@ -408,13 +407,10 @@ extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
 #define RN_STAMP2(k)
 #endif
 
-// RPW = rays per wave.  2: no idle lanes in the decode passes, but the colours of 2 x (Sc + Sf) samples in LDS leave room for ONE
-// wave per SIMD, which then has nobody to hide its latencies behind.  1: two waves per SIMD (8 per workgroup); a ray's 48 samples
-// take two passes of 32 (the second half empty) and both lane halves run the per-ray stages of the same ray.
-// GCOL: the samples' colours go to a global workspace (p.col_ws; written and read back by the same wave, L2-resident) instead of
-// LDS: 7 KB of LDS per wave instead of 34 KB, so two 4-wave workgroups... eight waves fit a CU (two per SIMD) with RPW = 2 and no
-// lanes idle; the texel prefetch is dropped (the second wave covers the loads, and 256 registers per wave do not hold it).
-template <int RPW, bool GCOL>
+// Two rays per wave: no idle lanes in the decode passes; the colours of 2 x (Sc + Sf) samples live in LDS, which leaves room for
+// one wave per SIMD (variants with two waves per SIMD — one ray per wave, or the colours parked in a global workspace — were
+// measured equal or slower in round 2 and are gone: DESIGN.md 3.2).
+constexpr int RPW = 2;
 __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hb = lane >> 5;
     const int n = blockIdx.y;
@@ -427,16 +423,16 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     RN_STAMP(0);
     const float* wl = smem + lane;
     const float bsig = p.b2[0];
-    const int cp = GCOL ? RN_C : RN_CP;                                  // colour row pitch
-    const int rlf = GCOL ? 8 * M : ray_lds_floats(M);                     // LDS floats per ray
+    const int cp = RN_CP;                                                // colour row pitch
+    const int rlf = ray_lds_floats(M);                                    // LDS floats per ray
     float* wsm = smem + RN_WROWS * 64 + wave * RPW * rlf;                 // this wave's rays
     RayLds Ls[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         RayLds& L = Ls[q];
         float* base = wsm + (q < RPW ? q : 0) * rlf;
-        L.col = GCOL ? p.col_ws + ((int64_t)n * RR + min(ray0 + q, RR - 1)) * M * RN_C : base;
-        L.sig = GCOL ? base : base + M * RN_CP;
+        L.col = base;
+        L.sig = base + M * RN_CP;
         L.dep = L.sig + M; L.wgt = L.dep + M; L.fac = L.wgt + M; L.trn = L.fac + M; L.cdf = L.trn + M; L.bins = L.cdf + M;
         L.order = reinterpret_cast<int*>(L.bins + M);
     }
@@ -486,19 +482,6 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     };
     auto decode_all = [&](int cnt, int slot0) {
         const int total = nrays * cnt;
-        if (RPW == 1 || GCOL) {                                           // two waves per SIMD: the other wave covers this one's loads
-            for (int g0 = 0; g0 < total; g0 += 32) {
-                PassFetch F;
-                taps(g0, cnt, slot0, F);
-#pragma unroll
-                for (int part = 0; part < 4; ++part) pass_load(F, part);
-                float f[16], rgb[16], sigma;
-                pass_blend(F, f);
-                pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, F);
-                store_pass(F.slot, F.q, rgb, sigma);
-            }
-            return;
-        }
         PassFetch F;
         taps(0, cnt, slot0, F);
 #pragma unroll
@@ -594,7 +577,6 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         march_weights(L, Sc, l31, [](int i) { return i; });
     }
 
-    if (GCOL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the colour rows were written by this wave's own global stores
     // ---- composite (ray_marcher.py:48-59): the ray's 32 lanes take one colour channel each; depth and weight total as
     // lane-strided partial sums
     float acc = 0.f, dacc = 0.f, wt = 0.f;
@@ -635,15 +617,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body<2, false>(p, smem);
-}
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_rays1_kernel(RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body<1, false>(p, smem);
-}
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void render_rays_g_kernel(RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body<2, true>(p, smem);
+    render_rays_body(p, smem);
 }
 
 // global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
@@ -742,29 +716,10 @@ extern "C" int n3d_planes_to_channels_last(const float* planes, float* planes_cl
     return 0;
 }
 
-extern "C" int n3d_render_rays_ws(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
-                                  const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
-                                  int Sf, int PH, int PW, float depth_delta, float coord_scale, float* workspace, int64_t workspace_bytes,
-                                  n3d_stream_t stream_);
-
-extern "C" int64_t n3d_render_rays_workspace_bytes(int N, int R, int Sc, int Sf) {
-    return (int64_t)N * R * R * (Sc + Sf) * RN_C * (int64_t)sizeof(float);
-}
-
 extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
                                const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
                                int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream_) {
-    return n3d_render_rays_ws(planes_cl, cam2world, intrinsics, tlin, jitter, u, w1, b1, w2, b2, feat, depth, wsum, bounds_ws, N, R, Sc, Sf, PH, PW,
-                              depth_delta, coord_scale, nullptr, 0, stream_);
-}
-
-extern "C" int n3d_render_rays_ws(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
-                                  const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
-                                  const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
-                                  int Sf, int PH, int PW, float depth_delta, float coord_scale, float* workspace, int64_t workspace_bytes,
-                                  n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(N >= 0 && R > 0 && R * R <= 1 << 24, "render_rays: bad resolution");
     N3D_CHECK(Sc >= 4 && Sf >= 0 && Sc + Sf <= RN_MAX_S, "render_rays: need 4 <= Sc and Sc + Sf <= %d", RN_MAX_S);
@@ -778,25 +733,13 @@ extern "C" int n3d_render_rays_ws(const float* planes_cl, const float* cam2world
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.bounds = bounds_ws; p.feat = feat; p.depth = depth; p.wsum = wsum;
     p.N = N; p.R = R; p.Sc = Sc; p.Sf = Sf; p.PH = PH; p.PW = PW; p.depth_delta = depth_delta; p.coord_scale = coord_scale;
     const int M = Sc + Sf;
-    // rays per wave (see render_rays_body) and waves per workgroup: as many as the LDS holds beside the shared decoder image.
-    // With a colour workspace: render_rays_g_kernel (8 waves per workgroup, two per SIMD).
-    int rpw = 2;
-    { const char* e = getenv("N3D_RENDER_RPW"); if (e) rpw = atoi(e) == 1 ? 1 : 2; }
-    bool gcol = workspace != nullptr && rpw == 2;
-    if (gcol) {
-        N3D_CHECK(workspace_bytes >= n3d_render_rays_workspace_bytes(N, R, Sc, Sf) && ((uintptr_t)workspace & 15) == 0,
-                  "render_rays: workspace smaller than n3d_render_rays_workspace_bytes() or misaligned");
-        p.col_ws = workspace;
-    } else {
-        p.col_ws = nullptr;
-    }
-    const size_t per_wave = (size_t)rpw * (gcol ? 8 * M : ray_lds_floats(M)) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
-    const int wmax = (rpw == 1 || gcol) ? 8 : 4;
+    // waves per workgroup: as many as the LDS holds beside the shared decoder image (at most one per SIMD)
+    const size_t per_wave = (size_t)RPW * ray_lds_floats(M) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
     int wpb = (int)((160 * 1024 - image) / per_wave);
-    wpb = wpb > wmax ? wmax : wpb;
+    wpb = wpb > 4 ? 4 : wpb;
     N3D_CHECK(wpb >= 1, "render_rays: %d samples per ray do not fit the LDS", M);
     const size_t lds = image + wpb * per_wave;
-    const void* kfn = gcol ? (const void*)render_rays_g_kernel : (rpw == 1 ? (const void*)render_rays1_kernel : (const void*)render_rays_kernel);
+    const void* kfn = (const void*)render_rays_kernel;
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
@@ -808,9 +751,7 @@ extern "C" int n3d_render_rays_ws(const float* planes_cl, const float* cam2world
     hipLaunchKernelGGL(render_depth_bounds_kernel, dim3((unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256))), dim3(256), 0, stream,
                        tlin, jitter, nrays, Sc, depth_delta, bounds_ws);
     N3D_LAUNCH_CHECK();
-    if (gcol) hipLaunchKernelGGL(render_rays_g_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
-    else if (rpw == 1) hipLaunchKernelGGL(render_rays1_kernel, dim3(cdiv(R * R, wpb), N), dim3(64 * wpb), lds, stream, p);
-    else hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
+    hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -55,9 +55,6 @@ def _attach(root, dotted, tensor, is_buffer):
         mod.register_parameter(parts[-1], torch.nn.Parameter(tensor, requires_grad=False))
 
 
-RENDER_WORKSPACE = os.environ.get('N3D_RENDER_GCOL', '0') == '1'
-
-
 class TriPlaneGenerator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path, sr_num_fp16_res=0,
                  mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, uv_face_mask=None, **synthesis_kwargs):
@@ -88,9 +85,6 @@ class TriPlaneGenerator(torch.nn.Module):
         self.orth_scale = torch.tensor([[5.0]])
         self.orth_shift = torch.tensor([[0, -0.01, -0.01]])
         self.overlap_static = os.environ.get('N3D_OVERLAP_STATIC', '1') != '0'
-        # texture + static backbone in lock step with shared grids for their <= 32x32 layers (_planes): OFF by default — measured no
-        # better than the static backbone on its side stream
-        self.pair_backbones = os.environ.get('N3D_PAIR_BACKBONES', '0') == '1'
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
@@ -139,8 +133,18 @@ class TriPlaneGenerator(torch.nn.Module):
         self._prepared = None
         self._last_planes = None
         self._identity_cache = None
+        self._cache_gen = getattr(self, '_cache_gen', 0) + 1      # generation of the two caches above (synthesis_graph keys on it)
         self._param_stamp = None
         self._graphs = None             # captured HIP graphs (synthesis_graph): they hold pointers into the prepared weights and caches
+
+    def _set_cache(self, name, value):
+        """(Re)assign a cross-call cache (`_last_planes` / `_identity_cache`).  Captured graphs bake in the device pointers of the
+        cache they were captured with: a new cache gets a new generation number — never an id(), which CPython re-uses — and the
+        graphs captured against the old one are dropped with their private memory pools (they could only ever replay stale data)."""
+        setattr(self, name, value)
+        self._cache_gen += 1
+        if self._graphs:
+            self._graphs = {sig: e for sig, e in self._graphs.items() if not e[3]}       # e[3]: the graph reads a cache
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -202,7 +206,7 @@ class TriPlaneGenerator(torch.nn.Module):
             ent += list(net.bank.entries)
         ent += S.sr.bank_entries(nw - 1)
         S.all_bank = layers.StyleBank(ent, dev)
-        S.one_bank = os.environ.get('N3D_ONE_BANK', '1') != '0' 
+        S.one_bank = True           # False: every network computes its own styles (10 instead of 2 affine launches; tests)
         lr = float(self.rendering_kwargs.get('decoder_lr_mul', 1))
         S.dec_w1 = (P['decoder.net.0.weight'] * (lr / np.sqrt(32))).contiguous()
         S.dec_b1 = (P['decoder.net.0.bias'] * lr).contiguous() if lr != 1 else P['decoder.net.0.bias']
@@ -320,28 +324,8 @@ class TriPlaneGenerator(torch.nn.Module):
         cur = torch.cuda.current_stream()
         ident = self._identity_cache if use_cached_identity else None
         static = None
-        paired = False
         if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
             textures, static = ident
-        elif self.pair_backbones and noise_mode != 'random' and networks._img_stream(ws.device) is None:
-            # The texture and the static tri-plane backbone are two StyleGAN2 networks of identical layer shapes on different
-            # latents: their launches are recorded and issued in lock step, the <= 32x32 layers (a handful of workgroups each)
-            # as ONE grid per layer pair (n3d_conv2d_bf16x3_pair), the large ones one after the other.
-            with _lib.Recording() as rec_t:
-                textures = S.texture(texture_ws, noise_mode, bank=bank)
-            with _lib.Recording() as rec_s:
-                static = S.static(eg3d_ws, noise_mode, bank=bank)
-            # ... and the static backbone's large layers (64x64 and up) go to a second HIP stream, where they overlap the texture ->
-            # mouth -> blending chain.  Measured on one box, one launch stream: 315 frames/s paired only, 341 paired + side stream,
-            # 347 side stream only (the default): the lock step puts the static backbone's small layers on the critical path of the
-            # texture -> mouth -> blending chain, which costs more than the shared grids save.
-            sstream = None
-            if self.overlap_static:
-                sstream = S.side_streams.get(cur.cuda_stream)
-                if sstream is None:
-                    sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
-            _lib.replay_paired(rec_t, rec_s, side_stream=sstream)
-            paired = True
         elif self.overlap_static:
             sstream = S.side_streams.get(cur.cuda_stream)
             if sstream is None:
@@ -365,12 +349,10 @@ class TriPlaneGenerator(torch.nn.Module):
         stitch = S.blend(stitch_in, eg3d_ws, noise_mode, bank=bank)
         if ident is None and self.overlap_static:
             cur.wait_stream(sstream)
-            if paired:
-                rec_s.release()                     # the recorded tensors outlive the side stream's work
         elif static is None:
             static = S.static(eg3d_ws, noise_mode, bank=bank)
         if cache_identity:
-            self._identity_cache = (textures, static)
+            self._set_cache('_identity_cache', (textures, static))
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
         _lib.check(L.n3d_blend_planes(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
                                       _lib.ptr(planes), N, 256, 256, _lib.stream()))
@@ -401,14 +383,11 @@ class TriPlaneGenerator(torch.nn.Module):
         feat = torch.empty(N, 32, R, R, **f32)
         depth = torch.empty(N, 1, R, R, **f32)
         bounds = torch.empty(2, **f32)              # scratch of this call (calls may be in flight on several streams)
-        # N3D_RENDER_GCOL=1: colour workspace variant (eight waves per CU instead of four; measured equal: DESIGN.md 3.2)
-        ws_bytes = _lib.lib().n3d_render_rays_workspace_bytes(N, R, Sc, Sf) if RENDER_WORKSPACE else 0
-        ws = torch.empty(ws_bytes // 4, **f32) if ws_bytes else None
-        _lib.check(_lib.lib().n3d_render_rays_ws(
+        _lib.check(_lib.lib().n3d_render_rays(
             _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter),
             _lib.ptr(u), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
             _lib.ptr(depth), None, _lib.ptr(bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
-            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.ptr(ws), ws_bytes, _lib.stream()))
+            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
         return feat, depth
 
     def synthesis(self, ws, c, v, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
@@ -440,7 +419,7 @@ class TriPlaneGenerator(torch.nn.Module):
         else:
             planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank)
         if cache_backbone:
-            self._last_planes = planes
+            self._set_cache('_last_planes', planes)
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
         rgb_image = feature_image[:, :3]
         sr_noise = self.rendering_kwargs.get('superresolution_noise_mode', 'none')     # triplane_next3d.py:182
@@ -471,8 +450,11 @@ class TriPlaneGenerator(torch.nn.Module):
         sig = (tuple(ws.shape), tuple(c.shape), tuple(v.shape), tuple((k, tuple(t.shape)) for k, t in sorted(tensors.items())),
                tuple(sorted((k, repr(val)) for k, val in plain.items())), plain.get('neural_rendering_resolution') or self.neural_rendering_resolution,
                rk['depth_resolution'], rk['depth_resolution_importance'], rk.get('superresolution_noise_mode', 'none'), layers.PRECISION,
-               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, os.environ.get('N3D_SR_FP16', 'native'), self.overlap_static,
-               id(self._last_planes), id(self._identity_cache))
+               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, self.overlap_static)
+        uses_cache = bool((plain.get('use_cached_backbone') and self._last_planes is not None) or
+                          (plain.get('use_cached_identity') and self._identity_cache is not None))
+        if uses_cache:
+            sig = sig + (self._cache_gen,)
         if self._graphs is None:
             self._graphs = {}
         entry = self._graphs.get(sig)
@@ -492,8 +474,9 @@ class TriPlaneGenerator(torch.nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = call()
-            entry = self._graphs[sig] = (graph, st, out)
-        graph, st, out = entry
+            # the caches the graph reads stay referenced by its entry: they outlive the graph whatever the caller does next
+            entry = self._graphs[sig] = (graph, st, out, uses_cache, (self._last_planes, self._identity_cache) if uses_cache else None)
+        graph, st, out = entry[:3]
         st['ws'].copy_(ws); st['c'].copy_(c); st['v'].copy_(v)
         for k, t in tensors.items():
             st[k].copy_(t)
@@ -517,7 +500,7 @@ class TriPlaneGenerator(torch.nn.Module):
         else:
             planes, _ = self._planes(ws, v, noise_mode)
             if cache_backbone:
-                self._last_planes = planes
+                self._set_cache('_last_planes', planes)
         coords = coordinates.to(device=self.device, dtype=torch.float32).contiguous()
         N, M = coords.shape[0], coords.shape[1]
         if N != planes.shape[0] or coords.shape[2] != 3:

@@ -31,16 +31,14 @@ PRECISION = os.environ.get('N3D_PRECISION', 'bf16x3')
 
 
 # Pre-split hand-off between an up-sampling layer and the 3x3 convolution behind it (include/n3d.h "split8"): the FIR epilogue
-# writes bf16 hi / lo planes already multiplied by the next layer's style, the convolution stages them by LDS-DMA.
-# N3D_PRESPLIT=0 keeps the float32 hand-off (A/B on one box).
-PRESPLIT = os.environ.get('N3D_PRESPLIT', '1') != '0'
-# ... and for the transposed convolution in front of it: its input (a block output with two consumers) is converted once
-# (n3d_split8_from_nchw, with the layer's style) so that the transposed kernel, too, stages by LDS-DMA.  N3D_UP_PRESPLIT=0: A/B.
-S2_PRESPLIT = os.environ.get('N3D_S2_PRESPLIT', '1') != '0'      # stride-2 encoder layers on split8 input (A/B: 0)
-UP_PRESPLIT = os.environ.get('N3D_UP_PRESPLIT', '1') != '0'
-TORGB_SIDE = os.environ.get('N3D_TORGB_SIDE', '1') != '0'           # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
-DIRECT_SPLIT8 = os.environ.get('N3D_DIRECT_SPLIT8', '1') != '0'     # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
-CONVERT_MAX_BYTES = int(float(os.environ.get('N3D_CONVERT_MAX_MB', '70')) * 1e6)     # see _conv3x3
+# writes bf16 hi / lo planes already multiplied by the next layer's style, the convolution stages them by LDS-DMA.  These are
+# module constants, not environment switches (tools/ and tests flip them in-process for A/B runs).
+PRESPLIT = True
+S2_PRESPLIT = True         # stride-2 encoder layers on split8 input
+UP_PRESPLIT = True         # the transposed convolution's input (a block output with two consumers) converted once, LDS-DMA staging
+TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
+DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
+CONVERT_MAX_BYTES = int(70e6)     # see _conv3x3
 
 
 def set_precision(mode):
@@ -186,16 +184,14 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, fp16=False, x_split8=None):
+                    split_for=None, x_split8=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
     the device generator like the reference) — the kernels' epilogue takes one noise image per launch, so that mode runs
     the layer sample by sample.  `split_for` (up = 2 only): the styles [N,O] of the 3x3 layer that consumes this layer's
-    output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  `fp16`: the layer belongs to one of the
-    reference's fp16 blocks — every tensor an operator of such a block returns is float16 (networks_stylegan2.py:548-552); here
-    the arithmetic stays float32 / split-bf16 and the values are rounded to float16 at exactly those points (the transposed
-    convolution's output, the FIR + bias_act output, the convolution + bias_act output: n3d_epilogue.round_f16)."""
+    output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  (The reference's float16 blocks run on their own
+    kernels: synthesis_layer_f16.)"""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
         dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
@@ -210,14 +206,12 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
         return out if out is not None else torch.cat(outs, 0)
     noise = _noise if _noise is not None else (L.noise_const if noise_mode == 'const' else None)
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
-               gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain, round_f16=fp16)
-    if fp16 and not (isinstance(x, _lib.Split8) or split_for is not None):
-        raise RuntimeError('the fp16 block mode runs on the pre-split path only (N3D_PRESPLIT=1, eligible layer shapes)')
+               gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:
         return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out)
     assert up == 2 and out is None
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
-        zepi = _lib.make_epilogue(row_scale=dcoef, round_f16=fp16)
+        zepi = _lib.make_epilogue(row_scale=dcoef)
         if UP_PRESPLIT and x.shape[1] % 16 == 0:
             # modulation + operand split once, then pure LDS-DMA staging; `x_split8`: the previous block's toRGB made it already
             xs = x_split8 if x_split8 is not None else cg.split8_from_nchw(x, styles)
@@ -249,7 +243,7 @@ def torgb_side_ok(L, x):
             L.out_channels <= 128 and x.shape[1] % 32 == 0 and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 1, 0))
 
 
-def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None, fp16=False, side_style=None):
+def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_up_filter=None, side_style=None):
     """ToRGBLayer.forward (reference networks_stylegan2.py:353-357) + the skip-image accumulation (:580-584).  With
     `residual_up_filter`, `residual` is the PREVIOUS block's half-resolution image and upsample2d (:582) is evaluated
     inside the convolution's epilogue.  With `side_style` (the styles of the NEXT block's transposed convolution, the other reader
@@ -259,7 +253,7 @@ def torgb_layer(L, x, w, conv_clamp=None, residual=None, styles=None, residual_u
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=g / np.sqrt(w.shape[1]), bgain=g)
     return _conv1x1(L, x, style=styles, epilogue=_lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual,
-                                                                    residual_up_filter=residual_up_filter, round_f16=fp16), side_style=side_style)
+                                                                    residual_up_filter=residual_up_filter), side_style=side_style)
 
 
 def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1.0, residual=None, out=None, sole_consumer=None):
@@ -383,7 +377,7 @@ def fir4_h8(z, fir, epi, gain=4.0):
     """upfirdn2d(z, fir, padding=1, gain) + the layer epilogue on h8 tensors (n3d_fir4_h8): [N,C,H,W] -> [N,C,H-1,W-1]."""
     n, c, h, w = z.shape
     y = _lib.H8(n, c, h - 1, w - 1, z.device)
-    f1d = fir_factor(fir) if os.environ.get('N3D_FIR_SEP', '1') != '0' else None
+    f1d = fir_factor(fir) if uf.FIR_SEP else None
     _lib.check(_lib.lib().n3d_fir4_h8(_lib.ptr(z.data), _lib.ptr(fir), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, 0, float(gain), epi, _lib.stream()))
     y._keep = (z, epi, f1d)
     return y

@@ -44,12 +44,10 @@ class _Block:
         """Does conv0 read its [n, I, h, w] input in the split8 layout (layers.synthesis_layer, the transposed pre-split kernel)?"""
         return bool(L.UP_PRESPLIT and xshape[1] % 16 == 0 and self._presplit(n, xshape, fir, noise_mode))
 
-    def __call__(self, x, img, bank, n, fir, noise_mode, img_stream=None, x_out=None, fp16=False, x_split8=None, next_block=None):
-        """SynthesisBlock.forward; `bank` = StyleBank.compute(ws) result.  fp16=True: the reference's fp16 block (use_fp16 and
-        not force_fp32, networks_stylegan2.py:548) — float32 arithmetic with float16 storage rounding (layers.synthesis_layer);
-        the skip image stays float32 as in the reference (:582-585).  -> (x, img, xs): `next_block` = the block whose conv0 reads
-        THIS block's x unchanged; when it takes split8 input, toRGB writes it on the side (layers.torgb_layer) and `xs` is to be
-        passed to that block as `x_split8` (None otherwise)."""
+    def __call__(self, x, img, bank, n, fir, noise_mode, x_out=None, x_split8=None, next_block=None):
+        """SynthesisBlock.forward (float32 block); `bank` = StyleBank.compute(ws) result.  -> (x, img, xs): `next_block` = the block
+        whose conv0 reads THIS block's x unchanged; when it takes split8 input, toRGB writes it on the side (layers.torgb_layer) and
+        `xs` is to be passed to that block as `x_split8` (None otherwise)."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
@@ -57,47 +55,22 @@ class _Block:
         else:
             pre = self._presplit(n, x.shape, fir, noise_mode)
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
-                                  split_for=bank[self.conv1.prefix][0] if pre else None, fp16=fp16, x_split8=x_split8 if pre else None,
+                                  split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if pre else None,
                                   **sl(self.conv0))
-            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, fp16=fp16,
-                                  **sl(self.conv1))
-        # skip-image branch (upsample2d + toRGB): HBM-bound 1x1 / FIR work that only joins the feature path at the very end
-        # of the network -> issued on `img_stream` (when given) so it overlaps the MFMA-bound convolutions of the next block.
-        if img_stream is None:
-            # upsample2d(img) is evaluated inside the toRGB epilogue (4 taps of the half-resolution image per pixel)
-            up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
-            if img is not None and up is None:
-                img = uf.upsample2d(img, fir)
-            side = (bank[next_block.conv0.prefix][0] if (next_block is not None and L.torgb_side_ok(self.torgb, x) and
-                                                          next_block.takes_split8(n, x.shape, fir, noise_mode)) else None)
-            img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0],
-                                residual_up_filter=up, fp16=fp16, side_style=side)
-            if side is not None:
-                img, xs = img
-                return x, img, xs
-        else:
-            ev = torch.cuda.current_stream().record_event()
-            with torch.cuda.stream(img_stream):
-                img_stream.wait_event(ev)
-                if img is not None:
-                    img = uf.upsample2d(img, fir)
-                img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0], fp16=fp16)
+            x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
+        # skip-image update img = upsample2d(img) + toRGB(x): upsample2d is evaluated inside the toRGB epilogue (4 taps of the
+        # half-resolution image per pixel)
+        up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
+        if img is not None and up is None:
+            img = uf.upsample2d(img, fir)
+        side = (bank[next_block.conv0.prefix][0] if (next_block is not None and L.torgb_side_ok(self.torgb, x) and
+                                                      next_block.takes_split8(n, x.shape, fir, noise_mode)) else None)
+        img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0],
+                            residual_up_filter=up, side_style=side)
+        if side is not None:
+            img, xs = img
+            return x, img, xs
         return x, img, None
-
-
-_IMG_STREAMS = {}
-
-
-def _img_stream(device):
-    """Side stream for the skip-image branch of the network running on the CURRENT stream (one per (device, stream)), or
-    None unless N3D_OVERLAP_IMG=1 (measured: no gain on MI355X — the large convolutions already fill the chip — so opt-in)."""
-    import os
-    if os.environ.get('N3D_OVERLAP_IMG', '0') == '0':
-        return None
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    if key not in _IMG_STREAMS:
-        _IMG_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _IMG_STREAMS[key]
 
 
 def _first_slots(block_resolutions):
@@ -123,6 +96,7 @@ class SynthesisNet:
         self.num_ws = 2 * len(self.block_res)
         slots = _first_slots(self.block_res)
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.block_res), []), self.fir.device)
+        uf.fir_factor(self.fir)            # the one host read of the filter happens here, at model preparation
 
     def __call__(self, ws, noise_mode='const', bank=None):
         """`bank`: this network's styles / demodulation coefficients when the caller computed them already (generator: one
@@ -130,21 +104,10 @@ class SynthesisNet:
         ws = _ws3(ws)
         if bank is None:
             bank = self.bank.compute(ws)
-        side = _img_stream(ws.device)
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        x = img = None
-        keep = []                      # feature maps read by the side stream stay referenced until the join
-        from . import _lib
-        xs = None
+        x = img = xs = None
         for k, res in enumerate(self.block_res):
-            if res == 64:
-                _lib.mark('high')              # the layers up to 32x32 are a handful of workgroups each (generator._planes pairs them)
             nxt = self.blocks[self.block_res[k + 1]] if k + 1 < len(self.block_res) else None
-            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_split8=xs, next_block=nxt)
-            keep.append(x)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, next_block=nxt)
         return img
 
 
@@ -183,6 +146,7 @@ class StyleUNet:
         self.fir = P[f'{prefix}.b4.resample_filter']
         slots = _first_slots(self.block_res)
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.used_res), []), self.fir.device)
+        uf.fir_factor(self.fir)
 
     def __call__(self, x_in, ws, noise_mode='const', bank=None):
         ws = _ws3(ws)
@@ -207,11 +171,7 @@ class StyleUNet:
             x_in, cond = enc(x_in, cond, self.fir, out_buf)
             conds[idx] = cond
             h = hin
-        side = _img_stream(ws.device)
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
         x = img = xs = None
-        keep = []
         for idx, res in enumerate(self.used_res):
             if idx < len(self.fusion):
                 xs = None                                             # this block reads the fusion layer's output, not the previous x
@@ -223,12 +183,9 @@ class StyleUNet:
             x_out = nxt[:, :self.cd[res]] if (nxt is not None and nxt.shape[2] == res) else None
             # the next block reads this x directly unless a fusion layer (or the concatenation buffer's channel-slice view) is in between
             nb = self.blocks[self.used_res[idx + 1]] if (idx + 1 < len(self.used_res) and idx + 1 >= len(self.fusion) and x_out is None) else None
-            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, side, x_out=x_out, x_split8=xs, next_block=nb)
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_out=x_out, x_split8=xs, next_block=nb)
             if nxt is not None and x_out is None:                 # shapes did not line up: fall back to a copy
                 nxt[:, :self.cd[res]].copy_(x)
-            keep.append(x)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
         return img
 
 
@@ -240,35 +197,22 @@ class SuperRes8XDC:
         self.fir = P[f'{prefix}.block0.resample_filter']
         self.input_resolution = 128
         self._banks = {}
+        uf.fir_factor(self.fir)
 
-    def _fp16_mode(self, x, noise_mode):
-        """Which implementation runs the reference's float16 blocks: 'native' (f16 matrix cores, conv2d_f16.hip; the default),
-        'emulate' (N3D_SR_FP16=emulate: round 2's storage-rounding emulation on the split-bf16 kernels) or 'fp32' (the float32
-        blocks, with a one-time warning) when the requested one cannot take the configuration — never an error: the reference's
-        default `synthesis(ws, c, v)` call must run under every precision / layout switch."""
-        import os
+    def _f16_ok(self, x, noise_mode):
+        """Can the reference's float16 blocks run on the f16 kernels for this input (conv2d_f16.hip)?  When not (random SR noise, a
+        non-4x4 resampling filter, odd shapes) they run in float32 — the force_fp32=True arithmetic, a superset in accuracy — with
+        a one-time warning, never an error: the reference's default `synthesis(ws, c, v)` call must run."""
         import warnings
-        want = os.environ.get('N3D_SR_FP16', 'native')
-        n, _, h, w = x.shape
-        native_ok = (noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and
-                     all(L.f16_layer_ok(b.conv0, hh, hh, 2) and L.f16_layer_ok(b.conv1, 2 * hh, 2 * hh, 1) and b.torgb.in_channels <= 512
-                         for b, hh in ((self.block0, h), (self.block1, 2 * h))))
-        if want == 'native' and native_ok:
-            return 'native'
-        emulate_ok = (L.PRESPLIT and L.UP_PRESPLIT and L.PRECISION == 'bf16x3' and noise_mode != 'random' and _img_stream(x.device) is None and
-                      all(L.presplit_ok(n, b.conv1, 2 * hh, 2 * hh) and b.conv0.out_channels % 64 == 0 and b.conv0.in_channels % 16 == 0 and
-                          L.cg.pick_ksplit_bf16x3(n, b.conv0.in_channels, b.conv0.out_channels, hh, hh, 2) == 1
-                          for b, hh in ((self.block0, h), (self.block1, 2 * h))))
-        if want in ('native', 'emulate') and emulate_ok:
-            if want == 'native' and not getattr(self, '_warned', False):
-                self._warned = True
-                warnings.warn('float16 super-resolution blocks: configuration not eligible for the f16 kernels, running the storage-rounding emulation')
-            return 'emulate'
-        if not getattr(self, '_warned32', False):
+        h = x.shape[2]
+        ok = (noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and
+              all(L.f16_layer_ok(b.conv0, hh, hh, 2) and L.f16_layer_ok(b.conv1, 2 * hh, 2 * hh, 1) and b.torgb.in_channels <= 512
+                  for b, hh in ((self.block0, h), (self.block1, 2 * h))))
+        if not ok and not getattr(self, '_warned32', False):
             self._warned32 = True
-            warnings.warn('float16 super-resolution blocks are not available for this configuration (precision / layout switches, random '
-                          'noise): running them in float32 (the force_fp32=True arithmetic)')
-        return 'fp32'
+            warnings.warn('float16 super-resolution blocks are not available for this configuration (random noise / filter / shapes): '
+                          'running them in float32 (the force_fp32=True arithmetic)')
+        return ok
 
     def _forward_f16(self, x, rgb, bank, noise_mode):
         """Both blocks on the f16 kernels (layers.synthesis_layer_f16 / torgb_layer_f16): h8 activations, float32 skip image."""
@@ -302,19 +246,8 @@ class SuperRes8XDC:
         if x.shape[-1] != self.input_resolution:
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
-        side = _img_stream(ws.device)
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        if fp16:
-            mode = self._fp16_mode(x, noise_mode)
-            if mode == 'native':
-                return self._forward_f16(x, rgb, bank, noise_mode)
-            fp16 = mode == 'emulate'
-        if fp16:        # N3D_SR_FP16=emulate: float32 / split-bf16 arithmetic with float16 storage rounding (round 2's route, A/B)
-            from . import _lib
-            x = _lib.cast(_lib.cast(x.contiguous(), torch.float16), torch.float32)
-        x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16, next_block=self.block1)
-        x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, side, fp16=fp16, x_split8=xs)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        if fp16 and self._f16_ok(x, noise_mode):
+            return self._forward_f16(x, rgb, bank, noise_mode)
+        x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, next_block=self.block1)
+        x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs)
         return rgb

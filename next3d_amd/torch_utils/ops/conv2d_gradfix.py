@@ -91,7 +91,7 @@ def split8_from_nchw(x, scale=None):
     return y
 
 
-KSPLIT_MAX = int(os.environ.get('N3D_KSPLIT_MAX', '64'))      # tuning: cap on the split-K factor of the split-bf16 3x3 kernels
+KSPLIT_MAX = 64      # cap on the split-K factor of the split-bf16 3x3 kernels (module constant; tools sweep it in-process)
 
 
 def out_shape(h, w, mode):

@@ -83,23 +83,30 @@ def _launch(x, f2d, up, down, padding, flip_filter, gain, epilogue=None, row_pit
     return y
 
 
-_FIR1D = {}
+_FIR1D = {}                # id(filter tensor) -> (weak reference to it, its version counter, factor or None)
+FIR_SEP = True             # separable evaluation of separable 4x4 filters (module constant; tools/fir_bench.py flips it in-process)
 
 
 def fir_factor(fir):
-    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter tensor (a host read at model preparation).
+    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter TENSOR (one host read; the networks call this
+    at model preparation, networks.py, so that no forward — and no HIP-graph capture — ever does it).  The entry is tied to the
+    tensor object by a weak reference and dropped with it: a later tensor at the same address never sees a stale factor.
     The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (:96-116): the separable kernels
     (n3d_fir4_split8_sep, n3d_fir4_h8) evaluate the same float32 sum with half the multiply-adds."""
-    key = (fir.data_ptr(), fir._version, str(fir.device))
-    if key not in _FIR1D:
-        f = fir.detach().to('cpu', torch.float64)
-        a = None
-        if tuple(f.shape) == (4, 4) and float(f.sum()) > 0:
-            v = f.sum(1) / f.sum().sqrt()
-            if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
-                a = v.to(torch.float32).to(fir.device).contiguous()
-        _FIR1D[key] = a
-    return _FIR1D[key]
+    import weakref
+    key = id(fir)
+    hit = _FIR1D.get(key)
+    if hit is not None and hit[0]() is fir and hit[1] == fir._version:
+        return hit[2]
+    f = fir.detach().to('cpu', torch.float64)
+    a = None
+    if tuple(f.shape) == (4, 4) and float(f.sum()) > 0:
+        v = f.sum(1) / f.sum().sqrt()
+        if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
+            a = v.to(torch.float32).to(fir.device).contiguous()
+    _FIR1D[key] = (weakref.ref(fir), fir._version, a)
+    weakref.finalize(fir, lambda k=key: _FIR1D.pop(k, None) if (_FIR1D.get(k) and _FIR1D[k][0]() is None) else None)
+    return a
 
 
 def _fir4_split8(x, f2d, gain, epilogue, out_scale):
@@ -109,10 +116,9 @@ def _fir4_split8(x, f2d, gain, epilogue, out_scale):
     assert isinstance(x, _lib.C8) and tuple(f2d.shape) == (4, 4) and out_scale.stride(1) == 1
     n, c, h, w = x.shape
     y = _lib.Split8(n, c, h - 1, w - 1, x.device)
-    import os
-    # (64 x 64 outputs: the 16-tap kernel's staged tile is the faster one, 21 vs 24 us — profiles/r03_fir_bench.txt)
-    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and (epilogue is None or epilogue.act in (1, 3)) and
-                              (h > 100 or os.environ.get('N3D_FIR_SEP') == '1')) else None
+    # (64 x 64 outputs: the 16-tap kernel's staged tile is the faster one, 21 vs 24 us — profiles/r03_fir_bench.txt; FIR_SEP = 'all'
+    # forces the separable kernel there too: tests / tools)
+    f1d = fir_factor(f2d) if (FIR_SEP and (epilogue is None or epilogue.act in (1, 3)) and (h > 100 or FIR_SEP == 'all')) else None
     if f1d is not None:
         _lib.check(_lib.lib().n3d_fir4_split8_sep(_lib.ptr(x.data), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, w, 0, 0, float(gain),
                                                   epilogue, _lib.ptr(out_scale), out_scale.stride(0), _lib.stream()))
@@ -131,9 +137,7 @@ def _fir4_split8_nchw(x, f2d, pad, gain=1.0, epilogue=None, out_scale=None):
         x = x.contiguous()
     n, c, h, w = x.shape
     y = _lib.Split8(n, c, h + 2 * pad - 3, w + 2 * pad - 3, x.device)
-    import os
-    f1d = fir_factor(f2d) if (os.environ.get('N3D_FIR_SEP', '1') != '0' and os.environ.get('N3D_FIR_SEP_NCHW', '1') != '0' and
-                              (epilogue is None or epilogue.act in (1, 3))) else None
+    f1d = fir_factor(f2d) if (FIR_SEP and (epilogue is None or epilogue.act in (1, 3))) else None
     if f1d is not None and h * x.stride(2) * 32 < 2 ** 31:
         _lib.check(_lib.lib().n3d_fir4_split8_nchw_sep(_lib.ptr(x), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, x.stride(2), x.stride(0), pad, 0,
                                                        float(gain), epilogue, _lib.ptr(out_scale), out_scale.stride(0) if out_scale is not None else 0,

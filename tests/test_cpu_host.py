@@ -348,9 +348,8 @@ def test_layout_grid_tiling():
         frames.layout_grid(img.float(), grid_w=3, grid_h=2)          # CPU tensor: no fallback for the conversion
 
 
-def test_ptr_keepalive_window_and_recording():
-    """`_lib.ptr()` holds every tensor whose pointer crosses the C ABI until `check()` (the launch is enqueued by then); inside a
-    `Recording` launches are deferred and the tensors move to the recording; marks are kept in order."""
+def test_ptr_keepalive_window():
+    """`_lib.ptr()` holds every tensor whose pointer crosses the C ABI until `check()` (the launch is enqueued by then)."""
     import weakref
     import torch
     from next3d_amd import _lib
@@ -363,20 +362,27 @@ def test_ptr_keepalive_window_and_recording():
     assert r() is None
     with pytest.raises(RuntimeError):
         _lib.check(-1)
-    with _lib.Recording() as rec:
-        x = torch.ones(4)
-        rc = _lib.lib().n3d_fma(_lib.ptr(x), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 1, 4, 0, 1, 0, 1, None)     # deferred: nothing is launched
-        _lib.check(rc)
-        _lib.mark('high')
-        assert _lib.lib().n3d_abi_version() == _lib.ABI_VERSION      # host-only entry points pass through
-        with pytest.raises(RuntimeError):
-            with _lib.Recording():
-                pass
-    assert [e[0] for e in rec.entries] == ['n3d_fma', '__mark__'] and len(rec.keep) == 4
-    assert _lib.lib() is _lib._handle()                              # recording ended
-    rec.release()
-    assert rec.entries == [] and rec.keep == []
-    _lib.replay_paired(_lib.Recording(), _lib.Recording())          # empty recordings: a no-op
+
+
+def test_fir_factor_cache_is_tied_to_the_tensor_object():
+    """upfirdn2d.fir_factor: the separable factor is cached per filter TENSOR (weak reference + version counter), so a
+    new tensor at a recycled address or an in-place update never sees a stale factor, and the entry dies with the tensor."""
+    import gc
+    import torch
+    from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    f = uf.setup_filter([1, 3, 3, 1])
+    a = uf.fir_factor(f)
+    assert a is not None and torch.equal(torch.outer(a, a), f) and uf.fir_factor(f) is a
+    f.mul_(2.0)                                                       # in-place update: re-derived, still separable
+    b = uf.fir_factor(f)
+    assert b is not a and torch.allclose(torch.outer(b, b), f)
+    f[0, 0] = 5.0                                                     # no longer an outer product
+    assert uf.fir_factor(f) is None
+    key = id(f)
+    assert key in uf._FIR1D
+    del f
+    gc.collect()
+    assert key not in uf._FIR1D
 
 
 def test_third_party_shims_host_side():

@@ -41,7 +41,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert tuple(out['image'].shape) == (N, 3, 512, 512) and tuple(out['image_raw'].shape) == (N, 3, R, R)
     assert tuple(out['image_depth'].shape) == (N, 1, R, R)
     assert full['n3d_conv2d_prep_weight'] == 0 and full['n3d_conv2d_prep_weight_bf16x3'] == 0      # prepared once per model
-    assert full['n3d_rasterize_views'] == 1 and full['n3d_render_rays_ws'] == 1 and full['n3d_texture_project_planes'] == 1
+    assert full['n3d_rasterize_views'] == 1 and full['n3d_render_rays'] == 1 and full['n3d_texture_project_planes'] == 1
     assert full['n3d_resize_aa'] == (2 if R == 128 else 4)       # mouth crop + paste (+ feature / rgb resize unless R == 128)
     n_full = sum(full.values())
     # the launch count does not depend on the batch: one launch per layer, whatever N — plus the split8 conversion passes of
@@ -52,7 +52,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     dry.clear()
     G.synthesis(ws, c, v, use_cached_backbone=True, **kw)        # camera orbit: renderer + super-resolution only
     orbit = Counter(dry)
-    assert orbit['n3d_rasterize_views'] == 0 and orbit['n3d_render_rays_ws'] == 1 and sum(orbit.values()) < n_full // 4
+    assert orbit['n3d_rasterize_views'] == 0 and orbit['n3d_render_rays'] == 1 and sum(orbit.values()) < n_full // 4
     dry.clear()
     G.synthesis(ws, c, v, use_cached_identity=True, **kw)        # reenactment: no texture / static backbone
     reenact = Counter(dry)
@@ -75,36 +75,26 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     half = Counter(dry)                                                          # super-resolution blocks (sr_num_fp16_res = 4)
     assert sr16(half) == (1, 1, 4, 2, 2)
     assert sum(half.values()) - half['n3d_split8_from_nchw'] == 145 + (0 if R == 128 else 2) - 8 + 10
-    # the switches that used to make the default call raise: strict-fp32 arithmetic, no pre-split hand-off, random
-    # super-resolution noise -> the float16 blocks fall back (f16 kernels -> storage-rounding emulation -> float32), never an error
+    # the switches that once made the default call raise: strict-fp32 arithmetic, no pre-split hand-off -> the float16
+    # blocks run on their own kernels whatever the float32 layers use; random super-resolution noise -> float32 blocks, never an error
     import warnings
     from next3d_amd import layers
-    for env, attr, val in (('N3D_SR_FP16', None, 'emulate'), (None, 'PRECISION', 'fp32'), (None, 'PRESPLIT', False)):
-        old_env, old_attr = os.environ.get('N3D_SR_FP16'), getattr(layers, attr) if attr else None
+    for attr, val in (('PRECISION', 'fp32'), ('PRESPLIT', False)):
+        old_attr = getattr(layers, attr)
         try:
-            if env:
-                os.environ[env] = val
-            if attr:
-                setattr(layers, attr, val)
-                os.environ['N3D_SR_FP16'] = 'emulate'
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                dry.clear()
-                out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
-            assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry)) == (0, 0, 0, 0, 0)
+            setattr(layers, attr, val)
+            dry.clear()
+            out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
+            assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry)) == (1, 1, 4, 2, 2)
         finally:
-            if attr:
-                setattr(layers, attr, old_attr)
-            if old_env is None:
-                os.environ.pop('N3D_SR_FP16', None)
-            else:
-                os.environ['N3D_SR_FP16'] = old_env
+            setattr(layers, attr, old_attr)
     G.rendering_kwargs['superresolution_noise_mode'] = 'random'
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
+        dry.clear()
         out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
     G.rendering_kwargs['superresolution_noise_mode'] = 'none'
-    assert tuple(out['image'].shape) == (N, 3, 512, 512)
+    assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry)) == (0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
 

@@ -157,12 +157,13 @@ def test_fir4_h8(dev, N, C, H, W, noise):
     b_d, nz_d, ns_d, f_d = bias.to(dev), nz.to(dev), nstr.to(dev), fir.to(dev)
     assert layers.fir_factor(f_d) is not None and torch.equal(layers.fir_factor(f_d).cpu(), torch.tensor([1., 3., 3., 1.]) / 8)
     for sep in ('1', '0'):                    # the separable form and the generic 16-tap kernel
-        os.environ['N3D_FIR_SEP'] = sep
+        old = layers.uf.FIR_SEP
+        layers.uf.FIR_SEP = sep == '1'
         try:
             epi = _lib.make_epilogue(noise=nz_d if noise else None, noise_strength=ns_d if noise else None, bias=b_d, act='lrelu', gain=float(np.sqrt(2)), clamp=256.0)
             yh = layers.fir4_h8(_lib.H8.from_nchw(z.to(dev)), f_d, epi)
         finally:
-            del os.environ['N3D_FIR_SEP']
+            layers.uf.FIR_SEP = old
         _check_f16(f'fir4_h8 sep={sep} {N}x{C} {H}x{W}', yh.to_float(), ref, pre=[y32, _q(y32) + nz * nstr] if noise else y32, pre_gain=float(np.sqrt(2)))
 
 

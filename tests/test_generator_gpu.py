@@ -95,7 +95,7 @@ def test_fp16_superresolution_matches_reference_fp16_run(G, dev, case, monkeypat
     sr = G._prep().sr
     for mode in ('cpu', 'cuda'):
         monkeypatch.setattr(layers, 'F16_REF_CPU_ROUNDING', mode == 'cpu')
-        assert sr._fp16_mode(generator._resize_aa(feat, 128), 'none') == 'native'
+        assert sr._f16_ok(generator._resize_aa(feat, 128), 'none')
         out = sr(rgb, feat, ws, generator._resize_aa, noise_mode='none', fp16=True).cpu()[..., ::step, ::step]
         d = (out - ref).abs()
         print(case, mode, f'max {float(d.max()):.3e} mean {float(d.mean()):.3e} (image absmax {float(ref.abs().max()):.2f})')
@@ -332,10 +332,9 @@ def test_synthesis_graph_replay_is_bit_identical(G, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 4])
-def test_paired_backbones_equal_separate_launches(G, dev, batch):
-    """The texture and the static backbone issued in lock step — their <= 32x32 layers as shared grids (n3d_conv2d_bf16x3_pair), the
-    static backbone's large layers on the side stream (or in line) — against the two networks run one after the other (and against
-    the whole static backbone on its side stream): the same kernels on the same operands, so every stage is bit-identical."""
+def test_static_backbone_side_stream_equals_serial(G, dev, batch):
+    """The static tri-plane backbone on its side stream (the default) against the two backbones run one after the other on the launch
+    stream: the same kernels on the same operands, so every stage is bit-identical."""
     from next3d_amd import layers
     layers.set_precision('bf16x3')
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
@@ -348,35 +347,31 @@ def test_paired_backbones_equal_separate_launches(G, dev, batch):
     G.keep_stages = True
     res = {}
     try:
-        for mode, (pair, overlap) in {'paired': (True, True), 'paired_inline': (True, False), 'serial': (False, False), 'side_stream': (False, True)}.items():
-            G.pair_backbones, G.overlap_static = pair, overlap
+        for mode, overlap in {'serial': False, 'side_stream': True}.items():
+            G.overlap_static = overlap
             out = G.synthesis(ws, t('c'), t('v'), **kw)
             res[mode] = (G._debug['textures'].clone(), G._debug['static'].clone(), out['image'].clone())
     finally:
-        G.pair_backbones, G.overlap_static, G.keep_stages = False, True, False
-    for mode in ('paired_inline', 'serial', 'side_stream'):
-        for name, a, b in zip(('textures', 'static', 'image'), res['paired'], res[mode]):
-            assert torch.equal(a, b), (mode, name, _md(a, b))
+        G.overlap_static, G.keep_stages = True, False
+    for name, a, b in zip(('textures', 'static', 'image'), res['serial'], res['side_stream']):
+        assert torch.equal(a, b), (name, _md(a, b))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fp16', [False, True])
-def test_fused_layout_handovers_are_bit_identical_to_conversion_passes(G, dev, monkeypatch, fp16):
+def test_fused_layout_handovers_are_bit_identical_to_conversion_passes(G, dev, monkeypatch):
     """The two epilogue fusions that replace n3d_split8_from_nchw passes — toRGB writing its input as split8 for the next block's
     transposed convolution (layers.torgb_layer side_style) and the encoders' fromrgb writing split8 for conv1
     (layers.conv2d_layer sole_consumer) — against the same forward with both switched off: the same values reach the same
-    kernels, so every output is bit-identical (fp32 route, and the float16-emulating route whose block-0 feature map is
-    rounded to float16 before it is handed over)."""
+    kernels, so every output is bit-identical."""
     from next3d_amd import layers
     layers.set_precision('bf16x3')
-    monkeypatch.setenv('N3D_SR_FP16', 'emulate')
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
     R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
     jitter, u = cases.rng_inputs(4, R, Sc, Sf)
     t = lambda k: torch.from_numpy(d[k]).to(dev)
     ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
-    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=not fp16)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
     outs = {}
     for on in (True, False):
         monkeypatch.setattr(layers, 'TORGB_SIDE', on)

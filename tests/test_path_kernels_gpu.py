@@ -334,17 +334,6 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
                                            u if Sf else torch.zeros(1), w1, b1, w2t, b2)]
     _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
                                           Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
-    # the same call with a colour workspace (n3d_render_rays_ws: colours parked in global memory, eight waves per CU)
-    nbytes = _lib.lib().n3d_render_rays_workspace_bytes(N, R, Sc, Sf)
-    assert nbytes == N * R * R * (Sc + Sf) * 32 * 4
-    work = torch.full((nbytes // 4,), float('nan'), **t)
-    feat2, dep2, ws2 = torch.empty_like(feat), torch.empty_like(dep), torch.empty_like(ws_)
-    _lib.check(_lib.lib().n3d_render_rays_ws(*[_lib.ptr(x) for x in d], _lib.ptr(feat2), _lib.ptr(dep2), _lib.ptr(ws2), _lib.ptr(bounds), N, R, Sc,
-                                             Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.ptr(work), nbytes, _lib.stream()))
-    print(f'workspace variant vs LDS variant: feat {_md(feat2, feat):.2e} depth {_md(dep2, dep):.2e} wsum {_md(ws2, ws_):.2e}')
-    assert _md(feat2, feat) <= 2e-6 and _md(dep2, dep) <= 2e-6 and _md(ws2, ws_) <= 2e-6
-    assert _lib.lib().n3d_render_rays_ws(*[_lib.ptr(x) for x in d], _lib.ptr(feat2), _lib.ptr(dep2), None, _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
-                                         0.1, 2.0, _lib.ptr(work), nbytes - 4, _lib.stream()) != 0            # workspace too small
     e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
     e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
     e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
@@ -353,26 +342,6 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
     for e in (e_rgb, e_dep, e_w):
         assert float((e > 1e-3).float().mean()) <= 0.01
         assert float(e.median()) <= 1e-4
-
-
-def test_render_rays_one_ray_per_wave_variant(dev, monkeypatch):
-    """N3D_RENDER_RPW=1 (one ray per wave, two waves per SIMD, no texel prefetch) renders the same image as the default."""
-    from next3d_amd import _lib, demo as camera_utils
-    N, R, Sc, Sf, PH, PW = 2, 9, 48, 48, 32, 32
-    planes = _gen((N, 3, 32, PH, PW), 70, 2.0)
-    P, (w1, b1, w2t, b2) = _decoder(71)
-    c = torch.cat([camera_utils.demo_camera_params(angle_y=a, angle_p=-0.2)[0] for a in (0.3, -0.25)], 0).float()
-    jitter, u = cases.rng_inputs(N, R, Sc, Sf)
-    t = dict(dtype=torch.float32, device=dev)
-    d = [x.contiguous().to(dev) for x in (_channels_last(planes), c[:, :16], c[:, 16:25], torch.linspace(2.25, 3.3, Sc), jitter, u, w1, b1, w2t, b2)]
-    out = []
-    for rpw in ('2', '1'):
-        monkeypatch.setenv('N3D_RENDER_RPW', rpw)
-        feat, dep, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(2, **t)
-        _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), None, _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
-                                              float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
-        out.append((feat.cpu(), dep.cpu()))
-    assert _md(out[0][0], out[1][0]) <= 1e-5 and _md(out[0][1], out[1][1]) <= 1e-5
 
 
 def test_render_rays_empty_space(dev):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel timing of the float16 super-resolution route at the benchmark's shapes (batch 4): every kernel of
-networks.SuperRes8XDC._forward_f16, timed with events on the launch stream; variants through the N3D_F16_* switches."""
+networks.SuperRes8XDC._forward_f16, timed with events on the launch stream; the NBUF / ablation lines need the tuning build (tools/build_tuning.sh, N3D_LIB=)."""
 import os
 import sys
 
@@ -41,19 +41,16 @@ def main():
         print(f'modulate conv0 {timeit(lambda: L.modulate_weights_f16(conv0, s0)):8.1f} us   conv1 {timeit(lambda: L.modulate_weights_f16(conv1, s1)):8.1f} us'
               f'   torgb {timeit(lambda: L.modulate_weights_f16(torgb, s2, demodulate=False)):8.1f} us')
         gf = 2 * N * o * i * 9 * h * h / 1e9
-        for v in (0, 1, 2):
-            os.environ['N3D_F16_UP'] = str(v)
-            t = timeit(lambda: L.conv2d_f16(x, w0, o, 2))
-            print(f'transposed variant {v}: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
-        del os.environ['N3D_F16_UP']
+        t = timeit(lambda: L.conv2d_f16(x, w0, o, 2))
+        print(f'transposed: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
         z = L.conv2d_f16(x, w0, o, 2)
         epi = _lib.make_epilogue(bias=conv0.bias, act='lrelu', gain=2 ** 0.5, clamp=256.0)
         by = 2 * N * o * ((2 * h + 1) ** 2 + (2 * h) ** 2)
         for sep in ('0', '1'):
-            os.environ['N3D_FIR_SEP'] = sep
+            L.uf.FIR_SEP = sep == '1'
             t = timeit(lambda: L.fir4_h8(z, fir, epi))
             print(f'fir4_h8 separable={sep}: {t:8.1f} us  {by / t / 1e6:6.2f} TB/s')
-        del os.environ['N3D_FIR_SEP']
+        L.uf.FIR_SEP = True
         y = L.fir4_h8(z, fir, epi)
         gf = 2 * N * o * o * 9 * 4 * h * h / 1e9
         for nb in (1, 2):

@@ -37,18 +37,18 @@ def main():
         mb = 4 * n * c * ((h + 1) ** 2 + h * h) / 1e6
         row = []
         for sep in ('1', '0'):
-            os.environ['N3D_FIR_SEP'] = sep
+            uf.FIR_SEP = ('all' if sep == '1' else False)
             us = timed(lambda: uf._fir4_split8(z, f, 4, epi, style))
             row.append(f'sep={sep}: {us:7.1f} us {mb / us:5.2f} TB/s')
         print(f'  [{n},{c},{h + 1},{h + 1}] {mb:7.1f} MB   ' + '   '.join(row))
-    os.environ['N3D_FIR_SEP'] = '1'
+    uf.FIR_SEP = 'all'
     print('NCHW -> split8, padding 2 (stride-2 layers\' pre-filter)')
     for n, c, h in [(4, 128, 256), (4, 256, 128), (4, 512, 64), (4, 512, 32), (4, 256, 64)]:
         x = torch.randn(n, c, h, h, device=dev)
         mb = 4 * n * c * (h * h + (h + 1) ** 2) / 1e6
         row = []
         for sep in ('1', '0'):
-            os.environ['N3D_FIR_SEP_NCHW'] = sep
+            uf.FIR_SEP = ('all' if sep == '1' else False)
             us = timed(lambda: uf._fir4_split8_nchw(x, f, 2))
             row.append(f'sep={sep}: {us:7.1f} us {mb / us:5.2f} TB/s')
         print(f'  [{n},{c},{h},{h}] {mb:7.1f} MB   ' + '   '.join(row))

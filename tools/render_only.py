@@ -11,10 +11,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--planes', default='generator')
-    ap.add_argument('--workspace', action='store_true', help='N3D_RENDER_GCOL=1: colours in a global workspace, eight waves per CU')
     a = ap.parse_args()
-    if a.workspace:
-        os.environ['N3D_RENDER_GCOL'] = '1'
     from next3d_amd import demo
     dev = torch.device('cuda', 0)
     G, _ = demo.build_generator(dev)
