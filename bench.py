@@ -21,6 +21,10 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 on
   sr_fp16_mode   the same K steps with the reference's default float16 super-resolution blocks (no force_fp32): frames/s, speed-up over
                  the float32 route, `roofline_f16` (the f16 3x3 kernels against the 2.5 PFLOP/s dense f16 peak)
   config1        BASELINE.json configs[0]'s shape as a latency figure (batch 1), eager launches vs HIP-graph replay
+  config1b       the scripts' true call pattern (gen_samples / gen_videos call G.synthesis one frame at a time): batch 1 at the metric's
+                 512² / 64² / 48+48 — single-frame latency eager and from a HIP graph, and frames/s with requests pipelined over the lanes
+  b1_route       the OPERATOR-boundary route an un-reloaded pickle takes (oracle/b1_route.py: the reference's code pattern on
+                 next3d_amd.torch_utils.ops + shims; fused modulated convolutions as groups = batch calls): frames/s on the same workload
   config5        reenact_avatar_next3d.py's loop: one identity, a new FLAME mesh per frame (configs[4], synthetic sequence)
   cpu_baseline   the CPU oracle (a port of the reference's fp32 path) timed on the host cores.
 """
@@ -151,6 +155,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     args.gpus = world
+    if world > 1:
+        # one process per GPU: pin each rank to its own slice of the host's cores (launch threads of N ranks otherwise migrate over all
+        # sockets; the GPUs of a node hang off different NUMA domains, and a rank's ~600 launches per step are host-latency sensitive)
+        from next3d_amd.sharding import pin_rank_to_cores
+        pin_rank_to_cores(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -238,11 +247,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the inputs do not change between steps, so pipelined steps must return identical frames: a cheap guard against stream
-    # races in exactly the configuration that was timed (tests/test_generator_gpu.py has the per-stage version)
+    # the inputs do not change between steps, so pipelined steps must return identical frames — and the frames of a step issued ALONE
+    # on one stream with nothing else in flight: a cheap guard against stream races in exactly the configuration that was timed
+    # (tests/test_generator_gpu.py has the per-stage version)
     fa, fb, fc = step(), step(), step()
     sync()
-    reproducible = bool(torch.equal(fa, fb) and torch.equal(fb, fc))
+    one_lane[0] = True
+    f1 = step()
+    sync()
+    one_lane[0] = False
+    reproducible = bool(torch.equal(fa, fb) and torch.equal(fb, fc) and torch.equal(fc, f1))
 
     def conv_profile(steps):
         """`steps` steps with per-launch HIP events on the launch stream (outside the timed region; the static-backbone side
@@ -272,7 +286,7 @@ def main():
         single_stream = {'value': args.steps * B / t1, 'unit': 'frames/s', 'ms_per_step': 1e3 * t1 / args.steps,
                          'note': 'steps issued in order on one HIP stream'}
     roofline = None
-    if not args.no_roofline:
+    if not args.no_roofline and single:                           # (N > 1: the timed steps only — no extra passes on any rank)
         prof = conv_profile(args.steps)
         dom, peak = prof['conv2d_bf16x3'], PEAK_BF16_MFMA_TFLOPS / 3.0
         name = CONV_FAMILY
@@ -394,6 +408,68 @@ def main():
         G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
         extras['config1'] = {'workload': 'BASELINE.json configs[0] shape on the GPU: batch 1, 512² output, 32² neural render, 24 + 24 samples, frames issued back to back',
                              'eager_ms_per_frame': 1e3 * t_1e / 60, 'hip_graph_ms_per_frame': 1e3 * t_1g / 60, 'frames_timed': 60}
+        # ---- the scripts' TRUE call pattern: gen_samples_next3d.py:165-201 / gen_videos_next3d.py:131-158 call G.synthesis one frame at a
+        # time (batch 1) — at the metric's 512² / 64² / 48 + 48: latency of one frame (eager, HIP graph) and frames/s with independent
+        # requests pipelined over the lanes (a serving loop; each request = mapping + synthesis + uint8 conversion)
+        j1b = torch.rand((1, R * R, Sc, 1), device=dev, generator=g)
+        u1b = torch.rand((R * R, Sf), device=dev, generator=g)
+        kw1b = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=j1b, importance_u=u1b, force_fp32=True)
+        one_b = lambda fn: to_frames(fn(ws1, c1, v1, **kw1b)['image'])
+        one_b(G.synthesis); one_b(G.synthesis); torch.cuda.synchronize()
+        t_1be = timed(lambda: one_b(G.synthesis), 60)
+        t_1bg = graph_timed(lambda: one_b(G.synthesis_graph), 60)
+        req = [0]
+
+        def request():
+            lane = lanes[req[0] % len(lanes)]; req[0] += 1
+            with torch.cuda.stream(lane):
+                w_ = G.mapping(z1, c1_cond, truncation_psi=0.7, truncation_cutoff=14)
+                return to_frames(G.synthesis(w_, c1, v1, **kw1b)['image'])
+        for s_ in lanes:
+            s_.wait_stream(torch.cuda.current_stream())
+        request(); request(); request(); torch.cuda.synchronize()
+        t_1bp = timed(request, 120)
+        extras['config1b'] = {'workload': 'batch 1 (one G.synthesis call per frame, as gen_samples_next3d.py / gen_videos_next3d.py issue them), 512² output, '
+                                          '64² neural render, 48 + 48 samples, force_fp32=True',
+                              'eager_ms_per_frame': 1e3 * t_1be / 60, 'hip_graph_ms_per_frame': 1e3 * t_1bg / 60,
+                              'pipelined_frames_per_s': 120 / t_1bp, 'lanes': len(lanes), 'frames_timed': [60, 60, 120], 'unit': 'ms / frames/s'}
+        # ---- the OPERATOR-boundary route (B1): what the scripts' default `--reload_modules False` executes — the reference's own network
+        # code on next3d_amd.torch_utils.ops + shims.  /root/reference does not exist here: oracle/b1_route.py re-instantiates the
+        # oracle's restatement of that code on the operator layer (test infrastructure standing in for the pickled modules)
+        try:
+            from oracle import b1_route
+            from next3d_amd import mesh as _mesh, spec as _spec
+            dd = demo.demo_arrays()
+            Pb = _spec.synthetic_state_dict(0)
+            Pb.update(_mesh.mesh_buffers(dd['faces'], dd['uvs'], dd['uvfaces']))
+            route = b1_route.Route(dev)
+            Pb = route.to_device(Pb)
+            maskb = torch.nn.functional.interpolate(_mesh.synthetic_uv_face_mask().float(), [256, 256]).to(dev)
+            rkb = dict(demo.RENDERING_KWARGS)
+            zf = z.float()
+
+            def b1_step(fp32):
+                with torch.no_grad():
+                    w_ = route.mapping(Pb, zf, c_cond, rkb, truncation_psi=0.7, truncation_cutoff=14)
+                    return to_frames(route.synthesis(Pb, w_, c, v, maskb, rkb, jitter, u, neural_rendering_resolution=R, force_fp32=fp32)['image'])
+            res = {}
+            for name, fp32 in (('force_fp32', True), ('default_fp16_sr', False)):
+                fb1 = b1_step(fp32); b1_step(fp32); torch.cuda.synchronize()
+                kb = max(3, args.steps // 5)
+                tb = timed(lambda: b1_step(fp32), kb)
+                res[name] = {'value': kb * B / tb, 'unit': 'frames/s', 'ms_per_step': 1e3 * tb / kb, 'steps': kb}
+                if fp32:
+                    res[name]['max_abs_uint8_diff_vs_model_boundary'] = int((fb1.int() - fa.int()).abs().max())
+            b2_one = single_stream['value'] if single_stream else frames_total / elapsed_total
+            extras['b1_route'] = {'workload': 'the same batch (BASELINE.json configs[1]) through the operator boundary: reference code pattern (fused modulated '
+                                              'convolutions as groups = batch calls, torch weight modulation, separate bias_act / upfirdn2d / noise ops, the '
+                                              "reference's torch renderer, fill_mouth / gen_mouth_mask host round trips) on next3d_amd.torch_utils.ops + shims; one stream",
+                                  **res, 'fraction_of_model_boundary_single_stream': res['force_fp32']['value'] / b2_one,
+                                  'driver': 'oracle/b1_route.py (test infrastructure standing in for the un-reloaded pickle)'}
+            del route, Pb
+        except Exception as e:                                      # noqa: BLE001  (an optional figure must not cost the benchmark line)
+            print(f'bench.py: b1_route leg skipped ({type(e).__name__}: {e})', file=sys.stderr)
+            extras['b1_route'] = {'error': f'{type(e).__name__}: {e}'}
         # ---- configs[4]: reenactment — one identity (ws), a NEW mesh per frame (reenact_avatar_next3d.py:139-164); data/obama is
         # not in the tree: demo mesh + seeded smooth per-frame perturbation (sigma 1 mm), 4 consecutive frames per step
         zr, cr, cr_cond, vr = demo.demo_batch([0] * B, yaws=[0.0] * B, device=dev)

@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 4
+#define N3D_ABI_VERSION 5
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -196,8 +196,28 @@ typedef struct {
                              styles, networks_stylegan2.py:469-475) and is read from HBM once for both */
     const float* side_style;
     int64_t side_style_stride; /* floats between samples of side_style (0 = I) */
+    int64_t wt_batch_stride;   /* BYTES between consecutive samples' prepared weights (a multiple of 16), 0 = one weight tensor shared by
+                                  the batch.  Non-zero = PER-SAMPLE weights: what the FUSED branch of modulated_conv2d hands to F.conv2d /
+                                  F.conv_transpose2d with groups = batch (tat/networks_stylegan2.py:82-88, conv2d_resample.py:96-136) —
+                                  sample n of x is group n of the reference's [1, N*I, H, W] view, `wt` comes from
+                                  n3d_conv2d_prep_weight_grouped.  Taken by n3d_conv2d (modes 0 / 2) and by n3d_conv2d_bf16x3's stride-1
+                                  (NCHW or split8 input), transposed (NCHW) and 1x1 kernels; n3d_conv2d_f16's weights are per-sample by
+                                  construction (this field is ignored there) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+
+/* ---- per-sample ("grouped") weight preparation for the operator boundary: ONE launch re-tiles the weights of all G groups of a
+ *      grouped convolution into the layout a kernel family streams, group g at wt + g * (bytes per group):
+ *        w : float32 (w_dtype N3D_F32) or float16 (N3D_F16) elements, element (g, o, i, tap) at w[g*stride_g + o*stride_o + i*stride_i + tap]
+ *            — F.conv2d's [G*O, I, k, k] is (O*I*kk, I*kk, kk), F.conv_transpose2d's [G*I, O, k, k] is (I*O*kk, kk, O*kk);
+ *        wt_kind 0: float32 K-major [G][k*k][I][OP] (n3d_conv2d; bytes per group = k*k*I*OP*4, OP = O rounded up to 4)
+ *        wt_kind 1: split-bf16 tiles [G][k*k][I/16][2][2][OP64][8] (n3d_conv2d_bf16x3; k*k*I*OP64*4 bytes per group, I % 16 == 0)
+ *        wt_kind 2: float16 tiles [G][9][I/16][2][O][8] (n3d_conv2d_f16; ksize 3, I % 16 == 0; 9*I*O*2 bytes per group) — a pure
+ *                   re-tile for float16 input, one rounding for float32 input.
+ *      Replaces nothing in the reference: ATen's grouped convolution reads [G*O, I, k, k] directly; here the matrix-core kernels
+ *      stream K-major tiles, so the operator layer (torch_utils/ops/conv2d_gradfix.py) re-tiles once per call. */
+int n3d_conv2d_prep_weight_grouped(const void* w, int w_dtype, void* wt, int wt_kind, int G, int O, int I, int ksize, int64_t stride_g,
+                                   int64_t stride_o, int64_t stride_i, n3d_stream_t stream);
 
 /* ---- conv2d, split-bf16 ("bf16x3") variant of mode 0 / ksize 3: every fp32 operand is split into hi + lo bf16 halves and
  *      a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (5.3x the fp32
@@ -250,6 +270,9 @@ int n3d_fir4_h8(const void* x_h8, const float* f, const float* f1d, void* y_h8, 
 int n3d_torgb_h8(const void* x_h8, const void* w16, const float* bias, const float* img_lo, const float* up_filter, float* img, int N, int C,
                  int O, int H, int W, float clamp, n3d_stream_t stream);
 int n3d_cast_h8(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, n3d_stream_t stream);
+/* n3d_cast_h8_ex: the same with the NCHW side in float32 (nchw_dtype N3D_F32 = n3d_cast_h8) or float16 (N3D_F16: a pure layout change —
+ * the operator boundary hands the float16 tensors of a reference fp16 block to n3d_conv2d_f16 and back this way). */
+int n3d_cast_h8_ex(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, int nchw_dtype, n3d_stream_t stream);
 
 /* ---- fully connected: replaces addmm / matmul+bias_act of FullyConnectedLayer.forward
  *      (tat/networks_stylegan2.py:114-127).  y[n,o] = post(act(sum_i pre(x[n,i]) * w[o,i] * wgain + b[o]*bgain)).

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -35,7 +35,7 @@ class Conv2dDesc(ctypes.Structure):
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
                 ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int),
-                ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64)]
+                ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64), ('wt_batch_stride', c_int64)]
 
 
 class ModwJob(ctypes.Structure):
@@ -71,6 +71,7 @@ _SIGNATURES = {
     'n3d_split8_from_nchw': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
+    'n3d_conv2d_prep_weight_grouped': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     'n3d_conv2d_prep_weight_bf16x3': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d_bf16x3': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_bf16x3_blocks': (c_int, [c_int] * 5),
@@ -97,6 +98,7 @@ _SIGNATURES = {
     'n3d_modulate_weights_f16_multi': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'n3d_torgb_h8': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     'n3d_cast_h8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
+    'n3d_cast_h8_ex': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
     'n3d_fc_multi': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'n3d_fc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
                        c_float, c_int, c_int, c_void_p]),

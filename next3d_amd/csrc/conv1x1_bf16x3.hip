@@ -30,6 +30,7 @@ struct C1Params {
     bf16x8* side; const float* side_style; int64_t side_style_stride;    // n3d_conv2d_desc.side_split8 (NULL = none)
     int y_split8;                // y is the split8 layout (bf16 [N][2][O/8][HW][8]) of the following 3x3 layer instead of float32 NCHW
     int64_t xbs, ybs, style_stride, yrs;
+    int64_t wbs;                 // 16-byte units between consecutive samples' weight tiles (0 = shared by the batch)
     n3d_epilogue epi;
 };
 
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_bf16x3_kernel(C1Params p) {
         const int e = tid + j * NTHR;
         const int row = e % BM, hf = (e / BM) & 1, hl = (e / (2 * BM)) & 1, kc = e / (4 * BM);
         a_ok[j] = e < A_ITEMS && m0 + row < p.OP64;
-        a_src[j] = p.wt16 + (a_ok[j] ? ((int64_t)(kc * 2 + hl) * 2 + hf) * p.OP64 + m0 + row : 0);
+        a_src[j] = p.wt16 + (int64_t)n * p.wbs + (a_ok[j] ? ((int64_t)(kc * 2 + hl) * 2 + hf) * p.OP64 + m0 + row : 0);
     }
     const int64_t a_step = (int64_t)KC * 4 * p.OP64;                      // KC chunks x 4 slabs of OP64 slots per K step
     // buffer loads: one descriptor per sample (SGPRs), 32-bit per-lane byte offset, per-channel offset in an SGPR — the 16
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bf16x3_ksplit_kernel(C1Params 
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch)
                 raw[g][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_voff, (c * 16 + ch) * p.HW * 4, 0));
-            const bf16x8* a = p.wt16 + ((int64_t)c * 4 + half) * p.OP64 + m0 + l31;
+            const bf16x8* a = p.wt16 + (int64_t)n * p.wbs + ((int64_t)c * 4 + half) * p.OP64 + m0 + l31;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool ok = m0 + mt * 32 + l31 < p.OP64;
@@ -423,6 +424,8 @@ int conv1x1_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.HW = d->H * d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
+    N3D_CHECK((d->wt_batch_stride & 15) == 0, "conv2d_bf16x3: wt_batch_stride must be a multiple of 16 bytes");
+    p.wbs = d->wt_batch_stride / 16;
     p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.side = (bf16x8*)d->side_split8; p.side_style = d->side_style;

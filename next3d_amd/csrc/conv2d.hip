@@ -34,6 +34,7 @@ struct ConvParams {
     int tiles_x, tiles_y, nphase, ksplit, ic_per_split;
     int dbg;                         // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads
     int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
+    int64_t wbs;                              // floats between consecutive samples' prepared weights (0 = shared by the batch)
     n3d_epilogue epi;
 };
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvParams p) {
         b_goff[j] = ok ? ic * HW + iy * p.W + ix : 0;
         b_loff[j] = e < B_ELEMS ? (ic * PH + r) * PWP + q : -1;
     }
-    const float* a_base = p.wt + (int64_t)ic_begin * p.OP;
+    const float* a_base = p.wt + (int64_t)n * p.wbs + (int64_t)ic_begin * p.OP;
     const float* b_base = xn + (int64_t)ic_begin * HW;
 
     f32x4 ra[A_PER_T];
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up_mfma_kernel(ConvParams p) {
 
     // Register budget: 128 accumulators + the prefetched stage (47 VGPRs).  Staging addresses are therefore recomputed
     // from `tid` every stage (constant divisors -> a few VALU ops that run beside the MFMAs) instead of being kept.
-    const float* a_base = p.wt + (int64_t)ic_begin * p.OP;
+    const float* a_base = p.wt + (int64_t)n * p.wbs + (int64_t)ic_begin * p.OP;
     const float* b_base = xn + (int64_t)ic_begin * HW;
     f32x4 ra[A_PER_T];
     float rb[B_PER_T];
@@ -583,6 +584,8 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP = (d->O + 3) & ~3; p.H = d->H; p.W = d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
+    N3D_CHECK((d->wt_batch_stride & 15) == 0, "conv2d: wt_batch_stride must be a multiple of 16 bytes");
+    p.wbs = d->wt_batch_stride / 4;
     p.nphase = 1;
     p.dbg = n3d_tune("N3D_CONV_DBG", 0);
     if (d->mode == 0) { p.OH = d->H; p.OW = d->W; p.GH = p.OH; p.GW = p.OW; }

@@ -34,6 +34,7 @@ struct Conv16Params {
     int y_c8;     // transposed kernel only: write y channel-interleaved, [N][O/8][OH][yrs pixels][8] float32 (N3D_LAYOUT_C8_F32)
     int dbg;      // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip stage loads, 8 skip LDS fragment reads
     int64_t xbs, ybs, style_stride, yrs;      // yrs: output row pitch in floats
+    int64_t wbs;                              // 16-byte units between consecutive samples' weight tiles (0 = shared by the batch)
     n3d_epilogue epi;
 };
 
@@ -112,7 +113,7 @@ __device__ __forceinline__ void conv2d_bf16x3_body(const Conv16Params& p, const 
     // A staging: thread owns (row, half, hl) for all 9 taps
     const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
     const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
-    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
+    const bf16x8* a_src = p.wt16 + (int64_t)n * p.wbs + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
     bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row + a_t0 * 2 * BM;
     // B staging: work item e = tid + 256 j -> (half, patch pixel)
     int b_goff[B_PER_T];
@@ -364,7 +365,7 @@ __device__ __forceinline__ void conv2d_up_bf16x3_body(const Conv16Params& p, con
 
     const int a_row = tid & 63, a_q = (tid >> 6) & 3, a_half = a_q & 1, a_hl = a_q >> 1, a_t0 = tid >> 8;
     const int64_t a_tap_stride = (int64_t)KC * 4 * p.OP64, a_stage_stride = (int64_t)4 * p.OP64;
-    const bf16x8* a_src = p.wt16 + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
+    const bf16x8* a_src = p.wt16 + (int64_t)n * p.wbs + ((int64_t)(ic_begin / ICB) * 4 + a_hl * 2 + a_half) * p.OP64 + m0 + a_row + a_t0 * a_tap_stride;
     bf16x8* a_dst = (a_hl ? A_lo : A_hi) + a_half * BM + a_row + a_t0 * 2 * BM;
     int b_goff[B_PER_T];
     bool b_ok[B_PER_T];
@@ -738,6 +739,8 @@ static int conv16_setup(const n3d_conv2d_desc* d, Conv16Params& p, int& kind, in
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = up ? 2 * d->H + 1 : d->H; p.OW = up ? 2 * d->W + 1 : d->W;
     p.xbs = d->x_batch_stride; p.ybs = d->y_batch_stride; p.epi = d->epi;
+    N3D_CHECK((d->wt_batch_stride & 15) == 0, "conv2d_bf16x3: wt_batch_stride must be a multiple of 16 bytes");
+    p.wbs = d->wt_batch_stride / 16;
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
@@ -784,12 +787,14 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
     N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
     N3D_CHECK(!d->side_split8 || (d->ksize == 1 && d->x_layout == N3D_LAYOUT_NCHW_F32), "conv2d_bf16x3: side_split8 is written by the 1x1 kernel only");
+    N3D_CHECK(d->wt_batch_stride == 0 || d->x_layout != N3D_LAYOUT_SPLIT8 || d->mode == 0, "conv2d_bf16x3: per-sample weights with a split8 input: stride-1 kernel only");
     if (d->x_layout == N3D_LAYOUT_SPLIT8)
         return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : (d->mode == 1 ? conv2d_s2_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream));
     if (d->ksize == 1) return conv1x1_bf16x3_launch(d, stream);
     N3D_CHECK(!d->epi.round_f16 || d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: round_f16 is supported by the pre-split path (split8 / c8 layouts) and the 1x1 kernel only");
+    N3D_CHECK(d->mode != 1 || d->wt_batch_stride == 0, "conv2d_bf16x3: the stride-2 kernels take one weight tensor for the whole batch (wt_batch_stride 0)");
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
-    if (d->mode == 0) {                                                    // few-pixel layers: K split inside the workgroup, one launch
+    if (d->mode == 0 && d->wt_batch_stride == 0) {                         // few-pixel layers: K split inside the workgroup, one launch (samples share its weight fragments)
         const int r = conv2d_sk_bf16x3_try_launch(d, stream);
         if (r <= 0) return r;
     }
@@ -805,7 +810,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     if (up) hipLaunchKernelGGL(conv2d_up_bf16x3_kernel<8>, grid, dim3(512), 0, stream, p);
     else if (big) {
         int launched = 0;                  // several tiles per CU: the persistent kernel (K loop pipelined across tiles)
-        if (p.ksplit == 1 && p.dbg == 0 && conv2d_p_bf16x3_try_launch(d, p.tiles_x, p.tiles_y, stream, &launched) != 0) return -1;
+        if (p.ksplit == 1 && p.dbg == 0 && p.wbs == 0 && conv2d_p_bf16x3_try_launch(d, p.tiles_x, p.tiles_y, stream, &launched) != 0) return -1;
         if (!launched) hipLaunchKernelGGL((conv2d_bf16x3_kernel<8, false>), grid, dim3(512), 0, stream, p);
     }
     else if (d->W < 32) hipLaunchKernelGGL((conv2d_bf16x3_kernel<4, true>), grid, dim3(256), 0, stream, p);

@@ -31,6 +31,7 @@ struct ConvPsParams {
     int N, I, O, OP64, H, W;
     int tiles_x, tiles_y, tiles_m;
     int64_t xbs;                 // 16-byte units between consecutive samples of x (= 2 * I/8 * H * W for a dense tensor)
+    int64_t wbs;                 // 16-byte units between consecutive samples' weight tiles (0 = shared by the batch)
     int64_t ybs, yrs;            // floats
     int dbg;                     // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
                                  // 8 no per-chunk barrier / vmcnt wait (wrong results; timing only)
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
     // descriptors (range-checked: a lane offset beyond the buffer reads as zero -> the halo of the patch).  hi and lo planes of
     // one sample are contiguous, so ONE descriptor covers both and the plane is selected through the scalar offset.
     const int plane_bytes = (p.I / 8) * HW * 16;
-    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt16, 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wt16 + (int64_t)n * p.wbs), 0, PS_TAPS * KC * 4 * p.OP64 * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, 2 * plane_bytes, 0x00020000);
 
     // This wave's copy pieces, all constants hoisted out of the K loop (the chunk only adds a stride to the scalar offsets):
@@ -271,6 +272,8 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.tiles_x = cdiv(d->W, PS_TW); p.tiles_y = cdiv(d->H, PS_TH); p.tiles_m = cdiv(d->O, PS_BM);
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;      // x_batch_stride counts fp32-sized elements
+    N3D_CHECK((d->wt_batch_stride & 15) == 0, "conv2d_bf16x3: wt_batch_stride must be a multiple of 16 bytes");
+    p.wbs = d->wt_batch_stride / 16;
     p.ybs = d->y_batch_stride; p.yrs = d->y_row_stride ? d->y_row_stride : d->W;
     N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");

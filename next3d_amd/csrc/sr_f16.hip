@@ -165,42 +165,52 @@ extern "C" int n3d_modulate_weights_f16_multi(const n3d_modw_job* jobs, int njob
 // ------------------------------------------------------------------------------------------------------------------------------
 // float32 NCHW -> h8 (the block entry `x.to(torch.float16)`, training/networks_stylegan2.py:437) and back (tests, callers that want
 // the feature map).  One work item = one 16-byte unit.
-__global__ __launch_bounds__(256) void nchw_to_h8_kernel(const float* __restrict__ x, f16x8* __restrict__ y, int C8, int64_t HW, int64_t xbs) {
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_h8_kernel(const T* __restrict__ x, f16x8* __restrict__ y, int C8, int64_t HW, int64_t xbs) {
     const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8 = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
-    const float* xp = x + (int64_t)n * xbs + (int64_t)c8 * 8 * HW + pix;
+    const T* xp = x + (int64_t)n * xbs + (int64_t)c8 * 8 * HW + pix;
     f16x8 v;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = (_Float16)xp[k * HW];
     y[((int64_t)n * C8 + c8) * HW + pix] = v;
 }
-__global__ __launch_bounds__(256) void h8_to_nchw_kernel(const f16x8* __restrict__ x, float* __restrict__ y, int C8, int64_t HW) {
+template <typename T>
+__global__ __launch_bounds__(256) void h8_to_nchw_kernel(const f16x8* __restrict__ x, T* __restrict__ y, int C8, int64_t HW) {
     const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8 = blockIdx.y, n = blockIdx.z;
     if (pix >= HW) return;
     const f16x8 v = x[((int64_t)n * C8 + c8) * HW + pix];
-    float* yp = y + ((int64_t)n * C8 + c8) * 8 * HW + pix;
+    T* yp = y + ((int64_t)n * C8 + c8) * 8 * HW + pix;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) yp[k * HW] = (float)v[k];
+    for (int k = 0; k < 8; ++k) yp[k * HW] = (T)v[k];
 }
 
-extern "C" int n3d_cast_h8(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, n3d_stream_t stream_) {
+extern "C" int n3d_cast_h8_ex(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, int nchw_dtype, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(N >= 0 && C > 0 && C % 8 == 0 && HW > 0, "cast_h8: C %% 8 == 0");
+    N3D_CHECK(nchw_dtype == N3D_F32 || nchw_dtype == N3D_F16, "cast_h8: the NCHW side is float32 or float16");
     if (N == 0) return 0;
     N3D_CHECK(x && y && C / 8 <= 65535 && N <= 65535, "cast_h8: null tensor or grid too large");
-    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 6.0 * N * C * (double)HW);
+    const bool f16 = nchw_dtype == N3D_F16;
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, (f16 ? 4.0 : 6.0) * N * C * (double)HW);
     const dim3 grid((unsigned)cdiv64(HW, 256), C / 8, N);
     if (to_h8) {
         N3D_CHECK(((uintptr_t)y & 15) == 0, "cast_h8: misaligned h8 tensor");
-        hipLaunchKernelGGL(nchw_to_h8_kernel, grid, dim3(256), 0, stream, (const float*)x, (f16x8*)y, C / 8, HW, x_batch_stride ? x_batch_stride : (int64_t)C * HW);
+        const int64_t xbs = x_batch_stride ? x_batch_stride : (int64_t)C * HW;
+        if (f16) hipLaunchKernelGGL(nchw_to_h8_kernel<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)x, (f16x8*)y, C / 8, HW, xbs);
+        else hipLaunchKernelGGL(nchw_to_h8_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (f16x8*)y, C / 8, HW, xbs);
     } else {
         N3D_CHECK(((uintptr_t)x & 15) == 0 && x_batch_stride == 0, "cast_h8: misaligned / strided h8 tensor");
-        hipLaunchKernelGGL(h8_to_nchw_kernel, grid, dim3(256), 0, stream, (const f16x8*)x, (float*)y, C / 8, HW);
+        if (f16) hipLaunchKernelGGL(h8_to_nchw_kernel<_Float16>, grid, dim3(256), 0, stream, (const f16x8*)x, (_Float16*)y, C / 8, HW);
+        else hipLaunchKernelGGL(h8_to_nchw_kernel<float>, grid, dim3(256), 0, stream, (const f16x8*)x, (float*)y, C / 8, HW);
     }
     N3D_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int n3d_cast_h8(const void* x, void* y, int N, int C, int64_t HW, int64_t x_batch_stride, int to_h8, n3d_stream_t stream_) {
+    return n3d_cast_h8_ex(x, y, N, C, HW, x_batch_stride, to_h8, N3D_F32, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

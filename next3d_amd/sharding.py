@@ -67,3 +67,26 @@ def unshard_strided(gathered, world):
     b = gathered.shape[0] // world
     idx = torch.arange(world * b)
     return gathered[(idx % world) * b + idx // world]
+
+
+def pin_rank_to_cores(local_rank, local_world, cores=None):
+    """One process per GPU: restrict rank `local_rank` (of `local_world` on this node) to its own contiguous slice of the cores
+    this process may run on — block r of `local_world` equal blocks — and size torch's intra-op pool to it.  Contiguous core ids
+    are one NUMA domain's on the usual numbering, so a rank's launch thread, its pinned staging buffers and its GPU stay together;
+    an explicit `cores` list overrides the slice.  Returns the core list in effect (unchanged affinity on platforms without
+    sched_setaffinity or when the slice would be empty)."""
+    import os
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    avail = sorted(os.sched_getaffinity(0))
+    if cores is None:
+        per = len(avail) // max(1, local_world)
+        if per < 1:
+            return avail
+        cores = avail[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, set(cores))
+    except OSError:
+        return avail
+    torch.set_num_threads(max(1, min(len(cores), 16)))
+    return list(cores)

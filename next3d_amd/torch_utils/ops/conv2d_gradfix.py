@@ -1,12 +1,22 @@
-"""conv2d / conv_transpose2d front-ends with the reference's names (torch_utils/ops/conv2d_gradfix.py:37-45),
-executed by the fp32-MFMA implicit-GEMM kernel of libn3d.so (forward only; `enabled` / `no_weight_gradients`
-exist for import compatibility and have no effect at inference).
+"""conv2d / conv_transpose2d front-ends with the reference's names (torch_utils/ops/conv2d_gradfix.py:37-45), executed by libn3d.so
+(forward only; `enabled` / `no_weight_gradients` exist for import compatibility and have no effect at inference).
 
-dtypes: float32, or float16 for BOTH input and weight (what the reference's fp16 blocks pass, networks_stylegan2.py:84-88
-`w.to(x.dtype)`): fp16 tensors are converted on the device (n3d_cast), multiplied with float32 accumulation and the result is
-stored as float16 — fp16 x fp16 products are exact in fp32, so this is the arithmetic of an fp16 convolution with fp32
-accumulation (cuDNN's default for half).  Anything else raises RuntimeError (the analogue of ATen's dtype check) — a
-non-float32 pointer never reaches a float32 kernel."""
+This is what a pickled, UN-RELOADED reference network reaches (gen_samples_next3d.py:119,150-151: `--reload_modules False` is the
+default): Conv2dLayer and the non-fused modulated convolution call with groups = 1, the FUSED modulated convolution
+(training_avatar_texture/networks_stylegan2.py:82-88, the inference default) with groups = batch and per-sample weights
+[N*O, I, k, k].  Either way ONE launch runs the whole batch:
+  * float32: the split-bf16 kernels (`layers.PRECISION == 'bf16x3'`, the same switch as the model boundary) or the fp32-MFMA kernels;
+    the weights are re-tiled by one launch (n3d_conv2d_prep_weight_grouped: all groups, coalesced both ways) and reach the kernels
+    through n3d_conv2d_desc.wt_batch_stride; large 3x3 stride-1 layers convert their input once to the split8 layout and run on the
+    LDS-DMA kernel, as at the model boundary;
+  * float16 (both operands: what the reference's fp16 blocks pass, `w.to(x.dtype)`): the f16 matrix-core kernels (n3d_conv2d_f16) on
+    h8 tensors — float16 x float16 products are exact in float32, the accumulation is float32 and the result is rounded once: the
+    arithmetic of ATen's half convolution.  Shapes those kernels do not take (1x1, O % 64 != 0) are converted on the device
+    (n3d_cast), multiplied on the split-bf16 kernels (exact for float16 operands) and stored as float16.
+Prepared weights of groups == 1 calls are cached per weight TENSOR OBJECT (weak reference + version counter), so a persistent
+parameter is re-tiled once; temporaries (Conv2dLayer's `self.weight * self.weight_gain`) are re-tiled per call — a cache keyed on
+(data_ptr, _version) would hand layer B the tiles of layer A's freed temporary of the same shape.
+Anything else raises RuntimeError (the analogue of ATen's dtype check) — a non-float32 pointer never reaches a float32 kernel."""
 import contextlib
 
 import os
@@ -128,14 +138,16 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
 
 
 def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False,
-                out_c8=False, out_split8=False, side_style=None):
+                out_c8=False, out_split8=False, side_style=None, _wt_batch_stride=0, _wt_flat=False):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
     `out` may itself be such a view.  out_c8=True (un-split transposed split-bf16 layer, O % 64 == 0, demodulation-only epilogue):
     the result is a `_lib.C8` (channel-interleaved float32) for upfirdn2d._fir4_split8.  out_split8=True (1x1 split-bf16 layer,
     O % 32 == 0): the result is a `_lib.Split8` for a following pre-split 3x3 layer without modulation.  side_style [N,I] (1x1
-    split-bf16 layer, O <= 128): returns (y, `_lib.Split8` of x * side_style) — n3d_conv2d_desc.side_split8."""
+    split-bf16 layer, O <= 128): returns (y, `_lib.Split8` of x * side_style) — n3d_conv2d_desc.side_split8.
+    _wt_batch_stride (bytes; `wt` is then the flat per-sample tensor of prep_weight_grouped, _wt_flat=True): per-sample weights,
+    n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
         if not (bf16x3 and ksize == 3 and (mode in (0, 1) or (mode == 2 and out_c8)) and style is None):
@@ -161,10 +173,13 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     if out is not None and out.dtype != torch.float32:
         raise RuntimeError(f'conv2d: float32 output buffer expected, got {out.dtype}')
     if bf16x3:
-        assert wt.dtype == torch.bfloat16 and tuple(wt.shape) == (ksize * ksize, i // 16, 2, 2, (o + 63) // 64 * 64, 8)
+        assert wt.dtype == torch.bfloat16 and (_wt_flat or tuple(wt.shape) == (ksize * ksize, i // 16, 2, 2, (o + 63) // 64 * 64, 8))
         assert (ksize == 3 and mode in (0, 1, 2)) or (ksize == 1 and mode == 0)
-    else:
+    elif not _wt_flat:
         assert wt.shape[0] == ksize * ksize and wt.shape[1] == i and wt.shape[2] == (o + 3) // 4 * 4, (tuple(wt.shape), ksize, i, o)
+    if _wt_flat:
+        per = ksize * ksize * i * ((o + 63) // 64 * 64 if bf16x3 else (o + 3) // 4 * 4) * 4
+        assert wt.numel() * wt.element_size() == per * (n if _wt_batch_stride else 1) and _wt_batch_stride in (0, per), (wt.numel(), per, n, _wt_batch_stride)
     pitched_in = bf16x3 and mode == 1 and ksize == 3 and x.stride(3) == 1 and x.stride(2) > w and x.stride(1) == h * x.stride(2)
     if not split8 and not pitched_in and x.stride()[1:] != (h * w, w, 1):
         x = x.contiguous()
@@ -189,7 +204,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=wt.device)
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
-    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and _lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w):
+    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and _lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w):
         ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
@@ -204,6 +219,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.y_row_stride = y.stride(2)                         # c8: pitch in pixels (= OW, dense), batch stride O * OH * OW floats
     d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
+    d.wt_batch_stride = int(_wt_batch_stride)
     side = None
     if side_style is not None:
         if not (bf16x3 and ksize == 1 and not split8 and s8 is None and o <= 128 and i % 32 == 0 and out_dtype == torch.float32 and
@@ -221,21 +237,152 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)
 
 
-def _grouped(x, weight, groups, ksize, mode, transposed):
-    """groups == batch-folded samples (modulated_conv2d's fused path reshapes x to [1, N*I, H, W])."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# Operator boundary (B1): F.conv2d / F.conv_transpose2d with shared or per-group weights, one launch for the whole batch.
+
+_PREP_CACHE = {}           # id(weight tensor) -> {(kind, transposed, groups): (weakref, version, data_ptr, prepared)}
+CONVERT_MAX_BYTES = int(70e6)      # float32 inputs up to this size are converted to split8 for the LDS-DMA stride-1 kernel (layers._conv3x3's rule)
+
+
+def _precision():
+    from ... import layers
+    return layers.PRECISION
+
+
+def prep_weight_grouped(weight, groups, transposed, kind):
+    """weight [G*O, I, k, k] (F.conv2d) or [G*I, O, k, k] (F.conv_transpose2d), float32 or float16, -> the per-group prepared
+    weights of `kind` (0 float32 K-major, 1 split-bf16 tiles, 2 float16 tiles: include/n3d.h n3d_conv2d_prep_weight_grouped) as one
+    flat tensor + the byte stride between groups.  ONE launch; the transposition of F.conv_transpose2d's layout is done by the
+    kernel's strides, not by a torch copy."""
+    _lib.require_device(weight)
+    if weight.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'conv2d weight: float32 or float16 expected, got {weight.dtype}')
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    a, b, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise RuntimeError(f'conv2d: kernel {kh}x{kw} unsupported (1x1 or 3x3)')
+    kk = kh * kw
+    if transposed:
+        i, o = a // groups, b
+        sg, so, si = i * o * kk, kk, o * kk
+    else:
+        o, i = a // groups, b
+        sg, so, si = o * i * kk, i * kk, kk
+    if kind == 0:
+        per = kk * i * ((o + 3) // 4 * 4) * 4
+        out = torch.empty(groups * per // 4, dtype=torch.float32, device=w.device)
+    elif kind == 1:
+        per = kk * i * ((o + 63) // 64 * 64) * 4
+        out = torch.empty(groups * per // 2, dtype=torch.bfloat16, device=w.device)
+    else:
+        per = kk * i * o * 2
+        out = torch.empty(groups * per // 2, dtype=torch.float16, device=w.device)
+    _lib.check(_lib.lib().n3d_conv2d_prep_weight_grouped(_lib.ptr(w), 0 if w.dtype == torch.float32 else 1, _lib.ptr(out), kind, groups, o, i, kh,
+                                                         sg, so, si, _lib.stream()))
+    return out, per, o, i
+
+
+def _prepared(weight, groups, transposed, kind):
+    """prep_weight_grouped with the per-tensor-object cache for groups == 1 (module docstring)."""
+    if groups != 1:
+        return prep_weight_grouped(weight, groups, transposed, kind)
+    import weakref
+    key, sub = id(weight), (kind, transposed)
+    ent = _PREP_CACHE.get(key)
+    if ent is not None:
+        hit = ent.get(sub)
+        if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+            return hit[3]
+        if not any(h[0]() is weight for h in ent.values()):
+            ent.clear()                                  # the id was recycled by another tensor
+    res = prep_weight_grouped(weight, 1, transposed, kind)
+    if ent is None:
+        ent = _PREP_CACHE[key] = {}
+        weakref.finalize(weight, lambda k=key: _PREP_CACHE.pop(k, None) if all(h[0]() is None for h in _PREP_CACHE.get(k, {}).values()) else None)
+    ent[sub] = (weakref.ref(weight), weight._version, weight.data_ptr(), res)
+    return res
+
+
+def _launch_prepared(x, wt, wbs, kind, ksize, mode, o):
+    """x [N,I,H,W] float32 (or a `_lib.Split8`), prepared weights of `kind` (0 / 1) with byte stride `wbs` between samples (0 = shared)
+    -> y [N,O,OH,OW] float32: conv_launch with n3d_conv2d_desc.wt_batch_stride."""
+    return conv_launch(x, wt, ksize, mode, o, bf16x3=(kind == 1), _wt_batch_stride=wbs, _wt_flat=True)
+
+
+def _conv_f16_native(xv, weight, groups, transposed, mode, o, i):
+    """float16 x float16 3x3 convolution on the f16 matrix cores: xv [N,I,H,W] float16 -> [N,O,OH,OW] float16 (module docstring)."""
+    n, _, h, w = xv.shape
+    xv = xv if xv.is_contiguous() else xv.contiguous()
+    w16, per, _, _ = prep_weight_grouped(weight, groups, transposed, 2)      # (the f16 kernels take one weight tile set per sample: groups == N)
+    xh = _lib.H8(n, i, h, w, xv.device)
+    _lib.check(_lib.lib().n3d_cast_h8_ex(_lib.ptr(xv), _lib.ptr(xh.data), n, i, h * w, 0, 1, 1, _lib.stream()))
+    oh, ow = out_shape(h, w, mode)
+    yh = _lib.H8(n, o, oh, ow, xv.device)
+    d = _lib.Conv2dDesc()
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xh.data), _lib.ptr(w16), None, _lib.ptr(yh.data), None
+    d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
+    d.ksize, d.mode, d.ksplit = 3, mode, 1
+    d.x_layout = d.y_layout = 3
+    d.epi = _lib.make_epilogue()
+    _lib.check(_lib.lib().n3d_conv2d_f16(d, _lib.stream()))
+    y = torch.empty(n, o, oh, ow, dtype=torch.float16, device=xv.device)
+    _lib.check(_lib.lib().n3d_cast_h8_ex(_lib.ptr(yh.data), _lib.ptr(y), n, o, oh * ow, 0, 0, 1, _lib.stream()))
+    return y
+
+
+def _conv1x1_f16_native(xv, weight, o, i):
+    """float16 1x1 convolution with O <= 4 per-sample output channels (the toRGB layer of a reference fp16 block,
+    networks_stylegan2.py:353-357 -> conv2d(groups = N) on [N*O, I, 1, 1] weights): n3d_torgb_h8 without bias / skip image — the
+    reference's weight tensor already IS that kernel's [N][O][C] operand — instead of widening a [N, I, 512, 512] tensor to float32."""
+    n, _, h, w = xv.shape
+    xv = xv if xv.is_contiguous() else xv.contiguous()
+    wv = weight if weight.is_contiguous() else weight.contiguous()
+    xh = _lib.H8(n, i, h, w, xv.device)
+    _lib.check(_lib.lib().n3d_cast_h8_ex(_lib.ptr(xv), _lib.ptr(xh.data), n, i, h * w, 0, 1, 1, _lib.stream()))
+    y32 = torch.empty(n, o, h, w, dtype=torch.float32, device=xv.device)
+    _lib.check(_lib.lib().n3d_torgb_h8(_lib.ptr(xh.data), _lib.ptr(wv), None, None, None, _lib.ptr(y32), n, i, o, h, w, -1.0, _lib.stream()))
+    return _lib.cast(y32, torch.float16)             # (the kernel rounds the sum to float16 itself: the conversion is exact)
+
+
+def _f16_native_ok(i, o, h, w, ksize, mode):
+    return ksize == 3 and i % 16 == 0 and o % 64 == 0 and i * 9 <= 4608 and ((mode == 0 and h >= 16 and w >= 32) or (mode == 2 and h >= 4 and w >= 4))
+
+
+def _b1_conv(x, weight, groups, ksize, mode, transposed):
+    """The whole call in ONE launch: x [B, G*Ig, H, W], weight per F.conv2d / F.conv_transpose2d, -> [B, G*Og, OH, OW] in x's dtype."""
     if weight.dtype != x.dtype:
         raise RuntimeError(f'conv2d: input ({x.dtype}) and weight ({weight.dtype}) must have the same dtype')
-    n, ci, h, w = x.shape
-    ig = ci // groups
-    outs = []
-    for g in range(groups):
-        if transposed:      # weight [groups*I_g, O_g, k, k] -> per group [O_g, I_g, k, k]
-            wg = weight[g * ig:(g + 1) * ig].transpose(0, 1)
-        else:               # weight [groups*O_g, I_g, k, k]
-            og = weight.shape[0] // groups
-            wg = weight[g * og:(g + 1) * og]
-        outs.append(conv_launch(x[:, g * ig:(g + 1) * ig], prep_weight(wg), ksize, mode, wg.shape[0]))
-    return torch.cat(outs, dim=1)
+    if x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'conv2d input: float32 or float16 expected, got {x.dtype}')
+    b, c, h, w = x.shape
+    if groups > 1 and b != 1:           # not a call the reference makes (the fused branch folds the batch: B == 1): row by row
+        return torch.cat([_b1_conv(x[r:r + 1], weight, groups, ksize, mode, transposed) for r in range(b)], 0)
+    if c % groups != 0 or weight.shape[0] % groups != 0:
+        raise RuntimeError(f'conv2d: channels ({c}, weight {tuple(weight.shape)}) not divisible by groups ({groups})')
+    ig = c // groups
+    og = weight.shape[1] if transposed else weight.shape[0] // groups
+    if (weight.shape[0] // groups if transposed else weight.shape[1]) != ig:
+        raise RuntimeError(f'conv2d: weight {tuple(weight.shape)} does not match {c} input channels in {groups} groups')
+    if not x.is_contiguous():
+        x = x.contiguous()
+    xv = x.reshape(groups, ig, h, w) if groups > 1 else x             # group g of the folded tensor = sample g
+    n = xv.shape[0]
+    if x.dtype == torch.float16 and groups == n and _f16_native_ok(ig, og, h, w, ksize, mode):
+        y = _conv_f16_native(xv, weight, groups, transposed, mode, og, ig)
+    elif x.dtype == torch.float16 and groups == n and ksize == 1 and og <= 4 and ig % 8 == 0 and 8 <= ig <= 512:
+        y = _conv1x1_f16_native(xv, weight, og, ig)
+    else:
+        xf = _as_f32(xv, 'conv2d input')
+        # kernel family: split-bf16 (exact for float16 operands; float32 operands to 2^-16) unless PRECISION == 'fp32' or the shape is not its
+        kind = 1 if ((_precision() == 'bf16x3' or x.dtype == torch.float16) and bf16x3_eligible(ig, h, w, ksize, mode)) else 0
+        wt, per, _, _ = _prepared(weight, groups, transposed, kind)
+        wbs = per if groups > 1 else 0
+        if (kind == 1 and ksize == 3 and mode == 0 and 4 * xf.numel() <= CONVERT_MAX_BYTES and split8_eligible(n, ig, og, h, w)):
+            xf = split8_from_nchw(xf)                                   # one conversion pass buys the LDS-DMA kernel (layers._conv3x3)
+        y = _launch_prepared(xf, wt, wbs, kind, ksize, mode, og)
+        if x.dtype == torch.float16:
+            y = _lib.cast(y, torch.float16)
+    return y.reshape(1, groups * og, *y.shape[2:]) if groups > 1 else y
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
@@ -252,11 +399,9 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
         mode = 1
     else:
         raise RuntimeError(f'conv2d: stride={stride} padding={pad} kernel={k} is outside the generator-forward path')
-    if weight.dtype != input.dtype:
-        raise RuntimeError(f'conv2d: input ({input.dtype}) and weight ({weight.dtype}) must have the same dtype')
-    if groups == 1:
-        return conv_launch(input, prep_weight(weight), k, mode, weight.shape[0])
-    return _grouped(input, weight, groups, k, mode, transposed=False)
+    if mode == 1 and groups != 1:
+        raise RuntimeError('conv2d: a grouped stride-2 convolution is outside the generator-forward path')
+    return _b1_conv(input, weight, groups, k, mode, transposed=False)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
@@ -266,8 +411,4 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     pad = padding if isinstance(padding, int) else padding[0]
     if stride != 2 or pad != 0 or weight.shape[2] != 3 or output_padding != 0 or dilation != 1 or bias is not None:
         raise RuntimeError('conv_transpose2d: only 3x3 / stride 2 / padding 0 is on the generator-forward path')
-    if weight.dtype != input.dtype:
-        raise RuntimeError(f'conv_transpose2d: input ({input.dtype}) and weight ({weight.dtype}) must have the same dtype')
-    if groups == 1:
-        return conv_launch(input, prep_weight(weight.transpose(0, 1)), 3, 2, weight.shape[1])
-    return _grouped(input, weight, groups, 3, 2, transposed=True)
+    return _b1_conv(input, weight, groups, 3, 2, transposed=True)

@@ -129,7 +129,10 @@ with torch.no_grad():
     img = net(torch.randn(2, net.num_ws, 512), noise_mode='const')
     assert tuple(img.shape) == (2, 32, 64, 64), img.shape
     c1 = Counter(calls)
-    assert c1['n3d_conv2d'] + c1['n3d_conv2d_bf16x3'] >= 2 * (2 * 5 - 1 + 5) and c1['n3d_upfirdn2d'] + c1['n3d_upfirdn2d_pitched'] >= 4, c1
+    # ONE launch per layer for the whole batch (the fused modulated convolution's groups = batch call: per-sample weights through
+    # n3d_conv2d_desc.wt_batch_stride) + one re-tile launch per layer: 9 convolutions + 5 toRGB at 64 x 64
+    assert c1['n3d_conv2d'] + c1['n3d_conv2d_bf16x3'] == 2 * 5 - 1 + 5 == c1['n3d_conv2d_prep_weight_grouped'], c1
+    assert c1['n3d_upfirdn2d'] + c1['n3d_upfirdn2d_pitched'] >= 4, c1
     calls.clear()
     unet = nu.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=32, in_size=64, final_size=16, cond_channels=32, num_cond_res=64,
                                channel_base=32768, channel_max=512, num_fp16_res=0, fused_modconv_default='inference_only').eval().requires_grad_(False)
@@ -160,7 +163,33 @@ def test_operator_layer_dtype_handling_dry_run(dry):
     f = upfirdn2d.setup_filter([1, 3, 3, 1])
     y = conv2d_resample.conv2d_resample(x.half().contiguous(memory_format=torch.channels_last), w.half(), f=f, up=2, padding=1, flip_weight=False)
     assert y.dtype == torch.float16 and tuple(y.shape) == (2, 8, 24, 24)
-    assert dry == ['n3d_cast', 'n3d_conv2d_prep_weight', 'n3d_cast', 'n3d_conv2d', 'n3d_cast', 'n3d_cast', 'n3d_upfirdn2d_pitched', 'n3d_cast']
+    # float16 operands outside the f16 kernels' shapes (O % 64 != 0): widened on the device, multiplied on the split-bf16 kernels (exact
+    # for float16 operands; the float16 weights are re-tiled directly), stored as float16
+    assert dry == ['n3d_cast', 'n3d_conv2d_prep_weight_grouped', 'n3d_conv2d_bf16x3', 'n3d_cast', 'n3d_cast', 'n3d_upfirdn2d_pitched', 'n3d_cast']
+    dry.clear()
+    # the fused modulated convolution of a reference fp16 block: groups = batch, per-sample float16 weights -> the f16 matrix-core kernels
+    xg, wg = torch.randn(1, 3 * 32, 20, 40).half(), torch.randn(3 * 64, 32, 3, 3).half()
+    y = cg.conv2d(xg, wg, padding=1, groups=3)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (1, 3 * 64, 20, 40)
+    assert dry == ['n3d_conv2d_prep_weight_grouped', 'n3d_cast_h8_ex', 'n3d_conv2d_f16', 'n3d_cast_h8_ex']
+    dry.clear()
+    y = cg.conv_transpose2d(xg, torch.randn(3 * 32, 64, 3, 3).half(), stride=2, groups=3)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (1, 3 * 64, 41, 81)
+    assert dry == ['n3d_conv2d_prep_weight_grouped', 'n3d_cast_h8_ex', 'n3d_conv2d_f16', 'n3d_cast_h8_ex']
+    dry.clear()
+    y = cg.conv2d(xg, torch.randn(3 * 3, 32, 1, 1).half(), groups=3)               # toRGB of such a block: [N*3, I, 1, 1]
+    assert y.dtype == torch.float16 and tuple(y.shape) == (1, 9, 20, 40) and dry == ['n3d_cast_h8_ex', 'n3d_torgb_h8', 'n3d_cast']
+    dry.clear()
+    # float32, groups = batch: one launch, per-sample weights; a persistent weight tensor with groups == 1 is re-tiled once
+    y = cg.conv2d(xg.float(), wg.float(), padding=1, groups=3)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (1, 3 * 64, 20, 40) and dry == ['n3d_conv2d_prep_weight_grouped', 'n3d_conv2d_bf16x3']
+    dry.clear()
+    wp = torch.randn(8, 16, 3, 3)
+    cg.conv2d(x, wp, padding=1); cg.conv2d(x, wp, padding=1)
+    assert dry.count('n3d_conv2d_prep_weight_grouped') == 1 and dry.count('n3d_conv2d_bf16x3') == 2
+    wp.mul_(2.0)                                                                   # in-place update: re-tiled
+    cg.conv2d(x, wp, padding=1)
+    assert dry.count('n3d_conv2d_prep_weight_grouped') == 2
     dry.clear()
     y = conv2d_resample.conv2d_resample(x, w, f=f, down=2, padding=1)
     assert y.dtype == torch.float32 and tuple(y.shape) == (2, 8, 6, 6) and 'n3d_cast' not in dry
@@ -225,3 +254,49 @@ print('B1_DRY_RUN_OK', sum(cnt.values()))
 """ % (repo, os.path.join(repo, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'B1_DRY_RUN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_b1_route_driver_dry_run():
+    """oracle/b1_route.py (the reference's code pattern on the operator layer + shims: what tests/test_b1_route_gpu.py and bench.py's
+    `b1_route` extra run on the GPU box, where /root/reference does not exist) against the recording stand-in of libn3d.so: the whole
+    forward — fused modulated convolutions as groups = batch calls, the float16 super-resolution blocks on real half tensors, the
+    rasteriser / flood-fill shims — is accepted and marshalled; one launch per convolution layer whatever the batch."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from collections import Counter
+from next3d_amd import demo, mesh, spec
+import next3d_amd.shims.cv2 as cv2
+cv2._device = lambda: torch.device('cpu')
+import _dryrun
+pts, calls = _dryrun.patches()
+for obj, attr, val in pts:
+    setattr(obj, attr, val)
+_empty = torch.empty
+torch.empty = lambda *a, **k: _empty(*a, **k).zero_()          # un-launched kernels leave their outputs untouched: keep gather indices valid
+from oracle import b1_route, cases
+route = b1_route.Route('cpu')
+P = spec.synthetic_state_dict(0)
+d = demo.demo_arrays()
+P.update(mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces']))
+rk = dict(demo.RENDERING_KWARGS, depth_resolution=12, depth_resolution_importance=12)
+z, c, c_cond, v = demo.demo_batch([0, 1])
+jitter, u = cases.rng_inputs(2, 32, 12, 12)
+mask = torch.nn.functional.interpolate(mesh.synthetic_uv_face_mask().float(), [256, 256])
+with torch.no_grad():
+    ws = route.mapping(P, z, c_cond, rk, truncation_psi=0.7, truncation_cutoff=14)
+    assert tuple(ws.shape) == (2, 28, 512)
+    calls.clear()
+    out = route.synthesis(P, ws, c, v, mask, rk, jitter, u, neural_rendering_resolution=32, force_fp32=False)
+cnt = Counter(calls)
+assert tuple(out['image'].shape) == (2, 3, 512, 512) and out['image'].dtype == torch.float32 and tuple(out['image_raw'].shape) == (2, 3, 32, 32)
+assert cnt['n3d_rasterize_meshes'] == 4 and cnt['n3d_flood_fill'] == 4 * 2, cnt
+convs = cnt['n3d_conv2d'] + cnt['n3d_conv2d_bf16x3'] + cnt['n3d_conv2d_f16'] + cnt['n3d_torgb_h8']
+assert cnt['n3d_conv2d_f16'] == 4 and cnt['n3d_torgb_h8'] == 2 and cnt['n3d_cast_h8_ex'] == 2 * 4 + 2, cnt     # the two float16 blocks
+assert convs == cnt['n3d_bias_act'] == 101, (convs, cnt)     # one launch per convolution layer of the five networks (each followed by its bias_act), whatever the batch
+print('B1_ROUTE_DRY_RUN_OK', convs, sum(cnt.values()))
+""" % (repo, os.path.join(repo, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'B1_ROUTE_DRY_RUN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
