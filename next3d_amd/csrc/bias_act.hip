@@ -47,6 +47,46 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T* __restrict__ x, 
     }
 }
 
+// The common geometry — the bias runs along a dimension whose inner extent (step_b) is a multiple of 4, e.g. dim 1 of an NCHW tensor —
+// as a 2-D grid: blockIdx.y = row (one bias value per row), blockIdx.x walks the row's 16-byte vectors.  No 64-bit divisions per
+// element (the generic kernel above pays four per vector) and the activation is a template parameter: the operator boundary issues
+// one bias_act per convolution layer (103 per generator forward), most of them linear / leaky-ReLU on large feature maps.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bias_act_rows_kernel(const T* __restrict__ x, const T* __restrict__ b, T* __restrict__ y, int64_t row_vecs,
+                                                            int size_b, int act, float alpha, float gain, float clamp) {
+    using V = typename Vec4<T>::type;
+    const int64_t row = blockIdx.y;
+    const float bias = b ? ld(&b[row % size_b]) : 0.f;
+    const V* xr = reinterpret_cast<const V*>(x) + row * row_vecs;
+    V* yr = reinterpret_cast<V*>(y) + row * row_vecs;
+    const float cl = clamp >= 0.f ? clamp : INFINITY;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < row_vecs; v += (int64_t)gridDim.x * 256) {
+        V in = xr[v];
+        T* e = reinterpret_cast<T*>(&in);
+        V out;
+        T* oe = reinterpret_cast<T*>(&out);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f = ld(&e[k]) + bias;
+            if (ACT == N3D_ACT_LRELU) f = (f > 0.f ? f : f * alpha);
+            else if (ACT != N3D_ACT_LINEAR) f = n3d_act(f, act, alpha);
+            st(&oe[k], fminf(fmaxf(f * gain, -cl), cl));
+        }
+        yr[v] = out;
+    }
+}
+
+template <typename T>
+static void bias_act_rows_launch(const T* x, const T* b, T* y, int64_t rows, int64_t row_vecs, int size_b, int act, float alpha, float gain, float clamp,
+                                 hipStream_t stream) {
+    int gx = (int)(cdiv64(row_vecs, 256 * 4) < 1 ? 1 : cdiv64(row_vecs, 256 * 4));      // ~4 vectors per thread
+    if (gx > 1024) gx = 1024;
+    const dim3 grid(gx, (unsigned)rows);
+    if (act == N3D_ACT_LINEAR) hipLaunchKernelGGL((bias_act_rows_kernel<T, N3D_ACT_LINEAR>), grid, dim3(256), 0, stream, x, b, y, row_vecs, size_b, act, alpha, gain, clamp);
+    else if (act == N3D_ACT_LRELU) hipLaunchKernelGGL((bias_act_rows_kernel<T, N3D_ACT_LRELU>), grid, dim3(256), 0, stream, x, b, y, row_vecs, size_b, act, alpha, gain, clamp);
+    else hipLaunchKernelGGL((bias_act_rows_kernel<T, 0>), grid, dim3(256), 0, stream, x, b, y, row_vecs, size_b, act, alpha, gain, clamp);
+}
+
 extern "C" int n3d_bias_act(const void* x, const void* b, void* y, int64_t numel, int size_b, int64_t step_b, int dtype,
                             int act, float alpha, float gain, float clamp, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -63,6 +103,14 @@ extern "C" int n3d_bias_act(const void* x, const void* b, void* y, int64_t numel
     int64_t want = cdiv64(cdiv64(numel, 4), block);
     const int grid = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     N3dProfScope prof(N3D_K_BIAS_ACT, stream, (double)numel, 2.0 * esize * (double)numel);
+    if (!b && numel % 4 == 0) step_b = numel;                      // no bias: one "row"
+    if (step_b % 4 == 0 && step_b >= 64 && numel % step_b == 0 && numel / step_b <= 65535) {       // rows of step_b elements, one bias value each
+        const int64_t rows = numel / step_b;
+        if (dtype == N3D_F32) bias_act_rows_launch<float>((const float*)x, (const float*)b, (float*)y, rows, step_b / 4, size_b, act, alpha, gain, clamp, stream);
+        else bias_act_rows_launch<__half>((const __half*)x, (const __half*)b, (__half*)y, rows, step_b / 4, size_b, act, alpha, gain, clamp, stream);
+        N3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == N3D_F32)
         hipLaunchKernelGGL(bias_act_kernel<float>, dim3(grid), dim3(block), 0, stream, (const float*)x, (const float*)b,
                            (float*)y, numel, size_b, step_b, act, alpha, gain, clamp);

@@ -241,12 +241,17 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
 # Operator boundary (B1): F.conv2d / F.conv_transpose2d with shared or per-group weights, one launch for the whole batch.
 
 _PREP_CACHE = {}           # id(weight tensor) -> {(kind, transposed, groups): (weakref, version, data_ptr, prepared)}
-CONVERT_MAX_BYTES = int(70e6)      # float32 inputs up to this size are converted to split8 for the LDS-DMA stride-1 kernel (layers._conv3x3's rule)
+
+
+_layers = None
 
 
 def _precision():
-    from ... import layers
-    return layers.PRECISION
+    global _layers
+    if _layers is None:
+        from ... import layers
+        _layers = layers
+    return _layers.PRECISION
 
 
 def prep_weight_grouped(weight, groups, transposed, kind):
@@ -303,10 +308,45 @@ def _prepared(weight, groups, transposed, kind):
     return res
 
 
-def _launch_prepared(x, wt, wbs, kind, ksize, mode, o):
-    """x [N,I,H,W] float32 (or a `_lib.Split8`), prepared weights of `kind` (0 / 1) with byte stride `wbs` between samples (0 = shared)
-    -> y [N,O,OH,OW] float32: conv_launch with n3d_conv2d_desc.wt_batch_stride."""
-    return conv_launch(x, wt, ksize, mode, o, bf16x3=(kind == 1), _wt_batch_stride=wbs, _wt_flat=True)
+_EPI0 = None
+
+
+def _launch_prepared(x, wt, wbs, kind, ksize, mode, n, i, o, h, w, row_pitch=False):
+    """x [N,I,H,W] float32 (dense) or a `_lib.Split8`, prepared weights of `kind` (0 float32 K-major / 1 split-bf16 tiles) with byte
+    stride `wbs` between samples (0 = shared) -> y [N,O,OH,OW] float32 (row_pitch: rows padded to 16 bytes, the [..., :OW] view).
+    The operator boundary's launcher: no epilogue, no style — a lean twin of conv_launch (one descriptor, one ctypes call; this
+    runs ~100 times per generator forward of an un-reloaded pickle, where the host, not the GPU, sets the pace of the small layers)."""
+    global _EPI0
+    if _EPI0 is None:
+        _EPI0 = _lib.make_epilogue()
+    split8 = isinstance(x, _lib.Split8)
+    oh, ow = out_shape(h, w, mode)
+    dev = wt.device
+    if row_pitch:
+        y = torch.empty([n, o, oh, (ow + 3) // 4 * 4], dtype=torch.float32, device=dev)[..., :ow]
+    else:
+        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=dev)
+    bf16x3 = kind == 1
+    ksplit = 1
+    if not split8:
+        if bf16x3:
+            ksplit = 1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)
+        else:
+            gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
+            ksplit = pick_ksplit(n, i, o, gh, gw, ksize, mode)
+    ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=dev) if ksplit > 1 else None
+    d = _lib.Conv2dDesc()
+    d.x, d.wt, d.y, d.workspace = _lib.ptr(x.data if split8 else x), _lib.ptr(wt), _lib.ptr(y), _lib.ptr(ws)
+    d.x_layout = 1 if split8 else 0
+    d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
+    d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
+    d.x_batch_stride, d.y_batch_stride = i * h * w, y.stride(0)
+    d.y_row_stride, d.x_row_stride = y.stride(2), w
+    d.epi = _EPI0
+    d.wt_batch_stride = wbs
+    L = _lib.lib()
+    _lib.check((L.n3d_conv2d_bf16x3 if bf16x3 else L.n3d_conv2d)(d, _lib.stream()))
+    return y
 
 
 def _conv_f16_native(xv, weight, groups, transposed, mode, o, i):
@@ -348,15 +388,16 @@ def _f16_native_ok(i, o, h, w, ksize, mode):
     return ksize == 3 and i % 16 == 0 and o % 64 == 0 and i * 9 <= 4608 and ((mode == 0 and h >= 16 and w >= 32) or (mode == 2 and h >= 4 and w >= 4))
 
 
-def _b1_conv(x, weight, groups, ksize, mode, transposed):
-    """The whole call in ONE launch: x [B, G*Ig, H, W], weight per F.conv2d / F.conv_transpose2d, -> [B, G*Og, OH, OW] in x's dtype."""
+def _b1_conv(x, weight, groups, ksize, mode, transposed, row_pitch=False):
+    """The whole call in ONE launch: x [B, G*Ig, H, W], weight per F.conv2d / F.conv_transpose2d, -> [B, G*Og, OH, OW] in x's dtype
+    (row_pitch: a float32 result may be the [..., :OW] view of rows padded to 16 bytes — for the FIR conv2d_resample runs next)."""
     if weight.dtype != x.dtype:
         raise RuntimeError(f'conv2d: input ({x.dtype}) and weight ({weight.dtype}) must have the same dtype')
     if x.dtype not in (torch.float32, torch.float16):
         raise RuntimeError(f'conv2d input: float32 or float16 expected, got {x.dtype}')
     b, c, h, w = x.shape
     if groups > 1 and b != 1:           # not a call the reference makes (the fused branch folds the batch: B == 1): row by row
-        return torch.cat([_b1_conv(x[r:r + 1], weight, groups, ksize, mode, transposed) for r in range(b)], 0)
+        return torch.cat([_b1_conv(x[r:r + 1], weight, groups, ksize, mode, transposed, row_pitch) for r in range(b)], 0)
     if c % groups != 0 or weight.shape[0] % groups != 0:
         raise RuntimeError(f'conv2d: channels ({c}, weight {tuple(weight.shape)}) not divisible by groups ({groups})')
     ig = c // groups
@@ -377,9 +418,13 @@ def _b1_conv(x, weight, groups, ksize, mode, transposed):
         kind = 1 if ((_precision() == 'bf16x3' or x.dtype == torch.float16) and bf16x3_eligible(ig, h, w, ksize, mode)) else 0
         wt, per, _, _ = _prepared(weight, groups, transposed, kind)
         wbs = per if groups > 1 else 0
-        if (kind == 1 and ksize == 3 and mode == 0 and 4 * xf.numel() <= CONVERT_MAX_BYTES and split8_eligible(n, ig, og, h, w)):
-            xf = split8_from_nchw(xf)                                   # one conversion pass buys the LDS-DMA kernel (layers._conv3x3)
-        y = _launch_prepared(xf, wt, wbs, kind, ksize, mode, og)
+        if kind == 1 and ksize == 3 and mode == 0 and split8_eligible(n, ig, og, h, w):
+            # one conversion pass buys the LDS-DMA kernel (30 % faster on the >= 64 x 64 layers; at the MODEL boundary the producer's
+            # epilogue writes this layout, here the operator's input is whatever torch tensor the reference code holds)
+            xf = split8_from_nchw(xf)
+        elif not xf.is_contiguous():
+            xf = xf.contiguous()
+        y = _launch_prepared(xf, wt, wbs, kind, ksize, mode, n, ig, og, h, w, row_pitch and x.dtype == torch.float32)
         if x.dtype == torch.float16:
             y = _lib.cast(y, torch.float16)
     return y.reshape(1, groups * og, *y.shape[2:]) if groups > 1 else y
@@ -402,6 +447,16 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if mode == 1 and groups != 1:
         raise RuntimeError('conv2d: a grouped stride-2 convolution is outside the generator-forward path')
     return _b1_conv(input, weight, groups, k, mode, transposed=False)
+
+
+def conv_transpose2d_conv_layout(input, weight, groups=1, row_pitch=False):
+    """F.conv_transpose2d(input, W_t, stride=2, groups=groups) where W_t is the transposition conv2d_resample.py:117-125 builds from
+    the CONVOLUTION-layout weight [G*Og, Ig, 3, 3] passed here — the transposition itself is skipped (module docstring of
+    conv2d_resample.conv2d_resample's 'tconv' step)."""
+    _lib.require_device(input, weight)
+    if weight.shape[2] != 3 or weight.shape[3] != 3:
+        raise RuntimeError('conv_transpose2d: only 3x3 / stride 2 / padding 0 is on the generator-forward path')
+    return _b1_conv(input, weight, groups, 3, 2, transposed=False, row_pitch=row_pitch)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):

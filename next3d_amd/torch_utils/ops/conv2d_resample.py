@@ -95,6 +95,13 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         elif kind == 'conv':
             x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight, **kw_)
         else:   # 'tconv': conv_transpose2d scatters with the kernel as stored = a true convolution, hence the inverted flag
-            x = _conv2d_wrapper(x=x, w=_transposed_weight(w, groups), groups=groups, transpose=True,
-                                flip_weight=(not flip_weight), **kw_)
+            if (kh, kw) == (3, 3) and kw_['stride'] == 2 and tuple(kw_['padding']) == (0, 0) and not flip_weight:
+                # The generator's up-sampling layers.  F.conv_transpose2d wants [G*Ig, Og, k, k]; the kernels stream tiles indexed
+                # (group, out, in, tap), which the one-launch re-tile reads from ANY strides — so the convolution-layout weight goes in
+                # as it is (no transposition copy of the per-sample weights: 37.7 MB each way for a 512 -> 512 layer at batch 4), and the
+                # (2W+1)-wide result is handed to the interpolation FIR with rows padded to 16 bytes (aligned vector loads there).
+                x = conv2d_gradfix.conv_transpose2d_conv_layout(x, w, groups=groups, row_pitch=True)
+            else:
+                x = _conv2d_wrapper(x=x, w=_transposed_weight(w, groups), groups=groups, transpose=True,
+                                    flip_weight=(not flip_weight), **kw_)
     return x
