@@ -437,3 +437,35 @@ print('SHIMS_OK')
         assert torch.equal(v, pv) and torch.equal(f.verts_idx, pf) and torch.equal(f.textures_idx, pft) and torch.equal(aux.verts_uvs, puv)
     finally:
         os.remove(obj)
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/gen_samples_next3d.py'), reason='needs the reference tree (build container only)')
+@pytest.mark.parametrize('script', ['gen_samples_next3d.py', 'gen_videos_next3d.py', 'reenact_avatar_next3d.py'])
+def test_launcher_runs_reference_scripts_unchanged(script):
+    """`python -m next3d_amd.run <script> --help`: the reference's script, unedited, is executed as __main__ after install_dropin —
+    its imports of torch_utils.ops.*, training_avatar_texture.triplane_next3d, pytorch3d and cv2 resolve to next3d_amd, the
+    rest (dnnlib, legacy, camera_utils, click options) to the reference tree next to the script.  (`--help` ends the run before a
+    pickle or a GPU is needed.  Packages this container lacks and the scripts import at the top — mrcfile, imageio, torchvision,
+    pydantic.NoneStr, turtle — are stubbed by oracle/ref_shims.py as for the pin script; on a deployment they are installed.)"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import ref_shims
+ref_shims.install(np.zeros((4, 4), np.float32), third_party=False)          # import-time stubs only; cv2 / pytorch3d are left to install_dropin
+sys.path.remove('/root/reference')                                          # the launcher must find the tree from the script path itself
+from next3d_amd import run
+try:
+    run.main(['--third-party', 'shims', '/root/reference/%s', '--help'])
+except SystemExit as e:
+    assert e.code in (0, None), e.code
+import torch_utils.ops.bias_act as ba, training_avatar_texture.triplane_next3d as tp, cv2, pytorch3d
+assert ba.__name__ == 'next3d_amd.torch_utils.ops.bias_act' and tp.__name__ == 'next3d_amd.generator', (ba.__name__, tp.__name__)
+assert cv2.__name__ == 'next3d_amd.shims.cv2' and pytorch3d.__name__ == 'next3d_amd.shims.pytorch3d'
+import legacy, dnnlib
+assert legacy.__file__.startswith('/root/reference/') and dnnlib.__file__.startswith('/root/reference/')
+print('LAUNCHER_OK')
+""" % (repo, script)
+    r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'LAUNCHER_OK' in r.stdout and '--network' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
