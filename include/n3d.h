@@ -339,6 +339,32 @@ int n3d_render_rays(const float* planes_cl, const float* cam2world, const float*
                     const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
                     int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream);
+/* n3d_render_rays_ex: the renderer with the rendering options that lie outside the ffhq configuration (`opts` NULL = n3d_render_rays):
+ *   white_back                 composite_rgb + 1 - weight_total (vr/ray_marcher.py:56-57);
+ *   density_noise (+ draws)    sigma += randn * density_noise on every decoded sample (vr/renderer.py:152-153); the normal draws are INPUTS
+ *                              like jitter / u: density_noise_coarse [N,R*R,Sc], density_noise_fine [N,R*R,Sf];
+ *   disparity_space_sampling   coarse depths 1 / (1/ray_start * (1 - d) + 1/ray_end * d), d = linspace(0, 1, Sc) + jitter / (Sc - 1)
+ *                              (vr/renderer.py:186-193): pass tlin = linspace(0, 1, Sc) and depth_delta = 1 / (Sc - 1);
+ *   auto_bounds                ray_start = ray_end = 'auto' (vr/renderer.py:99-106): per-ray box entry / exit (math_utils.get_ray_limits_box
+ *                              with box_side = rendering_kwargs['box_warp']), rays that miss the box repaired as the reference does, coarse
+ *                              depths start + (end - start) * i / (Sc - 1) + jitter * (end - start) / (Sc - 1); tlin / depth_delta are
+ *                              ignored; ray_bounds_ws = [N*R*R*2] floats of scratch (it holds every ray's (start, end) afterwards). */
+typedef struct {
+    int white_back;
+    int disparity_space_sampling;
+    float ray_start, ray_end;          /* disparity_space_sampling */
+    int auto_bounds;
+    float box_side;
+    float* ray_bounds_ws;
+    float density_noise;
+    const float* density_noise_coarse;
+    const float* density_noise_fine;
+} n3d_render_opts;
+int n3d_render_rays_ex(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
+                       const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
+                       const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
+                       int Sf, int PH, int PW, float depth_delta, float coord_scale, const n3d_render_opts* opts, n3d_stream_t stream);
+
 /* ---- point queries (shape extraction): replaces ImportanceRenderer.run_model (vr/renderer.py:149-155: sample_from_planes +
  *      OSGDecoder) as called by TriPlaneGenerator.sample / sample_mixed (tat/triplane_next3d.py:232-322).
  *      coords [N,M,3] world coordinates -> rgb [N,M,32], sigma [N,M,1]; coord_scale = 2 / box_warp; decoder weights as in

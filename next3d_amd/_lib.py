@@ -38,6 +38,12 @@ class Conv2dDesc(ctypes.Structure):
                 ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64), ('wt_batch_stride', c_int64)]
 
 
+class RenderOpts(ctypes.Structure):
+    _fields_ = [('white_back', c_int), ('disparity_space_sampling', c_int), ('ray_start', c_float), ('ray_end', c_float), ('auto_bounds', c_int),
+                ('box_side', c_float), ('ray_bounds_ws', c_void_p), ('density_noise', c_float), ('density_noise_coarse', c_void_p),
+                ('density_noise_fine', c_void_p)]
+
+
 class ModwJob(ctypes.Structure):
     _fields_ = [('w', c_void_p), ('w16', c_void_p), ('styles_offset', c_int64), ('O', c_int), ('I', c_int), ('ksize', c_int), ('demodulate', c_int)]
 
@@ -78,6 +84,7 @@ _SIGNATURES = {
     'n3d_blend_planes': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     'n3d_planes_to_channels_last': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_render_rays': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p]),
+    'n3d_render_rays_ex': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, ctypes.POINTER(RenderOpts), c_void_p]),
     'n3d_sample_points': (c_int, [c_void_p] * 8 + [c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     'n3d_rasterize_views': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 4 +
                             [c_int, c_int, c_void_p]),

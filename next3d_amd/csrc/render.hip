@@ -43,7 +43,51 @@ struct RenderParams {
     float* wsum;              // [N,R*R] or NULL
     int N, R, Sc, Sf, PH, PW;
     float depth_delta, coord_scale;
+    // rendering options outside the ffhq configuration (n3d_render_opts)
+    int depth_mode;           // 0: tlin[i] + jitter * depth_delta (fixed ray_start / ray_end, renderer.py:197-201);
+                              // 1: disparity-space sampling (:186-193: tlin = linspace(0, 1), depth = 1 / (1/start * (1 - d) + 1/end * d));
+                              // 2: per-ray (start, end) from ray_bounds (ray_start = ray_end = 'auto', :99-106 + :194-196)
+    float inv_start, inv_end; // depth_mode 1
+    const float* ray_bounds;  // depth_mode 2: [N*R*R][2]
+    int white_back;           // ray_marcher.py:56-57
+    const float* noise_c;     // density noise draws [N,R*R,Sc] / [N,R*R,Sf] (renderer.py:152-153: sigma += randn_like * density_noise) or NULL
+    const float* noise_f;
+    float noise_scale;
 };
+
+// total order on floats as unsigned keys (negative depths are possible with 'auto' bounds when the camera sits inside the box)
+__device__ __forceinline__ unsigned int f2key(float f) { const unsigned int b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+// coarse (stratified) depth of sample i of one ray, operation for operation as sample_stratified (renderer.py:184-207)
+__device__ __forceinline__ float coarse_depth(const RenderParams& p, int64_t gray /* n * R*R + ray */, int i, float jit) {
+    if (p.depth_mode == 0) return __fadd_rn(p.tlin[i], __fmul_rn(jit, p.depth_delta));
+    if (p.depth_mode == 1) {
+        const float d = __fadd_rn(p.tlin[i], __fmul_rn(jit, p.depth_delta));
+        return __fdiv_rn(1.f, __fadd_rn(__fmul_rn(p.inv_start, __fsub_rn(1.f, d)), __fmul_rn(p.inv_end, d)));
+    }
+    const float s = p.ray_bounds[2 * gray], e = p.ray_bounds[2 * gray + 1];
+    const float step = __fdiv_rn((float)i, (float)(p.Sc - 1));                    // math_utils.linspace: arange(num) / (num - 1)
+    const float span = __fsub_rn(e, s);
+    return __fadd_rn(__fadd_rn(s, __fmul_rn(step, span)), __fmul_rn(jit, __fdiv_rn(span, (float)(p.Sc - 1))));
+}
+
+// ray of pixel (ri, rj) of an R x R image (ray_sampler.py:33-61): direction (unit), origin = cam2world translation
+__device__ __forceinline__ void ray_direction(const float* c2w, const float* K, int R, int ray, float& dx, float& dy, float& dz) {
+    const float fx = K[0], fy = K[4], cxk = K[2], cyk = K[5], sk = K[1];
+    const int ri = ray / R, rj = ray % R;
+    const float inv = (float)(1.0 / (double)R), half = (float)(0.5 / (double)R);
+    const float x_cam = __fadd_rn(__fmul_rn((float)rj, inv), half);
+    const float y_cam = __fadd_rn(__fmul_rn((float)ri, inv), half);
+    const float x_lift = (x_cam - cxk + cyk * sk / fy - sk * y_cam / fy) / fx;
+    const float y_lift = (y_cam - cyk) / fy;
+    const float ox = c2w[3], oy = c2w[7], oz = c2w[11];
+    dx = c2w[0] * x_lift + c2w[1] * y_lift + c2w[2] + c2w[3] - ox;
+    dy = c2w[4] * x_lift + c2w[5] * y_lift + c2w[6] + c2w[7] - oy;
+    dz = c2w[8] * x_lift + c2w[9] * y_lift + c2w[10] + c2w[11] - oz;
+    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    dx /= nrm; dy /= nrm; dz /= nrm;
+}
 
 // softplus / sigmoid on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): the libm
 // log1pf(expf(x)) pair is ~100 VALU instructions and was 40 % of this VALU-bound kernel's instruction stream.  For very
@@ -440,24 +484,10 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     // ---- the two rays (ray_sampler.py:33-61); ray index m = i*R + j, x from j, y from i.  Every lane holds both.
     const float* c2w = p.cam2world + n * 16;
     const float* K = p.intrinsics + n * 9;
-    const float fx = K[0], fy = K[4], cxk = K[2], cyk = K[5], sk = K[1];
     const float ox = c2w[3], oy = c2w[7], oz = c2w[11];
     float rdx[2], rdy[2], rdz[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ray = min(ray0 + q, RR - 1);
-        const int ri = ray / R, rj = ray % R;
-        const float inv = (float)(1.0 / (double)R), half = (float)(0.5 / (double)R);
-        const float x_cam = __fadd_rn(__fmul_rn((float)rj, inv), half);
-        const float y_cam = __fadd_rn(__fmul_rn((float)ri, inv), half);
-        const float x_lift = (x_cam - cxk + cyk * sk / fy - sk * y_cam / fy) / fx;
-        const float y_lift = (y_cam - cyk) / fy;
-        float dx = c2w[0] * x_lift + c2w[1] * y_lift + c2w[2] + c2w[3] - ox;
-        float dy = c2w[4] * x_lift + c2w[5] * y_lift + c2w[6] + c2w[7] - oy;
-        float dz = c2w[8] * x_lift + c2w[9] * y_lift + c2w[10] + c2w[11] - oz;
-        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
-        rdx[q] = dx / nrm; rdy[q] = dy / nrm; rdz[q] = dz / nrm;
-    }
+    for (int q = 0; q < 2; ++q) ray_direction(c2w, K, R, min(ray0 + q, RR - 1), rdx[q], rdy[q], rdz[q]);
 
     // decode `cnt` samples per ray, slots slot0 .. slot0 + cnt - 1, whose depths are in the rays' dep[] arrays.  Passes of 32 samples
     // over the concatenated sample lists of the wave's rays; pass k + 1's gathers are issued before pass k's decoder runs.
@@ -474,7 +504,13 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     auto store_pass = [&](int slot, int q, const float (&rgb)[16], float sigma) {
         if (slot >= 0) {
             const RayLds& L = q ? Ls[1] : Ls[0];
-            if (hb == 0) L.sig[slot] = sigma;
+            if (hb == 0) {
+                if (p.noise_c) {                                          // density noise (renderer.py:152-153): one draw per decoded sample
+                    const int64_t gr = (int64_t)n * RR + ray0 + q;
+                    sigma += (slot < Sc ? p.noise_c[gr * Sc + slot] : p.noise_f[gr * Sf + (slot - Sc)]) * p.noise_scale;
+                }
+                L.sig[slot] = sigma;
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 *reinterpret_cast<f32x4*>(L.col + slot * cp + 8 * a + 4 * hb) = f32x4{rgb[4 * a], rgb[4 * a + 1], rgb[4 * a + 2], rgb[4 * a + 3]};
@@ -510,7 +546,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         const float* jit0 = p.jitter + ((int64_t)n * RR + ray0) * Sc;
         for (int g = lane; g < nrays * Sc; g += 64) {
             const int q = g >= Sc ? 1 : 0, i = g - q * Sc;
-            (q ? Ls[1] : Ls[0]).dep[i] = __fadd_rn(p.tlin[i], __fmul_rn(jit0[g], p.depth_delta));
+            (q ? Ls[1] : Ls[0]).dep[i] = coarse_depth(p, (int64_t)n * RR + ray0 + q, i, jit0[g]);
         }
     }
     wave_sync();
@@ -604,11 +640,12 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     for (int off = 16; off > 0; off >>= 1) { dacc += __shfl_xor(dacc, off, 64); wt += __shfl_xor(wt, off, 64); }
     RN_STAMP(8);
     if (store) {
+        if (p.white_back) acc = acc + 1.f - wt;               // ray_marcher.py:56-57
         p.feat[((int64_t)n * RN_C + l31) * RR + ray] = acc * 2.f - 1.f;
         if (l31 == 0) {
             float d = dacc / wt;
             if (isnan(d)) d = INFINITY;                       // nan_to_num(nan=inf)
-            d = fminf(fmaxf(d, p.bounds[0]), p.bounds[1]);
+            d = fminf(fmaxf(d, key2f(__float_as_uint(p.bounds[0]))), key2f(__float_as_uint(p.bounds[1])));
             p.depth[(int64_t)n * RR + ray] = d;
             if (p.wsum) p.wsum[(int64_t)n * RR + ray] = wt;
         }
@@ -621,29 +658,76 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
-// block reduces a slice and merges with integer atomics on the float bit patterns (the depths are positive, so the bit
-// patterns order like the values); bounds_ws is initialised by a one-thread launch in front.
-__global__ void render_depth_bounds_init_kernel(float* __restrict__ bounds) {
-    bounds[0] = INFINITY; bounds[1] = 0.f;
+// block reduces a slice and merges with integer atomics on order-preserving keys (f2key); bounds_ws is initialised by a
+// one-thread launch in front and read back through key2f by the renderer.  The depths of a ray increase with the sample index in
+// every depth mode, so its first / last coarse samples are its extremes.
+__global__ void render_depth_bounds_init_kernel(unsigned int* __restrict__ bounds) {
+    bounds[0] = 0xffffffffu; bounds[1] = 0u;
 }
-__global__ __launch_bounds__(256) void render_depth_bounds_kernel(const float* __restrict__ tlin, const float* __restrict__ jitter,
-                                                                  int64_t rays, int Sc, float delta, float* __restrict__ bounds) {
-    __shared__ float smin[4], smax[4];
-    float lo = INFINITY, hi = 0.f;
-    const float t0 = tlin[0], t1 = tlin[Sc - 1];
+__global__ __launch_bounds__(256) void render_depth_bounds_kernel(RenderParams p, int64_t rays, unsigned int* __restrict__ bounds) {
+    __shared__ unsigned int smin[4], smax[4];
+    unsigned int lo = 0xffffffffu, hi = 0u;
+    const int Sc = p.Sc;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (int64_t)gridDim.x * blockDim.x) {
-        lo = fminf(lo, __fadd_rn(t0, __fmul_rn(jitter[r * Sc], delta)));
-        hi = fmaxf(hi, __fadd_rn(t1, __fmul_rn(jitter[r * Sc + Sc - 1], delta)));
+        lo = min(lo, f2key(coarse_depth(p, r, 0, p.jitter[r * Sc])));
+        hi = max(hi, f2key(coarse_depth(p, r, Sc - 1, p.jitter[r * Sc + Sc - 1])));
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned int)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned int)__shfl_xor((int)hi, off, 64)); }
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, smin[w]); hi = fmaxf(hi, smax[w]); }
-        atomicMin(reinterpret_cast<unsigned int*>(bounds), __float_as_uint(lo));
-        atomicMax(reinterpret_cast<unsigned int*>(bounds) + 1, __float_as_uint(hi));
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = min(lo, smin[w]); hi = max(hi, smax[w]); }
+        atomicMin(bounds, lo);
+        atomicMax(bounds + 1, hi);
     }
+}
+
+// ray_start = ray_end = 'auto' (renderer.py:99-106): every ray's entry / exit distance of the box [-side/2, side/2]^3
+// (math_utils.get_ray_limits_box, the slab test with its operation order), then the reference's repair of the rays that miss the box:
+// their start becomes the smallest, their END the largest START among the rays that hit it (sic, :103-104).
+__global__ __launch_bounds__(256) void ray_limits_box_kernel(RenderParams p, float* __restrict__ rb, float half_side, unsigned int* __restrict__ keys) {
+    const int RR = p.R * p.R;
+    const int64_t rays = (int64_t)p.N * RR;
+    __shared__ unsigned int smin[4], smax[4];
+    unsigned int lo = 0xffffffffu, hi = 0u;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(r / RR), ray = (int)(r % RR);
+        const float* c2w = p.cam2world + n * 16;
+        float d[3];
+        ray_direction(c2w, p.intrinsics + n * 9, p.R, ray, d[0], d[1], d[2]);
+        const float o[3] = {c2w[3], c2w[7], c2w[11]};
+        float t0[3], t1[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float inv = __fdiv_rn(1.f, d[a]);
+            const bool neg = inv < 0.f;
+            t0[a] = __fmul_rn(__fsub_rn(neg ? half_side : -half_side, o[a]), inv);
+            t1[a] = __fmul_rn(__fsub_rn(neg ? -half_side : half_side, o[a]), inv);
+        }
+        bool valid = !(t0[0] > t1[1] || t0[1] > t1[0]);
+        float tmin = fmaxf(t0[0], t0[1]), tmax = fminf(t1[0], t1[1]);
+        if (tmin > t1[2] || t0[2] > tmax) valid = false;
+        tmin = fmaxf(tmin, t0[2]); tmax = fminf(tmax, t1[2]);
+        if (!valid) { tmin = -1.f; tmax = -2.f; }
+        rb[2 * r] = tmin; rb[2 * r + 1] = tmax;
+        if (tmax > tmin) { lo = min(lo, f2key(tmin)); hi = max(hi, f2key(tmin)); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned int)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned int)__shfl_xor((int)hi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = min(lo, smin[w]); hi = max(hi, smax[w]); }
+        atomicMin(keys, lo);
+        atomicMax(keys + 1, hi);
+    }
+}
+__global__ __launch_bounds__(256) void ray_limits_fixup_kernel(float* __restrict__ rb, int64_t rays, const unsigned int* __restrict__ keys) {
+    if (keys[0] == 0xffffffffu) return;                                   // no ray hits the box: left as they are (torch.any(...) false)
+    const float lo = key2f(keys[0]), hi = key2f(keys[1]);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (int64_t)gridDim.x * blockDim.x)
+        if (!(rb[2 * r + 1] > rb[2 * r])) { rb[2 * r] = lo; rb[2 * r + 1] = hi; }
 }
 
 // planes_cl[n][p][y][x][c] = dyn_p[n][c][y][x] * a + static[n][p*32+c][y][x] * (1 - a),  a = alpha[n][p][y][x]
@@ -716,10 +800,10 @@ extern "C" int n3d_planes_to_channels_last(const float* planes, float* planes_cl
     return 0;
 }
 
-extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
-                               const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
-                               const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
-                               int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream_) {
+extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
+                                  const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
+                                  int Sf, int PH, int PW, float depth_delta, float coord_scale, const n3d_render_opts* opts, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(N >= 0 && R > 0 && R * R <= 1 << 24, "render_rays: bad resolution");
     N3D_CHECK(Sc >= 4 && Sf >= 0 && Sc + Sf <= RN_MAX_S, "render_rays: need 4 <= Sc and Sc + Sf <= %d", RN_MAX_S);
@@ -732,6 +816,30 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
     p.planes = planes_cl; p.cam2world = cam2world; p.intrinsics = intrinsics; p.tlin = tlin; p.jitter = jitter; p.u = u;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.bounds = bounds_ws; p.feat = feat; p.depth = depth; p.wsum = wsum;
     p.N = N; p.R = R; p.Sc = Sc; p.Sf = Sf; p.PH = PH; p.PW = PW; p.depth_delta = depth_delta; p.coord_scale = coord_scale;
+    p.depth_mode = 0; p.inv_start = p.inv_end = 0.f; p.ray_bounds = nullptr; p.white_back = 0; p.noise_c = p.noise_f = nullptr; p.noise_scale = 0.f;
+    const int64_t nrays = (int64_t)N * R * R;
+    const unsigned bgrid = (unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256));
+    unsigned int* keys = reinterpret_cast<unsigned int*>(bounds_ws);
+    if (opts) {
+        p.white_back = opts->white_back != 0;
+        if (opts->density_noise > 0.f) {
+            N3D_CHECK(opts->density_noise_coarse && (opts->density_noise_fine || Sf == 0), "render_rays: density_noise > 0 needs the normal draws (density_noise_coarse / _fine)");
+            p.noise_c = opts->density_noise_coarse; p.noise_f = opts->density_noise_fine; p.noise_scale = opts->density_noise;
+        }
+        N3D_CHECK(!(opts->auto_bounds && opts->disparity_space_sampling), "render_rays: 'auto' ray bounds with disparity-space sampling is not a combination the reference can run");
+        if (opts->disparity_space_sampling) {                             // tlin = linspace(0, 1, Sc), depth_delta = 1 / (Sc - 1) (the caller's, as for mode 0)
+            N3D_CHECK(opts->ray_start > 0.f && opts->ray_end > 0.f, "render_rays: disparity-space sampling needs positive ray_start / ray_end");
+            p.depth_mode = 1;
+            p.inv_start = (float)(1.0 / (double)opts->ray_start); p.inv_end = (float)(1.0 / (double)opts->ray_end);
+        } else if (opts->auto_bounds) {
+            N3D_CHECK(opts->ray_bounds_ws && opts->box_side > 0.f, "render_rays: 'auto' ray bounds need the [N*R*R*2] scratch and the box side length");
+            p.depth_mode = 2; p.ray_bounds = opts->ray_bounds_ws;
+            hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, keys);
+            hipLaunchKernelGGL(ray_limits_box_kernel, dim3(bgrid), dim3(256), 0, stream, p, opts->ray_bounds_ws, opts->box_side * 0.5f, keys);
+            hipLaunchKernelGGL(ray_limits_fixup_kernel, dim3(bgrid), dim3(256), 0, stream, opts->ray_bounds_ws, nrays, (const unsigned int*)keys);
+            N3D_LAUNCH_CHECK();
+        }
+    }
     const int M = Sc + Sf;
     // waves per workgroup: as many as the LDS holds beside the shared decoder image (at most one per SIMD)
     const size_t per_wave = (size_t)RPW * ray_lds_floats(M) * sizeof(float), image = (size_t)RN_WROWS * 64 * sizeof(float);
@@ -745,15 +853,21 @@ extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, c
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
     if (lds > 48 * 1024)
         N3D_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "render_rays: %zu bytes of LDS refused", lds);
-    hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, bounds_ws);
+    hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, keys);
     N3D_LAUNCH_CHECK();
-    const int64_t nrays = (int64_t)N * R * R;
-    hipLaunchKernelGGL(render_depth_bounds_kernel, dim3((unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256))), dim3(256), 0, stream,
-                       tlin, jitter, nrays, Sc, depth_delta, bounds_ws);
+    hipLaunchKernelGGL(render_depth_bounds_kernel, dim3(bgrid), dim3(256), 0, stream, p, nrays, keys);
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int n3d_render_rays(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
+                               const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* feat, float* depth, float* wsum, float* bounds_ws, int N, int R, int Sc,
+                               int Sf, int PH, int PW, float depth_delta, float coord_scale, n3d_stream_t stream_) {
+    return n3d_render_rays_ex(planes_cl, cam2world, intrinsics, tlin, jitter, u, w1, b1, w2, b2, feat, depth, wsum, bounds_ws, N, R, Sc, Sf, PH, PW,
+                              depth_delta, coord_scale, nullptr, stream_);
 }
 
 // ---- point queries: tri-plane features + decoder at arbitrary 3-D points (shape extraction).  One lane per point, the

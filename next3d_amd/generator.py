@@ -360,20 +360,51 @@ class TriPlaneGenerator(torch.nn.Module):
                            stitch_in=stitch_in, stitch=stitch, static=static) if getattr(self, 'keep_stages', False) else None
         return planes, eg3d_ws
 
-    def render(self, planes_cl, c, neural_rendering_resolution, depth_jitter=None, importance_u=None):
-        """RaySampler + ImportanceRenderer on channels-last planes -> (feature_image [N,32,R,R], depth_image [N,1,R,R])."""
+    def render(self, planes_cl, c, neural_rendering_resolution, depth_jitter=None, importance_u=None, density_noise_draws=None):
+        """RaySampler + ImportanceRenderer on channels-last planes -> (feature_image [N,32,R,R], depth_image [N,1,R,R]).
+        rendering_kwargs as the reference reads them (vr/renderer.py:95-147, vr/ray_marcher.py:27-66): fixed `ray_start` / `ray_end` or
+        both 'auto' (per-ray box limits), `disparity_space_sampling`, `white_back`, `density_noise` (the normal draws come from the
+        device RNG like the reference's torch.randn_like, or from `density_noise_draws = (coarse [N,R²,Sc], fine [N,R²,Sf])`);
+        `clamp_mode` must be 'softplus' (the reference asserts the same, ray_marcher.py:37-40)."""
         S = self._prep()
         rk = self.rendering_kwargs
         dev, N, R = planes_cl.device, planes_cl.shape[0], int(neural_rendering_resolution)
         Sc, Sf = int(rk['depth_resolution']), int(rk['depth_resolution_importance'])
         t0, t1 = rk['ray_start'], rk['ray_end']
-        if t0 == 'auto' or t1 == 'auto' or rk.get('disparity_space_sampling', False):
-            raise RuntimeError("ray_start/ray_end='auto' and disparity sampling are not part of the ffhq configuration")
-        if rk.get('white_back', False) or rk.get('density_noise', 0) > 0 or rk.get('clamp_mode', 'softplus') != 'softplus':
-            raise RuntimeError('white_back / density_noise / non-softplus clamp_mode are not part of the ffhq configuration')
-        key = (Sc, float(t0), float(t1))
+        if rk.get('clamp_mode', 'softplus') != 'softplus':
+            raise RuntimeError("MipRayMarcher only supports `clamp_mode`=`softplus`!")                 # ray_marcher.py:40
+        auto = t0 == 'auto' and t1 == 'auto'                                   # renderer.py:98: both, or the fixed branch
+        if not auto and (isinstance(t0, str) or isinstance(t1, str)):
+            raise RuntimeError("ray_start / ray_end: two numbers, or both 'auto'")
+        disparity = bool(rk.get('disparity_space_sampling', False))
+        if auto and disparity:
+            raise RuntimeError("ray_start = ray_end = 'auto' with disparity_space_sampling: the reference's broadcast of per-ray bounds against "
+                               '[N, M, S, 1] depths (renderer.py:193) does not run either')
+        noise_amp = float(rk.get('density_noise', 0) or 0)
+        opts = None
+        if auto or disparity or rk.get('white_back', False) or noise_amp > 0:
+            opts = _lib.RenderOpts()
+            opts.white_back = 1 if rk.get('white_back', False) else 0
+            opts.disparity_space_sampling = 1 if disparity else 0
+            opts.auto_bounds = 1 if auto else 0
+            opts.box_side = float(rk['box_warp'])
+            keep = []
+            if auto:
+                keep.append(torch.empty(N * R * R * 2, dtype=torch.float32, device=dev))
+                opts.ray_bounds_ws = _lib.ptr(keep[-1])
+            else:
+                opts.ray_start, opts.ray_end = float(t0), float(t1)
+            if noise_amp > 0:
+                nc, nf = density_noise_draws if density_noise_draws is not None else (torch.randn(N, R * R, Sc, device=dev), torch.randn(N, R * R, max(Sf, 1), device=dev))
+                keep += [nc.to(dev).contiguous(), nf.to(dev).contiguous()]
+                opts.density_noise, opts.density_noise_coarse, opts.density_noise_fine = noise_amp, _lib.ptr(keep[-2]), _lib.ptr(keep[-1])
+            opts._keep = keep
+        # coarse sample positions: linspace(ray_start, ray_end) (fixed) or linspace(0, 1) (disparity); unused with 'auto'
+        lo, hi = (0.0, 1.0) if (disparity or auto) else (float(t0), float(t1))
+        key = (Sc, lo, hi)
         if key not in S.tlin:
-            S.tlin[key] = torch.linspace(t0, t1, Sc).to(dev)
+            S.tlin[key] = torch.linspace(lo, hi, Sc).to(dev)
+        t0, t1 = lo, hi
         c = c.to(device=dev, dtype=torch.float32)
         cam2world = c[:, :16].contiguous()
         intrinsics = c[:, 16:25].contiguous()
@@ -383,11 +414,11 @@ class TriPlaneGenerator(torch.nn.Module):
         feat = torch.empty(N, 32, R, R, **f32)
         depth = torch.empty(N, 1, R, R, **f32)
         bounds = torch.empty(2, **f32)              # scratch of this call (calls may be in flight on several streams)
-        _lib.check(_lib.lib().n3d_render_rays(
+        _lib.check(_lib.lib().n3d_render_rays_ex(
             _lib.ptr(planes_cl), _lib.ptr(cam2world), _lib.ptr(intrinsics), _lib.ptr(S.tlin[key]), _lib.ptr(jitter),
             _lib.ptr(u), _lib.ptr(S.dec_w1), _lib.ptr(S.dec_b1), _lib.ptr(S.dec_w2), _lib.ptr(S.dec_b2), _lib.ptr(feat),
             _lib.ptr(depth), None, _lib.ptr(bounds), N, R, Sc, Sf, planes_cl.shape[2], planes_cl.shape[3],
-            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), _lib.stream()))
+            float((t1 - t0) / (Sc - 1)), float(2 / rk['box_warp']), opts, _lib.stream()))
         return feat, depth
 
     def synthesis(self, ws, c, v, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
@@ -420,7 +451,8 @@ class TriPlaneGenerator(torch.nn.Module):
             planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank)
         if cache_backbone:
             self._set_cache('_last_planes', planes)
-        feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u)
+        feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u,
+                                                 synthesis_kwargs.get('density_noise_draws'))
         rgb_image = feature_image[:, :3]
         sr_noise = self.rendering_kwargs.get('superresolution_noise_mode', 'none')     # triplane_next3d.py:182
         # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is

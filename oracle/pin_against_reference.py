@@ -59,6 +59,9 @@ CASES = {
     # BASELINE.json configs[1] EXACTLY as bench.py runs it: batch 4, seeds 0-3, demo_batch's yaw pattern, R=64, 48+48, psi 0.7
     # (mesh 1 perturbed as in the other batched cases so that the four samples do not share one z-buffer)
     'case_r64_s48_b4': dict(seeds=[0, 1, 2, 3], yaws=[0.4, 0.0, -0.4, 0.4], R=64, Sc=48, Sf=48, psi=0.7),
+    # BASELINE.json configs[3]'s per-GPU share: 8 seeds in ONE call (other kernels are selected at batch 8: split-K factors, pre-split
+    # eligibility, grid shapes), demo_batch's yaw pattern; `lean`: only what the parity test reads is stored (file size)
+    'case_r64_s48_b8': dict(seeds=list(range(8)), yaws=[0.4, 0.0, -0.4, 0.4, 0.0, -0.4, 0.4, 0.0], R=64, Sc=48, Sf=48, psi=0.7, lean=True),
 }
 
 
@@ -210,6 +213,15 @@ def main():
         ok = all(v <= 1e-4 for v in rep.values())
         overall_ok &= ok
         planes = stages['renderer'][0]
+        if cfg.get('lean', False):
+            np.savez_compressed(
+                os.path.join(GOLDEN, f'{cname}.npz'),
+                z=z.numpy(), c=c.numpy(), c_cond=c_cond.numpy(), v=v.numpy(), R=R, Sc=Sc, Sf=Sf, psi=cfg['psi'], cutoff=14,
+                ws=ws_ref.numpy(), image_raw=out_ref['image_raw'].numpy(), image_depth=out_ref['image_depth'].numpy(),
+                image_sub4=sub(out_ref['image'], 4), image_mean=out_ref['image'].mean(dim=(2, 3)).numpy(),
+                textures_sub8=sub(stages['textures'], 8), static_plane_sub8=sub(stages['static_plane'], 8),
+                alpha=(st['alpha'].numpy() * 255).round().astype(np.uint8), mouth_mask=st['mouth_mask'].numpy())
+            continue
         np.savez_compressed(
             os.path.join(GOLDEN, f'{cname}.npz'),
             # inputs

@@ -68,8 +68,32 @@ def osg_decoder(P, prefix, feats):
     return rgb, x[..., 0:1]
 
 
-def ray_march(colors, densities, depths):
-    """vr/ray_marcher.py:27-66 (MipRayMarcher2.run_forward), clamp_mode='softplus', no white_back."""
+def ray_limits_box(rays_o, rays_d, box_side_length):
+    """vr/math_utils.py:46-100 (get_ray_limits_box): slab test against [-side/2, side/2]^3 -> (tmin, tmax) [..., 1]; -1 / -2 for misses."""
+    shape = rays_o.shape
+    o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    h = box_side_length / 2
+    bounds = torch.tensor([[-h, -h, -h], [h, h, h]], dtype=o.dtype)
+    valid = torch.ones(o.shape[:-1], dtype=bool)
+    inv = 1 / d
+    sign = (inv < 0).long()
+    tmin = (bounds.index_select(0, sign[..., 0])[..., 0] - o[..., 0]) * inv[..., 0]
+    tmax = (bounds.index_select(0, 1 - sign[..., 0])[..., 0] - o[..., 0]) * inv[..., 0]
+    tymin = (bounds.index_select(0, sign[..., 1])[..., 1] - o[..., 1]) * inv[..., 1]
+    tymax = (bounds.index_select(0, 1 - sign[..., 1])[..., 1] - o[..., 1]) * inv[..., 1]
+    valid[torch.logical_or(tmin > tymax, tymin > tmax)] = False
+    tmin, tmax = torch.max(tmin, tymin), torch.min(tmax, tymax)
+    tzmin = (bounds.index_select(0, sign[..., 2])[..., 2] - o[..., 2]) * inv[..., 2]
+    tzmax = (bounds.index_select(0, 1 - sign[..., 2])[..., 2] - o[..., 2]) * inv[..., 2]
+    valid[torch.logical_or(tmin > tzmax, tzmin > tmax)] = False
+    tmin, tmax = torch.max(tmin, tzmin), torch.min(tmax, tzmax)
+    tmin[~valid] = -1
+    tmax[~valid] = -2
+    return tmin.reshape(*shape[:-1], 1), tmax.reshape(*shape[:-1], 1)
+
+
+def ray_march(colors, densities, depths, white_back=False):
+    """vr/ray_marcher.py:27-66 (MipRayMarcher2.run_forward), clamp_mode='softplus'."""
     deltas = depths[:, :, 1:] - depths[:, :, :-1]
     colors_mid = (colors[:, :, :-1] + colors[:, :, 1:]) / 2
     dens_mid = F.softplus((densities[:, :, :-1] + densities[:, :, 1:]) / 2 - 1)
@@ -82,6 +106,8 @@ def ray_march(colors, densities, depths):
     depth = torch.sum(weights * depths_mid, -2) / wtot
     depth = torch.nan_to_num(depth, float('inf'))
     depth = torch.clamp(depth, torch.min(depths), torch.max(depths))
+    if white_back:                                               # :56-57
+        rgb = rgb + 1 - wtot
     return rgb * 2 - 1, depth, weights
 
 
@@ -116,29 +142,51 @@ def sample_importance(z_vals, weights, u):
     return sample_pdf(z_mid, w[:, 1:-1], u).reshape(B, R, u.shape[1], 1)
 
 
-def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u):
-    """vr/renderer.py:95-147 (ImportanceRenderer.forward), fixed ray_start/ray_end branch.
+def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u, noise=None):
+    """vr/renderer.py:95-147 (ImportanceRenderer.forward): fixed ray_start / ray_end, or both 'auto' (:98-106); sample_stratified with
+    or without disparity_space_sampling (:184-207); white_back (ray_marcher.py:56-57); density_noise (:152-153).
 
     jitter: [N, R, S_coarse, 1] uniform [0,1)   (replaces torch.rand_like, :205)
     u     : [N*R, S_importance] uniform [0,1)    (replaces torch.rand, :252)
+    noise : (coarse [N, R*Sc, 1], fine [N, R*Sf, 1]) normal draws (replace torch.randn_like, :153) when opts['density_noise'] > 0
     """
     N, R, _ = ray_o.shape
     Sc, Sf = opts['depth_resolution'], opts['depth_resolution_importance']
     t0, t1 = opts['ray_start'], opts['ray_end']
-    depths_c = torch.linspace(t0, t1, Sc).reshape(1, 1, Sc, 1).repeat(N, R, 1, 1)
-    depths_c = depths_c + jitter * ((t1 - t0) / (Sc - 1))
+    white = opts.get('white_back', False)
+    if t0 == t1 == 'auto':
+        rs, re = ray_limits_box(ray_o, ray_d, opts['box_warp'])
+        ok = re > rs
+        if torch.any(ok).item():
+            rs[~ok] = rs[ok].min()
+            re[~ok] = rs[ok].max()
+        steps = torch.arange(Sc, dtype=torch.float32) / (Sc - 1)                     # math_utils.linspace
+        depths_c = (rs[None] + steps.reshape(-1, 1, 1, 1) * (re - rs)[None]).permute(1, 2, 0, 3)
+        depths_c = depths_c + jitter * ((re - rs) / (Sc - 1))[..., None]
+    elif opts.get('disparity_space_sampling', False):
+        d = torch.linspace(0, 1, Sc).reshape(1, 1, Sc, 1).repeat(N, R, 1, 1)
+        d = d + jitter * (1 / (Sc - 1))
+        depths_c = 1. / (1. / t0 * (1. - d) + 1. / t1 * d)
+    else:
+        depths_c = torch.linspace(t0, t1, Sc).reshape(1, 1, Sc, 1).repeat(N, R, 1, 1)
+        depths_c = depths_c + jitter * ((t1 - t0) / (Sc - 1))
+    amp = opts.get('density_noise', 0) or 0
 
-    def run(depths, S):
+    def run(depths, S, nz):
         pts = (ray_o.unsqueeze(-2) + depths * ray_d.unsqueeze(-2)).reshape(N, -1, 3)
         feats = sample_from_planes(planes, pts, opts['box_warp'])
         rgb, sigma = osg_decoder(P, decoder_prefix, feats)
+        if amp > 0:
+            sigma = sigma + nz * amp
         return rgb.reshape(N, R, S, -1), sigma.reshape(N, R, S, 1)
 
-    col_c, den_c = run(depths_c, Sc)
+    _rm = ray_march
+    ray_march_ = lambda c_, d_, z_: _rm(c_, d_, z_, white)
+    col_c, den_c = run(depths_c, Sc, noise[0] if amp > 0 else None)
     if Sf > 0:
-        _, _, w = ray_march(col_c, den_c, depths_c)
+        _, _, w = ray_march_(col_c, den_c, depths_c)
         depths_f = sample_importance(depths_c, w, u)
-        col_f, den_f = run(depths_f, Sf)
+        col_f, den_f = run(depths_f, Sf, noise[1] if amp > 0 else None)
         all_d = torch.cat([depths_c, depths_f], -2)
         all_c = torch.cat([col_c, col_f], -2)
         all_s = torch.cat([den_c, den_f], -2)
@@ -146,7 +194,7 @@ def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u
         all_d = torch.gather(all_d, -2, idx)
         all_c = torch.gather(all_c, -2, idx.expand(-1, -1, -1, all_c.shape[-1]))
         all_s = torch.gather(all_s, -2, idx)
-        rgb, depth, w = ray_march(all_c, all_s, all_d)
+        rgb, depth, w = ray_march_(all_c, all_s, all_d)
     else:
-        rgb, depth, w = ray_march(col_c, den_c, depths_c)
+        rgb, depth, w = ray_march_(col_c, den_c, depths_c)
     return rgb, depth, w.sum(2)

@@ -135,6 +135,45 @@ def test_renderer_properties():
     assert float((inside - inside.mean(dim=1, keepdim=True)).abs().max()) < 5e-2
 
 
+RENDER_OPT_CASES = {'white_back': dict(ray_start=2.25, ray_end=3.3, white_back=True),
+                    'disparity': dict(ray_start=2.25, ray_end=3.3, disparity_space_sampling=True),
+                    'auto': dict(ray_start='auto', ray_end='auto'), 'auto_wide_fov': dict(ray_start='auto', ray_end='auto'),
+                    'density_noise': dict(ray_start=2.25, ray_end=3.3, density_noise=0.5),
+                    'all': dict(ray_start='auto', ray_end='auto', white_back=True, density_noise=0.25)}
+
+
+def load_render_opts_golden():
+    """tests/golden/render_opts.npz (oracle/pin_renderer_options.py: the REFERENCE's ImportanceRenderer on seeded inputs, one run per
+    option set) -> (inputs dict, {case: (opts, cams, rgb, depth, wsum)})."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'render_opts.npz'))
+    Sc, Sf = int(g['Sc']), int(g['Sf'])
+    inp = dict(planes=torch.from_numpy(g['planes']), jitter=torch.from_numpy(g['jitter']), u=torch.from_numpy(g['u']), R=int(g['R']), Sc=Sc, Sf=Sf,
+               noise=(torch.from_numpy(g['noise_c']), torch.from_numpy(g['noise_f'])),
+               P={k.replace('__', '.'): torch.from_numpy(g[k]) for k in g.files if k.startswith('decoder')})
+    out = {}
+    for name in [str(c) for c in g['cases']]:
+        opts = dict(dict(depth_resolution=Sc, depth_resolution_importance=Sf, box_warp=1), **RENDER_OPT_CASES[name])
+        out[name] = (opts, torch.from_numpy(g[name + '_cams']), torch.from_numpy(g[name + '_rgb']), torch.from_numpy(g[name + '_depth']),
+                     torch.from_numpy(g[name + '_wsum']))
+    return inp, out
+
+
+def test_renderer_options_match_reference_golden():
+    """The rendering options beyond the ffhq configuration — 'auto' ray bounds (incl. the repair of rays that miss the box),
+    disparity-space sampling, white_back, density noise — in oracle/renderer.py against the reference's own outputs."""
+    inp, cases_ = load_render_opts_golden()
+    N = inp['planes'].shape[0]
+    for name, (opts, cams, rgb, depth, wsum) in cases_.items():
+        ro, rd = renderer.ray_sampler(cams[:, :16].reshape(N, 4, 4), cams[:, 16:25].reshape(N, 3, 3), inp['R'])
+        o = renderer.importance_renderer(inp['P'], 'decoder', inp['planes'], ro, rd, opts, inp['jitter'], inp['u'], noise=inp['noise'])
+        d = [float((a - b).abs().max()) for a, b in zip(o, (rgb, depth, wsum))]
+        assert max(d) <= 1e-5, (name, d)
+        if name == 'auto_wide_fov':
+            rs, re = renderer.ray_limits_box(ro, rd, 1)
+            assert 0.05 < float((re > rs).float().mean()) < 0.9        # the case does exercise the repair branch
+
+
 # Tolerances of the float16 super-resolution route against the REFERENCE's own float16 run (tests/golden/*_fp16sr.npz: its float16
 # SynthesisBlocks executed on the CPU with the off-GPU float32 guard disabled, oracle/pin_against_reference.py --fp16), max-abs /
 # mean-abs on the 512x512 image (values up to ~8 with the synthetic weights; float16 ulp 2^-11 relative):

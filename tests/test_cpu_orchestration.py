@@ -41,7 +41,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert tuple(out['image'].shape) == (N, 3, 512, 512) and tuple(out['image_raw'].shape) == (N, 3, R, R)
     assert tuple(out['image_depth'].shape) == (N, 1, R, R)
     assert full['n3d_conv2d_prep_weight'] == 0 and full['n3d_conv2d_prep_weight_bf16x3'] == 0      # prepared once per model
-    assert full['n3d_rasterize_views'] == 1 and full['n3d_render_rays'] == 1 and full['n3d_texture_project_planes'] == 1
+    assert full['n3d_rasterize_views'] == 1 and full['n3d_render_rays_ex'] == 1 and full['n3d_texture_project_planes'] == 1
     assert full['n3d_resize_aa'] == (2 if R == 128 else 4)       # mouth crop + paste (+ feature / rgb resize unless R == 128)
     n_full = sum(full.values())
     # the launch count does not depend on the batch: one launch per layer, whatever N — plus the split8 conversion passes of
@@ -52,7 +52,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     dry.clear()
     G.synthesis(ws, c, v, use_cached_backbone=True, **kw)        # camera orbit: renderer + super-resolution only
     orbit = Counter(dry)
-    assert orbit['n3d_rasterize_views'] == 0 and orbit['n3d_render_rays'] == 1 and sum(orbit.values()) < n_full // 4
+    assert orbit['n3d_rasterize_views'] == 0 and orbit['n3d_render_rays_ex'] == 1 and sum(orbit.values()) < n_full // 4
     dry.clear()
     G.synthesis(ws, c, v, use_cached_identity=True, **kw)        # reenactment: no texture / static backbone
     reenact = Counter(dry)

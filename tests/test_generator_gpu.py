@@ -408,3 +408,38 @@ def test_batch8_rows_equal_two_batch4_forwards(G, dev, fp32):
             e, m = _md(full[k][s], part[k]), float((full[k][s] - part[k]).abs().mean())
             print(f'batch 8 rows {4 * h}-{4 * h + 3} vs batch 4, fp32={fp32}, {k}: max abs diff {e:.3e}, mean {m:.3e}')
             assert e <= tol and m <= (2e-5 if (fp32 or k != 'image') else 1.2e-3), (k, h, e, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opts', [dict(ray_start='auto', ray_end='auto', white_back=True, density_noise=0.25), dict(disparity_space_sampling=True)])
+def test_rendering_kwargs_outside_the_ffhq_configuration(G, dev, opts):
+    """generator.render reads rendering_kwargs the way the reference's renderer does (vr/renderer.py:95-153, vr/ray_marcher.py:56-57):
+    'auto' ray bounds, white_back, density_noise, disparity-space sampling reach n3d_render_rays_ex — against the oracle (pinned
+    to the reference for these options: tests/golden/render_opts.npz) on the generator's own decoder; other values still raise."""
+    from oracle import renderer as oren
+    N, R, Sc, Sf = 2, 16, 12, 12
+    rk_old = dict(G.rendering_kwargs)
+    try:
+        G.rendering_kwargs.update(depth_resolution=Sc, depth_resolution_importance=Sf, **opts)
+        g = torch.Generator().manual_seed(5)
+        planes = torch.randn(N, 3, 32, 256, 256, generator=g) * 2
+        jitter, u = cases.rng_inputs(N, R, Sc, Sf)
+        nz = (torch.randn(N, R * R * Sc, 1, generator=g), torch.randn(N, R * R * Sf, 1, generator=g))
+        d = np.load(os.path.join(GOLDEN, 'case_r64_s48.npz'))
+        c = torch.from_numpy(d['c'])
+        feat, depth = G.render(planes.permute(0, 1, 3, 4, 2).contiguous().to(dev), c.to(dev), R, jitter, u,
+                               density_noise_draws=(nz[0].reshape(N, R * R, Sc), nz[1].reshape(N, R * R, Sf)))
+        P = {k: v.detach().cpu() for k, v in G.state_dict().items() if k.startswith('decoder')}
+        ro, rd = oren.ray_sampler(c[:, :16].reshape(N, 4, 4), c[:, 16:25].reshape(N, 3, 3), R)
+        rgb_o, dep_o, _ = oren.importance_renderer(P, 'decoder', planes, ro, rd, dict(G.rendering_kwargs), jitter, u, noise=nz)
+        e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb_o).abs().amax(-1)
+        e_dep = (depth.cpu().reshape(N, R * R) - dep_o[..., 0]).abs()
+        print(opts, f'rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e} depth max {float(e_dep.max()):.2e}')
+        for e in (e_rgb, e_dep):
+            assert float((e > 1e-3).float().mean()) <= 0.01 and float(e.median()) <= 1e-4
+        G.rendering_kwargs['clamp_mode'] = 'mip'
+        with pytest.raises(RuntimeError):
+            G.render(planes.permute(0, 1, 3, 4, 2).contiguous().to(dev), c.to(dev), R, jitter, u)
+    finally:
+        G.rendering_kwargs.clear()
+        G.rendering_kwargs.update(rk_old)

@@ -344,6 +344,53 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
         assert float(e.median()) <= 1e-4
 
 
+@pytest.mark.parametrize('name', ['white_back', 'disparity', 'auto', 'auto_wide_fov', 'density_noise', 'all'])
+def test_render_rays_options_match_reference_golden(dev, name):
+    """n3d_render_rays_ex — 'auto' ray bounds (per-ray box limits + the reference's repair of the rays that miss the box),
+    disparity-space sampling, white_back, density noise — against the REFERENCE's own ImportanceRenderer outputs
+    (tests/golden/render_opts.npz, oracle/pin_renderer_options.py), and through generator.render's reading of rendering_kwargs."""
+    from next3d_amd import _lib
+    from test_cpu_oracle import load_render_opts_golden
+    inp, cases_ = load_render_opts_golden()
+    opts, cams, rgb, depth, wsum = cases_[name]
+    planes, R, Sc, Sf = inp['planes'], inp['R'], inp['Sc'], inp['Sf']
+    N, PH, PW = planes.shape[0], planes.shape[3], planes.shape[4]
+    P = inp['P']
+    w1 = (P['decoder.net.0.weight'] / np.sqrt(32)).contiguous()
+    w2t = torch.cat([(P['decoder.net.2.weight'] / np.sqrt(64)).t(), torch.zeros(64, 1)], 1).contiguous()
+    auto, disp = opts['ray_start'] == 'auto', opts.get('disparity_space_sampling', False)
+    lo, hi = (0.0, 1.0) if (auto or disp) else (opts['ray_start'], opts['ray_end'])
+    t = dict(dtype=torch.float32, device=dev)
+    feat, dep, ws_, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(N, R * R, **t), torch.empty(2, **t)
+    d = [x.contiguous().to(dev) for x in (_channels_last(planes), cams[:, :16], cams[:, 16:25], torch.linspace(lo, hi, Sc), inp['jitter'], inp['u'], w1,
+                                           P['decoder.net.0.bias'], w2t, P['decoder.net.2.bias'])]
+    ro = _lib.RenderOpts()
+    ro.white_back, ro.disparity_space_sampling, ro.auto_bounds, ro.box_side = int(opts.get('white_back', False)), int(disp), int(auto), 1.0
+    rb = torch.empty(N * R * R * 2, **t)
+    nc, nf = (x.reshape(N, R * R, -1).contiguous().to(dev) for x in inp['noise'])
+    if auto:
+        ro.ray_bounds_ws = _lib.ptr(rb)
+    else:
+        ro.ray_start, ro.ray_end = opts['ray_start'], opts['ray_end']
+    if opts.get('density_noise', 0) > 0:
+        ro.density_noise, ro.density_noise_coarse, ro.density_noise_fine = opts['density_noise'], _lib.ptr(nc), _lib.ptr(nf)
+    _lib.check(_lib.lib().n3d_render_rays_ex(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
+                                             float((hi - lo) / (Sc - 1)), 2.0, ro, _lib.stream()))
+    e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
+    e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
+    e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
+    print(f'{name}: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, wsum max {float(e_w.max()):.2e}')
+    for e in (e_rgb, e_dep, e_w):                                         # the importance pass is discontinuous in the coarse weights (as in test_render_rays_matches_oracle)
+        assert float((e > 1e-3).float().mean()) <= 0.01 and float(e.median()) <= 1e-4
+    if auto:                                                              # the per-ray limits themselves: exactly the reference's slab test + repair
+        o_ro, o_rd = renderer.ray_sampler(cams[:, :16].reshape(N, 4, 4), cams[:, 16:25].reshape(N, 3, 3), R)
+        rs, re = renderer.ray_limits_box(o_ro, o_rd, 1)
+        ok = re > rs
+        rs[~ok], re[~ok] = rs[ok].min(), rs[ok].max()
+        got = rb.cpu().reshape(N, R * R, 2)
+        assert _md(got[..., 0:1], rs) <= 2e-6 and _md(got[..., 1:2], re) <= 2e-6
+
+
 def test_render_rays_empty_space(dev):
     """Zero density everywhere: all weights are 0, the composite colour is 0 (-> -1 after rgb*2-1), the depth is 0/0 ->
     nan_to_num(inf) -> clamped to the GLOBAL maximum sample depth of the batch (ray_marcher.py:52-54; the kernel's
