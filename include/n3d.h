@@ -251,7 +251,8 @@ int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);
  *        job j reads styles_base[n * styles_stride + styles_offset + i].
  *      n3d_torgb_h8: ToRGBLayer of a float16 block + `img = upsample2d(img) + y.to(float32)` (:446-451): x h8 [N,C,H,W], w16 [N][O][C]
  *        (n3d_modulate_weights_f16, ksize 1, demodulate 0, styles already times weight_gain), bias [O], img_lo [N,O,H/2,W/2] float32 or
- *        NULL, up_filter = the 4x4 taps (required with img_lo) -> img [N,O,H,W] float32.  O <= 4, C <= 512; clamp < 0: none.
+ *        NULL, up_filter = the 4x4 taps (required with img_lo) -> img [N,O,H,W] float32.  C <= 512 (O <= 4: the image layers; larger O — the 32 / 96
+ *        feature channels of the backbones' toRGB layers in float16 blocks — runs 16 output channels per workgroup); clamp < 0: none.
  *      n3d_cast_h8: float32 NCHW [N,C,HW] (batch stride x_batch_stride floats, 0 = dense) -> h8 (to_h8 != 0; `x.to(float16)` at the
  *        block entry, :437) or h8 -> dense float32 NCHW (to_h8 == 0). */
 int n3d_modulate_weights_f16(const float* w, const float* styles, int64_t styles_stride, void* w16, int N, int O, int I, int ksize,

@@ -236,6 +236,14 @@ class H8:
         n, c, h, w = self.shape
         return self.data.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).float()
 
+    def to_nchw(self):
+        """`x.to(torch.float32)`: dense float32 [N,C,H,W] on libn3d.so (n3d_cast_h8) — where a float16 block's feature map is read by
+        float32 code (the StyleUNets' fusion layers concatenate it with the float32 encoder features)."""
+        n, c, h, w = self.shape
+        y = torch.empty(n, c, h, w, dtype=torch.float32, device=self.device)
+        check(lib().n3d_cast_h8(ptr(self.data), ptr(y), n, c, h * w, 0, 0, stream()))
+        return y
+
     @classmethod
     def from_nchw(cls, x):
         """`x.to(torch.float16)` of a float32 [N,C,H,W] tensor (dense planes, any batch stride) on libn3d.so (n3d_cast_h8)."""

@@ -462,10 +462,48 @@ __global__ __launch_bounds__(256) void torgb_h8_kernel(ToRgbH8Params p) {
     }
 }
 
+// The same layer with MORE than 4 output channels — the toRGB layers of fp16 blocks inside the StyleGAN2 backbones (32 neural-texture
+// channels, 96 tri-plane channels: num_fp16_res > 0 / legacy.load_network_pkl(force_fp16=True)).  A workgroup takes 16 output channels
+// (blockIdx.z) of 256 pixels; x is re-read O/16 times (from L2 / Infinity Cache: 2-6 passes over a tensor the 3x3 layer before just wrote).
+__global__ __launch_bounds__(256) void torgb_h8_wide_kernel(ToRgbH8Params p) {
+    __shared__ f16x8 s_w[16 * 64];                                        // [o][C/8] units, C <= 512
+    const int n = blockIdx.y, C8 = p.C / 8, o0 = blockIdx.z * 16, no = min(16, p.O - o0);
+    for (int e = threadIdx.x; e < no * C8; e += 256) s_w[e] = reinterpret_cast<const f16x8*>(p.w16 + ((int64_t)n * p.O + o0) * p.C)[e];
+    __syncthreads();
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const f16x8* xp = p.x + (int64_t)n * C8 * HW + pix;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int u = 0; u < C8; ++u) {
+        const f16x8 v = xp[(int64_t)u * HW];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const f16x8 wv = s_w[(o < no ? o : 0) * C8 + u];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2)
+                acc[o] = __builtin_amdgcn_fdot2(f16x2{v[k], v[k + 1]}, f16x2{wv[k], wv[k + 1]}, acc[o], false);
+        }
+    }
+    const int oy = (int)(pix / p.W), ox = (int)(pix % p.W);
+    n3d_up2_taps taps;
+    if (p.img_lo) taps = n3d_up2_setup(p.upf, oy, ox, p.H >> 1, p.W >> 1);
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        if (o >= no) break;
+        const float t = (float)(_Float16)acc[o] + (p.bias ? (float)(_Float16)p.bias[o0 + o] : 0.f);
+        float v = (float)(_Float16)fminf(fmaxf(t, -p.clamp), p.clamp);
+        if (p.img_lo) v += n3d_up2_apply(taps, p.img_lo + ((int64_t)n * p.O + o0 + o) * (HW >> 2));
+        p.img[((int64_t)n * p.O + o0 + o) * HW + pix] = v;
+    }
+}
+
 extern "C" int n3d_torgb_h8(const void* x, const void* w16, const float* bias, const float* img_lo, const float* up_filter, float* img, int N, int C,
                             int O, int H, int W, float clamp, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    N3D_CHECK(N >= 0 && C >= 8 && C % 8 == 0 && C <= 512 && O >= 1 && O <= 4 && H > 0 && W > 0, "torgb_h8: C %% 8 == 0, C <= 512, O <= 4");
+    N3D_CHECK(N >= 0 && C >= 8 && C % 8 == 0 && C <= 512 && O >= 1 && O <= 1024 && H > 0 && W > 0, "torgb_h8: C %% 8 == 0, C <= 512, O <= 1024");
     N3D_CHECK(!img_lo || (up_filter && H % 2 == 0 && W % 2 == 0), "torgb_h8: the low-resolution image needs the 4x4 filter and even H, W");
     if (N == 0) return 0;
     N3D_CHECK(x && w16 && img && (((uintptr_t)x | (uintptr_t)w16) & 15) == 0 && N <= 65535, "torgb_h8: null or misaligned tensor");
@@ -474,7 +512,8 @@ extern "C" int n3d_torgb_h8(const void* x, const void* w16, const float* bias, c
     p.N = N; p.C = C; p.O = O; p.H = H; p.W = W; p.clamp = clamp >= 0.f ? clamp : INFINITY;
     const double HW = (double)H * W;
     N3dProfScope prof(N3D_K_CONV1X1_BF16X3, stream, 2.0 * N * O * C * HW, N * HW * (2.0 * C + 4.0 * O + (img_lo ? 1.0 * O : 0.0)));
-    hipLaunchKernelGGL(torgb_h8_kernel, dim3((unsigned)cdiv64((int64_t)H * W, 256), N), dim3(256), 0, stream, p);
+    if (O <= 4) hipLaunchKernelGGL(torgb_h8_kernel, dim3((unsigned)cdiv64((int64_t)H * W, 256), N), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(torgb_h8_wide_kernel, dim3((unsigned)cdiv64((int64_t)H * W, 256), N, cdiv(O, 16)), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -65,12 +65,12 @@ class TriPlaneGenerator(torch.nn.Module):
             raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
         if synthesis_kwargs.get('channel_base', 32768) != 32768 or synthesis_kwargs.get('channel_max', 512) != 512:
             raise RuntimeError('channel_base=32768 / channel_max=512 expected')
-        if synthesis_kwargs.get('num_fp16_res', 0) > 0:
-            # legacy.load_network_pkl(force_fp16=True) (legacy.py:49-59) or a custom config: float16 blocks in the BACKBONES.  The ffhq-512
-            # configuration has none (train_next3d.py: num_fp16_res = 0); they would run in float32 here — a superset in accuracy — so say so
-            import warnings
-            warnings.warn('num_fp16_res > 0: the StyleGAN2 backbones run all their blocks in float32 in this build (only the '
-                          'super-resolution module has float16 blocks: sr_num_fp16_res)')
+        # float16 blocks in the four StyleGAN2 / StyleUNet backbones: num_fp16_res > 0 — what legacy.load_network_pkl(force_fp16=True)
+        # sets (legacy.py:49-59: num_fp16_res = 4, conv_clamp = 256; the ffhq-512 pickle itself has 0).  The blocks of resolution >=
+        # fp16_resolution run on the f16 matrix-core kernels unless force_fp32 is passed (tat/networks_stylegan2.py:615-621, :548-562)
+        nfp16 = int(synthesis_kwargs.get('num_fp16_res', 0) or 0)
+        self.backbone_fp16_resolution = max(2 ** (8 + 1 - nfp16), 8) if nfp16 > 0 else None            # the backbones are 256 x 256 networks
+        self.backbone_conv_clamp = synthesis_kwargs.get('conv_clamp', None)
         self.init_args = (z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path)
         self.init_kwargs = dict(sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs,
                                 rendering_kwargs=rendering_kwargs, sr_kwargs=sr_kwargs, **synthesis_kwargs)
@@ -193,10 +193,11 @@ class TriPlaneGenerator(torch.nn.Module):
         P = {k: v.detach() for k, v in self.state_dict().items()}
         S = type('Prepared', (), {})()
         S.P = P
-        S.texture = networks.SynthesisNet(P, 'texture_backbone.synthesis')
-        S.static = networks.SynthesisNet(P, 'backbone.synthesis')
-        S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64)
-        S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256)
+        bk = dict(fp16_resolution=self.backbone_fp16_resolution, conv_clamp=self.backbone_conv_clamp)
+        S.texture = networks.SynthesisNet(P, 'texture_backbone.synthesis', **bk)
+        S.static = networks.SynthesisNet(P, 'backbone.synthesis', **bk)
+        S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64, **bk)
+        S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256, **bk)
         S.sr = networks.SuperRes8XDC(P, 'superresolution', conv_clamp=self.sr_conv_clamp)
         # every style affine and demodulation coefficient of the five networks in TWO launches per forward (layers.StyleBank over the
         # full [N, 28, 512] latents: the texture backbone reads slots 14-27, the others 0-13, the super-resolution slot 13)
@@ -299,7 +300,7 @@ class TriPlaneGenerator(torch.nn.Module):
         grid, alpha, bbox = self.raster_geometry(v, lms)
         return self.project_textures(textures, grid), alpha, bbox
 
-    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False, bank=None):
+    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False, bank=None, force_fp32=False):
         """Everything up to the blended tri-planes (channels-last [N,3,256,256,32]).  `cache_identity` keeps the two
         latent-only results (neural texture, static tri-planes); `use_cached_identity` re-uses them for a new mesh `v` (the
         reenactment loop, reenact_avatar_next3d.py:139-160: one identity, one mesh per frame)."""
@@ -332,25 +333,25 @@ class TriPlaneGenerator(torch.nn.Module):
                 sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
             sstream.wait_stream(cur)                # ... after the rasterisation
             with torch.cuda.stream(sstream):
-                static = S.static(eg3d_ws, noise_mode, bank=bank)
+                static = S.static(eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
             static.record_stream(cur)
-            textures = S.texture(texture_ws, noise_mode, bank=bank)
+            textures = S.texture(texture_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         else:
-            textures = S.texture(texture_ws, noise_mode, bank=bank)
+            textures = S.texture(texture_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         front, side, top = self.project_textures(textures, grid)
         f32 = dict(dtype=torch.float32, device=ws.device)
         crop = torch.empty(N, 32, 64, 64, **f32)
         _lib.check(L.n3d_resize_aa(_lib.ptr(front), _lib.ptr(crop), _lib.ptr(bbox), None, N, 32, 256, 256, 64, 64, 0, _lib.stream()))
-        mouths = S.mouth(crop, eg3d_ws, noise_mode, bank=bank)
+        mouths = S.mouth(crop, eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         # the mouth is pasted into the front plane in place (the reference copies it first, :158-160); a copy is kept only
         # when the stage tensors are requested for inspection
         stitch_in = front.clone() if getattr(self, 'keep_stages', False) else front
         _lib.check(L.n3d_resize_aa(_lib.ptr(mouths), _lib.ptr(stitch_in), None, _lib.ptr(bbox), N, 32, 256, 256, 256, 256, 1, _lib.stream()))
-        stitch = S.blend(stitch_in, eg3d_ws, noise_mode, bank=bank)
+        stitch = S.blend(stitch_in, eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         if ident is None and self.overlap_static:
             cur.wait_stream(sstream)
         elif static is None:
-            static = S.static(eg3d_ws, noise_mode, bank=bank)
+            static = S.static(eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         if cache_identity:
             self._set_cache('_identity_cache', (textures, static))
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
@@ -448,7 +449,8 @@ class TriPlaneGenerator(torch.nn.Module):
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank)
+            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank,
+                                     force_fp32=bool(synthesis_kwargs.get('force_fp32', False)))
         if cache_backbone:
             self._set_cache('_last_planes', planes)
         feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u,
@@ -530,7 +532,7 @@ class TriPlaneGenerator(torch.nn.Module):
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes, _ = self._planes(ws, v, noise_mode)
+            planes, _ = self._planes(ws, v, noise_mode, force_fp32=bool(synthesis_kwargs.get('force_fp32', False)))
             if cache_backbone:
                 self._set_cache('_last_planes', planes)
         coords = coordinates.to(device=self.device, dtype=torch.float32).contiguous()

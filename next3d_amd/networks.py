@@ -73,6 +73,44 @@ class _Block:
         return x, img, None
 
 
+def _f16_block(blk, xh, img, fir, noise_mode, w16):
+    """SynthesisBlock.forward with use_fp16 and not force_fp32 (tat/networks_stylegan2.py:544-588, dtype float16) on the f16 kernels:
+    xh `_lib.H8` [N,I,h,w] -> (`_lib.H8` [N,O,2h,2w], float32 skip image).  w16 = the block's per-sample weights (conv0, conv1, torgb)."""
+    w0, w1, wt = w16
+    xh = L.synthesis_layer_f16(blk.conv0, xh, None, fir, up=2, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w0)
+    xh = L.synthesis_layer_f16(blk.conv1, xh, None, fir, up=1, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w1)
+    img = L.torgb_layer_f16(blk.torgb, xh, None, fir, conv_clamp=blk.conv_clamp, img_lo=img, w16=wt)
+    return xh, img
+
+
+def _f16_blocks_ok(blocks, fir, noise_mode, in_res):
+    """Can these blocks (res -> _Block, each fed an [*, I, res/2, res/2] input) run on the f16 kernels?"""
+    return (noise_mode in ('const', 'none') and tuple(fir.shape) == (4, 4) and
+            all(b.conv0 is not None and L.f16_layer_ok(b.conv0, r // 2, r // 2, 2) and L.f16_layer_ok(b.conv1, r, r, 1) and
+                b.torgb.in_channels <= 512 and b.torgb.in_channels % 8 == 0 for r, b in blocks.items()))
+
+
+def _f16_weights(blocks, bank, n):
+    """Per-sample float16 weights of every layer of `blocks` (res -> _Block): n3d_modulate_weights_f16_multi, 8 layers per launch
+    -> {res: (w_conv0, w_conv1, w_torgb)}."""
+    st = lambda layer: bank[layer.prefix][0]
+    jobs = [(l, st(l), k == 'conv') for r in sorted(blocks) for (l, _, k) in blocks[r].entries(0)]
+    base = jobs[0][1]
+    base = base._base if base._base is not None else base            # StyleBank's packed [N, total] styles buffer
+    flat = []
+    for a in range(0, len(jobs), 8):
+        flat += L.modulate_weights_f16_multi(jobs[a:a + 8], base, n)
+    return {r: tuple(flat[3 * k:3 * k + 3]) for k, r in enumerate(sorted(blocks))}
+
+
+def _warn_f16_once(obj, what):
+    import warnings
+    if not getattr(obj, '_warned32', False):
+        obj._warned32 = True
+        warnings.warn(f'float16 blocks of {what} are not available for this configuration (random noise / filter / shapes): running them in '
+                      'float32 (the force_fp32=True arithmetic)')
+
+
 def _first_slots(block_resolutions):
     """ws index of each block's first conv: b4 has one conv, the others two (networks_stylegan2.py:632-640)."""
     out, idx = {}, 0
@@ -88,25 +126,41 @@ def _ws3(ws):
 
 
 class SynthesisNet:
-    def __init__(self, P, prefix, img_resolution=256):
+    def __init__(self, P, prefix, img_resolution=256, fp16_resolution=None, conv_clamp=None):
+        """fp16_resolution: blocks of that resolution and up are the reference's float16 blocks (`num_fp16_res` > 0: fp16_resolution =
+        max(2 ** (log2(img_resolution) + 1 - num_fp16_res), 8), tat/networks_stylegan2.py:615-621; legacy.load_network_pkl(force_fp16=True)
+        sets num_fp16_res = 4, conv_clamp = 256, legacy.py:49-59); conv_clamp applies to every block."""
         self.cd = S.channels_dict(img_resolution)
         self.block_res = sorted(self.cd)
-        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2] if r > 4 else 0) for r in self.block_res}
+        self.prefix, self.fp16_resolution = prefix, fp16_resolution
+        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2] if r > 4 else 0, conv_clamp=conv_clamp) for r in self.block_res}
         self.fir = P[f'{prefix}.b4.resample_filter']
         self.num_ws = 2 * len(self.block_res)
         slots = _first_slots(self.block_res)
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.block_res), []), self.fir.device)
         uf.fir_factor(self.fir)            # the one host read of the filter happens here, at model preparation
 
-    def __call__(self, ws, noise_mode='const', bank=None):
+    def __call__(self, ws, noise_mode='const', bank=None, force_fp32=False):
         """`bank`: this network's styles / demodulation coefficients when the caller computed them already (generator: one
-        StyleBank over all five networks, two launches per forward instead of ten)."""
+        StyleBank over all five networks, two launches per forward instead of ten).  force_fp32: SynthesisBlock.forward's flag
+        (tat/networks_stylegan2.py:544-550) — the float16 blocks, if any, run in float32."""
+        from . import _lib
         ws = _ws3(ws)
         if bank is None:
             bank = self.bank.compute(ws)
-        x = img = xs = None
+        f16 = {r: self.blocks[r] for r in self.block_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32}
+        if f16 and not _f16_blocks_ok(f16, self.fir, noise_mode, None):
+            _warn_f16_once(self, self.prefix)
+            f16 = {}
+        w16 = _f16_weights(f16, bank, ws.shape[0]) if f16 else {}
+        x = img = xs = xh = None
         for k, res in enumerate(self.block_res):
-            nxt = self.blocks[self.block_res[k + 1]] if k + 1 < len(self.block_res) else None
+            if res in f16:
+                if xh is None:
+                    xh = _lib.H8.from_nchw(x)                 # x.to(float16) at the first float16 block's entry (:560-562)
+                xh, img = _f16_block(self.blocks[res], xh, img, self.fir, noise_mode, w16[res])
+                continue
+            nxt = self.blocks[self.block_res[k + 1]] if (k + 1 < len(self.block_res) and self.block_res[k + 1] not in f16) else None
             x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, next_block=nxt)
         return img
 
@@ -131,7 +185,8 @@ class _EncoderBlock:
 
 
 class StyleUNet:
-    def __init__(self, P, prefix, img_resolution=256, in_size=64, final_size=4, num_cond_res=64):
+    def __init__(self, P, prefix, img_resolution=256, in_size=64, final_size=4, num_cond_res=64, fp16_resolution=None, conv_clamp=None):
+        self.prefix, self.fp16_resolution = prefix, fp16_resolution
         self.cd = S.channels_dict(img_resolution)
         self.block_res = sorted(self.cd)
         self.final_log2 = int(np.log2(final_size))
@@ -140,7 +195,7 @@ class StyleUNet:
         enc_res = [2 ** i for i in range(int(np.log2(in_size)), self.final_log2 - 1, -1)]
         self.encoder = [_EncoderBlock(P, f'{prefix}.encoder.{i}', downsample=(r < in_size)) for i, r in enumerate(enc_res[:-1])]
         self.used_res = self.block_res[self.start:]
-        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2]) for r in self.used_res}
+        self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2], conv_clamp=conv_clamp) for r in self.used_res}
         n_fusion = sum(1 for i in range(len(self.used_res)) if 2 ** (i + self.final_log2) < num_cond_res)
         self.fusion = [L.PreparedConv(P, f'{prefix}.fusion.{i}', modulated=False) for i in range(n_fusion)]
         self.fir = P[f'{prefix}.b4.resample_filter']
@@ -148,10 +203,17 @@ class StyleUNet:
         self.bank = L.StyleBank(sum((self.blocks[r].entries(slots[r]) for r in self.used_res), []), self.fir.device)
         uf.fir_factor(self.fir)
 
-    def __call__(self, x_in, ws, noise_mode='const', bank=None):
+    def __call__(self, x_in, ws, noise_mode='const', bank=None, force_fp32=False):
+        from . import _lib
         ws = _ws3(ws)
         if bank is None:
             bank = self.bank.compute(ws)
+        f16 = {r: self.blocks[r] for r in self.used_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32}
+        if f16 and not _f16_blocks_ok(f16, self.fir, noise_mode, None):
+            _warn_f16_once(self, self.prefix)
+            f16 = {}
+        w16 = _f16_weights(f16, bank, ws.shape[0]) if f16 else {}
+        cat_copy = _CAT_COPY or bool(f16)          # float16 blocks hand their feature map over as h8: the concatenation is a copy then
         # The decoder concatenates its feature map with the encoder's condition before every fusion conv (reference
         # networks_stylegan2_styleunet.py:565-567: torch.cat([x, conds[idx]], 1)).  Both halves are WRITTEN IN PLACE into one
         # buffer by the convolutions that produce them (channel-slice views: the kernels take a batch stride), so no
@@ -164,25 +226,33 @@ class StyleUNet:
             idx = n_enc - 1 - i                                    # position of this encoder block's output in conds[::-1]
             hin = h // 2 if enc.downsample else h
             out_buf = None
-            if 1 <= idx < len(self.fusion) and not _CAT_COPY:
+            if 1 <= idx < len(self.fusion) and not cat_copy:
                 cx, cc = self.cd[self.used_res[idx - 1]], enc.conv2.out_channels
                 cat[idx] = torch.empty(n, cx + cc, hin // 2, hin // 2, dtype=torch.float32, device=x_in.device)
                 out_buf = cat[idx][:, cx:]
             x_in, cond = enc(x_in, cond, self.fir, out_buf)
             conds[idx] = cond
             h = hin
-        x = img = xs = None
+        x = img = xs = xh = None
         for idx, res in enumerate(self.used_res):
             if idx < len(self.fusion):
                 xs = None                                             # this block reads the fusion layer's output, not the previous x
                 if idx == 0:
                     x = L.conv2d_layer(self.fusion[0], conds[0], self.fir, activation='linear')
                 else:
+                    if xh is not None:         # torch.cat([x (float16), cond (float32)]) promotes to float32 (styleunet.py:565-567)
+                        x, xh = xh.to_nchw(), None
                     x = L.conv2d_layer(self.fusion[idx], cat[idx] if idx in cat else torch.cat([x, conds[idx]], dim=1), self.fir, activation='linear')
+            if res in f16:
+                if xh is None:
+                    xh = _lib.H8.from_nchw(x)
+                xh, img = _f16_block(self.blocks[res], xh, img, self.fir, noise_mode, w16[res])
+                continue
             nxt = cat.get(idx + 1)
             x_out = nxt[:, :self.cd[res]] if (nxt is not None and nxt.shape[2] == res) else None
             # the next block reads this x directly unless a fusion layer (or the concatenation buffer's channel-slice view) is in between
-            nb = self.blocks[self.used_res[idx + 1]] if (idx + 1 < len(self.used_res) and idx + 1 >= len(self.fusion) and x_out is None) else None
+            nb = self.blocks[self.used_res[idx + 1]] if (idx + 1 < len(self.used_res) and idx + 1 >= len(self.fusion) and x_out is None and
+                                                         self.used_res[idx + 1] not in f16) else None
             x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_out=x_out, x_split8=xs, next_block=nb)
             if nxt is not None and x_out is None:                 # shapes did not line up: fall back to a copy
                 nxt[:, :self.cd[res]].copy_(x)

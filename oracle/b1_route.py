@@ -103,17 +103,21 @@ class Route:
                                     groups=n, flip_weight=(up == 1))
             return y.reshape(n, -1, *y.shape[2:])
 
-        def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=False):
-            """SynthesisBlock.forward with use_fp16 and not force_fp32 (training/networks_stylegan2.py:417-452), noise_mode 'none'."""
+        def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=False, noise_mode='none'):
+            """SynthesisBlock.forward with use_fp16 and not force_fp32 (training/networks_stylegan2.py:417-452)."""
             w0, w1, w2 = ws.unbind(dim=1)
             aff = lambda k, w: ops.fully_connected(w, P[f'{prefix}.{k}.affine.weight'], P[f'{prefix}.{k}.affine.bias'])
             x = x.to(torch.float16)
             for k, w, up in (('conv0', w0, 2), ('conv1', w1, 1)):
                 x = modconv16(P[f'{prefix}.{k}.weight'], x, aff(k, w), up, True)
+                if noise_mode == 'const':
+                    x = x.add_(P[f'{prefix}.{k}.noise_const'] * P[f'{prefix}.{k}.noise_strength'])
                 x = ops.bias_act(x, P[f'{prefix}.{k}.bias'].to(x.dtype), act='lrelu', gain=_SQRT2, clamp=conv_clamp)
             wt = P[f'{prefix}.torgb.weight']
             y = modconv16(wt, x, aff('torgb', w2) * (1.0 / np.sqrt(wt.shape[1] * wt.shape[2] ** 2)), 1, False)
             y = ops.bias_act(y, P[f'{prefix}.torgb.bias'].to(x.dtype), clamp=conv_clamp)
+            if img is None:
+                return x, y.to(torch.float32)
             img = ops.upsample2d(img, net.FIR)
             return x, img.add_(y.to(torch.float32))
 

@@ -53,15 +53,16 @@ def rasterize(P, v, lms, textures, uv_face_mask):
     return [rend[0], side, rend[3]], [alphas[0], alpha_side, alphas[3]], lm2ds
 
 
-def blended_planes(P, ws, v, uv_face_mask, noise_mode='const', st=None):
+def blended_planes(P, ws, v, uv_face_mask, noise_mode='const', st=None, net_kw=None):
     """triplane_next3d.py:119-174 (synthesis) == :236-276 (sample) == :282-322 (sample_mixed): everything up to the
     blended tri-planes [N,3,32,256,256].  Returns (planes, eg3d_ws); `st` (a dict) collects the stage tensors."""
     st = {} if st is None else st
+    net_kw = net_kw or {}           # fp16_resolution / conv_clamp / cpu_rounding of the four backbones (num_fp16_res > 0: legacy.py:49-59)
     v, lms = v[:, :5023], v[:, 5023:]
     N = ws.shape[0]
     eg3d_ws, texture_ws = ws[:, :NUM_WS_HALF], ws[:, NUM_WS_HALF:]
 
-    textures = networks.synthesis_network(P, 'texture_backbone.synthesis', texture_ws, noise_mode=noise_mode)
+    textures = networks.synthesis_network(P, 'texture_backbone.synthesis', texture_ws, noise_mode=noise_mode, **net_kw)
     st['textures'] = textures
     rend, alphas, lm2ds = rasterize(P, v, lms, textures, uv_face_mask)
     st['rendering_front'], st['rendering_side'], st['rendering_top'] = rend
@@ -74,7 +75,7 @@ def blended_planes(P, ws, v, uv_face_mask, noise_mode='const', st=None):
     crops = torch.cat([F.interpolate(cr, size=(64, 64), mode='bilinear', antialias=True) for cr in crops], 0)
     st['rendering_mouth'] = crops
     mouths = networks.styleunet_synthesis(P, 'mouth_backbone.synthesis', crops, eg3d_ws, in_size=64,
-                                          final_size=4, num_cond_res=64, noise_mode=noise_mode)
+                                          final_size=4, num_cond_res=64, noise_mode=noise_mode, **net_kw)
     st['mouths_plane'] = mouths
     stitch = []
     for i, m in enumerate(mm):
@@ -86,10 +87,10 @@ def blended_planes(P, ws, v, uv_face_mask, noise_mode='const', st=None):
     stitch = torch.cat(stitch, 0)
     st['rendering_stitch_in'] = stitch
     stitch = networks.styleunet_synthesis(P, 'neural_blending.synthesis', stitch, eg3d_ws, in_size=256,
-                                          final_size=32, num_cond_res=256, noise_mode=noise_mode)
+                                          final_size=32, num_cond_res=256, noise_mode=noise_mode, **net_kw)
     st['rendering_stitch'] = stitch
 
-    static = networks.synthesis_network(P, 'backbone.synthesis', eg3d_ws, noise_mode=noise_mode)
+    static = networks.synthesis_network(P, 'backbone.synthesis', eg3d_ws, noise_mode=noise_mode, **net_kw)
     static = static.view(N, 3, 32, static.shape[-2], static.shape[-1])
     st['static_plane'] = static
     alpha = torch.cat(alphas, 1).unsqueeze(2)
@@ -115,7 +116,7 @@ def sample_mixed(P, coordinates, ws, v, uv_face_mask, rendering_kwargs, noise_mo
 
 
 def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_rendering_resolution=64,
-              noise_mode='const', return_stages=False, force_fp32=True):
+              noise_mode='const', return_stages=False, force_fp32=True, net_kw=None):
     """triplane_next3d.py:117-188 (synthesis).  `jitter`/`u`: see oracle/renderer.py.  force_fp32=False: the float16
     super-resolution blocks the reference runs on a GPU by default (oracle/networks.py::synthesis_block_fp16)."""
     st = {}
@@ -124,7 +125,7 @@ def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_ren
     intrinsics = c[:, 16:25].view(-1, 3, 3)
     R = neural_rendering_resolution
     ray_o, ray_d = renderer.ray_sampler(cam2world, intrinsics, R)
-    planes, eg3d_ws = blended_planes(P, ws, v, uv_face_mask, noise_mode, st)
+    planes, eg3d_ws = blended_planes(P, ws, v, uv_face_mask, noise_mode, st, net_kw)
 
     feat, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, rendering_kwargs,
                                                      jitter, u)

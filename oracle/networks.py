@@ -84,7 +84,7 @@ def _q16(t):
     return t.half().float()
 
 
-def _modconv_fp16(P, prefix, x, styles, up, demodulate):
+def _modconv_fp16(P, prefix, x, styles, up, demodulate, noise=None):
     """modulated_conv2d's float16 branch (tat/networks_stylegan2.py:56-91, fused): weight / style pre-normalisation against
     overflow (:57-59), per-sample weights `w.to(float16)`, grouped convolution.  Emulated on float32 arithmetic: every tensor
     the reference holds in float16 is rounded to float16 here (products of two float16 values are exact in float32, the
@@ -100,7 +100,10 @@ def _modconv_fp16(P, prefix, x, styles, up, demodulate):
         w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, -1, 1, 1, 1)
     y = ops.conv2d_resample(x.reshape(1, -1, *x.shape[2:]), _q16(w.reshape(-1, i, kh, kw)), f=FIR, up=up, padding=kh // 2, groups=n,
                             flip_weight=(up == 1), quant=_q16)
-    return y.reshape(n, -1, *y.shape[2:])
+    y = y.reshape(n, -1, *y.shape[2:])
+    if noise is not None:                                  # `x.add_(noise)` on the float16 result (:89-90): float32 sum, float16 storage
+        y = _q16(y + noise)
+    return y
 
 
 def _bias_act_half_cpu(x, b, act='linear', gain=1.0, clamp=None):
@@ -114,9 +117,10 @@ def _bias_act_half_cpu(x, b, act='linear', gain=1.0, clamp=None):
     return x.clamp(-clamp, clamp) if clamp is not None else x
 
 
-def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=False):
-    """SynthesisBlock.forward with use_fp16 and not force_fp32 (training/networks_stylegan2.py:417-452), noise_mode='none' (the
-    super-resolution blocks): x is cast to float16 at entry, every layer returns float16, the skip image is float32.
+def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=False, noise_mode='none'):
+    """SynthesisBlock.forward with use_fp16 and not force_fp32 (training/networks_stylegan2.py:417-452; noise_mode 'none': the
+    super-resolution blocks, 'const': float16 blocks of the backbones, num_fp16_res > 0): x is cast to float16 at entry, every layer
+    returns float16, the skip image is float32.
     bias_act: `cpu_rounding=False` models bias_act.cu (bias_act.cu:19-50: float32 inside, ONE float16 rounding — the reference on a
     GPU); `cpu_rounding=True` models _bias_act_ref on half tensors (the reference off-GPU).  The latter reproduces the reference's
     own CPU run of this branch (oracle/pin_against_reference.py --fp16, tests/golden/*_fp16sr.npz) up to the accumulation order
@@ -126,12 +130,13 @@ def synthesis_block_fp16(P, prefix, x, img, ws, conv_clamp=256, cpu_rounding=Fal
     ba = _bias_act_half_cpu if cpu_rounding else (lambda x, b, **kw: _q(ops.bias_act(x, _q(b), **kw)))
     x = _q(x)
     for k, w, up in (('conv0', w0, 2), ('conv1', w1, 1)):
-        x = _modconv_fp16(P, f'{prefix}.{k}', x, aff(k, w), up, True)
+        nz = P[f'{prefix}.{k}.noise_const'] * P[f'{prefix}.{k}.noise_strength'] if noise_mode == 'const' else None
+        x = _modconv_fp16(P, f'{prefix}.{k}', x, aff(k, w), up, True, noise=nz)
         x = ba(x, P[f'{prefix}.{k}.bias'], act='lrelu', gain=_LRELU_GAIN, clamp=conv_clamp)
     wt = P[f'{prefix}.torgb.weight']
     y = _modconv_fp16(P, f'{prefix}.torgb', x, aff('torgb', w2) * (1.0 / np.sqrt(wt.shape[1] * wt.shape[2] ** 2)), 1, False)
     y = ba(y, P[f'{prefix}.torgb.bias'], clamp=conv_clamp)
-    img = ops.upsample2d(img, FIR) + y
+    img = ops.upsample2d(img, FIR) + y if img is not None else y
     return x, img
 
 
@@ -161,14 +166,19 @@ def _split_ws(ws, block_resolutions):
     return out
 
 
-def synthesis_network(P, prefix, ws, img_resolution=256, noise_mode='const', return_features=False):
-    """tat/networks_stylegan2.py:630-645 (SynthesisNetwork.forward)."""
+def synthesis_network(P, prefix, ws, img_resolution=256, noise_mode='const', return_features=False, fp16_resolution=None, conv_clamp=None,
+                      cpu_rounding=False):
+    """tat/networks_stylegan2.py:630-645 (SynthesisNetwork.forward).  fp16_resolution (num_fp16_res > 0, :615-621): the blocks of that
+    resolution and up are float16 blocks (emulated, synthesis_block_fp16); conv_clamp applies to every block."""
     cd = channels_dict(img_resolution)
     block_res = sorted(cd.keys())
     x = img = None
     for res, cur_ws in zip(block_res, _split_ws(ws.to(torch.float32), block_res)):
         in_ch = cd[res // 2] if res > 4 else 0
-        x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode)
+        if fp16_resolution is not None and res >= fp16_resolution:
+            x, img = synthesis_block_fp16(P, f'{prefix}.b{res}', x, img, cur_ws, conv_clamp=conv_clamp, cpu_rounding=cpu_rounding, noise_mode=noise_mode)
+        else:
+            x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode, conv_clamp=conv_clamp)
     return (img, x) if return_features else img
 
 
@@ -185,7 +195,7 @@ def encoder_res_block(P, prefix, inp, skip, downsample):
 
 
 def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, final_size=4, num_cond_res=64,
-                        noise_mode='const'):
+                        noise_mode='const', fp16_resolution=None, conv_clamp=None, cpu_rounding=False):
     """tat/networks_stylegan2_styleunet.py:554-588 (conditional SynthesisNetwork.forward)."""
     cd = channels_dict(img_resolution)
     block_res = sorted(cd.keys())
@@ -209,7 +219,10 @@ def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, fin
                 x = conv2d_layer(P, f'{prefix}.fusion.{index}', torch.cat([x, cond_list[index]], dim=1), 3,
                                  activation='linear')
         in_ch = cd[res // 2] if res > 4 else 0
-        x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode)
+        if fp16_resolution is not None and res >= fp16_resolution:     # (torch.cat above promoted a float16 x to float32: same values)
+            x, img = synthesis_block_fp16(P, f'{prefix}.b{res}', x, img, cur_ws, conv_clamp=conv_clamp, cpu_rounding=cpu_rounding, noise_mode=noise_mode)
+        else:
+            x, img = synthesis_block(P, f'{prefix}.b{res}', x, img, cur_ws, in_ch, noise_mode=noise_mode, conv_clamp=conv_clamp)
     return img
 
 

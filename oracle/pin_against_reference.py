@@ -68,12 +68,14 @@ CASES = {
 FP16_CASES = ('case_r32_s24', 'case_r64_s48', 'case_r64_s48_b4')      # full-resolution image for batch 1 / 2; every second pixel for the benched batch 4 (file size)
 
 
-def enable_reference_fp16_on_cpu():
-    """Disable SynthesisBlock.forward's off-GPU float32 guard (training/networks_stylegan2.py:421-422) in the imported reference
+def enable_reference_fp16_on_cpu(module_name='training.networks_stylegan2'):
+    """Disable SynthesisBlock.forward's off-GPU float32 guard (training/networks_stylegan2.py:421-422; the same two lines in
+    training_avatar_texture/networks_stylegan2.py:548-549 and networks_stylegan2_styleunet.py:445-446) in the imported reference
     module: the method's own source, with that one condition replaced, is compiled in the module's namespace."""
+    import importlib
     import inspect
     import textwrap
-    import training.networks_stylegan2 as m
+    m = importlib.import_module(module_name)
     fn = m.SynthesisBlock.forward
     src = textwrap.dedent(inspect.getsource(fn))
     guard = "if ws.device.type != 'cuda':"
@@ -88,7 +90,88 @@ def sub(t, step):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
+def fp16_backbones():
+    """--fp16-backbones: the reference rebuilt the way legacy.load_network_pkl(force_fp16=True) rebuilds it (legacy.py:49-59:
+    num_fp16_res = 4, conv_clamp = 256 in every backbone) and run END TO END on the CPU with the off-GPU float32 guards of all three
+    SynthesisBlock classes disabled: the blocks of resolution >= 32 of the four backbones and both super-resolution blocks execute in
+    float16.  Writes tests/golden/<case>_fp16bb.npz (inputs + the reference's outputs) and reports the oracle's emulation against it."""
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    uv_mask = n3d_mesh.synthetic_uv_face_mask()
+    ref_shims.install(uv_mask[0, 0].numpy())
+    import camera_utils as ref_cam
+    G = ref_shims.build_reference_generator(RENDERING_KWARGS, num_fp16_res=4, conv_clamp=256)
+    sd = n3d_spec.synthetic_state_dict(seed=0)
+    verts, faces, uvs, uvfaces = n3d_mesh.parse_obj(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    sd.update(n3d_mesh.mesh_buffers(faces, uvs, uvfaces))
+    G.load_state_dict(sd, strict=True)
+    v_demo = n3d_mesh.parse_obj_vertices(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    lms = n3d_mesh.parse_landmarks(os.path.join(ref_shims.REF, 'data/demo/demo_kpt2d.txt'))
+    stages = {}
+    for name, mod in [('textures', G.texture_backbone.synthesis), ('mouths_plane', G.mouth_backbone.synthesis),
+                      ('rendering_stitch', G.neural_blending.synthesis), ('static_plane', G.backbone.synthesis)]:
+        mod.register_forward_hook(lambda m, i, o, name=name: stages.__setitem__(name, o))
+    originals = [(mn, enable_reference_fp16_on_cpu(mn)) for mn in ('training.networks_stylegan2', 'training_avatar_texture.networks_stylegan2',
+                                                                    'training_avatar_texture.networks_stylegan2_styleunet')]
+    ok = True
+    for cname in ('case_r32_s24', 'case_r64_s48'):
+        cfg = CASES[cname]
+        N, R, Sc, Sf = len(cfg['seeds']), cfg['R'], cfg['Sc'], cfg['Sf']
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+        rk = dict(RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+        z = torch.from_numpy(np.concatenate([np.random.RandomState(s).randn(1, 512) for s in cfg['seeds']], 0))
+        pivot = torch.tensor(rk['avg_camera_pivot'])
+        K = ref_cam.FOV_to_intrinsics(18.837)
+        cams, conds = [], []
+        for yaw in cfg['yaws']:
+            c2w = ref_cam.LookAtPoseSampler.sample(np.pi / 2 + yaw, np.pi / 2 - 0.2, pivot, radius=2.7)
+            cnd = ref_cam.LookAtPoseSampler.sample(np.pi / 2, np.pi / 2, pivot, radius=2.7)
+            cams.append(torch.cat([c2w.reshape(-1, 16), K.reshape(-1, 9)], 1))
+            conds.append(torch.cat([cnd.reshape(-1, 16), K.reshape(-1, 9)], 1))
+        c, c_cond = torch.cat(cams, 0), torch.cat(conds, 0)
+        v = torch.cat((v_demo, lms), 1).repeat(N, 1, 1)
+        if N > 1:
+            g = torch.Generator().manual_seed(1234)
+            v[1] = v[1] + 0.0005 * torch.randn(v[1].shape, generator=g)
+        jitter, u = cases.rng_inputs(N, R, Sc, Sf)
+        orig_rand, orig_rand_like = torch.rand, torch.rand_like
+        torch.rand_like = lambda t, *a, **k: jitter.clone() if tuple(t.shape) == tuple(jitter.shape) else orig_rand_like(t, *a, **k)
+        torch.rand = lambda *a, **k: u.clone() if (tuple(a) == tuple(u.shape) or (len(a) == 1 and tuple(a[0]) == tuple(u.shape))) else orig_rand(*a, **k)
+        try:
+            t0 = time.time()
+            ws_ref = G.mapping(z, c_cond, truncation_psi=cfg['psi'], truncation_cutoff=14)
+            out_ref = G.synthesis(ws_ref, c, v, neural_rendering_resolution=R, noise_mode='const')
+            t_ref = time.time() - t0
+        finally:
+            torch.rand, torch.rand_like = orig_rand, orig_rand_like
+        net_kw = dict(fp16_resolution=32, conv_clamp=256, cpu_rounding=True)
+        out_or, st = ogen.synthesis(sd, ogen.mapping(sd, z, c_cond, rk, truncation_psi=cfg['psi'], truncation_cutoff=14), c, v, uv_mask, rk, jitter, u,
+                                    neural_rendering_resolution=R, return_stages=True, force_fp32=False, net_kw=net_kw)
+        out32 = ogen.synthesis(sd, ws_ref, c, v, uv_mask, rk, jitter, u, neural_rendering_resolution=R)
+        rep = {k: float((stages[k].float() - st[k].reshape(stages[k].shape)).abs().max()) for k in ('textures', 'static_plane', 'mouths_plane', 'rendering_stitch')}
+        rep.update({k: float((out_ref[k] - out_or[k]).abs().max()) for k in ('image_raw', 'image_depth', 'image')})
+        d32 = {k: float((out_ref[k] - out32[k]).abs().max()) for k in ('image_raw', 'image')}
+        print(f'[{cname} fp16 backbones] reference {t_ref:.1f}s; max-abs(reference - oracle emulation): ' + ' '.join(f'{k}={x:.2e}' for k, x in rep.items()) +
+              f'; reference fp16 vs float32 route: image_raw {d32["image_raw"]:.2e} image {d32["image"]:.2e}')
+        assert all(t.dtype == torch.float32 for t in stages.values())
+        np.savez_compressed(os.path.join(GOLDEN, f'{cname}_fp16bb.npz'),
+                            z=z.numpy(), c=c.numpy(), c_cond=c_cond.numpy(), v=v.numpy(), R=R, Sc=Sc, Sf=Sf, psi=cfg['psi'], cutoff=14,
+                            ws=ws_ref.numpy(), image_raw=out_ref['image_raw'].numpy(), image_depth=out_ref['image_depth'].numpy(),
+                            image_sub2=sub(out_ref['image'], 2), textures_sub4=sub(stages['textures'], 4), static_plane_sub8=sub(stages['static_plane'], 8),
+                            mouths_plane_sub4=sub(stages['mouths_plane'], 4), rendering_stitch_sub4=sub(stages['rendering_stitch'], 4),
+                            stage_absmax=np.array([float(stages[k].abs().max()) for k in ('textures', 'static_plane', 'mouths_plane', 'rendering_stitch')]),
+                            oracle_max_abs=np.array([rep[k] for k in ('textures', 'static_plane', 'mouths_plane', 'rendering_stitch', 'image_raw', 'image')]),
+                            fp32_route_max_abs=np.array([d32['image_raw'], d32['image']]))
+    import importlib
+    for mn, fn in originals:
+        importlib.import_module(mn).SynthesisBlock.forward = fn
+    print('PIN fp16 backbones done')
+    return 0 if ok else 1
+
+
 def main():
+    if '--fp16-backbones' in sys.argv:
+        return fp16_backbones()
     only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
     do_fp16 = '--fp16' in sys.argv
     timings = {}

@@ -203,3 +203,49 @@ def test_oracle_fp16_superresolution_against_reference_fp16_run(case):
         assert float(d.max()) <= FP16_SR_TOL[mode][0] and float(d.mean()) <= FP16_SR_TOL[mode][1]
     out32 = ON.superresolution(sd, 'superresolution', *args, force_fp32=True)[..., ::step, ::step]
     assert float((out32 - ref).abs().mean()) > FP16_SR_TOL['cpu'][1]          # the float32 route is NOT within the tight bound
+
+
+# Float16 blocks in the BACKBONES (num_fp16_res = 4, conv_clamp = 256: what legacy.load_network_pkl(force_fp16=True) builds) against the
+# reference's own end-to-end float16 run on the CPU (tests/golden/*_fp16bb.npz, oracle/pin_against_reference.py --fp16-backbones).  Two
+# implementations of such a network agree to about ONE float16 ulp of the largest activation of a stage (accumulation order moves
+# values across rounding boundaries; 36 float16 layers deep the roundings decorrelate) — which is also the distance between the float16
+# and the float32 route (5e-3 .. 8e-3 on the image).  Stage tolerance: 2.5 ulp (2^-10 relative) of the stage's largest value; image: the
+# super-resolution route's bounds.
+FP16_BB_STAGE_ULPS = 2.5
+FP16_BB_IMAGE_TOL = (1.5e-2, 1.5e-3)       # max-abs, mean-abs on the 512 x 512 image
+FP16_BB_RAW_TOL = 5e-3                     # max-abs on image_raw
+
+
+def check_fp16_backbone_outputs(g, stages, out, who):
+    """stages: dict textures / static_plane / mouths_plane / rendering_stitch (full resolution, float32), out: image / image_raw."""
+    sub = {'textures': ('textures_sub4', 4), 'static_plane': ('static_plane_sub8', 8), 'mouths_plane': ('mouths_plane_sub4', 4),
+           'rendering_stitch': ('rendering_stitch_sub4', 4)}
+    absmax = dict(zip(('textures', 'static_plane', 'mouths_plane', 'rendering_stitch'), g['stage_absmax']))
+    for k, (key, step) in sub.items():
+        ref = torch.from_numpy(g[key])
+        d = float((stages[k].float().cpu().reshape(ref.shape[0], ref.shape[1], *stages[k].shape[-2:])[..., ::step, ::step] - ref).abs().max())
+        tol = FP16_BB_STAGE_ULPS * 2.0 ** -10 * float(absmax[k])
+        print(f'{who} {k}: max-abs {d:.3e} (tolerance {tol:.3e} = {FP16_BB_STAGE_ULPS} float16 ulps of {float(absmax[k]):.1f})')
+        assert d <= tol, (k, d, tol)
+    d_raw = float((out['image_raw'].cpu() - torch.from_numpy(g['image_raw'])).abs().max())
+    d_img = (out['image'].cpu()[..., ::2, ::2] - torch.from_numpy(g['image_sub2'])).abs()
+    print(f'{who} image_raw max-abs {d_raw:.3e}; image max-abs {float(d_img.max()):.3e} mean {float(d_img.mean()):.3e}')
+    assert d_raw <= FP16_BB_RAW_TOL and float(d_img.max()) <= FP16_BB_IMAGE_TOL[0] and float(d_img.mean()) <= FP16_BB_IMAGE_TOL[1]
+
+
+def test_oracle_fp16_backbones_against_reference_fp16_run():
+    """oracle/networks.py's emulation of float16 blocks inside the four backbones against the reference's own float16 run."""
+    import os
+    from next3d_amd import mesh, spec
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'case_r32_s24_fp16bb.npz'))
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'demo_inputs.npz'))
+    sd = spec.synthetic_state_dict(0)
+    sd.update(mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces']))
+    R, Sc, Sf = int(g['R']), int(g['Sc']), int(g['Sf'])
+    rk = dict(ogen.DEFAULT_RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(g[k])
+    ws = ogen.mapping(sd, t('z'), t('c_cond'), rk, truncation_psi=float(g['psi']), truncation_cutoff=int(g['cutoff']))
+    out, st = ogen.synthesis(sd, ws, t('c'), t('v'), mesh.synthetic_uv_face_mask(), rk, jitter, u, neural_rendering_resolution=R, return_stages=True,
+                             force_fp32=False, net_kw=dict(fp16_resolution=32, conv_clamp=256, cpu_rounding=True))
+    check_fp16_backbone_outputs(g, st, out, 'oracle')

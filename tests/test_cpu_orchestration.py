@@ -300,3 +300,36 @@ print('B1_ROUTE_DRY_RUN_OK', convs, sum(cnt.values()))
 """ % (repo, os.path.join(repo, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'B1_ROUTE_DRY_RUN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_fp16_backbones_launch_sequence_dry_run(dry):
+    """num_fp16_res = 4 / conv_clamp = 256 (legacy.load_network_pkl(force_fp16=True), legacy.py:49-59): the blocks of resolution >= 32
+    of the four backbones run on the f16 kernels — texture / static backbone 4 blocks each, mouth StyleUNet 4, blending StyleUNet 3
+    (b64-b256: its b32 does not exist) — and force_fp32=True gives the float32 launch sequence back."""
+    from next3d_amd import demo, mesh
+    from next3d_amd.generator import TriPlaneGenerator
+    d = demo.demo_arrays()
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, (d['faces'], d['uvs'], d['uvfaces']), sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2),
+                          rendering_kwargs=dict(demo.RENDERING_KWARGS, depth_resolution=12, depth_resolution_importance=12),
+                          sr_kwargs=dict(channel_base=32768, channel_max=512), uv_face_mask=mesh.synthetic_uv_face_mask(), channel_base=32768,
+                          channel_max=512, num_fp16_res=4, conv_clamp=256)
+    assert G.backbone_fp16_resolution == 32 and G.backbone_conv_clamp == 256
+    G.overlap_static = False
+    z, c, c_cond, v = demo.demo_batch([0, 1])
+    ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=32, noise_mode='const')
+    G.synthesis(ws, c, v, **kw)
+    dry.clear()
+    out = G.synthesis(ws, c, v, **kw)
+    cnt = Counter(dry)
+    blocks = 4 + 4 + 4 + 3
+    assert tuple(out['image'].shape) == (2, 3, 512, 512)
+    assert cnt['n3d_conv2d_f16'] == 2 * (blocks + 2) and cnt['n3d_torgb_h8'] == blocks + 2 == cnt['n3d_fir4_h8'], cnt
+    assert cnt['n3d_modulate_weights_f16_multi'] == 2 * 3 + 2 + 1      # 12 layers = two launches per 4-block network, 9 = two for the blending net, one for the SR
+    dry.clear()
+    G.synthesis(ws, c, v, force_fp32=True, **kw)
+    cnt32 = Counter(dry)
+    assert cnt32['n3d_conv2d_f16'] == 0 and cnt32['n3d_cast_h8'] == 0
+    dry.clear()
+    G.synthesis(ws, c, v, neural_rendering_resolution=32, noise_mode='random')      # random noise: the float16 blocks fall back to float32 (warning), never an error
+    assert Counter(dry)['n3d_conv2d_f16'] == 4                                      # (the super-resolution blocks have noise_mode 'none': still float16)

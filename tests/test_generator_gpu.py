@@ -443,3 +443,51 @@ def test_rendering_kwargs_outside_the_ffhq_configuration(G, dev, opts):
     finally:
         G.rendering_kwargs.clear()
         G.rendering_kwargs.update(rk_old)
+
+
+@pytest.fixture(scope='module')
+def G16(dev):
+    """The generator as legacy.load_network_pkl(force_fp16=True) rebuilds it (legacy.py:49-59): num_fp16_res = 4, conv_clamp = 256 in every
+    backbone — the blocks of resolution >= 32 of all four StyleGAN2 / StyleUNet networks are float16 blocks."""
+    from next3d_amd.generator import TriPlaneGenerator
+    d = np.load(os.path.join(GOLDEN, 'demo_inputs.npz'))
+    g = TriPlaneGenerator(512, 25, 512, 512, 3, (d['faces'], d['uvs'], d['uvfaces']), sr_num_fp16_res=4,
+                          mapping_kwargs=dict(num_layers=2), rendering_kwargs=dict(RK),
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
+                          uv_face_mask=mesh.synthetic_uv_face_mask(), channel_base=32768, channel_max=512,
+                          fused_modconv_default='inference_only', num_fp16_res=4, conv_clamp=256)
+    sd = spec.synthetic_state_dict(0)
+    sd.update(mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces']))
+    g.load_state_dict(sd, strict=True)
+    return g.eval().requires_grad_(False).to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['case_r32_s24', 'case_r64_s48'])
+def test_fp16_backbones_match_reference_fp16_run(G16, dev, case):
+    """SURVEY 8 (f4), backbone half: float16 blocks in the texture / static backbones and both StyleUNets (num_fp16_res = 4, conv_clamp
+    = 256) on the f16 matrix-core kernels against the REFERENCE's own end-to-end float16 run (tests/golden/*_fp16bb.npz: its three
+    SynthesisBlock classes executed on the CPU with the off-GPU float32 guard disabled, oracle/pin_against_reference.py
+    --fp16-backbones).  Tolerances and their derivation: tests/test_cpu_oracle.py::FP16_BB_*.  force_fp32=True must give the float32
+    route back (the float32 goldens, with conv_clamp = 256 never reached by these activations)."""
+    from next3d_amd import layers
+    from test_cpu_oracle import check_fp16_backbone_outputs
+    layers.set_precision('bf16x3')
+    g = np.load(os.path.join(GOLDEN, case + '_fp16bb.npz'))
+    N, R, Sc, Sf = g['z'].shape[0], int(g['R']), int(g['Sc']), int(g['Sf'])
+    G16.rendering_kwargs['depth_resolution'], G16.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(N, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    ws = G16.mapping(t('z'), t('c_cond'), truncation_psi=float(g['psi']), truncation_cutoff=int(g['cutoff']))
+    G16.keep_stages = True
+    try:
+        out = G16.synthesis(ws, t('c'), t('v'), neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u)
+        st = G16._debug
+        stages = {'textures': st['textures'], 'static_plane': st['static'], 'mouths_plane': st['mouths'], 'rendering_stitch': st['stitch']}
+        check_fp16_backbone_outputs(g, stages, out, 'HIP')
+        out32 = G16.synthesis(ws, t('c'), t('v'), neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
+    finally:
+        G16.keep_stages = False
+    d32 = np.load(os.path.join(GOLDEN, case + '.npz'))
+    assert _md(out32['image'][..., ::4, ::4], d32['image_sub4']) <= 1e-3 and _md(out32['image_raw'], d32['image_raw']) <= 1e-3
+    assert _md(out['image'], out32['image']) > 1e-4                       # the float16 blocks do run
