@@ -429,10 +429,33 @@ def main():
             s_.wait_stream(torch.cuda.current_stream())
         request(); request(); request(); torch.cuda.synchronize()
         t_1bp = timed(request, 120)
+        # ... and the same requests replayed from one captured HIP graph PER LANE (synthesis_graph(graph_slot=k) on stream k): eager
+        # issue costs ~4 ms of host time per frame (160 ctypes launches) — one Python thread cannot feed three lanes that way
+        greq = [0]
+
+        def request_graph():
+            k = greq[0] % len(lanes); greq[0] += 1
+            with torch.cuda.stream(lanes[k]):
+                return to_frames(G.synthesis_graph(ws1, c1, v1, graph_slot=k, **kw1b)['image'])
+
+        def lanes_graph_timed():
+            try:
+                for _ in range(2 * len(lanes)):
+                    request_graph()
+                torch.cuda.synchronize()
+                return timed(request_graph, 240)
+            except Exception as e:                                      # noqa: BLE001
+                print(f'bench.py: pipelined HIP-graph leg skipped ({type(e).__name__}: {e})', file=sys.stderr)
+                torch.cuda.synchronize()
+                return float('nan')
+        t_1bpg = lanes_graph_timed()
         extras['config1b'] = {'workload': 'batch 1 (one G.synthesis call per frame, as gen_samples_next3d.py / gen_videos_next3d.py issue them), 512² output, '
                                           '64² neural render, 48 + 48 samples, force_fp32=True',
                               'eager_ms_per_frame': 1e3 * t_1be / 60, 'hip_graph_ms_per_frame': 1e3 * t_1bg / 60,
-                              'pipelined_frames_per_s': 120 / t_1bp, 'lanes': len(lanes), 'frames_timed': [60, 60, 120], 'unit': 'ms / frames/s'}
+                              'pipelined_frames_per_s': 120 / t_1bp, 'pipelined_hip_graph_frames_per_s': 240 / t_1bpg, 'lanes': len(lanes),
+                              'frames_timed': [60, 60, 120, 240], 'unit': 'ms / frames/s',
+                              'note': 'pipelined: independent single-frame requests round-robin over the lanes; eager issue is bound by the one Python '
+                                      'thread (~160 launches per frame), the HIP-graph form (one captured graph per lane) by the GPU'}
         # ---- the OPERATOR-boundary route (B1): what the scripts' default `--reload_modules False` executes — the reference's own network
         # code on next3d_amd.torch_utils.ops + shims.  /root/reference does not exist here: oracle/b1_route.py re-instantiates the
         # oracle's restatement of that code on the operator layer (test infrastructure standing in for the pickled modules)

@@ -480,11 +480,14 @@ class TriPlaneGenerator(torch.nn.Module):
         self._prep()
         rk = self.rendering_kwargs
         tensors = {k: synthesis_kwargs[k] for k in ('depth_jitter', 'importance_u') if synthesis_kwargs.get(k) is not None}
-        plain = {k: val for k, val in synthesis_kwargs.items() if k not in tensors}
+        plain = {k: val for k, val in synthesis_kwargs.items() if k not in tensors and k != 'graph_slot'}
+        # graph_slot: independent instances of the same signature (own static buffers): a serving loop replays slot k on stream k so
+        # that several single-frame requests are in flight at once (bench.py config1b)
+        slot = int(synthesis_kwargs.get('graph_slot', 0))
         sig = (tuple(ws.shape), tuple(c.shape), tuple(v.shape), tuple((k, tuple(t.shape)) for k, t in sorted(tensors.items())),
                tuple(sorted((k, repr(val)) for k, val in plain.items())), plain.get('neural_rendering_resolution') or self.neural_rendering_resolution,
                rk['depth_resolution'], rk['depth_resolution_importance'], rk.get('superresolution_noise_mode', 'none'), layers.PRECISION,
-               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, self.overlap_static)
+               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, self.overlap_static, slot)
         uses_cache = bool((plain.get('use_cached_backbone') and self._last_planes is not None) or
                           (plain.get('use_cached_identity') and self._identity_cache is not None))
         if uses_cache:

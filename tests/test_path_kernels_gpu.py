@@ -415,7 +415,10 @@ def test_render_rays_empty_space(dev):
     assert float(feat.min()) == -1.0 and float(feat.max()) == -1.0
     assert _md(dep, torch.full_like(dep, float(depth.max())).cpu()) <= 5e-7
     lo = (torch.linspace(2.25, 3.3, Sc)[0] + jitter[:, :, 0, 0] * ((3.3 - 2.25) / (Sc - 1))).min()
-    assert abs(float(bounds[0]) - float(lo)) <= 5e-7 and abs(float(bounds[1]) - float(depth.max())) <= 5e-7
+    # the scratch holds the two bounds as order-preserving unsigned keys (render.hip f2key: 'auto' ray bounds can be negative)
+    keys = bounds.cpu().view(torch.int32).numpy().astype(np.uint32)
+    dec = [np.array([(k ^ 0x80000000) if (k & 0x80000000) else (~k & 0xffffffff)], dtype=np.uint32).view(np.float32)[0] for k in keys.tolist()]
+    assert abs(float(dec[0]) - float(lo)) <= 5e-7 and abs(float(dec[1]) - float(depth.max())) <= 5e-7
 
 
 def test_render_rays_rejects_bad_arguments(dev):
