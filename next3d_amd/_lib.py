@@ -74,6 +74,7 @@ _SIGNATURES = {
     'n3d_fir4_split8_nchw': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
     'n3d_conv2d_sk_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_split8_eligible': (c_int, [c_int] * 5),
+    'n3d_conv2d_split8_ksplit': (c_int, [c_int] * 5),
     'n3d_split8_from_nchw': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     'n3d_conv2d_prep_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),

@@ -238,10 +238,20 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
-    const int tile_i = lb % p.plan.total, n = lb / p.plan.total;
+    // Launch order: every FULL tile of the layer first, the thin edge tiles (position row gy = H, position column gx = W) of all samples
+    // last.  With two workgroups per CU (512 slots) a 64 x 64 layer at batch 4 is 512 full + 64 thin workgroups, a 128 x 128 one
+    // 1024 + 32: the tail of the launch then consists of thin tiles only, whose idle waves skip their multiplies (wave_on below),
+    // instead of a last round of full tiles on an eighth of the chip.
+    int m0, tile_i, n;
+    {
+        const int main_per = p.plan.tiles_x * p.plan.tiles_y, thin_per = p.plan.total - main_per;
+        const int main_total = main_per * p.tiles_m * p.N;
+        if (lb < main_total) { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % main_per; n = lb / main_per; }
+        else { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+    }
     int y0, x0, th, tw, end_y, end_x;
     up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
+    const bool wave_on = (wn * PG) * 32 < th * tw;                         // wave-uniform: does this wave own any position of the tile?
     const int PW = tw + 1, prows = th + 1;
     const int KC = p.I / 16, HW = p.H * p.W, GH = p.H + 1, GW = p.W + 1;
 
@@ -299,7 +309,7 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
                 if (wn + NW * j < FU_B_PIECES)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + (kc + 1) * strideB, 0, 0);
         }
-        if (kc >= 0) {
+        if (kc >= 0 && wave_on) {
             const f16x8* A = smem + (kc & 1) * BUF, *B = A + A_SZ;
             __builtin_amdgcn_s_setprio(1);
             f16x8 b[PG][4];

@@ -22,14 +22,19 @@
 #include "common.h"
 #include "up_tiles.h"
 
+int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
+                                  const n3d_epilogue& epi, hipStream_t stream);      // conv2d_bf16x3.hip
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 struct ConvPsParams {
     const bf16x8* x; const bf16x8* wt16; float* y;
+    float* partial;              // ksplit > 1: raw partial sums [ksplit][N][O][H][W] (reduced + epilogue by conv16_splitk_epilogue_launch)
     int N, I, O, OP64, H, W;
     int tiles_x, tiles_y, tiles_m;
+    int ksplit, kc_per_split;    // split-K over extra workgroups: 16-channel chunks per split (layers whose tiles alone leave CUs idle)
     int64_t xbs;                 // 16-byte units between consecutive samples of x (= 2 * I/8 * H * W for a dense tensor)
     int64_t wbs;                 // 16-byte units between consecutive samples' weight tiles (0 = shared by the batch)
     int64_t ybs, yrs;            // floats
@@ -65,9 +70,11 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
     const int m0 = (lb % p.tiles_m) * PS_BM; lb /= p.tiles_m;
+    const int ks = lb % p.ksplit; lb /= p.ksplit;
     const int tile_i = lb % (p.tiles_x * p.tiles_y), n = lb / (p.tiles_x * p.tiles_y);
     const int y0 = (tile_i / p.tiles_x) * PS_TH, x0 = (tile_i % p.tiles_x) * PS_TW;
     const int KC = p.I / 16, HW = p.H * p.W;
+    const int kc0 = ks * p.kc_per_split, kc1 = min(KC, kc0 + p.kc_per_split);        // this workgroup's chunks
 
     // descriptors (range-checked: a lane offset beyond the buffer reads as zero -> the halo of the patch).  hi and lo planes of
     // one sample are contiguous, so ONE descriptor covers both and the plane is selected through the scalar offset.
@@ -160,8 +167,8 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
 
     if (NBUF == 1) {
         __builtin_amdgcn_s_barrier();                                     // (the epilogue factors above are plain LDS stores)
-        for (int kc = 0; kc < KC; ++kc) {
-            if (!(p.dbg & 4) || kc == 0) copy_chunk(kc, 0);
+        for (int kc = kc0; kc < kc1; ++kc) {
+            if (!(p.dbg & 4) || kc == kc0) copy_chunk(kc, 0);
             __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): this wave's pieces are in LDS ...
             __builtin_amdgcn_s_barrier();                                 // ... and after the barrier everybody's are
             if (!(p.dbg & 2)) mfma_block(0);
@@ -169,19 +176,19 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
         }
         if (p.dbg & 1) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
     } else {
-    copy_chunk(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): this wave's pieces of chunk 0 are in LDS ...
+    copy_chunk(kc0, kc0 & 1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): this wave's pieces of the first chunk are in LDS ...
     __builtin_amdgcn_s_barrier();                                         // ... and after the barrier everybody's are
     if (p.dbg == 0) {
-        for (int kc = 0; kc < KC; ++kc) {
-            if (kc + 1 < KC) copy_chunk(kc + 1, (kc + 1) & 1);            // the other buffer's last readers passed the previous barrier
+        for (int kc = kc0; kc < kc1; ++kc) {
+            if (kc + 1 < kc1) copy_chunk(kc + 1, (kc + 1) & 1);           // the other buffer's last readers passed the previous barrier
             mfma_block(kc & 1);
             __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_barrier();
         }
     } else {                                                              // ablations (N3D_CONV_DBG): which part of the loop costs what
-        for (int kc = 0; kc < KC; ++kc) {
-            if (kc + 1 < KC && !(p.dbg & 4)) copy_chunk(kc + 1, (kc + 1) & 1);
+        for (int kc = kc0; kc < kc1; ++kc) {
+            if (kc + 1 < kc1 && !(p.dbg & 4)) copy_chunk(kc + 1, (kc + 1) & 1);
             if (!(p.dbg & 2)) mfma_block(kc & 1);
             if (!(p.dbg & 8)) { __builtin_amdgcn_s_waitcnt(0x0f70); __builtin_amdgcn_s_barrier(); }
         }
@@ -196,6 +203,31 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
     // the channel-per-register form was 10-17 % of the kernel, store-issue bound: tools/conv_ps_abl.py), and the per-channel
     // factors are two registers per lane instead of 32.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if (p.ksplit > 1) {                                                   // split-K: raw partial sums, dense [ks][n][o][H][W]; the reduce pass applies the epilogue
+        float* part = p.partial + (((int64_t)ks * p.N + n) * p.O) * (int64_t)p.H * p.W;
+        const bool vec4 = (p.W & 3) == 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int o = m0 + mt * 32 + l31;
+            if (o >= p.O) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oy = y0 + wn * 2 + nt;
+                if (oy >= p.H) continue;
+                float* drow = part + ((int64_t)o * p.H + oy) * p.W;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = x0 + 8 * g + 4 * half;
+                    if (ox >= p.W) continue;
+                    if (vec4) *reinterpret_cast<f32x4*>(drow + ox) = f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    else
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (ox + k < p.W) drow[ox + k] = acc[mt][nt][4 * g + k];
+                }
+            }
+        }
+        return;
+    }
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU;
     const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
@@ -250,19 +282,27 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
 }
 
 // Layers this kernel takes (the host asks before it lets a producer write split8): 3x3 stride 1, I % 16 == 0, images of at
-// least 16 x 32 whose 8-wave tiles cover the chip, linear / leaky-ReLU (0 <= alpha <= 1) epilogue.
-extern "C" int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W) {
+// least 16 x 32 whose 8-wave tiles — times a split-K factor of at most I / 64 (four 16-channel chunks per workgroup at least) —
+// cover the chip, linear / leaky-ReLU (0 <= alpha <= 1) epilogue.  n3d_conv2d_split8_ksplit: the factor the launch will use (0 =
+// not this kernel's layer, 1 = no split; > 1: the caller provides the partial-sum workspace of ksplit * N * O * H * W floats).
+extern "C" int n3d_conv2d_split8_ksplit(int N, int I, int O, int H, int W) {
     if (I % 16 != 0 || I < 16 || H < 16 || W < 32 || N < 1 || O < 1) return 0;
     const int64_t blocks = (int64_t)cdiv(W, PS_TW) * cdiv(H, PS_TH) * cdiv(O, PS_BM) * N;
     if ((int64_t)(I / 8) * H * W * 16 >= (1ll << 31)) return 0;           // 32-bit buffer offsets per plane
-    return blocks >= 256 ? 1 : 0;
+    if (blocks >= 256) return 1;
+    static const int on = n3d_tune("N3D_PS_SPLITK", 1);
+    int ks = 1;
+    while (blocks * ks < 256 && I / (ks * 2) >= 64 && ks < 16) ks *= 2;
+    return (on && ks > 1 && blocks * ks >= 192) ? ks : 0;
 }
+extern "C" int n3d_conv2d_split8_eligible(int N, int I, int O, int H, int W) { return n3d_conv2d_split8_ksplit(N, I, O, H, W) > 0 ? 1 : 0; }
 
 int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->ksize == 3 && d->mode == 0, "conv2d_bf16x3: a split8 input is taken by the 3x3 stride-1 kernel only");
     N3D_CHECK(d->style == nullptr, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL)");
-    N3D_CHECK(d->ksplit <= 1, "conv2d_bf16x3: no split-K with a split8 input");
-    N3D_CHECK(n3d_conv2d_split8_eligible(d->N, d->I, d->O, d->H, d->W), "conv2d_bf16x3: shape not eligible for the split8 kernel (n3d_conv2d_split8_eligible)");
+    const int ksplit = n3d_conv2d_split8_ksplit(d->N, d->I, d->O, d->H, d->W);
+    N3D_CHECK(ksplit > 0, "conv2d_bf16x3: shape not eligible for the split8 kernel (n3d_conv2d_split8_eligible)");
+    N3D_CHECK(ksplit == 1 || d->workspace != nullptr, "conv2d_bf16x3: this split8 layer runs with split-K %d (n3d_conv2d_split8_ksplit): workspace required", ksplit);
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(E.act == N3D_ACT_LINEAR || (E.act == N3D_ACT_LRELU && E.alpha >= 0.f && E.alpha <= 1.f), "conv2d_bf16x3 (split8): linear or leaky-ReLU epilogue only");
     N3D_CHECK(!E.residual_up_filter, "conv2d_bf16x3: residual_up_filter is only supported by the 1x1 kernel");
@@ -271,6 +311,8 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.tiles_x = cdiv(d->W, PS_TW); p.tiles_y = cdiv(d->H, PS_TH); p.tiles_m = cdiv(d->O, PS_BM);
+    p.kc_per_split = cdiv(d->I / 16, ksplit); p.ksplit = cdiv(d->I / 16, p.kc_per_split);
+    p.partial = p.ksplit > 1 ? d->workspace : nullptr;
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;      // x_batch_stride counts fp32-sized elements
     N3D_CHECK((d->wt_batch_stride & 15) == 0, "conv2d_bf16x3: wt_batch_stride must be a multiple of 16 bytes");
     p.wbs = d->wt_batch_stride / 16;
@@ -279,7 +321,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.epi = d->epi;
     p.dbg = n3d_tune("N3D_CONV_DBG", 0);                                  // tuning builds re-read it per launch: tools/conv_ps_abl.py flips it in-process
-    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
+    const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->O * d->I * 9);
@@ -292,6 +334,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
       if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.H, p.W, p.ybs, p.yrs, p.epi, stream);
     return 0;
 }
 
@@ -345,10 +388,20 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
-    const int tile_i = lb % p.plan.total, n = lb / p.plan.total;
+    // Launch order: every FULL tile of the layer first, the thin edge tiles (position row gy = H, position column gx = W) of all samples
+    // last.  With two workgroups per CU (512 slots) a 64 x 64 layer at batch 4 is 512 full + 64 thin workgroups, a 128 x 128 one
+    // 1024 + 32: the tail of the launch then consists of thin tiles only, whose idle waves skip their multiplies (wave_on below),
+    // instead of a last round of full tiles on an eighth of the chip.
+    int m0, tile_i, n;
+    {
+        const int main_per = p.plan.tiles_x * p.plan.tiles_y, thin_per = p.plan.total - main_per;
+        const int main_total = main_per * p.tiles_m * p.N;
+        if (lb < main_total) { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % main_per; n = lb / main_per; }
+        else { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+    }
     int y0, x0, th, tw, end_y, end_x;
     up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
+    const bool wave_on = (wn * PG) * 32 < th * tw;                         // wave-uniform: does this wave own any position of the tile?
     const int PW = tw + 1, prows = th + 1;
     const int KC = p.I / 16, HW = p.H * p.W, GH = p.H + 1, GW = p.W + 1;
 
@@ -414,7 +467,7 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
                 if (j < NB - 1 || wn + NW * j < UP_B_PIECES)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + (kc + 1) * strideB, 0, 0);
         }
-        if (kc >= 0) {
+        if (kc >= 0 && wave_on) {
             const bf16x8* A_hi = smem + (kc & 1) * BUF, *A_lo = A_hi + A_SZ, *B_hi = A_hi + 2 * A_SZ, *B_lo = B_hi + UP_B_SZ;
             __builtin_amdgcn_s_setprio(1);
             bf16x8 bh[PG][4], bl[PG][4];

@@ -492,11 +492,12 @@ __global__ __launch_bounds__(256) void torgb_h8_wide_kernel(ToRgbH8Params p) {
     if (p.img_lo) taps = n3d_up2_setup(p.upf, oy, ox, p.H >> 1, p.W >> 1);
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-        if (o >= no) break;
-        const float t = (float)(_Float16)acc[o] + (p.bias ? (float)(_Float16)p.bias[o0 + o] : 0.f);
-        float v = (float)(_Float16)fminf(fmaxf(t, -p.clamp), p.clamp);
-        if (p.img_lo) v += n3d_up2_apply(taps, p.img_lo + ((int64_t)n * p.O + o0 + o) * (HW >> 2));
-        p.img[((int64_t)n * p.O + o0 + o) * HW + pix] = v;
+        if (o < no) {
+            const float t = (float)(_Float16)acc[o] + (p.bias ? (float)(_Float16)p.bias[o0 + o] : 0.f);
+            float v = (float)(_Float16)fminf(fmaxf(t, -p.clamp), p.clamp);
+            if (p.img_lo) v += n3d_up2_apply(taps, p.img_lo + ((int64_t)n * p.O + o0 + o) * (HW >> 2));
+            p.img[((int64_t)n * p.O + o0 + o) * HW + pix] = v;
+        }
     }
 }
 

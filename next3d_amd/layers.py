@@ -38,6 +38,7 @@ S2_PRESPLIT = True         # stride-2 encoder layers on split8 input
 UP_PRESPLIT = True         # the transposed convolution's input (a block output with two consumers) converted once, LDS-DMA staging
 TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
+NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)
 CONVERT_MAX_BYTES = int(70e6)     # see _conv3x3
 
 
@@ -184,14 +185,16 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, x_split8=None):
+                    split_for=None, x_split8=None, split_for_nchw=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
     the device generator like the reference) — the kernels' epilogue takes one noise image per launch, so that mode runs
     the layer sample by sample.  `split_for` (up = 2 only): the styles [N,O] of the 3x3 layer that consumes this layer's
-    output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  (The reference's float16 blocks run on their own
-    kernels: synthesis_layer_f16.)"""
+    output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  `split_for_nchw`: the same hand-over for the up-sampling
+    layers whose transposed convolution runs on the register-staged kernel (few positions: split-K, float32 NCHW result): their FIR
+    reads that result and writes split8 (n3d_fir4_split8_nchw, pad 1) instead of float32 + a conversion pass in front of conv1.
+    (The reference's float16 blocks run on their own kernels: synthesis_layer_f16.)"""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
         dcoef = fc(styles, L.wsq, pre_square=True, post_rsqrt=True)
@@ -222,6 +225,8 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2):
         t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,
                            row_pitch=True)
+        if split_for_nchw is not None:
+            return uf._fir4_split8_nchw(t, fir, 1, gain=4, epilogue=_lib.make_epilogue(**act), out_scale=split_for_nchw)
     else:
         t = cg.conv_launch(x, L.wt, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), row_pitch=True)
     return uf.upfirdn2d(t, fir, padding=[1, 1, 1, 1], gain=4, _epilogue=_lib.make_epilogue(**act))

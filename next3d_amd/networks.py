@@ -54,9 +54,13 @@ class _Block:
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
             pre = self._presplit(n, x.shape, fir, noise_mode)
+            # ... or, where conv0 runs on the register-staged transposed kernel (few positions, split-K), at least its FIR writes split8
+            pre_nchw = (not pre and L.NCHW_FIR_SPLIT8 and noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and
+                        self.conv0.out_channels % 8 == 0 and L.PRECISION == 'bf16x3' and self.conv0.wt16 is not None and
+                        L.cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2) and L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
                                   split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if pre else None,
-                                  **sl(self.conv0))
+                                  split_for_nchw=bank[self.conv1.prefix][0] if pre_nchw else None, **sl(self.conv0))
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image update img = upsample2d(img) + toRGB(x): upsample2d is evaluated inside the toRGB epilogue (4 taps of the
         # half-resolution image per pixel)

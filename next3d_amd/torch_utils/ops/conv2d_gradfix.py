@@ -155,8 +155,10 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         n, i, h, w = x.shape
         xs = x
         x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only
-        if mode != 1:
-            ksplit = 1                                                         # (the stride-2 kernel keeps split-K for its small grids)
+        if mode == 0:                                                          # the library's own split-K factor for this shape (few tiles, deep K)
+            ksplit = max(1, _lib.lib().n3d_conv2d_split8_ksplit(n, i, out_channels, h, w))
+        elif mode == 2:
+            ksplit = 1                                                         # (the stride-2 kernel keeps the caller's split-K for its small grids)
     _lib.require_device(None if split8 else x, wt, style, out)
     n, i, h, w = x.shape
     o = out_channels
@@ -328,7 +330,9 @@ def _launch_prepared(x, wt, wbs, kind, ksize, mode, n, i, o, h, w, row_pitch=Fal
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=dev)
     bf16x3 = kind == 1
     ksplit = 1
-    if not split8:
+    if split8:
+        ksplit = max(1, _lib.lib().n3d_conv2d_split8_ksplit(n, i, o, h, w)) if mode == 0 else 1
+    else:
         if bf16x3:
             ksplit = 1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)
         else:

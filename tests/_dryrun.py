@@ -26,7 +26,7 @@ def _check_conv_desc(name, d):
         assert bf16x3 and d.ksize == 1 and d.x_layout == 0 and d.O % 32 == 0 and d.ksplit <= 1
     if d.x_layout == 1:                                  # split8 input: the pre-split launchers' preconditions (conv2d_ps_bf16x3.hip)
         assert bf16x3 and d.ksize == 3 and not d.style and d.epi.act in (1, 3)
-        assert d.ksplit <= 1 or d.mode == 1              # only the stride-2 kernel keeps split-K
+        assert d.ksplit <= 1 or d.mode in (0, 1)         # stride 1 (the library's own factor, n3d_conv2d_split8_ksplit) and stride 2 split K
         assert d.I % 16 == 0 and d.x_batch_stride % 4 == 0
         assert (d.mode == 0 and d.H >= 16 and d.W >= 32) or (d.mode == 2 and d.y_layout == 2 and d.O % 64 == 0) or (d.mode == 1 and d.H >= 3 and d.W >= 3)
     if d.side_split8:                                    # toRGB's second output: x * the next block's styles as split8
@@ -64,7 +64,7 @@ def patches():
     class Recorder:
         def __getattr__(self, name):
             res, argtypes = _lib._SIGNATURES[name]
-            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_sk_eligible', 'n3d_abi_version', 'n3d_last_error'):
+            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_split8_ksplit', 'n3d_conv2d_sk_eligible', 'n3d_abi_version', 'n3d_last_error'):
                 return getattr(real, name)                       # pure host functions: the real ones
 
             def fn(*args):

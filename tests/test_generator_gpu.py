@@ -376,6 +376,7 @@ def test_fused_layout_handovers_are_bit_identical_to_conversion_passes(G, dev, m
     for on in (True, False):
         monkeypatch.setattr(layers, 'TORGB_SIDE', on)
         monkeypatch.setattr(layers, 'DIRECT_SPLIT8', on)
+        monkeypatch.setattr(layers, 'NCHW_FIR_SPLIT8', on)      # (the small up-sampling layers' FIR writing split8 for conv1 — at batch 4: 16 -> 32)
         o = G.synthesis(ws, t('c'), t('v'), **kw)
         outs[on] = {k: o[k].clone() for k in ('image', 'image_raw', 'image_depth')}
     for k in outs[True]:
