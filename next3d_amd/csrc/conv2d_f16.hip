@@ -220,6 +220,7 @@ struct ConvUpF16Params {
     int N, I, O, H, W, OH, OW;
     UpTilePlan plan; int tiles_m;
     int64_t xbs, wbs, ybs;
+    int thin_last;
     int dbg;
 };
 
@@ -245,9 +246,10 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
     int m0, tile_i, n;
     {
         const int main_per = p.plan.tiles_x * p.plan.tiles_y, thin_per = p.plan.total - main_per;
-        const int main_total = main_per * p.tiles_m * p.N;
+        const int main_total = p.thin_last ? main_per * p.tiles_m * p.N : 0;
         if (lb < main_total) { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % main_per; n = lb / main_per; }
-        else { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+        else if (p.thin_last) { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+        else { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % p.plan.total; n = lb / p.plan.total; }       // (tuning builds: the old order, A/B)
     }
     int y0, x0, th, tw, end_y, end_x;
     up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
@@ -425,6 +427,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     p.tiles_m = d->O / 32;
     p.xbs = (int64_t)(d->I / 8) * d->H * d->W; p.wbs = wbs; p.ybs = (int64_t)(d->O / 8) * p.OH * p.OW;
     p.dbg = dbg;
+    p.thin_last = n3d_tune("N3D_UP_THIN_LAST", 1);
     const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_f16: grid too large");
     const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->N * d->O * d->I * 9);

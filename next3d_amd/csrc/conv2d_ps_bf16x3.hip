@@ -359,6 +359,9 @@ struct ConvUpPsParams {
     int64_t xbs, ybs, yrs;       // xbs: 16-byte units; ybs floats; yrs pixels (c8 row pitch)
     const float* row_scale; int64_t row_scale_stride; float const_scale;
     int round_f16;
+    int y_nchw;                  // y is float32 NCHW (row pitch yrs floats) instead of c8: the few-position layers (4 x 4 .. 32 x 32 inputs), whose
+                                 // FIR reads NCHW — 4-byte stores, irrelevant next to these layers' launch latency
+    int thin_last;               // thin edge tiles at the end of the launch order (always, except N3D_UP_THIN_LAST=0 in tuning builds)
     int dbg;                     // N3D_CONV_DBG ablation bits (tuning only, wrong results): 1 skip stores, 4 skip the DMA of chunks > 0
 };
 
@@ -395,9 +398,10 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     int m0, tile_i, n;
     {
         const int main_per = p.plan.tiles_x * p.plan.tiles_y, thin_per = p.plan.total - main_per;
-        const int main_total = main_per * p.tiles_m * p.N;
+        const int main_total = p.thin_last ? main_per * p.tiles_m * p.N : 0;
         if (lb < main_total) { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % main_per; n = lb / main_per; }
-        else { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+        else if (p.thin_last) { lb -= main_total; m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = main_per + lb % thin_per; n = lb / thin_per; }
+        else { m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m; tile_i = lb % p.plan.total; n = lb / p.plan.total; }       // (tuning builds: the old order, A/B)
     }
     int y0, x0, th, tw, end_y, end_x;
     up_tile_decode(p.plan, tile_i, y0, x0, th, tw, end_y, end_x);
@@ -526,6 +530,12 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
                     for (int gg = 0; gg < 4; ++gg) {
                         const int c8 = (m0 >> 3) + mt * 4 + gg, ol = mt * 32 + 8 * gg + 4 * half;
                         const f32x16& a = acc[mt][g][pa * 2 + pb];
+                        if (p.y_nchw) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                yb[((int64_t)(m0 + ol + k) * p.OH + oy) * p.yrs + ox] = n3d_round16(a[4 * gg + k] * s_rs[ol + k], p.round_f16);
+                            continue;
+                        }
                         const f32x4 v = {n3d_round16(a[4 * gg + 0] * s_rs[ol + 0], p.round_f16), n3d_round16(a[4 * gg + 1] * s_rs[ol + 1], p.round_f16),
                                          n3d_round16(a[4 * gg + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * gg + 3] * s_rs[ol + 3], p.round_f16)};
                         *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
@@ -541,7 +551,8 @@ __global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsP
 }
 
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
-    N3D_CHECK(d->ksize == 3 && d->mode == 2 && d->y_layout == N3D_LAYOUT_C8_F32, "conv2d_bf16x3: a split8 input to the transposed kernel needs the c8 output layout");
+    const bool nchw = d->y_layout == N3D_LAYOUT_NCHW_F32;
+    N3D_CHECK(d->ksize == 3 && d->mode == 2 && (d->y_layout == N3D_LAYOUT_C8_F32 || nchw), "conv2d_bf16x3: a split8 input to the transposed kernel: c8 or float32 NCHW output");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_bf16x3: a split8 input carries its modulation already (style must be NULL), no split-K");
     N3D_CHECK(d->I % 16 == 0 && d->O % 64 == 0 && d->H >= 4 && d->W >= 4, "conv2d_bf16x3 (split8, transposed): I %% 16 == 0, O %% 64 == 0");
     // 32-channel workgroups, two per CU: measured 4-22 % faster than 64-channel ones on every transposed layer of the benchmark
@@ -550,7 +561,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const n3d_epilogue& E = d->epi;
     N3D_CHECK(E.act == N3D_ACT_LINEAR && !E.noise && !E.bias && !E.residual && E.clamp < 0.f && E.gain == 1.f,
               "conv2d_bf16x3: the channel-interleaved output takes the demodulation-only epilogue (the layer epilogue runs behind the FIR)");
-    N3D_CHECK(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->y & 15) == 0 && d->x_batch_stride % 4 == 0 && (d->y_batch_stride & 3) == 0, "conv2d_bf16x3: misaligned split8 / c8 tensor");
+    N3D_CHECK(((uintptr_t)d->x & 15) == 0 && d->x_batch_stride % 4 == 0 && (nchw || (((uintptr_t)d->y & 15) == 0 && (d->y_batch_stride & 3) == 0)), "conv2d_bf16x3: misaligned split8 / c8 tensor");
     ConvUpPsParams p;
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
@@ -562,7 +573,9 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.row_scale = E.row_scale; p.row_scale_stride = E.row_scale_stride ? E.row_scale_stride : d->O; p.const_scale = E.const_scale;
     p.round_f16 = E.round_f16;
+    p.y_nchw = nchw ? 1 : 0;
     p.dbg = n3d_tune("N3D_CONV_DBG", 0);
+    p.thin_last = n3d_tune("N3D_UP_THIN_LAST", 1);
     const int64_t nblk = (int64_t)p.plan.total * p.tiles_m * p.N;
     N3D_CHECK(nblk < (1ll << 31) && nblk > 0, "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;

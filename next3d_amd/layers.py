@@ -38,6 +38,7 @@ S2_PRESPLIT = True         # stride-2 encoder layers on split8 input
 UP_PRESPLIT = True         # the transposed convolution's input (a block output with two consumers) converted once, LDS-DMA staging
 TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
+UP_PS_NCHW = True          # few-position up-sampling layers on the pre-split transposed kernel writing NCHW (networks._Block._ps_nchw)
 NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)
 CONVERT_MAX_BYTES = int(70e6)     # see _conv3x3
 
@@ -185,7 +186,7 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, x_split8=None, split_for_nchw=None):
+                    split_for=None, x_split8=None, split_for_nchw=None, ps_nchw=False):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
@@ -223,8 +224,12 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
             t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=zepi, bf16x3=True, out_c8=True)
         return uf._fir4_split8(t, fir, 4, _lib.make_epilogue(**act), split_for)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2):
-        t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,
-                           row_pitch=True)
+        if ps_nchw:     # the pre-split transposed kernel writing float32 NCHW (same products as the register-staged kernel, no split-K reduction pass)
+            xs = x_split8 if x_split8 is not None else cg.split8_from_nchw(x, styles)
+            t = cg.conv_launch(xs, L.wt16, 3, 2, L.out_channels, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True, row_pitch=True)
+        else:
+            t = cg.conv_launch(x, L.wt16, 3, 2, L.out_channels, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef), bf16x3=True,
+                               row_pitch=True)
         if split_for_nchw is not None:
             return uf._fir4_split8_nchw(t, fir, 1, gain=4, epilogue=_lib.make_epilogue(**act), out_scale=split_for_nchw)
     else:

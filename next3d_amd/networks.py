@@ -33,16 +33,27 @@ class _Block:
         out.append((self.torgb, k, 'torgb'))
         return out
 
-    def _presplit(self, n, xshape, fir, noise_mode):
-        """conv0's FIR epilogue may hand its output to conv1 pre-split, with conv1's styles multiplied in (layers.presplit_ok)."""
+    def _ps_base(self, xshape, fir, noise_mode):
         return (self.conv0 is not None and noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and self.conv0.out_channels % 64 == 0 and
-                self.conv0.wt16 is not None and L.cg.bf16x3_eligible(xshape[1], xshape[2], xshape[3], 3, 2) and
-                L.cg.pick_ksplit_bf16x3(n, xshape[1], self.conv0.out_channels, xshape[2], xshape[3], 2) == 1 and
+                self.conv0.wt16 is not None and L.PRECISION == 'bf16x3' and L.cg.bf16x3_eligible(xshape[1], xshape[2], xshape[3], 3, 2))
+
+    def _presplit(self, n, xshape, fir, noise_mode):
+        """conv0 on the pre-split transposed kernel (c8 result) and its FIR handing the output to conv1 pre-split, with conv1's styles
+        multiplied in (layers.presplit_ok).  Layers the register-staged kernel would run with split-K take this route from 64 x 64
+        up (measured at batch 1, 64 x 64: 84 us against 46 + a 12 us conversion, tools/ps_splitk_bench.py)."""
+        return (self._ps_base(xshape, fir, noise_mode) and
+                (L.cg.pick_ksplit_bf16x3(n, xshape[1], self.conv0.out_channels, xshape[2], xshape[3], 2) == 1 or xshape[2] * xshape[3] >= 4096) and
                 L.presplit_ok(n, self.conv1, 2 * xshape[2], 2 * xshape[3]))
+
+    def _ps_nchw(self, n, xshape, fir, noise_mode):
+        """conv0 on the pre-split transposed kernel writing float32 NCHW: the few-position layers (conv1 not a pre-split layer) with at
+        least 1024 positions in the batch — 16 x 16 at batch 4: 43 us against 58 for the register-staged kernel + split-K reduction."""
+        return bool(L.UP_PRESPLIT and L.UP_PS_NCHW and xshape[1] % 16 == 0 and self._ps_base(xshape, fir, noise_mode) and
+                    not self._presplit(n, xshape, fir, noise_mode) and n * xshape[2] * xshape[3] >= 1024)
 
     def takes_split8(self, n, xshape, fir, noise_mode):
         """Does conv0 read its [n, I, h, w] input in the split8 layout (layers.synthesis_layer, the transposed pre-split kernel)?"""
-        return bool(L.UP_PRESPLIT and xshape[1] % 16 == 0 and self._presplit(n, xshape, fir, noise_mode))
+        return bool(L.UP_PRESPLIT and xshape[1] % 16 == 0 and self._presplit(n, xshape, fir, noise_mode)) or self._ps_nchw(n, xshape, fir, noise_mode)
 
     def __call__(self, x, img, bank, n, fir, noise_mode, x_out=None, x_split8=None, next_block=None):
         """SynthesisBlock.forward (float32 block); `bank` = StyleBank.compute(ws) result.  -> (x, img, xs): `next_block` = the block
@@ -58,9 +69,10 @@ class _Block:
             pre_nchw = (not pre and L.NCHW_FIR_SPLIT8 and noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and
                         self.conv0.out_channels % 8 == 0 and L.PRECISION == 'bf16x3' and self.conv0.wt16 is not None and
                         L.cg.bf16x3_eligible(x.shape[1], x.shape[2], x.shape[3], 3, 2) and L.presplit_ok(n, self.conv1, 2 * x.shape[2], 2 * x.shape[3]))
+            psn = self._ps_nchw(n, x.shape, fir, noise_mode)
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
-                                  split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if pre else None,
-                                  split_for_nchw=bank[self.conv1.prefix][0] if pre_nchw else None, **sl(self.conv0))
+                                  split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if (pre or psn) else None,
+                                  split_for_nchw=bank[self.conv1.prefix][0] if pre_nchw else None, ps_nchw=psn, **sl(self.conv0))
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image update img = upsample2d(img) + toRGB(x): upsample2d is evaluated inside the toRGB epilogue (4 taps of the
         # half-resolution image per pixel)

@@ -150,8 +150,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
-        if not (bf16x3 and ksize == 3 and (mode in (0, 1) or (mode == 2 and out_c8)) and style is None):
-            raise RuntimeError('conv2d: a split8 input goes to the 3x3 stride-1 / stride-2 (or transposed, c8 output) split-bf16 kernel, without a style')
+        if not (bf16x3 and ksize == 3 and mode in (0, 1, 2) and style is None):
+            raise RuntimeError('conv2d: a split8 input goes to the 3x3 split-bf16 kernels (stride 1, stride 2, transposed), without a style')
         n, i, h, w = x.shape
         xs = x
         x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only

@@ -376,11 +376,16 @@ def test_fused_layout_handovers_are_bit_identical_to_conversion_passes(G, dev, m
     for on in (True, False):
         monkeypatch.setattr(layers, 'TORGB_SIDE', on)
         monkeypatch.setattr(layers, 'DIRECT_SPLIT8', on)
-        monkeypatch.setattr(layers, 'NCHW_FIR_SPLIT8', on)      # (the small up-sampling layers' FIR writing split8 for conv1 — at batch 4: 16 -> 32)
         o = G.synthesis(ws, t('c'), t('v'), **kw)
         outs[on] = {k: o[k].clone() for k in ('image', 'image_raw', 'image_depth')}
     for k in outs[True]:
         assert torch.equal(outs[True][k], outs[False][k]), (k, _md(outs[True][k], outs[False][k]))
+    # the small up-sampling layers' FIR writing split8 itself (layers.NCHW_FIR_SPLIT8; at batch 4: the 16 -> 32 layers) is not a pure layout
+    # change — that kernel sums the separable filter's taps in another order than the float32 FIR kernel — so: equal to float32 rounding
+    monkeypatch.setattr(layers, 'NCHW_FIR_SPLIT8', False)
+    o = G.synthesis(ws, t('c'), t('v'), **kw)
+    for k in outs[True]:
+        assert _md(outs[True][k], o[k]) <= 2e-5, (k, _md(outs[True][k], o[k]))
 
 
 @pytest.mark.gpu
