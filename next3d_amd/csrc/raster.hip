@@ -184,6 +184,20 @@ __device__ __forceinline__ float bilinear_apply(const BilinearTaps& t, const flo
     return acc;
 }
 
+// The texture projection gathers single floats through per-lane addresses — the access class whose vector-L1-served form returned wrong
+// values in the rasteriser's kernels while 8-wave MFMA workgroups shared the CU.  TEXPROJ_AGENT = 1 (default): the same
+// agent-scope loads here, so that this kernel, too, is safe by construction and not only by soak test (A/B: tools/build_variant.sh
+// noagent raster.hip -DTEXPROJ_AGENT=0 -ffp-contract=off; profiles/r04_texproj_agent_ab.txt).
+#ifndef TEXPROJ_AGENT
+#define TEXPROJ_AGENT 1
+#endif
+__device__ __forceinline__ float bilinear_apply_tex(const BilinearTaps& t, const float* img) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (t.ok[k]) acc += (TEXPROJ_AGENT ? ld_agent(img + t.off[k]) : img[t.off[k]]) * t.w[k];
+    return acc;
+}
+
 // per pixel: uv = sum_k bary_k * face_uv[f][k], vis; alpha = grid_sample(uv_face_mask, uv) * vis   (renderer.py:425-437,
 // triplane_next3d.py:211-214).  grid [NV,H,W,2], alpha [NV,H,W]
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* tv, const int* __restrict__ faces,
@@ -365,8 +379,8 @@ __global__ __launch_bounds__(256) void texture_project_kernel(const float* __res
     BilinearTaps ta = bilinear_setup(TH, TW, ua, va), tb = bilinear_setup(TH, TW, ub, vb);
     for (int c = 0; c < C; ++c) {
         const float* tc = tn + (int64_t)c * TH * TW;
-        float v = bilinear_apply(ta, tc);
-        if (view_b >= 0) v = v + bilinear_apply(tb, tc);
+        float v = bilinear_apply_tex(ta, tc);
+        if (view_b >= 0) v = v + bilinear_apply_tex(tb, tc);
         on[(int64_t)c * H * W] = v;
     }
 }
