@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries (N = 1 on
   config3        gen_videos_next3d.py's 2x2-grid, 120-frame camera orbit over a fixed mesh (BASELINE.json configs[2])
   sr_fp16_mode   the same K steps with the reference's default float16 super-resolution blocks (no force_fp32): frames/s, speed-up over
                  the float32 route, `roofline_f16` (the f16 3x3 kernels against the 2.5 PFLOP/s dense f16 peak)
+  fp16_backbones_mode  the generator as legacy.load_network_pkl(force_fp16=True) builds it (float16 blocks in the four backbones as well)
   config1        BASELINE.json configs[0]'s shape as a latency figure (batch 1), eager launches vs HIP-graph replay
   config1b       the scripts' true call pattern (gen_samples / gen_videos call G.synthesis one frame at a time): batch 1 at the metric's
                  512² / 64² / 48+48 — single-frame latency eager and from a HIP graph, and frames/s with requests pipelined over the lanes
@@ -198,7 +199,7 @@ def main():
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
     for s_ in lanes:
         s_.wait_stream(torch.cuda.current_stream())
-    counter, one_lane, sr_fp32 = [0], [False], [not args.sr_fp16]
+    counter, one_lane, sr_fp32, gen = [0], [False], [not args.sr_fp16], [G]
 
     def step():
         if args.serial_gather:
@@ -206,9 +207,9 @@ def main():
         lane = lanes[counter[0] % (1 if one_lane[0] else len(lanes))]
         counter[0] += 1
         with torch.cuda.stream(lane):
-            ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-            img = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
-                              force_fp32=sr_fp32[0])['image']              # the fp32 path (the one the goldens pin)
+            ws = gen[0].mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+            img = gen[0].synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
+                                   force_fp32=sr_fp32[0])['image']              # the fp32 path (the one the goldens pin)
             frames = to_frames(img)
             gatherer.submit(frames)      # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
@@ -354,6 +355,25 @@ def main():
                                                    'avg_launch_ms': f16['ms'] / max(f16['launches'], 1),
                                                    'algorithmic_bytes_per_launch': f16['bytes'] / max(f16['launches'], 1)},
                                   'family_ms_per_step': {k: round(pv['ms'] / k16, 4) for k, pv in p16.items()}}
+        # ---- legacy.load_network_pkl(force_fp16=True) (legacy.py:49-59): num_fp16_res = 4, conv_clamp = 256 in all four backbones too —
+        # every block of resolution >= 32 of the five networks runs as a float16 block on the f16 matrix cores
+        G16, _ = demo.build_generator(dev, force_fp16=True)
+        gen[0] = G16
+        step(); step(); torch.cuda.synchronize()
+        tbb = timed(step, k16)
+        pbb = conv_profile(k16)
+        fbb = pbb['conv2d_f16']
+        abb = fbb['flops'] / (fbb['ms'] * 1e-3) / 1e12 if fbb['ms'] > 0 else 0.0
+        extras['fp16_backbones_mode'] = {'value': k16 * B / tbb, 'unit': 'frames/s', 'ms_per_step': 1e3 * tbb / k16, 'steps': k16,
+                                         'speedup_vs_fp32_route': (k16 * B / tbb) / (frames_total / elapsed_total),
+                                         'note': 'the generator as legacy.load_network_pkl(force_fp16=True) builds it (num_fp16_res = 4, conv_clamp = 256 in the four '
+                                                 'backbones, float16 super-resolution blocks): every block of resolution >= 32 on v_mfma_f32_32x32x16_f16',
+                                         'roofline_f16': {'bound': 'mfma', 'achieved': abb, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': abb / PEAK_BF16_MFMA_TFLOPS,
+                                                          'launches_per_step': fbb['launches'] / k16, 'algorithmic_gflop_per_step': fbb['flops'] / k16 / 1e9,
+                                                          'avg_launch_ms': fbb['ms'] / max(fbb['launches'], 1)},
+                                         'family_ms_per_step': {k: round(pv['ms'] / k16, 4) for k, pv in pbb.items()}}
+        gen[0] = G
+        del G16
         sr_fp32[0] = True
         step(); torch.cuda.synchronize()
         # ---- configs[2]: 2x2 grid (batch 4 = one video frame), 120-frame orbit, fixed mesh (gen_videos_next3d.py:126-158)

@@ -50,7 +50,9 @@ def demo_arrays():
     return np.load(DEMO_NPZ)
 
 
-def build_generator(device, seed=0, rendering_kwargs=None):
+def build_generator(device, seed=0, rendering_kwargs=None, force_fp16=False):
+    """force_fp16: the generator as legacy.load_network_pkl(force_fp16=True) rebuilds it (legacy.py:49-59): num_fp16_res = 4 and
+    conv_clamp = 256 in all four backbones."""
     from .generator import TriPlaneGenerator
     d = demo_arrays()
     topo = (d['faces'], d['uvs'], d['uvfaces'])
@@ -58,7 +60,7 @@ def build_generator(device, seed=0, rendering_kwargs=None):
                           rendering_kwargs=dict(rendering_kwargs or RENDERING_KWARGS),
                           sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
                           uv_face_mask=mesh.synthetic_uv_face_mask(), channel_base=32768, channel_max=512,
-                          fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None)
+                          fused_modconv_default='inference_only', num_fp16_res=4 if force_fp16 else 0, conv_clamp=256 if force_fp16 else None)
     sd = spec.synthetic_state_dict(seed)
     sd.update(mesh.mesh_buffers(*topo))
     G.load_state_dict(sd, strict=True)
