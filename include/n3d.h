@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 5
+#define N3D_ABI_VERSION 6
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -206,6 +206,17 @@ typedef struct {
                                   n3d_conv2d_prep_weight_grouped.  Taken by n3d_conv2d (modes 0 / 2) and by n3d_conv2d_bf16x3's stride-1
                                   (NCHW or split8 input), transposed (NCHW) and 1x1 kernels; n3d_conv2d_f16's weights are per-sample by
                                   construction (this field is ignored there) */
+    /* ---- ABI 6: toRGB fused into the LAST 3x3 layer of a network (SynthesisBlock.forward, tat/networks_stylegan2.py:575-584: the last block's
+     *      x has ONE reader, its ToRGBLayer :353-357).  n3d_conv2d_bf16x3, ksize 3 / mode 0 / split8 input, no split-K: the kernel applies the
+     *      layer epilogue to its tile and multiplies it, in float32, with rgb_weight [rgb_channels][O] (the toRGB layer's 1x1 weights) times
+     *      rgb_style [N][O] (its styles, weight_gain included) — the partial colours of each 64-channel workgroup go to
+     *      rgb_partial [N][ceil(O/64)][rgb_channels][H][W]; n3d_rgb_combine sums them and applies toRGB's own epilogue (bias, clamp, the skip image).
+     *      y may then be NULL: the feature map itself (537 MB per step for the 512 x 512 layer at batch 4) is neither written nor read back. */
+    const float* rgb_weight;   /* NULL (with rgb_partial NULL) = off */
+    const float* rgb_style;
+    float* rgb_partial;
+    int rgb_channels;          /* 1 .. 4 */
+    int64_t rgb_style_stride;  /* floats between samples of rgb_style (0 = O) */
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 
@@ -230,6 +241,10 @@ int n3d_conv2d_prep_weight_grouped(const void* w, int w_dtype, void* wt, int wt_
  *      Requires I % 16 == 0.  Same reference call sites as n3d_conv2d. */
 int n3d_conv2d_prep_weight_bf16x3(const float* w, void* wt16, int O, int I, int ksize, n3d_stream_t stream);
 int n3d_conv2d_bf16x3(const n3d_conv2d_desc* desc, n3d_stream_t stream);
+/* y[n][c][h][w] = epilogue(sum_m partial[n][m][c][h][w]) — the second half of the fused toRGB above: `epi` is the toRGB layer's epilogue
+ * (bias [C], clamp, residual = the skip image, with residual_up_filter the PREVIOUS block's half-resolution image, :580-584).  The M partial
+ * images are added in index order: bitwise reproducible. */
+int n3d_rgb_combine(const float* partial, float* y, int N, int M, int C, int H, int W, const n3d_epilogue* epi, n3d_stream_t stream);
 /* Number of workgroups n3d_conv2d_bf16x3 launches for this shape at ksplit = 1 (its tile plan): the host picks a split-K
  * factor from it so that small layers still cover the 256 CUs. */
 int n3d_conv2d_bf16x3_blocks(int N, int O, int H, int W, int mode);

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -35,7 +35,8 @@ class Conv2dDesc(ctypes.Structure):
                 ('ksize', c_int), ('mode', c_int), ('ksplit', c_int),
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
                 ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int),
-                ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64), ('wt_batch_stride', c_int64)]
+                ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64), ('wt_batch_stride', c_int64),
+                ('rgb_weight', c_void_p), ('rgb_style', c_void_p), ('rgb_partial', c_void_p), ('rgb_channels', c_int), ('rgb_style_stride', c_int64)]
 
 
 class RenderOpts(ctypes.Structure):
@@ -61,6 +62,7 @@ _SIGNATURES = {
     'n3d_prof_reset': (c_int, []),
     'n3d_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_double),
                               ctypes.POINTER(c_double)]),
+    'n3d_rgb_combine': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(Epilogue), c_void_p]),
     'n3d_bias_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float,
                              c_float, c_void_p]),
     'n3d_upfirdn2d': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 15 + [c_float, c_int64, c_int64,

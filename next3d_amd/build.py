@@ -54,7 +54,11 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in _sources()]
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs)
+        run([HIPCC, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-Wl,--no-undefined', '-o', LIB] + objs)
+        # a library that links but cannot be loaded (hipcc's host pass silently drops the launch stub of some __global__ templates:
+        # an undefined __device_stub__ symbol) must fail HERE, on the build machine, not on the GPU box
+        import ctypes
+        ctypes.CDLL(LIB)
     return LIB
 
 

@@ -577,6 +577,7 @@ extern "C" int n3d_conv2d(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d: unknown activation %d", d->epi.act);
     N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d: noise without noise_strength");
     if (d->N == 0) return 0;
+    N3D_CHECK(!d->rgb_partial, "conv2d: the fused toRGB (rgb_partial) is an option of n3d_conv2d_bf16x3");
     N3D_CHECK(d->x && d->wt && d->y, "conv2d: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d: wt must be 16-byte aligned");
     ConvParams p;

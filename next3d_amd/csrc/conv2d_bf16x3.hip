@@ -778,7 +778,8 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     N3D_CHECK(d->epi.act >= N3D_ACT_LINEAR && d->epi.act <= N3D_ACT_SWISH, "conv2d_bf16x3: unknown activation %d", d->epi.act);
     N3D_CHECK(d->epi.noise == nullptr || d->epi.noise_strength != nullptr, "conv2d_bf16x3: noise without noise_strength");
     if (d->N == 0) return 0;
-    N3D_CHECK(d->x && d->wt && d->y, "conv2d_bf16x3: null tensor");
+    N3D_CHECK(!d->rgb_partial || (d->x_layout == N3D_LAYOUT_SPLIT8 && d->ksize == 3 && d->mode == 0), "conv2d_bf16x3: the fused toRGB (rgb_partial) is an option of the 3x3 stride-1 kernel on split8 input");
+    N3D_CHECK(d->x && d->wt && (d->y || d->rgb_partial), "conv2d_bf16x3: null tensor");
     N3D_CHECK(((uintptr_t)d->wt & 15) == 0, "conv2d_bf16x3: wt must be 16-byte aligned");
     N3D_CHECK(d->x_row_stride == 0 || d->x_row_stride == d->W || (d->ksize == 3 && d->mode == 1), "conv2d_bf16x3: only the stride-2 kernel takes a pitched input");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_NCHW_F32 || d->x_layout == N3D_LAYOUT_SPLIT8, "conv2d_bf16x3: unknown x_layout %d", d->x_layout);

@@ -26,13 +26,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int F_BM = 64, F_TH = 16, F_TW = 32, F_TAPS = 9;
-constexpr int F_PH = F_TH + 2, F_PW = F_TW + 2, F_PPIX = F_PH * F_PW;                // 18 x 34 = 612 patch pixels
-constexpr int F_BCH = (F_PPIX + 63) / 64, F_BPAD = F_BCH * 64;                        // 10 DMA pieces = 640 slots per k half
-constexpr int F_A_SZ = F_TAPS * 2 * F_BM;                                             // 16-byte slots: [tap][k half][row]      (1152)
-constexpr int F_B_SZ = 2 * F_BPAD;                                                    //                [k half][patch pixel]   (1280)
-constexpr int F_A_PIECES = F_TAPS * 2, F_B_PIECES = 2 * F_BCH;                        // 18 + 20 pieces of 1 KB per chunk
-constexpr int F_BUF = F_A_SZ + F_B_SZ;                                                // 2432 slots = 38,912 B per buffer
+constexpr int F_TW = 32, F_TAPS = 9;
+// Tile shapes of the stride-1 kernel: a workgroup (8 waves) owns MT 32-channel groups x (8 NT rows x 32 pixels); every wave multiplies ALL
+// MT channel groups with its own NT rows, i.e. MT + NT fragment reads per MT * NT MFMAs and tap:
+//   <2, 2>  64 channels x 16 x 32 pixels   1.00 ds_read_b128 per MFMA — at the matrix pipe's data-sheet rate that is the whole LDS bandwidth
+//                                           of a CU (8 waves x 4 KB per 4 MFMAs of 32 cycles on each SIMD = 128 B/clk): the small-grid form;
+//   <2, 4>  64 channels x 32 x 32 pixels   0.75 — 0.5 with the row reuse of f16_mfma_chunk (round 4: long-K layers on grids that fill the chip)
+//   (<4, 2>, 128 channels x 16 x 32 pixels, 0.75: measured, not faster, not instantiated)
+template <int MT, int NT> struct F16Tile {
+    static constexpr int BM = 32 * MT, TH = 8 * NT;
+    static constexpr int PH = TH + 2, PW = F_TW + 2, PPIX = PH * PW;                     // patch with halo
+    static constexpr int BCH = (PPIX + 63) / 64, BPAD = BCH * 64;                         // DMA pieces (64 slots) per k half
+    static constexpr int A_SZ = F_TAPS * 2 * BM;                                          // 16-byte slots: [tap][k half][row]
+    static constexpr int B_SZ = 2 * BPAD;                                                 //                [k half][patch pixel]
+    static constexpr int A_PIECES = F_TAPS * 2 * (BM / 64), B_PIECES = 2 * BCH;           // pieces of 1 KB per chunk
+    static constexpr int BUF = A_SZ + B_SZ;                                               // <2,2>: 38,912 B; <4,2> and <2,4>: 57,344 B per buffer
+};
 
 struct ConvF16Params {
     const f16x8* x; const f16x8* w; f16x8* y;
@@ -66,11 +75,77 @@ __device__ __forceinline__ _Float16 f16_layer_epilogue(float acc, float nz, bool
     return (_Float16)__builtin_amdgcn_fmed3f(t, -clamp, clamp);
 }
 
+// One 16-channel chunk of a wave's MT x NT accumulator tiles from the staged weights A [tap][k half][row] and patch B [k half][patch pixel].
+// Every accumulator sums its taps in the order kx-major, ky-minor in BOTH loop forms, so the tile shapes are bit-identical.
+//   plain (MT > 2): per tap MT + NT fragment reads for MT * NT MFMAs;
+//   row reuse (MT <= 2): the B fragment of patch row pr and column offset kx serves the taps ky = 0..2 of the rows nt = pr - ky — it is read
+//   ONCE: per kx 3 MT + NT + 2 reads for 3 MT NT MFMAs (<2,4>: 0.5 ds_read_b128 per MFMA, <2,2>: 0.83).
+template <int MT, int NT>
+__device__ __forceinline__ void f16_mfma_chunk(const f16x8* A, const f16x8* B, int a_frag, int b_frag0, f32x16 (&acc)[MT][NT]) {
+    constexpr int BM = F16Tile<MT, NT>::BM, PW = F16Tile<MT, NT>::PW;
+    if constexpr (MT <= 2) {
+        f16x8 a[2][3][MT], b[2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[0][ky][mt] = A[(ky * 3) * 2 * BM + a_frag + mt * 32];
+        b[0] = B[b_frag0];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if (kx + 1 < 3) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[(kx + 1) & 1][ky][mt] = A[(ky * 3 + kx + 1) * 2 * BM + a_frag + mt * 32];
+            }
+#pragma unroll
+            for (int pr = 0; pr < NT + 2; ++pr) {
+                const int c = kx * (NT + 2) + pr;                         // running fragment counter (compile time after unrolling)
+                if (pr + 1 < NT + 2) b[(c + 1) & 1] = B[b_frag0 + (pr + 1) * PW + kx];
+                else if (kx + 1 < 3) b[(c + 1) & 1] = B[b_frag0 + kx + 1];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int nt = pr - ky;
+                    if (nt >= 0 && nt < NT) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)                    // weights = matrix rows: D[channel row][pixel column]
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kx & 1][ky][mt], b[c & 1], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        f16x8 a[2][MT], b[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = A[a_frag + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[0][nt] = B[b_frag0 + nt * PW];
+#pragma unroll
+        for (int tt = 0; tt < F_TAPS; ++tt) {                             // tt = kx * 3 + ky
+            const int s = tt & 1;
+            if (tt + 1 < F_TAPS) {
+                const int ky = (tt + 1) % 3, kx = (tt + 1) / 3, t = ky * 3 + kx;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[s ^ 1][mt] = A[t * 2 * BM + a_frag + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[s ^ 1][nt] = B[b_frag0 + (nt + ky) * PW + kx];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][mt], b[s][nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
 // NBUF = 2: one workgroup per CU, the next chunk's DMA under this chunk's MFMAs; NBUF = 1: two workgroups per CU with one buffer
 // each (the other workgroup's MFMAs fill this one's DMA waits and its tile stores) — see conv2d_ps_bf16x3_kernel.
-template <int NBUF>
-__global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(ConvF16Params p) {
-    __shared__ f16x8 smem[NBUF * F_BUF + F_BM * 4 / 16];
+template <int MT, int NT, int NBUF>
+__device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8* smem) {
+    using T = F16Tile<MT, NT>;
+    constexpr int F_BM = T::BM, F_TH = T::TH, F_PW = T::PW, F_PPIX = T::PPIX, F_BCH = T::BCH, F_BPAD = T::BPAD, F_A_SZ = T::A_SZ, F_A_PIECES = T::A_PIECES,
+                  F_B_PIECES = T::B_PIECES, F_BUF = T::BUF;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     int lb;
@@ -86,15 +161,15 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(C
     const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)n * p.wbs), 0, F_TAPS * KC * 2 * p.O * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.xbs), 0, (p.I / 8) * HW * 16, 0x00020000);
 
-    // this wave's copy pieces: weights pa = wn + 8 j = (tap, k half) slabs of 64 rows; patch q = wn + 8 j = (k half, 64-pixel run)
-    constexpr int NA = (F_A_PIECES + 7) / 8, NB = (F_B_PIECES + 7) / 8;      // 3, 3
-    int ldsA[NA], sofA[NA], ldsB[NB], sofB[NB], voffB[NB];
-    const int voffA = (m0 + lane) * 16;
+    // this wave's copy pieces: weights pa = wn + 8 j = (tap, k half, 64-row group) slabs; patch q = wn + 8 j = (k half, 64-pixel run)
+    constexpr int NA = (F_A_PIECES + 7) / 8, NB = (F_B_PIECES + 7) / 8, RG = F_BM / 64;
+    int ldsA[NA], sofA[NA], voffA[NA], ldsB[NB], sofB[NB], voffB[NB];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int pa = min(wn + 8 * j, F_A_PIECES - 1), t = pa >> 1, hf = pa & 1;
-        ldsA[j] = (t * 2 + hf) * F_BM;
+        const int pa = min(wn + 8 * j, F_A_PIECES - 1), rg = pa % RG, t = (pa / RG) >> 1, hf = (pa / RG) & 1;
+        ldsA[j] = (t * 2 + hf) * F_BM + rg * 64;
         sofA[j] = ((t * KC) * 2 + hf) * p.O * 16;
+        voffA[j] = (m0 + rg * 64 + lane) * 16;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -112,44 +187,26 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(C
 #pragma unroll
         for (int j = 0; j < NA; ++j)
             if (wn + 8 * j < F_A_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA, sofA[j] + kc * strideA, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + ldsA[j]), 16, voffA[j], sofA[j] + kc * strideA, 0, 0);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             if (wn + 8 * j < F_B_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + kc * strideB, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const int a_frag = half * F_BM + l31;                                 // + tap*2*BM + mt*32
-    const int b_frag0 = half * F_BPAD + (wn * 2) * F_PW + l31;            // + ky*PW + kx (+ PW for the wave's second row)
+    const int b_frag0 = half * F_BPAD + (wn * NT) * F_PW + l31;           // + ky*PW + kx (+ nt*PW for the wave's further rows)
     auto mfma_block = [&](int buf) {
-        const f16x8* A = smem + buf * F_BUF, *B = A + F_A_SZ;
+        const f16x8* A = smem + buf * F_BUF;
         __builtin_amdgcn_s_setprio(1);
-        f16x8 a[2][2], b[2][2];
-        auto fetch = [&](int t, int s) {
-            const int boff = (t / 3) * F_PW + (t % 3);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[s][mt] = A[t * 2 * F_BM + a_frag + mt * 32];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) b[s][nt] = B[b_frag0 + nt * F_PW + boff];
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int t = 0; t < F_TAPS; ++t) {
-            const int s = t & 1;
-            if (t + 1 < F_TAPS) fetch(t + 1, s ^ 1);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)      // weights = matrix rows: D[channel row][pixel column]
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][mt], b[s][nt], acc[mt][nt], 0, 0, 0);
-        }
+        f16_mfma_chunk<MT, NT>(A, A + F_A_SZ, a_frag, b_frag0, acc);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -185,12 +242,12 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(C
     if (ox >= p.W) return;
     _Float16* yb = reinterpret_cast<_Float16*>(p.y + (int64_t)n * p.ybs);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int oy = y0 + wn * 2 + nt;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = y0 + wn * NT + nt;
         if (oy >= p.H) continue;
         const float nz = p.noise ? p.noise[(int64_t)oy * p.W + ox] * nstr : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 const int ol = mt * 32 + 8 * gg + 4 * half;
@@ -202,6 +259,21 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_h8_f16_kernel(C
                 *reinterpret_cast<f16x4*>(yb + unit * 8 + 4 * half) = out;
             }
     }
+}
+
+// (concrete kernels around the body template: hipcc's host pass does not emit the launch stub of a __global__ TEMPLATE with this body)
+template <int MT, int NT, int NBUF> constexpr int f16_smem_slots() { return NBUF * F16Tile<MT, NT>::BUF + F16Tile<MT, NT>::BM * 4 / 16; }
+__global__ __launch_bounds__(512, 2) void conv2d_h8_f16_kernel(ConvF16Params p) {             // <2,2>, two buffers
+    __shared__ f16x8 smem[f16_smem_slots<2, 2, 2>()];
+    conv2d_h8_f16_body<2, 2, 2>(p, smem);
+}
+__global__ __launch_bounds__(512, 4) void conv2d_h8_f16_nbuf1_kernel(ConvF16Params p) {       // <2,2>, one buffer, two workgroups per CU (tuning builds)
+    __shared__ f16x8 smem[f16_smem_slots<2, 2, 1>()];
+    conv2d_h8_f16_body<2, 2, 1>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_h8_f16_r32_kernel(ConvF16Params p) {         // <2,4>: 64 channels x 32 x 32 pixels
+    __shared__ f16x8 smem[f16_smem_slots<2, 4, 2>()];
+    conv2d_h8_f16_body<2, 4, 2>(p, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -382,7 +454,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d && d->ksize == 3 && (d->mode == 0 || d->mode == 2), "conv2d_f16: 3x3, stride 1 (mode 0) or transposed stride 2 (mode 2)");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_H8_F16 && d->y_layout == N3D_LAYOUT_H8_F16, "conv2d_f16: input and output in the h8 layout (N3D_LAYOUT_H8_F16)");
-    N3D_CHECK(!d->side_split8, "conv2d_f16: no side output");
+    N3D_CHECK(!d->side_split8 && !d->rgb_partial, "conv2d_f16: no side output / fused toRGB");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_f16: the modulation is part of the per-sample weights (n3d_modulate_weights_f16); no split-K");
     N3D_CHECK(d->N >= 0 && d->I >= 16 && d->I % 16 == 0 && d->O >= 64 && d->O % 64 == 0, "conv2d_f16: I %% 16 == 0, O %% 64 == 0");
     if (d->N == 0) return 0;
@@ -402,7 +474,20 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         ConvF16Params p;
         p.x = (const f16x8*)d->x; p.w = (const f16x8*)d->wt; p.y = (f16x8*)d->y;
         p.N = d->N; p.I = d->I; p.O = d->O; p.H = d->H; p.W = d->W;
-        p.tiles_x = cdiv(d->W, F_TW); p.tiles_y = cdiv(d->H, F_TH); p.tiles_m = d->O / F_BM;
+        // tile shape (F16Tile): the 0.75-reads-per-MFMA forms when their grid still covers the chip
+        const int nbuf = n3d_tune("N3D_F16_NBUF", 2);     // measured (tools/f16_bench.py, 1024 / 2048 workgroups): two buffers 263 / 285 us, one buffer + two workgroups per CU 285 / 317 us
+        // <2,4> (one workgroup per CU, 115 KB of LDS) where its grid still covers the chip AND the K loop is long enough to amortise a tile's
+        // stores, which nothing overlaps then; measured (tools/f16_bench.py, batch 4): 256 -> 256 at 256 x 256: 264 us against 281 for <2,2>;
+        // 128 -> 128 at 512 x 512 (8 chunks per tile): 319 against 286 — <2,2>'s 78 KB let two workgroups share a CU.  (A 128-channel
+        // <4,2> form measured 274 / 324 us and is not built.)
+        const int wide_sel = n3d_tune("N3D_F16_WIDE", -1);                // tuning builds: 0 = <2,2> always, 2 = <2,4> wherever the image has 32 rows
+        int shape = 0;
+        if (nbuf == 2 && d->H >= 32) {
+            const bool ok24 = d->I >= 256 && (int64_t)cdiv(d->W, F_TW) * cdiv(d->H, 32) * d->N * (d->O / 64) >= 256;
+            shape = wide_sel < 0 ? (ok24 ? 2 : 0) : (wide_sel == 2 ? 2 : 0);
+        }
+        const int th = shape == 2 ? 32 : 16;
+        p.tiles_x = cdiv(d->W, F_TW); p.tiles_y = cdiv(d->H, th); p.tiles_m = d->O / 64;
         p.xbs = (int64_t)(d->I / 8) * d->H * d->W; p.wbs = wbs; p.ybs = (int64_t)(d->O / 8) * d->H * d->W;
         p.bias = E.bias; p.noise = E.noise; p.noise_strength = E.noise_strength;
         p.alpha = E.act == N3D_ACT_LRELU ? E.alpha : 1.f; p.gain = E.gain; p.clamp = E.clamp >= 0.f ? E.clamp : INFINITY;
@@ -411,9 +496,9 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         N3D_CHECK(nblk < (1ll << 31), "conv2d_f16: grid too large");
         const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->N * d->O * d->I * 9);
         N3dProfScope prof(N3D_K_CONV2D_F16, stream, flops, bytes);
-        const int nbuf = n3d_tune("N3D_F16_NBUF", 2);     // measured (tools/f16_bench.py, 1024 / 2048 workgroups): two buffers 263 / 285 us, one buffer + two workgroups per CU 285 / 317 us
-        if (nbuf == 2) hipLaunchKernelGGL(conv2d_h8_f16_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(conv2d_h8_f16_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+        if (shape == 2) hipLaunchKernelGGL(conv2d_h8_f16_r32_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+        else if (nbuf == 2) hipLaunchKernelGGL(conv2d_h8_f16_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(conv2d_h8_f16_nbuf1_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         N3D_LAUNCH_CHECK();
         return 0;
     }

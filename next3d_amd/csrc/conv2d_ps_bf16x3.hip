@@ -41,8 +41,12 @@ struct ConvPsParams {
     int dbg;                     // N3D_CONV_DBG ablation bits (tuning only): 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
                                  // 8 no per-chunk barrier / vmcnt wait (wrong results; timing only)
     n3d_epilogue epi;
+    // fused toRGB of a LAST block (n3d_conv2d_desc.rgb_*): the activated tile is multiplied with the RC x O toRGB weights (times the sample's
+    // toRGB styles) in the epilogue and only the partial colours of this workgroup's 64 channels leave the chip; y may then be NULL
+    const float* rgb_weight; const float* rgb_style; float* rgb_partial; int rgb_channels; int64_t rgb_style_stride;
 };
 
+constexpr int PS_RGB_MAX = 4, PS_RGB_PITCH = 16 * 32 + 4;                               // fused toRGB: colours, floats per staged channel row
 constexpr int PS_BM = 64, PS_TH = 16, PS_TW = 32, PS_TAPS = 9;
 constexpr int PS_PH = PS_TH + 2, PS_PW = PS_TW + 2, PS_PPIX = PS_PH * PS_PW;          // 18 x 34 = 612 patch pixels
 constexpr int PS_BCH = (PS_PPIX + 63) / 64, PS_BPAD = PS_BCH * 64;                     // 10 DMA pieces = 640 slots per (hi|lo, half)
@@ -58,9 +62,8 @@ constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                               
 //           workgroup fills the gaps: its MFMAs run while this one waits for its DMA or writes its tile.  With one workgroup per
 //           CU every chunk's DMA wait, every barrier skew and the whole epilogue (a 128 KB tile written while every other CU
 //           writes its own: ~7 us at the chip's ~4.7 TB/s of store bandwidth) leave the matrix pipe idle.
-template <int NBUF>
-__global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kernel(ConvPsParams p) {
-    __shared__ bf16x8 smem[NBUF * PS_BUF + 2 * PS_BM * 4 / 16];
+template <int NBUF, bool RGB>
+__device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf16x8* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware 1-D grid, M tile fastest (conv2d_bf16x3.hip): the O/64 workgroups reading one input patch share it in one L2
@@ -164,6 +167,11 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
         s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
         s_bs[tid] = E.bias ? E.bias[o] : 0.f;
     }
+    float* s_cw = s_bs + PS_BM;                                           // RGB: [colour][64 channels] toRGB weight x style of this sample
+    if (RGB && tid < PS_RGB_MAX * PS_BM) {
+        const int j = tid / PS_BM, o = m0 + tid % PS_BM;
+        s_cw[tid] = (j < p.rgb_channels && o < p.O) ? p.rgb_weight[(int64_t)j * p.O + o] * p.rgb_style[(int64_t)n * p.rgb_style_stride + o] : 0.f;
+    }
 
     if (NBUF == 1) {
         __builtin_amdgcn_s_barrier();                                     // (the epilogue factors above are plain LDS stores)
@@ -231,13 +239,61 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU;
     const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
+    if constexpr (RGB) {
+        // Fused toRGB.  The layer epilogue runs on the accumulators exactly as below; instead of going to HBM the activated tile is staged in
+        // LDS 32 channels at a time ([channel][16 x 32 pixels], the chunk buffers are free now) and every thread sums ITS pixel over the
+        // channels in float32: colour j += x[c] * (w[j][c] * style[n][c]).  The two 64-channel workgroups of a 128-channel layer write separate
+        // partial images; n3d_rgb_combine adds them in a fixed order (bitwise reproducible) and applies toRGB's own epilogue.
+        float* stage = reinterpret_cast<float*>(smem);
+        float col[PS_RGB_MAX] = {0.f, 0.f, 0.f, 0.f};
+        // (lane / thread index re-derived here so that nothing extra stays live across the K loop: the loop sits at the 128-VGPR limit)
+        const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), tid_e = wn * 64 + lane_e, l31_e = lane_e & 31, half_e = lane_e >> 5;
+        __syncthreads();                                                  // every wave is past its last fragment read; s_cw is visible
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float rs = s_rs[mt * 32 + l31_e], bs = s_bs[mt * 32 + l31_e];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oy = min(y0 + wn * 2 + nt, p.H - 1);
+                const float* nrow = E.noise ? E.noise + (int64_t)oy * p.W : nullptr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = x0 + 8 * g + 4 * half_e;
+                    f32x4 out;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = acc[mt][nt][4 * g + k] * rs + (nrow ? nrow[min(ox + k, p.W - 1)] * nstr : 0.f) + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;
+                        out[k] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                    }
+                    *reinterpret_cast<f32x4*>(stage + l31_e * PS_RGB_PITCH + (wn * 2 + nt) * 32 + 8 * g + 4 * half_e) = out;
+                }
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float xv = stage[c * PS_RGB_PITCH + tid_e];
+#pragma unroll
+                for (int j = 0; j < PS_RGB_MAX; ++j) col[j] = fmaf(xv, s_cw[j * PS_BM + mt * 32 + c], col[j]);
+            }
+            __syncthreads();
+        }
+        const int oy = y0 + (tid_e >> 5), ox = x0 + (tid_e & 31);
+        if (oy < p.H && ox < p.W) {
+            float* dst = p.rgb_partial + (((int64_t)n * p.tiles_m + m0 / PS_BM) * p.rgb_channels) * (int64_t)p.H * p.W + (int64_t)oy * p.W + ox;
+#pragma unroll
+            for (int j = 0; j < PS_RGB_MAX; ++j)
+                if (j < p.rgb_channels) dst[(int64_t)j * p.H * p.W] = col[j];
+        }
+    }
+    const bool store_y = !RGB || p.y != nullptr;          // (an early `return` here makes hipcc wrap every LDS-DMA copy of the K loop into a waterfall loop)
     const int64_t plane = (int64_t)p.H * p.W, yplane = (int64_t)p.H * p.yrs;
     const bool vec = ((p.W | p.yrs | p.ybs) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
                      (!E.residual || ((E.residual_batch_stride & 3) == 0 && ((uintptr_t)E.residual & 15) == 0)) && (!E.noise || ((uintptr_t)E.noise & 15) == 0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int o = m0 + mt * 32 + l31;
-        if (o >= p.O) continue;
+        if (o >= p.O || !store_y) continue;
         const float rs = s_rs[mt * 32 + l31], bs = s_bs[mt * 32 + l31];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -281,6 +337,25 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 4 : 2) void conv2d_ps_bf16x3_kerne
     }
 }
 
+// (concrete kernels around the body template: hipcc's host pass can drop the launch stub of a __global__ template, see conv2d_f16.hip)
+constexpr int ps_smem_slots(int nbuf, bool rgb) { return nbuf * PS_BUF + (2 + (rgb ? PS_RGB_MAX : 0)) * PS_BM * 4 / 16; }
+__global__ __launch_bounds__(512, 4) void conv2d_ps1_bf16x3_kernel(ConvPsParams p) {         // one buffer, two workgroups per CU
+    __shared__ bf16x8 smem[ps_smem_slots(1, false)];
+    conv2d_ps_bf16x3_body<1, false>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_ps2_bf16x3_kernel(ConvPsParams p) {         // two buffers, one workgroup per CU
+    __shared__ bf16x8 smem[ps_smem_slots(2, false)];
+    conv2d_ps_bf16x3_body<2, false>(p, smem);
+}
+__global__ __launch_bounds__(512, 4) void conv2d_ps1_rgb_bf16x3_kernel(ConvPsParams p) {     // + fused toRGB (a network's last layer)
+    __shared__ bf16x8 smem[ps_smem_slots(1, true)];
+    conv2d_ps_bf16x3_body<1, true>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_ps2_rgb_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[ps_smem_slots(2, true)];
+    conv2d_ps_bf16x3_body<2, true>(p, smem);
+}
+
 // Layers this kernel takes (the host asks before it lets a producer write split8): 3x3 stride 1, I % 16 == 0, images of at
 // least 16 x 32 whose 8-wave tiles — times a split-K factor of at most I / 64 (four 16-channel chunks per workgroup at least) —
 // cover the chip, linear / leaky-ReLU (0 <= alpha <= 1) epilogue.  n3d_conv2d_split8_ksplit: the factor the launch will use (0 =
@@ -320,21 +395,56 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->x_batch_stride % 4 == 0, "conv2d_bf16x3: split8 batch stride must be a multiple of 16 bytes");
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.epi = d->epi;
+    const bool rgb = d->rgb_partial != nullptr;
+    if (rgb) {
+        N3D_CHECK(d->rgb_weight && d->rgb_style && d->rgb_channels >= 1 && d->rgb_channels <= PS_RGB_MAX, "conv2d_bf16x3: fused toRGB needs rgb_weight, rgb_style and 1..4 colours");
+        N3D_CHECK(p.ksplit == 1 && !E.residual && !E.round_f16, "conv2d_bf16x3: fused toRGB on a layer without split-K, residual or float16 rounding");
+    }
+    N3D_CHECK(d->y != nullptr || rgb, "conv2d_bf16x3: y is NULL");
+    p.rgb_weight = d->rgb_weight; p.rgb_style = d->rgb_style; p.rgb_partial = d->rgb_partial; p.rgb_channels = d->rgb_channels;
+    p.rgb_style_stride = d->rgb_style_stride ? d->rgb_style_stride : d->O;
     p.dbg = n3d_tune("N3D_CONV_DBG", 0);                                  // tuning builds re-read it per launch: tools/conv_ps_abl.py flips it in-process
     const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N * p.ksplit;
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
-    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->O * d->I * 9);
+    const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (d->y ? (double)d->N * d->O * d->H * d->W : 0.0) + (double)d->O * d->I * 9 +
+                                (rgb ? (double)d->N * p.tiles_m * d->rgb_channels * d->H * d->W : 0.0));
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     // two workgroups per CU (single LDS buffer each) once the grid holds at least three per CU: with fewer, the in-workgroup
     // double buffering wins (measured, tools/conv_ps_abl.py: 64x64 x 512 channels = 256 workgroups: 156 us vs 201 us; 512
     // workgroups: equal; 1024+: 174 vs 182 us, 697 vs 735 us).  Starting every other batch of workgroups late to de-phase the
     // CUs' store bursts was measured too: no effect.
     { const int nbuf = n3d_tune("N3D_PS_NBUF", nblk >= 768 ? 1 : 2);
-      if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-      else hipLaunchKernelGGL(conv2d_ps_bf16x3_kernel<1>, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
+      if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (rgb) hipLaunchKernelGGL(conv2d_ps1_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else hipLaunchKernelGGL(conv2d_ps1_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.H, p.W, p.ybs, p.yrs, p.epi, stream);
+    return 0;
+}
+
+// The second half of the fused toRGB: sum the workgroups' partial colour images in index order and apply the toRGB layer's epilogue.
+__global__ __launch_bounds__(256) void rgb_combine_kernel(const float* __restrict__ partial, float* __restrict__ y, int N, int M, int C, int H, int W, n3d_epilogue E) {
+    const int64_t plane = (int64_t)H * W, total = (int64_t)N * C * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i % plane; const int c = (int)((i / plane) % C), n = (int)(i / (plane * C));
+        float v = 0.f;
+        for (int m = 0; m < M; ++m) v += partial[(((int64_t)n * M + m) * C + c) * plane + pix];
+        y[i] = n3d_apply_epilogue(v, E, n, c, C, (int)(pix / W), (int)(pix % W), H, W);
+    }
+}
+extern "C" int n3d_rgb_combine(const float* partial, float* y, int N, int M, int C, int H, int W, const n3d_epilogue* epi, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && M >= 1 && C >= 1 && H >= 1 && W >= 1 && epi, "rgb_combine: bad arguments");
+    if (N == 0) return 0;
+    N3D_CHECK(partial && y, "rgb_combine: null tensor");
+    N3D_CHECK(!epi->row_scale && !epi->noise && !epi->round_f16, "rgb_combine: toRGB epilogue only (const scale, bias, activation, clamp, residual)");
+    N3D_CHECK(!epi->residual_up_filter || (epi->residual && H % 2 == 0 && W % 2 == 0), "rgb_combine: residual_up_filter needs a residual and an even output size");
+    const int64_t total = (int64_t)N * C * H * W;
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * total * (M + 1));
+    hipLaunchKernelGGL(rgb_combine_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, stream, partial, y, N, M, C, H, W, *epi);
+    N3D_LAUNCH_CHECK();
     return 0;
 }
 

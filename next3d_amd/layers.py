@@ -37,6 +37,7 @@ PRESPLIT = True
 S2_PRESPLIT = True         # stride-2 encoder layers on split8 input
 UP_PRESPLIT = True         # the transposed convolution's input (a block output with two consumers) converted once, LDS-DMA staging
 TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
+FUSED_TORGB = True        # a network's last 3x3 layer evaluates its <= 4-colour toRGB in its epilogue (fused_torgb_ok)
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 UP_PS_NCHW = True          # few-position up-sampling layers on the pre-split transposed kernel writing NCHW (networks._Block._ps_nchw)
 NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)
@@ -87,11 +88,12 @@ class PreparedConv:
             self.noise_strength = P.get(f'{prefix}.noise_strength')
 
 
-def _conv3x3(L, x, style=None, epilogue=None, out=None):
+def _conv3x3(L, x, style=None, epilogue=None, out=None, rgb=None):
     """3x3 stride-1 convolution on the arithmetic selected by PRECISION.  A `_lib.Split8` input (written by the previous
     layer's epilogue with THIS layer's style multiplied in) goes to the pre-split kernel; `style` is then ignored."""
     if isinstance(x, _lib.Split8):
-        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True)
+        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True, rgb=rgb)
+    assert rgb is None
     n, i, h, w = x.shape
     if (PRESPLIT and PRECISION == 'bf16x3' and L.wt16 is not None and x.dtype == torch.float32 and 4 * n * i * h * w <= CONVERT_MAX_BYTES and
             cg.split8_eligible(n, i, L.out_channels, h, w) and (epilogue is None or epilogue.act in (1, 3))):
@@ -186,7 +188,7 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, x_split8=None, split_for_nchw=None, ps_nchw=False):
+                    split_for=None, x_split8=None, split_for_nchw=None, ps_nchw=False, rgb=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
@@ -195,6 +197,7 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     output -> the result is a `_lib.Split8` carrying them (see presplit_ok).  `split_for_nchw`: the same hand-over for the up-sampling
     layers whose transposed convolution runs on the register-staged kernel (few positions: split-K, float32 NCHW result): their FIR
     reads that result and writes split8 (n3d_fir4_split8_nchw, pad 1) instead of float32 + a conversion pass in front of conv1.
+    `rgb` (up = 1, x a `_lib.Split8`): see fused_torgb_ok — the layer's result is then the partial colour tensor for torgb_combine.
     (The reference's float16 blocks run on their own kernels: synthesis_layer_f16.)"""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
@@ -212,8 +215,8 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:
-        return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out)
-    assert up == 2 and out is None
+        return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out, rgb=rgb)
+    assert up == 2 and out is None and rgb is None
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
         zepi = _lib.make_epilogue(row_scale=dcoef)
         if UP_PRESPLIT and x.shape[1] % 16 == 0:
@@ -245,6 +248,20 @@ def _conv1x1(L, x, style=None, epilogue=None, out=None, out_split8=False, side_s
                               side_style=side_style)
     assert not out_split8 and side_style is None
     return cg.conv_launch(x, L.wt, 1, 0, L.out_channels, style=style, epilogue=epilogue, out=out)
+
+
+def fused_torgb_ok(conv, torgb, x, noise_mode):
+    """Can `conv` (the LAST 3x3 layer of a network, input `x`) evaluate `torgb` — its result's only reader — in its own epilogue
+    (n3d_conv2d_desc.rgb_*: at most 4 colours, the pre-split stride-1 kernel without split-K)?  The 512 x 512 x 128-channel feature map of the
+    super-resolution's last block (537 MB per step at batch 4) is then neither written nor read back."""
+    return (FUSED_TORGB and PRECISION == 'bf16x3' and isinstance(x, _lib.Split8) and noise_mode != 'random' and conv.wt16 is not None and
+            torgb.out_channels <= 4 and torgb.ksize == 1 and torgb.in_channels == conv.out_channels and
+            _lib.lib().n3d_conv2d_split8_ksplit(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
+
+
+def torgb_combine(L, partial, conv_clamp=None, residual=None, residual_up_filter=None):
+    """toRGB's epilogue on the partial colours of a fused last layer (synthesis_layer(..., rgb=...)): bias, clamp, skip image (torgb_layer)."""
+    return cg.rgb_combine(partial, _lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=residual, residual_up_filter=residual_up_filter))
 
 
 def torgb_side_ok(L, x):

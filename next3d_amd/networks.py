@@ -55,10 +55,11 @@ class _Block:
         """Does conv0 read its [n, I, h, w] input in the split8 layout (layers.synthesis_layer, the transposed pre-split kernel)?"""
         return bool(L.UP_PRESPLIT and xshape[1] % 16 == 0 and self._presplit(n, xshape, fir, noise_mode)) or self._ps_nchw(n, xshape, fir, noise_mode)
 
-    def __call__(self, x, img, bank, n, fir, noise_mode, x_out=None, x_split8=None, next_block=None):
+    def __call__(self, x, img, bank, n, fir, noise_mode, x_out=None, x_split8=None, next_block=None, last=False):
         """SynthesisBlock.forward (float32 block); `bank` = StyleBank.compute(ws) result.  -> (x, img, xs): `next_block` = the block
         whose conv0 reads THIS block's x unchanged; when it takes split8 input, toRGB writes it on the side (layers.torgb_layer) and
-        `xs` is to be passed to that block as `x_split8` (None otherwise)."""
+        `xs` is to be passed to that block as `x_split8` (None otherwise).  `last`: nobody reads this block's x but its own toRGB — where the
+        kernels allow (layers.fused_torgb_ok) conv1 evaluates toRGB in its epilogue and x is never written: -> (None, img, None)."""
         sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
@@ -73,6 +74,14 @@ class _Block:
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
                                   split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if (pre or psn) else None,
                                   split_for_nchw=bank[self.conv1.prefix][0] if pre_nchw else None, ps_nchw=psn, **sl(self.conv0))
+            if last and x_out is None and L.fused_torgb_ok(self.conv1, self.torgb, x, noise_mode):
+                t = self.torgb
+                part = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
+                                         rgb=(t.weight.reshape(t.out_channels, t.in_channels), bank[t.prefix][0]), **sl(self.conv1))
+                up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
+                if img is not None and up is None:
+                    img = uf.upsample2d(img, fir)
+                return None, L.torgb_combine(t, part, conv_clamp=self.conv_clamp, residual=img, residual_up_filter=up), None
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image update img = upsample2d(img) + toRGB(x): upsample2d is evaluated inside the toRGB epilogue (4 taps of the
         # half-resolution image per pixel)
@@ -335,5 +344,5 @@ class SuperRes8XDC:
         if fp16 and self._f16_ok(x, noise_mode):
             return self._forward_f16(x, rgb, bank, noise_mode)
         x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, next_block=self.block1)
-        x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs)
+        x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, last=True)
         return rgb

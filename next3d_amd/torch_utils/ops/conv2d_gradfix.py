@@ -138,7 +138,7 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
 
 
 def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False,
-                out_c8=False, out_split8=False, side_style=None, _wt_batch_stride=0, _wt_flat=False):
+                out_c8=False, out_split8=False, side_style=None, _wt_batch_stride=0, _wt_flat=False, rgb=None):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
     bf16x3=True) -> y [N,out_channels,OH,OW].  row_pitch=True returns y as the [..., :OW] view of a buffer whose rows are
     padded to a multiple of 4 floats (16-byte-aligned rows for the odd-width transposed-conv output; upfirdn2d accepts it).
@@ -147,7 +147,10 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     O % 32 == 0): the result is a `_lib.Split8` for a following pre-split 3x3 layer without modulation.  side_style [N,I] (1x1
     split-bf16 layer, O <= 128): returns (y, `_lib.Split8` of x * side_style) — n3d_conv2d_desc.side_split8.
     _wt_batch_stride (bytes; `wt` is then the flat per-sample tensor of prep_weight_grouped, _wt_flat=True): per-sample weights,
-    n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls."""
+    n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls.
+    rgb = (weight [C,O] float32, styles [N,O]) (split8 input, mode 0, no split-K, C <= 4): the toRGB layer that is this layer's ONLY reader is
+    evaluated in the epilogue (n3d_conv2d_desc.rgb_*): returns the partial colour images [N, ceil(O/64), C, H, W] for rgb_combine; the feature
+    map itself is not written."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
         if not (bf16x3 and ksize == 3 and mode in (0, 1, 2) and style is None):
@@ -198,6 +201,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
             raise RuntimeError('conv2d: the split8 output is written by the 1x1 split-bf16 kernel (O % 32 == 0)')
         s8 = _lib.Split8(n, o, oh, ow, wt.device)
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')
+    elif rgb is not None:
+        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')      # not written (checked below)
     elif out is not None:
         y = out
     elif row_pitch:
@@ -212,7 +217,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None
     d = _lib.Conv2dDesc()
-    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), _lib.ptr(c8.data if c8 else (s8.data if s8 else y)), _lib.ptr(ws)
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), (None if rgb is not None else _lib.ptr(c8.data if c8 else (s8.data if s8 else y))), _lib.ptr(ws)
     d.x_layout, d.y_layout = (1 if split8 else 0), (2 if c8 else (1 if s8 else 0))
     d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
@@ -222,6 +227,15 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     d.wt_batch_stride = int(_wt_batch_stride)
+    partial = None
+    if rgb is not None:
+        rw, rs = rgb
+        if not (split8 and bf16x3 and ksize == 3 and mode == 0 and ksplit == 1 and out is None and not row_pitch and c8 is None and s8 is None and rw.dtype == rs.dtype == torch.float32 and
+                rw.is_contiguous() and tuple(rw.shape[1:]) == (o,) and rw.shape[0] <= 4 and tuple(rs.shape) == (n, o) and rs.stride(1) == 1):
+            raise RuntimeError('conv2d: the fused toRGB is an option of the pre-split 3x3 stride-1 kernel without split-K (weights [C<=4, O], styles [N, O])')
+        _lib.require_device(rw, rs)
+        partial = torch.empty([n, (o + 63) // 64, rw.shape[0], h, w], dtype=torch.float32, device=wt.device)
+        d.rgb_weight, d.rgb_style, d.rgb_partial, d.rgb_channels, d.rgb_style_stride = _lib.ptr(rw), _lib.ptr(rs), _lib.ptr(partial), rw.shape[0], rs.stride(0)
     side = None
     if side_style is not None:
         if not (bf16x3 and ksize == 1 and not split8 and s8 is None and o <= 128 and i % 32 == 0 and out_dtype == torch.float32 and
@@ -232,11 +246,21 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         d.side_split8, d.side_style, d.side_style_stride = _lib.ptr(side.data), _lib.ptr(side_style), side_style.stride(0)
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
+    if partial is not None:
+        return partial
     if side is not None:
         return (y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)), side
     if c8 is not None or s8 is not None:
         return c8 if c8 is not None else s8
     return y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)
+
+
+def rgb_combine(partial, epilogue):
+    """The second half of conv_launch(rgb=...): [N, M, C, H, W] partial colours -> epilogue(sum over M) [N, C, H, W] (n3d_rgb_combine)."""
+    n, m, c, h, w = partial.shape
+    y = torch.empty([n, c, h, w], dtype=torch.float32, device=partial.device)
+    _lib.check(_lib.lib().n3d_rgb_combine(_lib.ptr(partial), _lib.ptr(y), n, m, c, h, w, epilogue, _lib.stream()))
+    return y
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

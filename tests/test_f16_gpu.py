@@ -108,9 +108,12 @@ def _ref_layer_epilogue(y32, bias, noise, gain, clamp, alpha=0.2, act='lrelu'):
     return _q(t)
 
 
-@pytest.mark.parametrize('N,I,O,H,W,nbuf,noise', [(2, 32, 64, 16, 32, 2, False), (1, 128, 128, 40, 70, 1, True), (2, 64, 192, 33, 64, 2, True),
-                                                    (1, 256, 64, 64, 64, 1, False)])
-def test_conv2d_f16_stride1(dev, N, I, O, H, W, nbuf, noise):
+# the last two shapes (I >= 256, >= 256 workgroups) run on the <2,4> tile form (conv2d_f16.hip: F16Tile, 64 channels x 32 x 32 pixels), the second
+# with ragged right / bottom tiles
+@pytest.mark.parametrize('N,I,O,H,W,noise', [(2, 32, 64, 16, 32, False), (1, 128, 128, 40, 70, True), (2, 64, 192, 33, 64, True),
+                                               (1, 256, 64, 64, 64, False), (4, 32, 256, 128, 256, True), (4, 256, 128, 128, 256, True),
+                                               (4, 256, 64, 200, 330, False)])
+def test_conv2d_f16_stride1(dev, N, I, O, H, W, noise):
     x, w, s = _q(_g((N, I, H, W), 3)), _g((O, I, 3, 3), 4), _g((N, I), 5) + 1.0
     bias, nz = _g((O,), 6, 0.1), _g((H, W), 7)
     nstr = torch.tensor(0.3)
@@ -120,31 +123,22 @@ def test_conv2d_f16_stride1(dev, N, I, O, H, W, nbuf, noise):
     L = _Layer(w.to(dev), bias.to(dev), nz.to(dev) if noise else None, nstr.to(dev))
     wt = _tile3(w16).to(dev)          # identical weights on both sides (one float16 ulp on a weight is 2^-11 of a product: many ulps of a small output)
     assert float((layers.modulate_weights_f16(L, s.to(dev)).float() - wt.float()).abs().max()) <= float(_ulp16(w16.float()).max())
-    os.environ['N3D_F16_NBUF'] = str(nbuf)
-    try:
-        epi = _lib.make_epilogue(noise=L.noise_const, noise_strength=L.noise_strength if noise else None, bias=L.bias, act='lrelu',
-                                 gain=float(np.sqrt(2)), clamp=256.0)
-        y = layers.conv2d_f16(_lib.H8.from_nchw(x.to(dev)), wt, O, 0, epi)
-    finally:
-        del os.environ['N3D_F16_NBUF']
+    epi = _lib.make_epilogue(noise=L.noise_const, noise_strength=L.noise_strength if noise else None, bias=L.bias, act='lrelu',
+                             gain=float(np.sqrt(2)), clamp=256.0)
+    y = layers.conv2d_f16(_lib.H8.from_nchw(x.to(dev)), wt, O, 0, epi)
     _check_f16(f'conv2d_f16 stride 1 {N}x{I}->{O} {H}x{W}', y.to_float(), ref, pre=[pre, _q(pre) + nz * nstr] if noise else pre, pre_gain=float(np.sqrt(2)))
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
 @pytest.mark.parametrize('N,I,O,H,W', [(2, 32, 64, 16, 16), (1, 64, 128, 33, 40), (1, 128, 64, 64, 64), (2, 16, 64, 4, 7), (1, 32, 64, 72, 160)])
-def test_conv2d_f16_transposed(dev, variant, N, I, O, H, W):
+def test_conv2d_f16_transposed(dev, N, I, O, H, W):
     x, w, s = _q(_g((N, I, H, W), 8)), _g((O, I, 3, 3), 9), _g((N, I), 10) + 1.0
     w16 = _ref_modulated_weights(w, s, True)
     # conv2d_resample.py:116-127: the layer weight [O,I,k,k], transposed to [I,O,k,k], goes to conv_transpose2d UNFLIPPED
     ref = _q(torch.cat([F.conv_transpose2d(x[n:n + 1], w16[n].float().transpose(0, 1), stride=2) for n in range(N)], 0))
     wt = _tile3(w16).to(dev)
-    os.environ['N3D_F16_UP'] = str(variant)
-    try:
-        y = layers.conv2d_f16(_lib.H8.from_nchw(x.to(dev)), wt, O, 2)
-    finally:
-        del os.environ['N3D_F16_UP']
+    y = layers.conv2d_f16(_lib.H8.from_nchw(x.to(dev)), wt, O, 2)
     assert y.shape == (N, O, 2 * H + 1, 2 * W + 1)
-    _check_f16(f'conv2d_f16 transposed v{variant} {N}x{I}->{O} {H}x{W}', y.to_float(), ref)
+    _check_f16(f'conv2d_f16 transposed {N}x{I}->{O} {H}x{W}', y.to_float(), ref)
 
 
 @pytest.mark.parametrize('N,C,H,W,noise', [(2, 64, 33, 33, False), (1, 16, 131, 70, True), (1, 8, 21, 257, True), (1, 8, 62, 123, False)])

@@ -215,6 +215,31 @@ def test_pipelined_steps_are_bitwise_reproducible(G, dev):
 
 
 @pytest.mark.gpu
+def test_fused_last_layer_torgb_equals_separate_torgb(G, dev, monkeypatch):
+    """layers.FUSED_TORGB: the super-resolution's last 3x3 layer (128 channels at 512 x 512) evaluates its toRGB in the epilogue and never
+    writes its feature map.  Against the same forward with the two layers separate: equal to the accuracy of the separate 1x1 kernel
+    (split-bf16: 2^-17 relative per product); everything in front of that layer is bit-identical."""
+    from next3d_amd import layers
+    layers.set_precision('bf16x3')
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
+    R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(4, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(d[k]).to(dev)
+    ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(layers, 'FUSED_TORGB', on)
+        o = G.synthesis(ws, t('c'), t('v'), **kw)
+        outs[on] = {k: o[k].clone() for k in ('image', 'image_raw', 'image_depth')}
+    assert torch.equal(outs[True]['image_raw'], outs[False]['image_raw']) and torch.equal(outs[True]['image_depth'], outs[False]['image_depth'])
+    e = _md(outs[True]['image'], outs[False]['image'])
+    print(f'fused vs separate toRGB of the last layer: image max abs diff {e:.3e}')
+    assert 0 < e <= 5e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch,R', [(3, 64), (1, 128)])
 def test_presplit_pipeline_equals_register_staged_pipeline(G, dev, monkeypatch, batch, R):
     """The whole forward with every pre-split (LDS-DMA) path switched off — register-staged kernels, float32 NCHW between all

@@ -676,6 +676,46 @@ def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
         cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True)      # the split8 input is modulated already
 
 
+@pytest.mark.parametrize('N,I,OC,H,W,C', [(4, 32, 128, 128, 128, 3), (2, 64, 128, 200, 330, 3), (2, 16, 64, 96, 160, 4), (3, 32, 100, 100, 70, 1)])
+def test_fused_torgb_epilogue_matches_separate_layers(dev, N, I, OC, H, W, C):
+    """n3d_conv2d_desc.rgb_* + n3d_rgb_combine (a network's LAST 3x3 layer evaluating its toRGB in the epilogue; the feature map is never
+    written) against the two layers run separately — the same pre-split kernel writing x, then the 1x1 toRGB kernel with the skip-image
+    upsample in its epilogue — and against float32 ATen; big grids (one LDS buffer, two workgroups per CU) and small ones (two buffers),
+    ragged tiles, O not a multiple of 64, 1 / 3 / 4 colours."""
+    from next3d_amd import _lib, layers
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg, upfirdn2d as uf
+    assert cg.split8_eligible(N, I, OC, H, W) and _lib.lib().n3d_conv2d_split8_ksplit(N, I, OC, H, W) == 1
+    x = _gen((N, I, H, W), 130).to(dev)
+    w = (_gen((OC, I, 3, 3), 131) / np.sqrt(9 * I)).to(dev)
+    wt16 = cg.prep_weight_bf16x3(w)
+    dco, bias, noise = (1 + 0.1 * _gen((N, OC), 132)).to(dev), _gen((OC,), 133).to(dev), _gen((H, W), 134).to(dev)
+    ns = torch.tensor(0.3, device=dev)
+    wrgb, srgb, brgb = (_gen((C, OC), 135) / np.sqrt(OC)).to(dev), (1 + 0.2 * _gen((N, OC), 136)).to(dev), _gen((C,), 137).to(dev)
+    fir = uf.setup_filter([1, 3, 3, 1]).to(dev)
+    even = H % 2 == 0 and W % 2 == 0
+    img_lo = _gen((N, C, H // 2, W // 2), 138).to(dev) if even else None
+    kw = dict(row_scale=dco, noise=noise, noise_strength=ns, bias=bias, act='lrelu', gain=1.4, clamp=2.0)
+    xs = _to_split8(x)
+    feat = cg.conv_launch(xs, wt16, 3, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True)
+    part = cg.conv_launch(xs, wt16, 3, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, rgb=(wrgb, srgb))
+    assert tuple(part.shape) == (N, (OC + 63) // 64, C, H, W)
+    tkw = dict(bias=brgb, clamp=1.5, residual=img_lo, residual_up_filter=fir if even else None)
+    got = cg.rgb_combine(part, _lib.make_epilogue(**tkw))
+    want = torch.einsum('nohw,co,no->nchw', feat.double(), wrgb.double(), srgb.double()).float() + brgb[None, :, None, None]
+    want = want.clamp(-1.5, 1.5)
+    if even:
+        want = want + uf.upsample2d(img_lo, fir)
+    print('fused toRGB vs float64 sum over the kernel\'s own feature map: max abs diff', float((got - want).abs().max()))
+    _close(got, want, atol=2e-6, rtol=2e-6)                                # float32 FMA chain over <= 128 channels
+    if OC % 16 == 0:                                                       # and against the separate 1x1 split-bf16 toRGB kernel (3 bf16 products per MAC)
+        sep = cg.conv_launch(feat, cg.prep_weight_bf16x3(wrgb.reshape(C, OC, 1, 1)), 1, 0, C, style=srgb, epilogue=_lib.make_epilogue(**tkw), bf16x3=True)
+        _close(got, sep, atol=2e-5, rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(x, wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True, rgb=(wrgb, srgb))     # NCHW input: not the pre-split kernel
+    with pytest.raises(RuntimeError):
+        cg.conv_launch(xs, wt16, 3, 0, OC, bf16x3=True, rgb=(torch.ones(5, OC, device=dev), srgb))                # more than 4 colours
+
+
 @pytest.mark.parametrize('N,C,H,W,pad', [(2, 32, 64, 64, 2), (1, 16, 37, 101, 2), (3, 8, 16, 20, 1), (1, 64, 128, 128, 2)])
 @pytest.mark.parametrize('sep', ['1', '0'])
 def test_fir4_split8_from_nchw_matches_float_fir(dev, monkeypatch, N, C, H, W, pad, sep):

@@ -53,16 +53,19 @@ def main():
         L.uf.FIR_SEP = True
         y = L.fir4_h8(z, fir, epi)
         gf = 2 * N * o * o * 9 * 4 * h * h / 1e9
-        for nb in (1, 2):
-            os.environ['N3D_F16_NBUF'] = str(nb)
+        # tile shapes of the stride-1 kernel (conv2d_f16.hip: F16Tile; tuning build): 0 = 64 ch x 16 x 32 px, 2 = 64 ch x 32 x 32 px
+        for wide, what in ((0, '<2,2> 64ch x 16x32'), (2, '<2,4> 64ch x 32x32')):
+            os.environ['N3D_F16_WIDE'] = str(wide)
             t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi))
-            print(f'stride-1 NBUF {nb}: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
-        for dbg, what in ((1, 'no stores'), (4, 'no DMA after chunk 0'), (5, 'neither')):
-            os.environ['N3D_CONV_DBG'] = str(dbg)
-            os.environ['N3D_F16_NBUF'] = '1'
-            t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi))
-            print(f'   ablation NBUF 1, {what}: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
-        del os.environ['N3D_CONV_DBG'], os.environ['N3D_F16_NBUF']
+            print(f'stride-1 tile {what}: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
+            for dbg, abl in ((1, 'no stores'), (4, 'no DMA after chunk 0'), (5, 'neither')):
+                os.environ['N3D_CONV_DBG'] = str(dbg)
+                t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi))
+                print(f'   ablation {abl}: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
+            del os.environ['N3D_CONV_DBG']
+        del os.environ['N3D_F16_WIDE']
+        t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi))
+        print(f'stride-1 library default: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
         b = L.conv2d_f16(y, w1, o, 0, epi)
         img_lo = torch.randn(N, 3, h, h, device=dev)
         t = timeit(lambda: L.torgb_layer_f16(torgb, b, s2, fir, conv_clamp=256, img_lo=img_lo))
