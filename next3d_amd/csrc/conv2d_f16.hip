@@ -52,7 +52,11 @@ struct ConvF16Params {
     float alpha, gain, clamp;    // alpha = 1: linear; clamp = INFINITY: none
     int multi_round;             // f16_layer_epilogue's `multi`
     int dbg;
+    // fused toRGB of a LAST block (n3d_conv2d_desc.rgb_*): per-sample float16 toRGB weights [N][RC][O] (n3d_modulate_weights_f16, demodulate = 0);
+    // the partial colours of this workgroup's 64 channels go to rgb_partial [N][O/64][RC][H][W]; y may be NULL
+    const _Float16* rgb_w16; float* rgb_partial; int rgb_channels;
 };
+constexpr int F_RGB_MAX = 4;
 
 // The layer epilogue in the reference's float16 order (training/networks_stylegan2.py:91 + :327-329): the convolution returns
 // float16; `x.add_(noise)` rounds again; bias_act reads float16 x and b (`self.bias.to(x.dtype)`) and returns float16.
@@ -141,7 +145,7 @@ __device__ __forceinline__ void f16_mfma_chunk(const f16x8* A, const f16x8* B, i
 
 // NBUF = 2: one workgroup per CU, the next chunk's DMA under this chunk's MFMAs; NBUF = 1: two workgroups per CU with one buffer
 // each (the other workgroup's MFMAs fill this one's DMA waits and its tile stores) — see conv2d_ps_bf16x3_kernel.
-template <int MT, int NT, int NBUF>
+template <int MT, int NT, int NBUF, bool RGB>
 __device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8* smem) {
     using T = F16Tile<MT, NT>;
     constexpr int F_BM = T::BM, F_TH = T::TH, F_PW = T::PW, F_PPIX = T::PPIX, F_BCH = T::BCH, F_BPAD = T::BPAD, F_A_SZ = T::A_SZ, F_A_PIECES = T::A_PIECES,
@@ -212,6 +216,11 @@ __device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8
 
     float* s_bs = reinterpret_cast<float*>(smem + NBUF * F_BUF);
     if (tid < F_BM) s_bs[tid] = p.bias ? (float)(_Float16)p.bias[m0 + tid] : 0.f;          // self.bias.to(float16)
+    float* s_cw = s_bs + F_BM;                                            // RGB: [colour][channel of this tile] toRGB weights of this sample
+    if (RGB && tid < F_RGB_MAX * F_BM) {
+        const int j = tid / F_BM, c = tid % F_BM;
+        s_cw[tid] = j < p.rgb_channels ? (float)p.rgb_w16[((int64_t)n * p.rgb_channels + j) * p.O + m0 + c] : 0.f;
+    }
 
     if (NBUF == 1) {
         __builtin_amdgcn_s_barrier();
@@ -239,12 +248,82 @@ __device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8
     // group mt -> registers 4 gg .. 4 gg + 3 are the channels 8 gg + 4 half + (0..3): one half of the h8 unit (m0 / 8 + 4 mt + gg).
     const float nstr = p.noise ? p.noise_strength[0] : 0.f;
     const int ox = x0 + l31;
-    if (ox >= p.W) return;
+    if constexpr (RGB) {
+        // Fused toRGB (ToRGBLayer on a float16 block: float16 x and weights, float32 accumulation — n3d_torgb_h8's sum).  A lane holds 32 of the
+        // tile's 64 channels of its pixel (the other 32 sit in lane ^ 32): it sums its share over the ROUNDED layer outputs, the halves are
+        // added across the lane pair, and the 64-channel partial colours go to rgb_partial; n3d_rgb_combine adds the tiles' partial images
+        // in index order and applies toRGB's float16 epilogue.
+        float col[NT][F_RGB_MAX], nz[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = min(y0 + wn * NT + nt, p.H - 1);
+            nz[nt] = p.noise ? p.noise[(int64_t)oy * p.W + min(ox, p.W - 1)] * nstr : 0.f;
+#pragma unroll
+            for (int j = 0; j < F_RGB_MAX; ++j) col[nt][j] = 0.f;
+        }
+        // pass 1: the layer outputs, rounded (the accumulators die here: 64 registers become 32 packed float16 pairs)
+        f16x4 o16[MT][4][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bs + mt * 32 + 8 * gg + 4 * half);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o16[mt][gg][nt][k] = f16_layer_epilogue(acc[mt][nt][4 * gg + k], nz[nt], p.noise != nullptr, bs[k], p.alpha, p.gain, p.clamp, p.multi_round);
+            }
+        if (p.y != nullptr && ox < p.W) {
+            _Float16* yb16 = reinterpret_cast<_Float16*>(p.y + (int64_t)n * p.ybs);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = y0 + wn * NT + nt;
+                if (oy >= p.H) continue;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg)
+                        *reinterpret_cast<f16x4*>(yb16 + (((int64_t)((m0 >> 3) + mt * 4 + gg) * p.H + oy) * p.W + ox) * 8 + 4 * half) = o16[mt][gg][nt];
+            }
+        }
+        // pass 2: colours
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int ol = mt * 32 + 8 * gg + 4 * half;
+#pragma unroll
+                for (int j = 0; j < F_RGB_MAX; ++j) {
+                    const f32x4 cw = *reinterpret_cast<const f32x4*>(s_cw + j * F_BM + ol);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) col[nt][j] = fmaf((float)o16[mt][gg][nt][k], cw[k], col[nt][j]);
+                }
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < F_RGB_MAX; ++j) col[nt][j] += __shfl_xor(col[nt][j], 32);
+        if (half == 0 && ox < p.W) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int oy = y0 + wn * NT + nt;
+                if (oy >= p.H) continue;
+                float* dst = p.rgb_partial + (((int64_t)n * p.tiles_m + m0 / F_BM) * p.rgb_channels) * (int64_t)p.H * p.W + (int64_t)oy * p.W + ox;
+#pragma unroll
+                for (int j = 0; j < F_RGB_MAX; ++j)
+                    if (j < p.rgb_channels) dst[(int64_t)j * p.H * p.W] = col[nt][j];
+            }
+        }
+    }
+    const bool store_y = !RGB && ox < p.W;                               // (RGB: stored above; no early `return` in front of stores: see conv2d_ps_bf16x3.hip)
     _Float16* yb = reinterpret_cast<_Float16*>(p.y + (int64_t)n * p.ybs);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int oy = y0 + wn * NT + nt;
-        if (oy >= p.H) continue;
+        if (oy >= p.H || !store_y) continue;
         const float nz = p.noise ? p.noise[(int64_t)oy * p.W + ox] * nstr : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -262,18 +341,22 @@ __device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8
 }
 
 // (concrete kernels around the body template: hipcc's host pass does not emit the launch stub of a __global__ TEMPLATE with this body)
-template <int MT, int NT, int NBUF> constexpr int f16_smem_slots() { return NBUF * F16Tile<MT, NT>::BUF + F16Tile<MT, NT>::BM * 4 / 16; }
+template <int MT, int NT, int NBUF, bool RGB = false> constexpr int f16_smem_slots() { return NBUF * F16Tile<MT, NT>::BUF + (1 + (RGB ? F_RGB_MAX : 0)) * F16Tile<MT, NT>::BM * 4 / 16; }
 __global__ __launch_bounds__(512, 2) void conv2d_h8_f16_kernel(ConvF16Params p) {             // <2,2>, two buffers
     __shared__ f16x8 smem[f16_smem_slots<2, 2, 2>()];
-    conv2d_h8_f16_body<2, 2, 2>(p, smem);
+    conv2d_h8_f16_body<2, 2, 2, false>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_h8_f16_rgb_kernel(ConvF16Params p) {         // <2,2> + fused toRGB (a network's last layer)
+    __shared__ f16x8 smem[f16_smem_slots<2, 2, 2, true>()];
+    conv2d_h8_f16_body<2, 2, 2, true>(p, smem);
 }
 __global__ __launch_bounds__(512, 4) void conv2d_h8_f16_nbuf1_kernel(ConvF16Params p) {       // <2,2>, one buffer, two workgroups per CU (tuning builds)
     __shared__ f16x8 smem[f16_smem_slots<2, 2, 1>()];
-    conv2d_h8_f16_body<2, 2, 1>(p, smem);
+    conv2d_h8_f16_body<2, 2, 1, false>(p, smem);
 }
 __global__ __launch_bounds__(512, 2) void conv2d_h8_f16_r32_kernel(ConvF16Params p) {         // <2,4>: 64 channels x 32 x 32 pixels
     __shared__ f16x8 smem[f16_smem_slots<2, 4, 2>()];
-    conv2d_h8_f16_body<2, 4, 2>(p, smem);
+    conv2d_h8_f16_body<2, 4, 2, false>(p, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -454,11 +537,14 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(d && d->ksize == 3 && (d->mode == 0 || d->mode == 2), "conv2d_f16: 3x3, stride 1 (mode 0) or transposed stride 2 (mode 2)");
     N3D_CHECK(d->x_layout == N3D_LAYOUT_H8_F16 && d->y_layout == N3D_LAYOUT_H8_F16, "conv2d_f16: input and output in the h8 layout (N3D_LAYOUT_H8_F16)");
-    N3D_CHECK(!d->side_split8 && !d->rgb_partial, "conv2d_f16: no side output / fused toRGB");
+    N3D_CHECK(!d->side_split8, "conv2d_f16: no side output");
+    const bool rgb = d->rgb_partial != nullptr;
+    N3D_CHECK(!rgb || (d->mode == 0 && d->rgb_weight && !d->rgb_style && d->rgb_channels >= 1 && d->rgb_channels <= F_RGB_MAX),
+              "conv2d_f16: fused toRGB on the stride-1 kernel: rgb_weight = per-sample float16 weights [N][C <= 4][O], rgb_style NULL");
     N3D_CHECK(d->style == nullptr && d->ksplit <= 1, "conv2d_f16: the modulation is part of the per-sample weights (n3d_modulate_weights_f16); no split-K");
     N3D_CHECK(d->N >= 0 && d->I >= 16 && d->I % 16 == 0 && d->O >= 64 && d->O % 64 == 0, "conv2d_f16: I %% 16 == 0, O %% 64 == 0");
     if (d->N == 0) return 0;
-    N3D_CHECK(d->x && d->wt && d->y && (((uintptr_t)d->x | (uintptr_t)d->wt | (uintptr_t)d->y) & 15) == 0, "conv2d_f16: null or misaligned tensor");
+    N3D_CHECK(d->x && d->wt && (d->y || rgb) && (((uintptr_t)d->x | (uintptr_t)d->wt | (uintptr_t)d->y) & 15) == 0, "conv2d_f16: null or misaligned tensor");
     N3D_CHECK((int64_t)(d->I / 8) * d->H * d->W * 16 < (1ll << 31), "conv2d_f16: one sample's input exceeds 2 GiB (32-bit buffer offsets)");
     N3D_CHECK(d->x_batch_stride == 0 && d->y_batch_stride == 0 && d->x_row_stride == 0 && d->y_row_stride == 0, "conv2d_f16: dense h8 tensors only (strides 0)");
     const n3d_epilogue& E = d->epi;
@@ -482,7 +568,7 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         // <4,2> form measured 274 / 324 us and is not built.)
         const int wide_sel = n3d_tune("N3D_F16_WIDE", -1);                // tuning builds: 0 = <2,2> always, 2 = <2,4> wherever the image has 32 rows
         int shape = 0;
-        if (nbuf == 2 && d->H >= 32) {
+        if (nbuf == 2 && d->H >= 32 && !rgb) {
             const bool ok24 = d->I >= 256 && (int64_t)cdiv(d->W, F_TW) * cdiv(d->H, 32) * d->N * (d->O / 64) >= 256;
             shape = wide_sel < 0 ? (ok24 ? 2 : 0) : (wide_sel == 2 ? 2 : 0);
         }
@@ -492,11 +578,13 @@ extern "C" int n3d_conv2d_f16(const n3d_conv2d_desc* d, n3d_stream_t stream_) {
         p.bias = E.bias; p.noise = E.noise; p.noise_strength = E.noise_strength;
         p.alpha = E.act == N3D_ACT_LRELU ? E.alpha : 1.f; p.gain = E.gain; p.clamp = E.clamp >= 0.f ? E.clamp : INFINITY;
         p.multi_round = E.round_f16 == 2; p.dbg = dbg;
+        p.rgb_w16 = (const _Float16*)d->rgb_weight; p.rgb_partial = d->rgb_partial; p.rgb_channels = d->rgb_channels;
         const int64_t nblk = (int64_t)p.tiles_x * p.tiles_y * p.tiles_m * p.N;
         N3D_CHECK(nblk < (1ll << 31), "conv2d_f16: grid too large");
         const double bytes = 2.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * d->H * d->W + (double)d->N * d->O * d->I * 9);
         N3dProfScope prof(N3D_K_CONV2D_F16, stream, flops, bytes);
-        if (shape == 2) hipLaunchKernelGGL(conv2d_h8_f16_r32_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+        if (rgb) hipLaunchKernelGGL(conv2d_h8_f16_rgb_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+        else if (shape == 2) hipLaunchKernelGGL(conv2d_h8_f16_r32_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         else if (nbuf == 2) hipLaunchKernelGGL(conv2d_h8_f16_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL(conv2d_h8_f16_nbuf1_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
         N3D_LAUNCH_CHECK();

@@ -431,6 +431,18 @@ __global__ __launch_bounds__(256) void rgb_combine_kernel(const float* __restric
         const int64_t pix = i % plane; const int c = (int)((i / plane) % C), n = (int)(i / (plane * C));
         float v = 0.f;
         for (int m = 0; m < M; ++m) v += partial[(((int64_t)n * M + m) * C + c) * plane + pix];
+        if (E.round_f16) {        // ToRGBLayer of a float16 block (n3d_torgb_h8's order): the float32 sum rounds to float16, bias_act on float16, float32 skip image
+            const float t = (float)(_Float16)v + (E.bias ? (float)(_Float16)E.bias[c] : 0.f);
+            const float cl = E.clamp >= 0.f ? E.clamp : INFINITY;
+            v = (float)(_Float16)fminf(fmaxf(t, -cl), cl);
+            if (E.residual) {
+                const int oy = (int)(pix / W), ox = (int)(pix % W);
+                if (E.residual_up_filter) v += n3d_up2_apply(n3d_up2_setup(E.residual_up_filter, oy, ox, H >> 1, W >> 1), E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)c * (plane >> 2));
+                else v += E.residual[(int64_t)n * E.residual_batch_stride + (int64_t)c * plane + pix];
+            }
+            y[i] = v;
+            continue;
+        }
         y[i] = n3d_apply_epilogue(v, E, n, c, C, (int)(pix / W), (int)(pix % W), H, W);
     }
 }
@@ -439,7 +451,8 @@ extern "C" int n3d_rgb_combine(const float* partial, float* y, int N, int M, int
     N3D_CHECK(N >= 0 && M >= 1 && C >= 1 && H >= 1 && W >= 1 && epi, "rgb_combine: bad arguments");
     if (N == 0) return 0;
     N3D_CHECK(partial && y, "rgb_combine: null tensor");
-    N3D_CHECK(!epi->row_scale && !epi->noise && !epi->round_f16, "rgb_combine: toRGB epilogue only (const scale, bias, activation, clamp, residual)");
+    N3D_CHECK(!epi->row_scale && !epi->noise, "rgb_combine: toRGB epilogue only (const scale, bias, activation, clamp, residual)");
+    N3D_CHECK(!epi->round_f16 || (epi->act == N3D_ACT_LINEAR && epi->const_scale == 1.f && epi->gain == 1.f), "rgb_combine: a float16 block's toRGB has a linear epilogue");
     N3D_CHECK(!epi->residual_up_filter || (epi->residual && H % 2 == 0 && W % 2 == 0), "rgb_combine: residual_up_filter needs a residual and an even output size");
     const int64_t total = (int64_t)N * C * H * W;
     N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * total * (M + 1));

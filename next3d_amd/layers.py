@@ -339,18 +339,30 @@ def modulate_weights_f16(L, styles, demodulate=True):
     return out
 
 
-def conv2d_f16(x, w16, out_channels, mode, epilogue=None):
-    """n3d_conv2d_f16: x `_lib.H8` [N,I,H,W], w16 from modulate_weights_f16 -> `_lib.H8` [N,O,H,W] (mode 0) or [N,O,2H+1,2W+1] (mode 2)."""
+def conv2d_f16(x, w16, out_channels, mode, epilogue=None, rgb=None):
+    """n3d_conv2d_f16: x `_lib.H8` [N,I,H,W], w16 from modulate_weights_f16 -> `_lib.H8` [N,O,H,W] (mode 0) or [N,O,2H+1,2W+1] (mode 2).
+    rgb = (per-sample float16 toRGB weights [N, C, O] flat, C <= 4) (mode 0): the layer's only reader, its toRGB, is evaluated in the epilogue —
+    returns the partial colours [N, O/64, C, H, W] float32 for torgb_combine_f16; the feature map is not written."""
     n, i, h, w = x.shape
     oh, ow = (h, w) if mode == 0 else (2 * h + 1, 2 * w + 1)
-    y = _lib.H8(n, out_channels, oh, ow, x.device)
     d = _lib.Conv2dDesc()
-    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x.data), _lib.ptr(w16), None, _lib.ptr(y.data), None
+    if rgb is not None:
+        rw, c = rgb
+        assert mode == 0 and rw.dtype == torch.float16 and rw.numel() == n * c * out_channels and 1 <= c <= 4
+        y = None
+        partial = torch.empty([n, out_channels // 64, c, h, w], dtype=torch.float32, device=x.device)
+        d.rgb_weight, d.rgb_partial, d.rgb_channels = _lib.ptr(rw), _lib.ptr(partial), c
+    else:
+        y = _lib.H8(n, out_channels, oh, ow, x.device)
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(x.data), _lib.ptr(w16), None, (_lib.ptr(y.data) if y is not None else None), None
     d.N, d.I, d.O, d.H, d.W = n, i, out_channels, h, w
     d.ksize, d.mode, d.ksplit = 3, mode, 1
     d.x_layout = d.y_layout = 3
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     _lib.check(_lib.lib().n3d_conv2d_f16(d, _lib.stream()))
+    if rgb is not None:
+        partial._keep = (x, w16, d.epi, rgb[0])
+        return partial
     y._keep = (x, w16, d.epi)
     return y
 
@@ -384,7 +396,7 @@ def modulate_weights_f16_multi(entries, styles_base, n):
     return outs
 
 
-def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=None, gain=1.0, w16=None):
+def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=None, gain=1.0, w16=None, rgb=None):
     """SynthesisLayer.forward of a float16 block (training/networks_stylegan2.py:311-330 with x.dtype == float16, fused_modconv):
     x `_lib.H8` -> `_lib.H8`.  `w16`: the layer's per-sample weights when already formed (modulate_weights_f16_multi)."""
     if noise_mode not in ('const', 'none'):
@@ -395,7 +407,8 @@ def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=N
     if w16 is None:
         w16 = modulate_weights_f16(L, styles, demodulate=True)
     if up == 1:
-        return conv2d_f16(x, w16, L.out_channels, 0, epi)
+        return conv2d_f16(x, w16, L.out_channels, 0, epi, rgb=rgb)
+    assert rgb is None
     z = conv2d_f16(x, w16, L.out_channels, 2)
     return fir4_h8(z, fir, epi)
 
@@ -408,6 +421,16 @@ def fir4_h8(z, fir, epi, gain=4.0):
     _lib.check(_lib.lib().n3d_fir4_h8(_lib.ptr(z.data), _lib.ptr(fir), _lib.ptr(f1d), _lib.ptr(y.data), n, c, h, w, 0, float(gain), epi, _lib.stream()))
     y._keep = (z, epi, f1d)
     return y
+
+
+def torgb_combine_f16(L, partial, fir, conv_clamp=None, img_lo=None):
+    """toRGB's float16 epilogue + skip image on the partial colours of a fused last layer (synthesis_layer_f16(..., rgb=...)); the
+    arithmetic of torgb_layer_f16: float32 sum -> float16, bias_act on float16, float32 skip image."""
+    if img_lo is not None:
+        img_lo = img_lo.contiguous()
+        assert tuple(fir.shape) == (4, 4)
+    return cg.rgb_combine(partial, _lib.make_epilogue(bias=L.bias, clamp=conv_clamp, residual=img_lo, residual_up_filter=fir if img_lo is not None else None,
+                                                      round_f16=1))
 
 
 def torgb_layer_f16(L, x, styles, fir, conv_clamp=None, img_lo=None, w16=None):

@@ -321,6 +321,11 @@ class SuperRes8XDC:
         for bi, blk in enumerate((self.block0, self.block1)):
             w0, w1, wt = w16[3 * bi:3 * bi + 3]
             xh = L.synthesis_layer_f16(blk.conv0, xh, None, self.fir, up=2, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w0)
+            if bi == 1 and L.FUSED_TORGB and blk.torgb.out_channels <= 4:
+                # the last layer's only reader is its toRGB: evaluated in conv1's epilogue, the 512 x 512 x 128-channel map is never written
+                part = L.synthesis_layer_f16(blk.conv1, xh, None, self.fir, up=1, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w1,
+                                             rgb=(wt, blk.torgb.out_channels))
+                return L.torgb_combine_f16(blk.torgb, part, self.fir, conv_clamp=blk.conv_clamp, img_lo=rgb)
             xh = L.synthesis_layer_f16(blk.conv1, xh, None, self.fir, up=1, noise_mode=noise_mode, conv_clamp=blk.conv_clamp, w16=w1)
             rgb = L.torgb_layer_f16(blk.torgb, xh, None, self.fir, conv_clamp=blk.conv_clamp, img_lo=rgb, w16=wt)
         return rgb

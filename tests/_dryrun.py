@@ -48,7 +48,9 @@ def _check_conv_desc(name, d):
 
 def _check_conv_f16_desc(d):
     """n3d_conv2d_f16's preconditions (conv2d_f16.hip)."""
-    assert d.x and d.wt and d.y and not d.style and d.ksplit <= 1
+    assert d.x and d.wt and (d.y or d.rgb_partial) and not d.style and d.ksplit <= 1
+    if d.rgb_partial:
+        assert d.mode == 0 and d.rgb_weight and not d.rgb_style and 1 <= d.rgb_channels <= 4
     assert d.ksize == 3 and d.mode in (0, 2) and d.x_layout == 3 and d.y_layout == 3
     assert d.I >= 16 and d.I % 16 == 0 and d.O >= 64 and d.O % 64 == 0
     assert d.x_batch_stride == 0 and d.y_batch_stride == 0 and d.x_row_stride == 0 and d.y_row_stride == 0

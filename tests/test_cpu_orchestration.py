@@ -66,8 +66,9 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     rnd = Counter(dry)                                           # networks_stylegan2.py:311): noisy layers run sample by sample
     # the default call runs the float16 super-resolution blocks on the f16 kernels: 10 launches (cast to h8, one weight
     # modulation for all six layers, per block transposed conv + FIR + conv + toRGB) instead of the float32 route's 8 (+ 2 conversion passes)
-    sr16 = lambda cnt: (cnt['n3d_cast_h8'], cnt['n3d_modulate_weights_f16_multi'], cnt['n3d_conv2d_f16'], cnt['n3d_fir4_h8'], cnt['n3d_torgb_h8'])
-    assert sr16(rnd) == (1, 1, 4, 2, 2) and sr16(full) == (0, 0, 0, 0, 0)
+    # (the last block's toRGB is evaluated in its conv1's epilogue — layers.FUSED_TORGB: one n3d_torgb_h8, one n3d_rgb_combine)
+    sr16 = lambda cnt: (cnt['n3d_cast_h8'], cnt['n3d_modulate_weights_f16_multi'], cnt['n3d_conv2d_f16'], cnt['n3d_fir4_h8'], cnt['n3d_torgb_h8'] + cnt['n3d_rgb_combine'])
+    assert sr16(rnd) == (1, 1, 4, 2, 2) and sr16(full) == (0, 0, 0, 0, 1)      # (float32 route: the fused toRGB's combine launch)
     n_rnd = sum(rnd.values()) - 10 + 8 - rnd['n3d_split8_from_nchw'] + full['n3d_split8_from_nchw']
     assert n_rnd > n_full if N > 1 else n_rnd == n_full
     dry.clear()
@@ -324,7 +325,8 @@ def test_fp16_backbones_launch_sequence_dry_run(dry):
     cnt = Counter(dry)
     blocks = 4 + 4 + 4 + 3
     assert tuple(out['image'].shape) == (2, 3, 512, 512)
-    assert cnt['n3d_conv2d_f16'] == 2 * (blocks + 2) and cnt['n3d_torgb_h8'] == blocks + 2 == cnt['n3d_fir4_h8'], cnt
+    # (the super-resolution's last toRGB is evaluated in its conv1's epilogue — layers.FUSED_TORGB: n3d_rgb_combine instead of n3d_torgb_h8)
+    assert cnt['n3d_conv2d_f16'] == 2 * (blocks + 2) and cnt['n3d_torgb_h8'] + cnt['n3d_rgb_combine'] == blocks + 2 == cnt['n3d_fir4_h8'] and cnt['n3d_rgb_combine'] == 1, cnt
     assert cnt['n3d_modulate_weights_f16_multi'] == 2 * 3 + 2 + 1      # 12 layers = two launches per 4-block network, 9 = two for the blending net, one for the SR
     dry.clear()
     G.synthesis(ws, c, v, force_fp32=True, **kw)

@@ -188,6 +188,34 @@ def test_torgb_h8(dev, N, C, H, W, with_img):
     assert err <= float(_ulp16(y).max()) + 1e-5
 
 
+@pytest.mark.parametrize('N,I,O,H,W,C,noise', [(4, 32, 128, 128, 128, 3, True), (2, 16, 64, 50, 70, 4, False), (1, 64, 192, 96, 160, 1, True)])
+def test_fused_torgb_of_a_float16_last_layer(dev, N, I, O, H, W, C, noise):
+    """n3d_conv2d_f16 with rgb_* + n3d_rgb_combine(round_f16): a float16 block's LAST conv1 evaluating its ToRGBLayer in the epilogue (the h8
+    feature map is never written) against the two layers run separately (n3d_conv2d_f16 -> n3d_torgb_h8): the same float16 operands, float32
+    sums in another order -> equal up to one float16 ulp of the colour where a sum lands on a rounding boundary."""
+    fir = layers.uf.setup_filter([1, 3, 3, 1]).to(dev)
+    x, w, s = _q(_g((N, I, H, W), 30)), _g((O, I, 3, 3), 31), _g((N, I), 32) + 1.0
+    bias, nz, nstr = _g((O,), 33, 0.1), _g((H, W), 34), torch.tensor(0.3)
+    wr, sr, br = _g((C, O, 1, 1), 35), (_g((N, O), 36) + 1.0) / np.sqrt(O), _g((C,), 37, 0.1)
+    even = H % 2 == 0 and W % 2 == 0
+    img_lo = _g((N, C, H // 2, W // 2), 38).to(dev) if even else None
+    L1 = _Layer(w.to(dev), bias.to(dev), nz.to(dev) if noise else None, nstr.to(dev))
+    LT = _Layer(wr.to(dev), br.to(dev))
+    w16 = layers.modulate_weights_f16(L1, s.to(dev))
+    wt16 = layers.modulate_weights_f16(LT, sr.to(dev), demodulate=False)
+    epi = _lib.make_epilogue(noise=L1.noise_const, noise_strength=L1.noise_strength if noise else None, bias=L1.bias, act='lrelu', gain=float(np.sqrt(2)), clamp=256.0)
+    xh = _lib.H8.from_nchw(x.to(dev))
+    feat = layers.conv2d_f16(xh, w16, O, 0, epi)
+    sep = layers.torgb_layer_f16(LT, feat, None, fir, conv_clamp=256, img_lo=img_lo, w16=wt16)
+    part = layers.conv2d_f16(xh, w16, O, 0, epi, rgb=(wt16, C))
+    assert tuple(part.shape) == (N, O // 64, C, H, W)
+    got = layers.torgb_combine_f16(LT, part, fir, conv_clamp=256, img_lo=img_lo)
+    d = (got - sep).abs()
+    y = sep - (layers.uf.upsample2d(img_lo, fir) if even else 0)
+    print(f'fused float16 toRGB {N}x{I}->{O}->{C} {H}x{W}: max-abs {float(d.max()):.3e}, differing {float((d > 0).float().mean()):.2e} of the values')
+    assert bool((d <= _ulp16(y.cpu()).to(dev) + 1e-5).all()) and float((d > 1e-6).float().mean()) < 0.02
+
+
 def test_cast_h8_round_trip(dev):
     x = _g((2, 24, 9, 13), 19, 100.0)
     h = _lib.H8.from_nchw(x.to(dev))

@@ -237,6 +237,16 @@ def test_fused_last_layer_torgb_equals_separate_torgb(G, dev, monkeypatch):
     e = _md(outs[True]['image'], outs[False]['image'])
     print(f'fused vs separate toRGB of the last layer: image max abs diff {e:.3e}')
     assert 0 < e <= 5e-5
+    # the scripts' default route (float16 blocks): the same fusion in n3d_conv2d_f16 — float16 operands, float32 sums in another order: colours equal
+    # up to one float16 ulp (2^-8 at |v| in [4, 8)) where a sum lands on a rounding boundary
+    kw.pop('force_fp32')
+    h = {}
+    for on in (True, False):
+        monkeypatch.setattr(layers, 'FUSED_TORGB', on)
+        h[on] = G.synthesis(ws, t('c'), t('v'), **kw)['image'].clone()
+    dh = (h[True] - h[False]).abs()
+    print(f'float16 route, fused vs separate toRGB: max abs diff {float(dh.max()):.3e}, differing {float((dh > 1e-6).float().mean()):.2e} of the values')
+    assert float(dh.max()) <= 2.0 ** -7 and float((dh > 1e-6).float().mean()) < 0.02
 
 
 @pytest.mark.gpu

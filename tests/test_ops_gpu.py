@@ -709,7 +709,7 @@ def test_fused_torgb_epilogue_matches_separate_layers(dev, N, I, OC, H, W, C):
     _close(got, want, atol=2e-6, rtol=2e-6)                                # float32 FMA chain over <= 128 channels
     if OC % 16 == 0:                                                       # and against the separate 1x1 split-bf16 toRGB kernel (3 bf16 products per MAC)
         sep = cg.conv_launch(feat, cg.prep_weight_bf16x3(wrgb.reshape(C, OC, 1, 1)), 1, 0, C, style=srgb, epilogue=_lib.make_epilogue(**tkw), bf16x3=True)
-        _close(got, sep, atol=2e-5, rtol=1e-5)
+        _close(got, sep, atol=1e-4, rtol=1e-5)                             # (that kernel's error: 2^-17 of the summed |products|; measured 2.4e-5)
     with pytest.raises(RuntimeError):
         cg.conv_launch(x, wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True, rgb=(wrgb, srgb))     # NCHW input: not the pre-split kernel
     with pytest.raises(RuntimeError):
