@@ -50,6 +50,7 @@ CPU_REFERENCE_PROFILE = os.path.join(REPO, 'profiles', 'r03_cpu_reference.json')
 # what the bf16 matrix pipe sustains with the kernels' instruction mix and RANDOM operands (tools/mfma_peak.hip, profiles/r02_mfma_peak_probe.txt:
 # 1850-1950 TFLOP/s bf16 = 617-650 fp32-equivalent; the chip power-limits to ~1.8 GHz under this load)
 MEASURED_BF16X3_CEILING_TFLOPS = 633.0
+MEASURED_F16_CEILING_TFLOPS = 1700.0          # profiles/r04_mfma_peak_f16_probe.txt: v_mfma_f32_32x32x16_f16, random operands, registers only (1560-1640 with the kernels' LDS reads)
 CONV_FAMILY = ('3x3 split-bf16 conv family: every conv2d*_bf16x3 kernel launched by n3d_conv2d_bf16x3 with ksize 3 '
                '(stride 1 incl. the persistent and pre-split variants, transposed stride 2, stride 2; all launches of the step)')
 
@@ -353,7 +354,11 @@ def main():
                                                    'kernel': 'conv2d_h8_f16_kernel / conv2d_up_h8_f16_*_kernel (n3d_conv2d_f16: the four 3x3 convolutions of the two float16 blocks)',
                                                    'launches_per_step': f16['launches'] / k16, 'algorithmic_gflop_per_step': f16['flops'] / k16 / 1e9,
                                                    'avg_launch_ms': f16['ms'] / max(f16['launches'], 1),
-                                                   'algorithmic_bytes_per_launch': f16['bytes'] / max(f16['launches'], 1)},
+                                                   'algorithmic_bytes_per_launch': f16['bytes'] / max(f16['launches'], 1),
+                                                   'frac_vs_measured_ceiling': a16 / MEASURED_F16_CEILING_TFLOPS,
+                                                   'measured_ceiling': {'value': MEASURED_F16_CEILING_TFLOPS, 'unit': 'TFLOP/s', 'source': 'profiles/r04_mfma_peak_f16_probe.txt '
+                                                                        '(tools/mfma_peak_f16.hip: the f16 MFMA with random operands sustains 1700-1720 TFLOP/s from registers, 1560-1640 with the '
+                                                                        "kernels' fragment reads: the chip clocks 1.5-1.64 GHz under this load)"}},
                                   'family_ms_per_step': {k: round(pv['ms'] / k16, 4) for k, pv in p16.items()}}
         # ---- legacy.load_network_pkl(force_fp16=True) (legacy.py:49-59): num_fp16_res = 4, conv_clamp = 256 in all four backbones too —
         # every block of resolution >= 32 of the five networks runs as a float16 block on the f16 matrix cores
@@ -370,7 +375,7 @@ def main():
                                                  'backbones, float16 super-resolution blocks): every block of resolution >= 32 on v_mfma_f32_32x32x16_f16',
                                          'roofline_f16': {'bound': 'mfma', 'achieved': abb, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': abb / PEAK_BF16_MFMA_TFLOPS,
                                                           'launches_per_step': fbb['launches'] / k16, 'algorithmic_gflop_per_step': fbb['flops'] / k16 / 1e9,
-                                                          'avg_launch_ms': fbb['ms'] / max(fbb['launches'], 1)},
+                                                          'avg_launch_ms': fbb['ms'] / max(fbb['launches'], 1), 'frac_vs_measured_ceiling': abb / MEASURED_F16_CEILING_TFLOPS},
                                          'family_ms_per_step': {k: round(pv['ms'] / k16, 4) for k, pv in pbb.items()}}
         gen[0] = G
         del G16

@@ -213,7 +213,7 @@ def test_fused_torgb_of_a_float16_last_layer(dev, N, I, O, H, W, C, noise):
     d = (got - sep).abs()
     y = sep - (layers.uf.upsample2d(img_lo, fir) if even else 0)
     print(f'fused float16 toRGB {N}x{I}->{O}->{C} {H}x{W}: max-abs {float(d.max()):.3e}, differing {float((d > 0).float().mean()):.2e} of the values')
-    assert bool((d <= _ulp16(y.cpu()).to(dev) + 1e-5).all()) and float((d > 1e-6).float().mean()) < 0.02
+    assert bool((d <= 2 * _ulp16(y.cpu()).to(dev) + 1e-5).all()) and float((d > 1e-6).float().mean()) < 0.02      # (one ulp of the LARGER neighbour at a binade boundary)
 
 
 def test_cast_h8_round_trip(dev):

@@ -67,6 +67,9 @@ def main():
         t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi))
         print(f'stride-1 library default: {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
         b = L.conv2d_f16(y, w1, o, 0, epi)
+        wt16 = L.modulate_weights_f16(torgb, s2, demodulate=False)
+        t = timeit(lambda: L.conv2d_f16(y, w1, o, 0, epi, rgb=(wt16, 3)))
+        print(f'stride-1 with the toRGB fused into its epilogue (no feature-map store): {t:8.1f} us  {gf / t * 1e3:7.1f} TFLOP/s')
         img_lo = torch.randn(N, 3, h, h, device=dev)
         t = timeit(lambda: L.torgb_layer_f16(torgb, b, s2, fir, conv_clamp=256, img_lo=img_lo))
         print(f'torgb_h8 (incl. its weight modulation): {t:8.1f} us  {2 * N * o * 4 * h * h / t / 1e6:6.2f} TB/s')
