@@ -787,7 +787,7 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
               (d->y_layout == N3D_LAYOUT_SPLIT8 && d->ksize == 1 && d->x_layout == N3D_LAYOUT_NCHW_F32),
               "conv2d_bf16x3: y_layout %d is not available for this kernel", d->y_layout);
     N3D_CHECK(d->x_layout != N3D_LAYOUT_SPLIT8 || d->ksize == 3, "conv2d_bf16x3: split8 input goes to the 3x3 kernels");
-    N3D_CHECK(!d->side_split8 || (d->ksize == 1 && d->x_layout == N3D_LAYOUT_NCHW_F32), "conv2d_bf16x3: side_split8 is written by the 1x1 kernel only");
+    N3D_CHECK(!d->side_split8 || (d->ksize == 1 && d->x_layout == N3D_LAYOUT_NCHW_F32) || d->rgb_partial, "conv2d_bf16x3: side_split8 is written by the 1x1 kernel, or by the 3x3 kernel with the fused toRGB");
     N3D_CHECK(d->wt_batch_stride == 0 || d->x_layout != N3D_LAYOUT_SPLIT8 || d->mode == 0, "conv2d_bf16x3: per-sample weights with a split8 input: stride-1 kernel only");
     if (d->x_layout == N3D_LAYOUT_SPLIT8)
         return d->mode == 2 ? conv2d_up_ps_bf16x3_launch(d, stream) : (d->mode == 1 ? conv2d_s2_ps_bf16x3_launch(d, stream) : conv2d_ps_bf16x3_launch(d, stream));

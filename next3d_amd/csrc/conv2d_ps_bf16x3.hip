@@ -44,6 +44,9 @@ struct ConvPsParams {
     // fused toRGB of a LAST block (n3d_conv2d_desc.rgb_*): the activated tile is multiplied with the RC x O toRGB weights (times the sample's
     // toRGB styles) in the epilogue and only the partial colours of this workgroup's 64 channels leave the chip; y may then be NULL
     const float* rgb_weight; const float* rgb_style; float* rgb_partial; int rgb_channels; int64_t rgb_style_stride;
+    // ... and, when the layer has a second reader (the next block's transposed convolution), its operand image: the activated tile times
+    // side_style [N][O] in the dense split8 layout — exactly n3d_split8_from_nchw(y, side_style) — written from the same LDS stage
+    bf16x8* side; const float* side_style; int64_t side_style_stride;
 };
 
 constexpr int PS_RGB_MAX = 4, PS_RGB_PITCH = 16 * 32 + 4;                               // fused toRGB: colours, floats per staged channel row
@@ -62,7 +65,7 @@ constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                               
 //           workgroup fills the gaps: its MFMAs run while this one waits for its DMA or writes its tile.  With one workgroup per
 //           CU every chunk's DMA wait, every barrier skew and the whole epilogue (a 128 KB tile written while every other CU
 //           writes its own: ~7 us at the chip's ~4.7 TB/s of store bandwidth) leave the matrix pipe idle.
-template <int NBUF, bool RGB>
+template <int NBUF, bool RGB, bool SIDE = false>
 __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf16x8* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -172,6 +175,8 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
         const int j = tid / PS_BM, o = m0 + tid % PS_BM;
         s_cw[tid] = (j < p.rgb_channels && o < p.O) ? p.rgb_weight[(int64_t)j * p.O + o] * p.rgb_style[(int64_t)n * p.rgb_style_stride + o] : 0.f;
     }
+    float* s_sd = s_cw + PS_RGB_MAX * PS_BM;                              // RGB + side output: the next layer's styles of this tile's channels
+    if (RGB && SIDE && tid < PS_BM) s_sd[tid] = (p.side && m0 + tid < p.O) ? p.side_style[(int64_t)n * p.side_style_stride + m0 + tid] : 0.f;
 
     if (NBUF == 1) {
         __builtin_amdgcn_s_barrier();                                     // (the epilogue factors above are plain LDS stores)
@@ -247,7 +252,9 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
         float* stage = reinterpret_cast<float*>(smem);
         float col[PS_RGB_MAX] = {0.f, 0.f, 0.f, 0.f};
         // (lane / thread index re-derived here so that nothing extra stays live across the K loop: the loop sits at the 128-VGPR limit)
-        const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), tid_e = wn * 64 + lane_e, l31_e = lane_e & 31, half_e = lane_e >> 5;
+        int lane_e;                                                       // (volatile asm: not hoisted above the loop as a loop invariant)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int tid_e = wn * 64 + lane_e, l31_e = lane_e & 31, half_e = lane_e >> 5;
         __syncthreads();                                                  // every wave is past its last fragment read; s_cw is visible
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -270,11 +277,34 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
                 }
             }
             __syncthreads();
-#pragma unroll 8
-            for (int c = 0; c < 32; ++c) {
-                const float xv = stage[c * PS_RGB_PITCH + tid_e];
+            const int oy_s = y0 + (tid_e >> 5), ox_s = x0 + (tid_e & 31);
+            const bool side_px = SIDE && p.side != nullptr && oy_s < p.H && ox_s < p.W;
+            // (buffer stores: one VGPR of address per lane — the pixel — and the (plane, unit) part in the scalar offset; pixels outside the image
+            // get an offset beyond the descriptor's range: dropped by the hardware)
+            const __amdgpu_buffer_rsrc_t r_side = __builtin_amdgcn_make_buffer_rsrc((void*)(p.side + (int64_t)n * 2 * (p.O / 8) * HW), 0, (SIDE && p.side) ? 2 * (p.O / 8) * HW * 16 : 0, 0x00020000);
+            const int voff_side = side_px ? (oy_s * p.W + ox_s) * 16 : (int)0x80000000;
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {                                 // 8-channel units of this 32-channel group (not unrolled: register budget)
+                bf16x8 hi, lo;
 #pragma unroll
-                for (int j = 0; j < PS_RGB_MAX; ++j) col[j] = fmaf(xv, s_cw[j * PS_BM + mt * 32 + c], col[j]);
+                for (int cc = 0; cc < 8; ++cc) {
+                    const int c = u * 8 + cc;
+                    const float xv = stage[c * PS_RGB_PITCH + tid_e];
+#pragma unroll
+                    for (int j = 0; j < PS_RGB_MAX; ++j) col[j] = fmaf(xv, s_cw[j * PS_BM + mt * 32 + c], col[j]);
+                    if constexpr (SIDE) {
+                        const float t = xv * s_sd[mt * 32 + c];            // n3d_split8_from_nchw's arithmetic
+                        const __bf16 h = (__bf16)t;
+                        hi[cc] = h;
+                        lo[cc] = (__bf16)(t - (float)h);
+                    }
+                }
+                const int unit = (m0 + mt * 32) / 8 + u;
+                if (SIDE && p.side != nullptr && unit * 8 < p.O) {
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hi), r_side, voff_side, unit * HW * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, lo), r_side, voff_side, (p.O / 8 + unit) * HW * 16, 0);
+                }
             }
             __syncthreads();
         }
@@ -338,7 +368,7 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
 }
 
 // (concrete kernels around the body template: hipcc's host pass can drop the launch stub of a __global__ template, see conv2d_f16.hip)
-constexpr int ps_smem_slots(int nbuf, bool rgb) { return nbuf * PS_BUF + (2 + (rgb ? PS_RGB_MAX : 0)) * PS_BM * 4 / 16; }
+constexpr int ps_smem_slots(int nbuf, bool rgb) { return nbuf * PS_BUF + (2 + (rgb ? PS_RGB_MAX + 1 : 0)) * PS_BM * 4 / 16; }
 __global__ __launch_bounds__(512, 4) void conv2d_ps1_bf16x3_kernel(ConvPsParams p) {         // one buffer, two workgroups per CU
     __shared__ bf16x8 smem[ps_smem_slots(1, false)];
     conv2d_ps_bf16x3_body<1, false>(p, smem);
@@ -354,6 +384,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_ps1_rgb_bf16x3_kernel(ConvPsPar
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_rgb_bf16x3_kernel(ConvPsParams p) {
     __shared__ bf16x8 smem[ps_smem_slots(2, true)];
     conv2d_ps_bf16x3_body<2, true>(p, smem);
+}
+// + the split8 side output for the layer's second reader.  Two buffers / one workgroup per CU only: the epilogue needs ~160 VGPRs, and under the
+// 128-register cap of the two-workgroups-per-CU form hipcc spills ACCUMULATORS inside the K loop
+__global__ __launch_bounds__(512, 2) void conv2d_ps2_rgbs_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[ps_smem_slots(2, true)];
+    conv2d_ps_bf16x3_body<2, true, true>(p, smem);
 }
 
 // Layers this kernel takes (the host asks before it lets a producer write split8): 3x3 stride 1, I % 16 == 0, images of at
@@ -401,6 +437,9 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
         N3D_CHECK(p.ksplit == 1 && !E.residual && !E.round_f16, "conv2d_bf16x3: fused toRGB on a layer without split-K, residual or float16 rounding");
     }
     N3D_CHECK(d->y != nullptr || rgb, "conv2d_bf16x3: y is NULL");
+    N3D_CHECK(!d->side_split8 || (rgb && d->side_style && d->O % 8 == 0 && ((uintptr_t)d->side_split8 & 15) == 0 && (int64_t)2 * (d->O / 8) * d->H * d->W * 16 < (1ll << 31)),
+              "conv2d_bf16x3 (split8 input): the split8 side output is an option of the fused toRGB (rgb_partial, side_style, O %% 8 == 0)");
+    p.side = (bf16x8*)d->side_split8; p.side_style = d->side_style; p.side_style_stride = d->side_style_stride ? d->side_style_stride : d->O;
     p.rgb_weight = d->rgb_weight; p.rgb_style = d->rgb_style; p.rgb_partial = d->rgb_partial; p.rgb_channels = d->rgb_channels;
     p.rgb_style_stride = d->rgb_style_stride ? d->rgb_style_stride : d->O;
     p.dbg = n3d_tune("N3D_CONV_DBG", 0);                                  // tuning builds re-read it per launch: tools/conv_ps_abl.py flips it in-process
@@ -408,14 +447,15 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(nblk < (1ll << 31), "conv2d_bf16x3: grid too large");
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (d->y ? (double)d->N * d->O * d->H * d->W : 0.0) + (double)d->O * d->I * 9 +
-                                (rgb ? (double)d->N * p.tiles_m * d->rgb_channels * d->H * d->W : 0.0));
+                                (rgb ? (double)d->N * p.tiles_m * d->rgb_channels * d->H * d->W : 0.0) + (d->side_split8 ? (double)d->N * d->O * d->H * d->W : 0.0));
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     // two workgroups per CU (single LDS buffer each) once the grid holds at least three per CU: with fewer, the in-workgroup
     // double buffering wins (measured, tools/conv_ps_abl.py: 64x64 x 512 channels = 256 workgroups: 156 us vs 201 us; 512
     // workgroups: equal; 1024+: 174 vs 182 us, 697 vs 735 us).  Starting every other batch of workgroups late to de-phase the
     // CUs' store bursts was measured too: no effect.
     { const int nbuf = n3d_tune("N3D_PS_NBUF", nblk >= 768 ? 1 : 2);
-      if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      if (rgb && d->side_split8) hipLaunchKernelGGL(conv2d_ps2_rgbs_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (rgb) hipLaunchKernelGGL(conv2d_ps1_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else hipLaunchKernelGGL(conv2d_ps1_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p); }

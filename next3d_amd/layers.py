@@ -88,12 +88,12 @@ class PreparedConv:
             self.noise_strength = P.get(f'{prefix}.noise_strength')
 
 
-def _conv3x3(L, x, style=None, epilogue=None, out=None, rgb=None):
+def _conv3x3(L, x, style=None, epilogue=None, out=None, rgb=None, side_style=None):
     """3x3 stride-1 convolution on the arithmetic selected by PRECISION.  A `_lib.Split8` input (written by the previous
     layer's epilogue with THIS layer's style multiplied in) goes to the pre-split kernel; `style` is then ignored."""
     if isinstance(x, _lib.Split8):
-        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True, rgb=rgb)
-    assert rgb is None
+        return cg.conv_launch(x, L.wt16, 3, 0, L.out_channels, epilogue=epilogue, out=out, bf16x3=True, rgb=rgb, side_style=side_style)
+    assert rgb is None and side_style is None
     n, i, h, w = x.shape
     if (PRESPLIT and PRECISION == 'bf16x3' and L.wt16 is not None and x.dtype == torch.float32 and 4 * n * i * h * w <= CONVERT_MAX_BYTES and
             cg.split8_eligible(n, i, L.out_channels, h, w) and (epilogue is None or epilogue.act in (1, 3))):
@@ -188,7 +188,7 @@ def presplit_ok(n, next_layer, h, w):
 
 
 def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gain=1.0, styles=None, dcoef=None, out=None, _noise=None,
-                    split_for=None, x_split8=None, split_for_nchw=None, ps_nchw=False, rgb=None):
+                    split_for=None, x_split8=None, split_for_nchw=None, ps_nchw=False, rgb=None, rgb_side_style=None):
     """SynthesisLayer.forward (reference networks_stylegan2.py:311-330).  `styles`/`dcoef` may come pre-computed from a
     StyleBank; otherwise they are computed here from the latent `w`.  noise_mode 'const' adds the learned noise image,
     'random' a fresh N(0,1) image PER SAMPLE (:318-319, the reference's training-time default; drawn with torch.randn from
@@ -198,6 +198,7 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     layers whose transposed convolution runs on the register-staged kernel (few positions: split-K, float32 NCHW result): their FIR
     reads that result and writes split8 (n3d_fir4_split8_nchw, pad 1) instead of float32 + a conversion pass in front of conv1.
     `rgb` (up = 1, x a `_lib.Split8`): see fused_torgb_ok — the layer's result is then the partial colour tensor for torgb_combine.
+    `rgb_side_style` (with rgb): the styles of the layer's second reader -> (partial, `_lib.Split8` of the layer's output * those styles).
     (The reference's float16 blocks run on their own kernels: synthesis_layer_f16.)"""
     if styles is None:
         styles = fc(w, L.affine_w, L.affine_b, wgain=1.0 / np.sqrt(w.shape[1]))
@@ -215,7 +216,7 @@ def synthesis_layer(L, x, w, fir, up=1, noise_mode='const', conv_clamp=None, gai
     act = dict(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain)
     if up == 1:
-        return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out, rgb=rgb)
+        return _conv3x3(L, x, style=styles, epilogue=_lib.make_epilogue(row_scale=dcoef, **act), out=out, rgb=rgb, side_style=rgb_side_style)
     assert up == 2 and out is None and rgb is None
     if split_for is not None:       # transposed conv -> channel-interleaved z -> FIR + epilogue + next style + hi/lo split
         zepi = _lib.make_epilogue(row_scale=dcoef)

@@ -65,6 +65,8 @@ class _Block:
             x = self.const.unsqueeze(0).expand(n, -1, -1, -1)
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv1))
         else:
+            if x is None:                  # the previous block never wrote its x in float32 (fused toRGB + split8 side output): only x_split8 exists
+                x = x_split8
             pre = self._presplit(n, x.shape, fir, noise_mode)
             # ... or, where conv0 runs on the register-staged transposed kernel (few positions, split-K), at least its FIR writes split8
             pre_nchw = (not pre and L.NCHW_FIR_SPLIT8 and noise_mode != 'random' and fir.ndim == 2 and tuple(fir.shape) == (4, 4) and
@@ -74,14 +76,19 @@ class _Block:
             x = L.synthesis_layer(self.conv0, x, None, fir, up=2, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
                                   split_for=bank[self.conv1.prefix][0] if pre else None, x_split8=x_split8 if (pre or psn) else None,
                                   split_for_nchw=bank[self.conv1.prefix][0] if pre_nchw else None, ps_nchw=psn, **sl(self.conv0))
-            if last and x_out is None and L.fused_torgb_ok(self.conv1, self.torgb, x, noise_mode):
+            # x's only readers are this block's toRGB (<= 4 colours) and, unless `last`, the next block's transposed convolution on split8 input:
+            # conv1 evaluates the toRGB in its epilogue and writes that operand image itself — x is never written in float32 (layers.fused_torgb_ok)
+            nb_split8 = next_block is not None and self.conv1.out_channels % 8 == 0 and next_block.takes_split8(n, (n, self.conv1.out_channels, x.shape[2], x.shape[3]), fir, noise_mode)
+            if (last or nb_split8) and x_out is None and L.fused_torgb_ok(self.conv1, self.torgb, x, noise_mode):
                 t = self.torgb
                 part = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
-                                         rgb=(t.weight.reshape(t.out_channels, t.in_channels), bank[t.prefix][0]), **sl(self.conv1))
+                                         rgb=(t.weight.reshape(t.out_channels, t.in_channels), bank[t.prefix][0]),
+                                         rgb_side_style=None if last else bank[next_block.conv0.prefix][0], **sl(self.conv1))
+                part, xs = (part, None) if last else part
                 up = fir if (img is not None and fir.ndim == 2 and tuple(fir.shape) == (4, 4)) else None
                 if img is not None and up is None:
                     img = uf.upsample2d(img, fir)
-                return None, L.torgb_combine(t, part, conv_clamp=self.conv_clamp, residual=img, residual_up_filter=up), None
+                return None, L.torgb_combine(t, part, conv_clamp=self.conv_clamp, residual=img, residual_up_filter=up), xs
             x = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
         # skip-image update img = upsample2d(img) + toRGB(x): upsample2d is evaluated inside the toRGB epilogue (4 taps of the
         # half-resolution image per pixel)

@@ -150,7 +150,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls.
     rgb = (weight [C,O] float32, styles [N,O]) (split8 input, mode 0, no split-K, C <= 4): the toRGB layer that is this layer's ONLY reader is
     evaluated in the epilogue (n3d_conv2d_desc.rgb_*): returns the partial colour images [N, ceil(O/64), C, H, W] for rgb_combine; the feature
-    map itself is not written."""
+    map itself is not written; with side_style [N,O] as well: returns (partial, `_lib.Split8` of the layer's output * side_style) — the operand
+    image of the layer's second reader (the next block's transposed convolution), exactly split8_from_nchw(y, side_style)."""
     split8 = isinstance(x, _lib.Split8)
     if split8:      # pre-split activations (already modulated): the LDS-DMA kernel; x.data is the flat bf16 storage
         if not (bf16x3 and ksize == 3 and mode in (0, 1, 2) and style is None):
@@ -237,7 +238,13 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         partial = torch.empty([n, (o + 63) // 64, rw.shape[0], h, w], dtype=torch.float32, device=wt.device)
         d.rgb_weight, d.rgb_style, d.rgb_partial, d.rgb_channels, d.rgb_style_stride = _lib.ptr(rw), _lib.ptr(rs), _lib.ptr(partial), rw.shape[0], rs.stride(0)
     side = None
-    if side_style is not None:
+    if side_style is not None and rgb is not None:        # the fused-toRGB layer's own OUTPUT times the next layer's styles, as split8 (its second reader)
+        if not (o % 8 == 0 and side_style.dtype == torch.float32 and side_style.stride(1) == 1 and tuple(side_style.shape) == (n, o)):
+            raise RuntimeError('conv2d: the split8 side output of a fused-toRGB layer needs O % 8 == 0 and float32 styles [N, O]')
+        _lib.require_device(side_style)
+        side = _lib.Split8(n, o, h, w, wt.device)
+        d.side_split8, d.side_style, d.side_style_stride = _lib.ptr(side.data), _lib.ptr(side_style), side_style.stride(0)
+    elif side_style is not None:
         if not (bf16x3 and ksize == 1 and not split8 and s8 is None and o <= 128 and i % 32 == 0 and out_dtype == torch.float32 and
                 side_style.dtype == torch.float32 and side_style.stride(1) == 1 and tuple(side_style.shape) == (n, i)):
             raise RuntimeError('conv2d: the split8 side output is written by the 1x1 split-bf16 kernel (O <= 128, I % 32 == 0, float32 styles [N,I])')
@@ -247,7 +254,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     fn = _lib.lib().n3d_conv2d_bf16x3 if bf16x3 else _lib.lib().n3d_conv2d
     _lib.check(fn(d, _lib.stream()))
     if partial is not None:
-        return partial
+        return partial if side is None else (partial, side)
     if side is not None:
         return (y if out_dtype == torch.float32 else _lib.cast(y, out_dtype)), side
     if c8 is not None or s8 is not None:

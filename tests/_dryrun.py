@@ -32,7 +32,9 @@ def _check_conv_desc(name, d):
         assert d.ksplit <= 1 or d.mode in (0, 1)         # stride 1 (the library's own factor, n3d_conv2d_split8_ksplit) and stride 2 split K
         assert d.I % 16 == 0 and d.x_batch_stride % 4 == 0
         assert (d.mode == 0 and d.H >= 16 and d.W >= 32) or (d.mode == 2 and d.y_layout in (0, 2) and d.O % 64 == 0 and d.H >= 4 and d.W >= 4) or (d.mode == 1 and d.H >= 3 and d.W >= 3)
-    if d.side_split8:                                    # toRGB's second output: x * the next block's styles as split8
+    if d.side_split8 and d.rgb_partial:                  # fused-toRGB layer with a second reader: its own output * that reader's styles as split8
+        assert d.side_style and d.O % 8 == 0
+    elif d.side_split8:                                  # toRGB's second output: x * the next block's styles as split8
         assert bf16x3 and d.ksize == 1 and d.x_layout == 0 and d.y_layout == 0 and d.O <= 128 and d.I % 32 == 0 and d.side_style
     if bf16x3:
         assert d.I % 16 == 0 and (d.ksize == 3 or d.mode == 0)

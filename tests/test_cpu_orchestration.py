@@ -68,7 +68,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     # modulation for all six layers, per block transposed conv + FIR + conv + toRGB) instead of the float32 route's 8 (+ 2 conversion passes)
     # (the last block's toRGB is evaluated in its conv1's epilogue — layers.FUSED_TORGB: one n3d_torgb_h8, one n3d_rgb_combine)
     sr16 = lambda cnt: (cnt['n3d_cast_h8'], cnt['n3d_modulate_weights_f16_multi'], cnt['n3d_conv2d_f16'], cnt['n3d_fir4_h8'], cnt['n3d_torgb_h8'] + cnt['n3d_rgb_combine'])
-    assert sr16(rnd) == (1, 1, 4, 2, 2) and sr16(full) == (0, 0, 0, 0, 1)      # (float32 route: the fused toRGB's combine launch)
+    assert sr16(rnd) == (1, 1, 4, 2, 2) and sr16(full) == (0, 0, 0, 0, 2)      # (float32 route: both blocks' toRGB fused into their conv1: two combine launches)
     n_rnd = sum(rnd.values()) - 10 + 8 - rnd['n3d_split8_from_nchw'] + full['n3d_split8_from_nchw']
     assert n_rnd > n_full if N > 1 else n_rnd == n_full
     dry.clear()

@@ -213,7 +213,9 @@ def test_fused_torgb_of_a_float16_last_layer(dev, N, I, O, H, W, C, noise):
     d = (got - sep).abs()
     y = sep - (layers.uf.upsample2d(img_lo, fir) if even else 0)
     print(f'fused float16 toRGB {N}x{I}->{O}->{C} {H}x{W}: max-abs {float(d.max()):.3e}, differing {float((d > 0).float().mean()):.2e} of the values')
-    assert bool((d <= 2 * _ulp16(y.cpu()).to(dev) + 1e-5).all()) and float((d > 1e-6).float().mean()) < 0.02      # (one ulp of the LARGER neighbour at a binade boundary)
+    # one ulp on the rounded sum can become two behind the second rounding (bias_act), and an ulp doubles across a binade boundary
+    # (the first rounding happens on the sum BEFORE the bias is added: its ulp is that of |y - bias|, bounded here by |y| + max |bias|)
+    assert bool((d <= 3 * _ulp16(y.abs().cpu() + float(br.abs().max())).to(dev) + 1e-5).all()) and float((d > 1e-6).float().mean()) < 0.02
 
 
 def test_cast_h8_round_trip(dev):

@@ -681,7 +681,8 @@ def test_fused_torgb_epilogue_matches_separate_layers(dev, N, I, OC, H, W, C):
     """n3d_conv2d_desc.rgb_* + n3d_rgb_combine (a network's LAST 3x3 layer evaluating its toRGB in the epilogue; the feature map is never
     written) against the two layers run separately — the same pre-split kernel writing x, then the 1x1 toRGB kernel with the skip-image
     upsample in its epilogue — and against float32 ATen; big grids (one LDS buffer, two workgroups per CU) and small ones (two buffers),
-    ragged tiles, O not a multiple of 64, 1 / 3 / 4 colours."""
+    ragged tiles, O not a multiple of 64, 1 / 3 / 4 colours; and with the split8 side output for the layer's second reader (bit-identical to
+    n3d_split8_from_nchw of the separately written feature map)."""
     from next3d_amd import _lib, layers
     from next3d_amd.torch_utils.ops import conv2d_gradfix as cg, upfirdn2d as uf
     assert cg.split8_eligible(N, I, OC, H, W) and _lib.lib().n3d_conv2d_split8_ksplit(N, I, OC, H, W) == 1
@@ -710,6 +711,12 @@ def test_fused_torgb_epilogue_matches_separate_layers(dev, N, I, OC, H, W, C):
     if OC % 16 == 0:                                                       # and against the separate 1x1 split-bf16 toRGB kernel (3 bf16 products per MAC)
         sep = cg.conv_launch(feat, cg.prep_weight_bf16x3(wrgb.reshape(C, OC, 1, 1)), 1, 0, C, style=srgb, epilogue=_lib.make_epilogue(**tkw), bf16x3=True)
         _close(got, sep, atol=1e-4, rtol=1e-5)                             # (that kernel's error: 2^-17 of the summed |products|; measured 2.4e-5)
+    if OC % 8 == 0:      # ... and with the layer's second reader served from the same epilogue: its output times that reader's styles, as split8
+        st2 = (1 + 0.3 * _gen((N, OC), 139)).to(dev)
+        part2, side = cg.conv_launch(xs, wt16, 3, 0, OC, epilogue=_lib.make_epilogue(**kw), bf16x3=True, rgb=(wrgb, srgb), side_style=st2)
+        want_side = cg.split8_from_nchw(feat, st2)
+        assert side.shape == (N, OC, H, W) and torch.equal(side.data.view(torch.int16), want_side.data.view(torch.int16))
+        _close(cg.rgb_combine(part2, _lib.make_epilogue(**tkw)), got, atol=1e-6, rtol=1e-6)      # (another kernel instance: same sums, FMA order equal)
     with pytest.raises(RuntimeError):
         cg.conv_launch(x, wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True, rgb=(wrgb, srgb))     # NCHW input: not the pre-split kernel
     with pytest.raises(RuntimeError):

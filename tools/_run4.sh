@@ -1,6 +1,6 @@
 cd /root/repo
 mkdir -p gpurun_out
-python -m pytest tests/test_f16_gpu.py -x -q -m gpu -k "fused_torgb" 2>&1 | tail -2
+python -m pytest tests/test_f16_gpu.py -q -m gpu -s -k "fused_torgb" 2>&1 | grep -E "fused float16|passed|failed|^E" | head -12
 N3D_LIB=tools/probe/libn3d_tuning.so timeout 300 python tools/f16_bench.py > gpurun_out/r4_f16_bench2.txt 2>&1; grep -E "^---|stride-1|torgb" gpurun_out/r4_f16_bench2.txt
 for rep in 1 2; do
 for on in True False; do
