@@ -509,19 +509,18 @@ __device__ __forceinline__ void conv2d_up_f16_body(const ConvUpF16Params& p, f16
             const int oy = 2 * gy + pa;
             if (oy >= p.OH) continue;
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const int ox = 2 * gx + pb;
-                if (ox >= p.OW) continue;
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt)
+                for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
+                    for (int pb = 0; pb < 2; ++pb) {                       // the two horizontally adjacent phases back to back (adjacent 16-byte units)
+                        const int ox = 2 * gx + pb;
+                        if (ox >= p.OW) continue;
                         const f32x16& a = acc[mt][g][pa * 2 + pb];
                         const f16x4 v = {(_Float16)a[4 * gg + 0], (_Float16)a[4 * gg + 1], (_Float16)a[4 * gg + 2], (_Float16)a[4 * gg + 3]};
                         const int64_t unit = ((int64_t)((m0 >> 3) + mt * 4 + gg) * p.OH + oy) * p.OW + ox;
                         *reinterpret_cast<f16x4*>(yb + unit * 8 + 4 * half) = v;
                     }
-            }
         }
     }
 }

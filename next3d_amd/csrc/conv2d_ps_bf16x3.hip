@@ -683,15 +683,17 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
         for (int pa = 0; pa < 2; ++pa) {
             const int oy = 2 * gy + pa;
             if (oy >= p.OH) continue;
+            // the two horizontally adjacent phases back to back: a lane's 16-byte pieces of pixel 2 gx and 2 gx + 1 are 32 bytes apart, the other
+            // channel half (lane ^ 32) fills the 16 bytes between — the four pieces of a 64-byte run leave the wave in two consecutive instructions
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                const int ox = 2 * gx + pb;
-                if (ox >= p.OW) continue;
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < NMT; ++mt)
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int c8 = (m0 >> 3) + mt * 4 + gg, ol = mt * 32 + 8 * gg + 4 * half;
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int c8 = (m0 >> 3) + mt * 4 + gg, ol = mt * 32 + 8 * gg + 4 * half;
+                    for (int pb = 0; pb < 2; ++pb) {
+                        const int ox = 2 * gx + pb;
+                        if (ox >= p.OW) continue;
                         const f32x16& a = acc[mt][g][pa * 2 + pb];
                         if (p.y_nchw) {
 #pragma unroll
@@ -703,7 +705,7 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
                                          n3d_round16(a[4 * gg + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * gg + 3] * s_rs[ol + 3], p.round_f16)};
                         *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
                     }
-            }
+                }
         }
     }
 }

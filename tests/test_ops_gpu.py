@@ -676,7 +676,7 @@ def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
         cg.conv_launch(_to_split8(x), wt16, 3, 0, OC, style=torch.ones(N, I, device=dev), bf16x3=True)      # the split8 input is modulated already
 
 
-@pytest.mark.parametrize('N,I,OC,H,W,C', [(4, 32, 128, 128, 128, 3), (2, 64, 128, 200, 330, 3), (2, 16, 64, 96, 160, 4), (3, 32, 100, 100, 70, 1)])
+@pytest.mark.parametrize('N,I,OC,H,W,C', [(4, 32, 128, 256, 256, 3), (2, 64, 128, 200, 330, 3), (2, 16, 64, 200, 330, 4), (3, 32, 100, 200, 200, 1)])
 def test_fused_torgb_epilogue_matches_separate_layers(dev, N, I, OC, H, W, C):
     """n3d_conv2d_desc.rgb_* + n3d_rgb_combine (a network's LAST 3x3 layer evaluating its toRGB in the epilogue; the feature map is never
     written) against the two layers run separately — the same pre-split kernel writing x, then the 1x1 toRGB kernel with the skip-image
