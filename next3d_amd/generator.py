@@ -17,7 +17,7 @@ from . import _lib, layers, mesh, networks, spec
 
 _BUFFER_LEAVES = ('noise_const', 'resample_filter', 'w_avg', 'dense_faces', 'faces', 'raw_uvcoords', 'uvcoords', 'uvfaces',
                   'face_uvcoords')
-RASTER_ON_SIDE_STREAM = True       # _planes: the mesh rasterisation in front of the static backbone on the side stream (A/B: tests / tools flip it)
+RASTER_ON_SIDE_STREAM = 1          # _planes: batch sizes up to which the mesh rasterisation runs in front of the static backbone on the side stream (0 = never)
 RENDERING_VIEWS = [[0, 0, 0], [0, 90, 0], [0, -90, 0], [90, 0, 0]]        # reference triplane_next3d.py:140-145
 
 
@@ -315,13 +315,15 @@ class TriPlaneGenerator(torch.nn.Module):
         N = ws.shape[0]
         nw = S.texture.num_ws
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
-        # The mesh rasterisation depends only on the vertices, the static tri-plane backbone only on the latents: both run on a second HIP
-        # stream — rasterisation first — so that they overlap the texture backbone (the rasteriser's ~0.3 ms of latency-bound launches
-        # are off the critical path texture -> projection -> mouth -> blending, and the static backbone's low-resolution layers, a handful
-        # of workgroups each, fill the chip beside it).  (Round 1 saw the rasteriser's results change from run to run while 8-wave split-bf16
-        # convolution workgroups of ANOTHER stream shared the CUs; round 2 bisected that to vector-L1-served gather loads of the vertex / face
-        # tables and the kernels now read those tables with agent-scope loads: DESIGN.md 3.3,
-        # tests/test_path_kernels_gpu.py::test_rasteriser_reproducible_under_coresident_convolutions.)
+        # The static tri-plane backbone depends only on the latents: it runs on a second HIP stream so that its low-resolution layers (a handful
+        # of workgroups each) overlap the texture -> mouth -> blending chain.  The mesh rasterisation depends only on the vertices: for single-frame
+        # calls (the scripts' pattern) it runs on that side stream too, in front of the static backbone, and the main stream waits for it only
+        # before the texture projection — ~0.3 ms of latency-bound launches off the critical path (batch 1: 4.53 -> 4.37 ms per frame from the graph).
+        # Not for larger batches: with several steps in flight on the chip's four hardware queues the early cross-stream wait costs more than it
+        # hides (batch 4, three lanes: 396 -> 387 frames/s; one stream: 352 -> 356) — profiles/r04_raster_side_stream_ab.txt.
+        # (Round 1 saw the rasteriser's results change from run to run while 8-wave split-bf16 convolution workgroups of ANOTHER stream shared the
+        # CUs; round 2 bisected that to vector-L1-served gather loads of the vertex / face tables and the kernels now read those tables with
+        # agent-scope loads: DESIGN.md 3.3, tests/test_path_kernels_gpu.py::test_rasteriser_reproducible_under_coresident_convolutions.)
         cur = torch.cuda.current_stream()
         ident = self._identity_cache if use_cached_identity else None
         static = None
@@ -333,17 +335,18 @@ class TriPlaneGenerator(torch.nn.Module):
             if sstream is None:
                 sstream = S.side_streams[cur.cuda_stream] = torch.cuda.Stream(device=ws.device)
             sstream.wait_stream(cur)
-            if not RASTER_ON_SIDE_STREAM:
+            side_raster = N <= RASTER_ON_SIDE_STREAM
+            if not side_raster:
                 grid, alpha, bbox = self.raster_geometry(v, lms)
                 sstream.wait_stream(cur)
             with torch.cuda.stream(sstream):
-                if RASTER_ON_SIDE_STREAM:
+                if side_raster:
                     grid, alpha, bbox = self.raster_geometry(v, lms)
                     raster_done = sstream.record_event()
                 static = S.static(eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
             static.record_stream(cur)
             textures = S.texture(texture_ws, noise_mode, bank=bank, force_fp32=force_fp32)
-            if RASTER_ON_SIDE_STREAM:
+            if side_raster:
                 for t in (grid, alpha, bbox):
                     t.record_stream(cur)
                 cur.wait_event(raster_done)
