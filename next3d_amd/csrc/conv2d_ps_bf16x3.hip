@@ -690,17 +690,23 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
                     const int c8 = (m0 >> 3) + mt * 4 + gg, ol = mt * 32 + 8 * gg + 4 * half;
+                    if (p.y_nchw) {                                        // float32 NCHW (few-position layers): the two phases of a row are adjacent floats
+                        const f32x16& a0 = acc[mt][g][pa * 2], &a1 = acc[mt][g][pa * 2 + 1];
+                        const int ox = 2 * gx;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float* dst = yb + ((int64_t)(m0 + ol + k) * p.OH + oy) * p.yrs + ox;
+                            const float v0 = n3d_round16(a0[4 * gg + k] * s_rs[ol + k], p.round_f16), v1 = n3d_round16(a1[4 * gg + k] * s_rs[ol + k], p.round_f16);
+                            if (ox + 1 < p.OW && ((p.yrs | p.ybs) & 1) == 0) *reinterpret_cast<float2*>(dst) = float2{v0, v1};      // (ox even, even row pitch: 8-byte aligned)
+                            else { dst[0] = v0; if (ox + 1 < p.OW) dst[1] = v1; }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int pb = 0; pb < 2; ++pb) {
                         const int ox = 2 * gx + pb;
                         if (ox >= p.OW) continue;
                         const f32x16& a = acc[mt][g][pa * 2 + pb];
-                        if (p.y_nchw) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                yb[((int64_t)(m0 + ol + k) * p.OH + oy) * p.yrs + ox] = n3d_round16(a[4 * gg + k] * s_rs[ol + k], p.round_f16);
-                            continue;
-                        }
                         const f32x4 v = {n3d_round16(a[4 * gg + 0] * s_rs[ol + 0], p.round_f16), n3d_round16(a[4 * gg + 1] * s_rs[ol + 1], p.round_f16),
                                          n3d_round16(a[4 * gg + 2] * s_rs[ol + 2], p.round_f16), n3d_round16(a[4 * gg + 3] * s_rs[ol + 3], p.round_f16)};
                         *reinterpret_cast<f32x4*>(yb + (((int64_t)c8 * p.OH + oy) * p.yrs + ox) * 8 + 4 * half) = v;
