@@ -1,3 +1,4 @@
+# GPU box (round 4): same-box A/B of layers.FUSED_TORGB — both super-resolution blocks / the last block only / off — on `bench.py --no-extras` (profiles/r04_fused_torgb_ab.txt).
 cd /root/repo
 mkdir -p gpurun_out
 python -m pytest tests/test_ops_gpu.py -q -m gpu -k "fused_torgb" 2>&1 | tail -3

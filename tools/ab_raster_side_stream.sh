@@ -1,3 +1,4 @@
+# GPU box (round 4): generator.RASTER_ON_SIDE_STREAM forced on / off for every batch size, on the full bench line (profiles/r04_raster_side_stream_ab.txt).
 cd /root/repo
 mkdir -p gpurun_out
 python -m pytest tests/test_generator_gpu.py tests/test_path_kernels_gpu.py -q -m gpu 2>&1 | tail -3
@@ -6,7 +7,7 @@ for on in True False; do
 python - > gpurun_out/r4_ab3_$on.json 2>gpurun_out/r4_ab3.err <<PY
 import sys
 from next3d_amd import generator
-generator.RASTER_ON_SIDE_STREAM = $on
+generator.RASTER_ON_SIDE_STREAM = 1 << 30 if $on else 0
 sys.argv = ['bench.py', '--no-cpu-baseline', '--no-roofline', '--steps', '30']
 import bench
 bench.main()

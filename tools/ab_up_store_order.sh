@@ -1,3 +1,5 @@
+# GPU box (round 4): transposed kernels, adjacent output phases stored back to back vs the previous order (N3D_LIB=tools/probe/libn3d_prev.so = a build of the previous
+# commit), one launch at a time (profiles/r04_up_store_order_ab.txt; the in-model re-check used tools/layer_trace.py and bench.py with the same two libraries).
 cd /root/repo
 mkdir -p gpurun_out
 for rep in 1 2; do
