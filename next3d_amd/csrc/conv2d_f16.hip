@@ -144,7 +144,7 @@ __device__ __forceinline__ void f16_mfma_chunk(const f16x8* A, const f16x8* B, i
 }
 
 // NBUF = 2: one workgroup per CU, the next chunk's DMA under this chunk's MFMAs; NBUF = 1: two workgroups per CU with one buffer
-// each (the other workgroup's MFMAs fill this one's DMA waits and its tile stores) — see conv2d_ps_bf16x3_kernel.
+// each (the other workgroup's MFMAs fill this one's DMA waits and its tile stores) — see conv2d_ps_bf16x3_body.
 template <int MT, int NT, int NBUF, bool RGB>
 __device__ __forceinline__ void conv2d_h8_f16_body(const ConvF16Params& p, f16x8* smem) {
     using T = F16Tile<MT, NT>;

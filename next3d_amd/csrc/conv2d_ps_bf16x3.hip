@@ -768,7 +768,7 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
 // phase and the chunk move through the scalar offset.  Three LDS buffers of 52 KB: the DMA of stage s + 2 is issued before the
 // MFMAs of stage s and the wait at the end of the iteration is `vmcnt(pieces of stage s + 2)` — stages carry 48 / 24 / 24 / 12
 // MFMAs per wave, a two-deep queue evens that out.  One workgroup per CU, MFMAs transposed (pixels as matrix rows) and the
-// epilogue of conv2d_ps_bf16x3_kernel; optional split-K like the register-staged kernel.
+// epilogue of conv2d_ps_bf16x3_body; optional split-K like the register-staged kernel.
 // Patch pixels beyond the image (only ever feeding outputs beyond OH x OW, which are not stored) read whatever follows in
 // the sample, or zeros beyond its end (descriptor range check).
 constexpr int S2_BM = 64, S2_TH = 16, S2_TW = 32;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {                      // pixels = matrix rows, as conv2d_ps_bf16x3_kernel
+                    for (int nt = 0; nt < 2; ++nt) {                      // pixels = matrix rows, as conv2d_ps_bf16x3_body
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
         __builtin_amdgcn_s_barrier();
     }
 
-    // epilogue (conv2d_ps_bf16x3_kernel's): lane = one channel of group mt, 16 pixels of the wave's row nt in 4 runs of 4
+    // epilogue (conv2d_ps_bf16x3_body's): lane = one channel of group mt, 16 pixels of the wave's row nt in 4 runs of 4
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int64_t plane = (int64_t)p.OH * p.OW, yplane = (int64_t)p.OH * p.yrs;
     if (p.partial) {                                                      // split-K: raw sums, reduced by conv16_splitk_epilogue_kernel

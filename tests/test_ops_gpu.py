@@ -654,7 +654,7 @@ def test_conv1x1_side_output_equals_conversion_pass(dev, N, I, OC, H, W):
 
 @pytest.mark.parametrize('N,I,OC,H,W', [(4, 256, 256, 128, 128), (4, 64, 512, 48, 80), (2, 128, 100, 256, 256), (8, 32, 64, 128, 160)])
 def test_presplit_conv_matches_plain_bf16x3_kernel(dev, N, I, OC, H, W):
-    """conv2d_ps_bf16x3_kernel (split8 input staged by LDS-DMA) against the register-staged split-bf16 kernels on the same
+    """conv2d_ps1 / ps2_bf16x3_kernel (split8 input staged by LDS-DMA) against the register-staged split-bf16 kernels on the same
     operands: same products, same accumulation order per output -> expected bit-identical; ragged sizes exercise the halo
     coming from the buffer descriptor's range check and the masked stores."""
     from next3d_amd import _lib

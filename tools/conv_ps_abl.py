@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Ablation timing of conv2d_ps_bf16x3_kernel (N3D_CONV_DBG bits: 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
+"""Ablation timing of conv2d_ps1 / ps2_bf16x3_kernel (N3D_CONV_DBG bits: 1 skip stores, 2 skip MFMA, 4 skip the DMA of chunks > 0,
 8 no per-chunk wait / barrier) on the layer shapes of the benchmark, next to the register-staged kernel on the same shape.
 Timing only — the ablated variants compute garbage.  Usage (GPU box): python tools/conv_ps_abl.py"""
 import os, sys, torch
