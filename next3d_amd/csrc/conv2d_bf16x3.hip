@@ -43,6 +43,7 @@ int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);    //
 int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);     // conv2d_ps_bf16x3.hip (split8 input)
 int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_sk_bf16x3.hip (few-pixel layers; 1 = not its layer)
 extern "C" int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W);
+int conv2d_up_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream);   // conv2d_sk_bf16x3.hip (few-position transposed layers; 1 = not its layer)
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, transposed, c8 output)
 int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream);  // conv2d_ps_bf16x3.hip (split8 input, stride 2)
 int conv2d_p_bf16x3_try_launch(const n3d_conv2d_desc* d, int tiles_x, int tiles_y, hipStream_t stream, int* launched);   // conv2d_p_bf16x3.hip
@@ -797,6 +798,10 @@ extern "C" int n3d_conv2d_bf16x3(const n3d_conv2d_desc* d, n3d_stream_t stream_)
     if (d->mode == 1) return conv2d_s2_bf16x3_launch(d, stream);
     if (d->mode == 0 && d->wt_batch_stride == 0) {                         // few-pixel layers: K split inside the workgroup, one launch (samples share its weight fragments)
         const int r = conv2d_sk_bf16x3_try_launch(d, stream);
+        if (r <= 0) return r;
+    }
+    if (d->mode == 2 && d->wt_batch_stride == 0 && d->y_layout == N3D_LAYOUT_NCHW_F32) {     // few-position transposed layers: the same, no split-K reduce launch
+        const int r = conv2d_up_sk_bf16x3_try_launch(d, stream);
         if (r <= 0) return r;
     }
     Conv16Params p;

@@ -237,3 +237,178 @@ int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The TRANSPOSED twin (round 4): 3x3 stride-2 transposed convolution of the few-position layers (4 x 4 and 8 x 8 inputs at batch 4, up to 16 x 16 at
+// batch 1: up to 512 positions in the batch) in ONE launch — conv_transpose2d inside the up-sampling SynthesisLayer (conv2d_resample.py:114-127) as conv2d_up_bf16x3_kernel
+// computes it: over the (H+1) x (W+1) POSITION grid, tap (ky, kx) feeds output phase (ky == 1, kx == 1) of position (gy, gx) = output pixel
+// (2 gy + pa, 2 gx + pb) from input pixel (gy - 1 + dy, gx - 1 + dx), dy = (ky != 2), dx = (kx != 2).  The general kernel splits K over 4-8
+// workgroups and needs a reduce + epilogue launch (conv16_splitk_epilogue_kernel) — 6 such pairs per forward at batch 4, 9 at batch 1; here, as
+// above, a workgroup owns 32 channels x 32 consecutive positions (flattened row-major over the position grid) x 4 phases for the whole K, its 8
+// waves split the 16-channel chunks, stage their own patch (the rows the 32 positions touch + one row above, W + 2 columns), and the partial sums
+// meet in LDS two phases at a time.
+struct SkUpParams {
+    const float* x; const bf16x8* wt16; const float* style; float* y;
+    int N, I, O, OP64, H, W, HW, GW, P, OH, OW;      // GW = W + 1 position columns, P = (H+1) * (W+1) positions per sample
+    int PW, tps, tiles_m;                            // patch pitch W + 2, position tiles per sample
+    int x_bytes;
+    int64_t xbs, ybs, yrs, style_stride;
+    n3d_epilogue epi;
+};
+
+__global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) {
+    __shared__ bf16x8 smem[8 * SK_WAVE_SLOTS];                             // 64 KB: the waves' patch regions; afterwards the partial sums of two phases
+    __shared__ float s_style[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    int mt_i, tile;
+    {
+        const int b = blockIdx.x;
+        if ((p.tiles_m & 7) == 0) { const int per = p.tiles_m >> 3, q = b >> 3; mt_i = (b & 7) + 8 * (q % per); tile = q / per; }
+        else { mt_i = b % p.tiles_m; tile = b / p.tiles_m; }
+    }
+    const int m0 = mt_i * 32;
+    const int n = tile / p.tps, q0 = (tile % p.tps) * 32;                  // sample, first flattened position of the tile
+    const int row0 = q0 / p.GW;                                            // first position row: patch row 0 = input row row0 - 1
+    const int KC = p.I / 16, nc = KC / 8, c_begin = wn * nc;
+    for (int i = tid; i < p.I; i += 512) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + i] : 1.f;
+
+    const int rows = min(q0 + 31, p.P - 1) / p.GW - row0 + 2, nslots = rows * p.PW;       // patch rows: the position rows + one
+    int voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = lane + 64 * j, pr = pp / p.PW, pc = pp - pr * p.PW;
+        const int yy = row0 - 1 + pr, xx = pc - 1;
+        const bool ok = pp < nslots && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        voff[j] = ok ? (int)(((int64_t)n * p.xbs + yy * p.W + xx) * 4) : (int)0x80000000;
+    }
+    const int q = q0 + l31;                                                // this lane's position
+    const bool q_act = q < p.P;
+    const int gy = (q_act ? q : q0) / p.GW, gx = (q_act ? q : q0) - gy * p.GW;
+    const int base = (gy - row0) * p.PW + gx;                              // patch slot of input pixel (gy - 1, gx - 1)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    bf16x8* Bw = smem + wn * SK_WAVE_SLOTS;
+
+    f32x16 acc[4];                                                         // one accumulator per output phase
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][r] = 0.f;
+    __syncthreads();                                                       // s_style
+
+    float raw[2][16];
+    bf16x8 ah[9], al[9];
+    auto load_raw = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch)
+                raw[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[j], (c * 16 + ch) * p.HW * 4, 0));
+    };
+    const bf16x8* a0 = p.wt16 + (int64_t)half * p.OP64 + m0 + l31;
+    const int64_t a_tap = (int64_t)KC * 4 * p.OP64, a_chunk = (int64_t)4 * p.OP64;
+    load_raw(c_begin);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { ah[t] = a0[t * a_tap + c_begin * a_chunk]; al[t] = a0[t * a_tap + c_begin * a_chunk + 2 * p.OP64]; }
+
+    for (int c = c_begin; c < c_begin + nc; ++c) {
+        const bool more = c + 1 < c_begin + nc;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* st = s_style + c * 16;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = raw[j][hf * 8 + k] * st[hf * 8 + k];
+                    const __bf16 h = (__bf16)v;
+                    hi[k] = h;
+                    lo[k] = (__bf16)(v - (float)h);
+                }
+                Bw[(0 * 2 + hf) * SK_SLOTS + lane + 64 * j] = hi;
+                Bw[(1 * 2 + hf) * SK_SLOTS + lane + 64 * j] = lo;
+            }
+        }
+        if (more) load_raw(c + 1);
+        bf16x8 bh[4], bl[4];                                               // the position's 2 x 2 input pixels (LDS operations of one wave complete in order)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bh[d] = Bw[(0 * 2 + half) * SK_SLOTS + base + (d >> 1) * p.PW + (d & 1)];
+            bl[d] = Bw[(1 * 2 + half) * SK_SLOTS + base + (d >> 1) * p.PW + (d & 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const int ph = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0), d = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1);
+            acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[d], acc[ph], 0, 0, 0);
+            acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[d], acc[ph], 0, 0, 0);
+            acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[d], acc[ph], 0, 0, 0);
+            if (more) { ah[t] = a0[t * a_tap + (c + 1) * a_chunk]; al[t] = a0[t * a_tap + (c + 1) * a_chunk + 2 * p.OP64]; }
+        }
+    }
+
+    // the eight partial sums through LDS in wave order, two phases (one output row pair... the phases pa = 0, then pa = 1) at a time: 8 x 2 x 16 x 64 floats = 64 KB
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+        __syncthreads();                                                   // the patch regions (pa = 0) / the previous round's sums (pa = 1) are dead
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wn * 2 + pb) * 16 + r) * 64 + lane] = acc[pa * 2 + pb][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                                   // 2 phases x 16 registers = 32 items over 8 waves
+            const int item = it * 8 + wn, pb = item >> 4, r = item & 15;
+            const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[((w * 2 + pb) * 16 + r) * 64 + lane];
+            const int oy = 2 * gy + pa, ox = 2 * gx + pb;
+            if (!q_act || o >= p.O || oy >= p.OH || ox >= p.OW) continue;
+            p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
+        }
+    }
+}
+
+static bool sk_up_plan(int N, int I, int O, int H, int W) {
+    static const bool enabled = n3d_tune("N3D_CONV_SK", 1) != 0;
+    if (!enabled) return false;
+    if (N < 1 || I % 128 != 0 || I > 1024 || O % 32 != 0 || O < 32 || H < 2 || W < 2 || W > 32) return false;
+    const int P = (H + 1) * (W + 1);
+    // every 32-position tile re-reads the layer's weights from L2: measured (layer trace inside a forward) 4 x 4 at batch 4 53 -> 44 us, 8 x 8 56 -> 41,
+    // 16 x 16 at batch 1 61 -> 42 — but 16 x 16 at batch 4 (1156 positions) 77 us against 62 for the pre-split kernel, 32 x 32 at batch 1 76 against 68
+    if ((int64_t)N * P > 512) return false;
+    // the patch of 32 consecutive positions: at most 32 / (W+1) + 2 position rows + 1, W + 2 wide
+    const int rows = (32 + W) / (W + 1) + 2;
+    return rows * (W + 2) <= SK_SLOTS;
+}
+
+extern "C" int n3d_conv2d_up_sk_eligible(int N, int I, int O, int H, int W) { return sk_up_plan(N, I, O, H, W) ? 1 : 0; }
+
+// called by n3d_conv2d_bf16x3 for ksize 3 / mode 2 / float32 NCHW in and out, shared weights; 1 = not this kernel's layer, 0 = launched, -1 = error
+int conv2d_up_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
+    if (d->epi.round_f16 || d->epi.residual || d->epi.residual_up_filter || d->side_split8 || d->y_layout != N3D_LAYOUT_NCHW_F32 || d->wt_batch_stride) return 1;
+    if (!sk_up_plan(d->N, d->I, d->O, d->H, d->W)) return 1;
+    const int64_t xbs = d->x_batch_stride;
+    const int64_t x_bytes = ((int64_t)(d->N - 1) * xbs + (int64_t)d->I * d->H * d->W) * 4;
+    if (x_bytes >= (1ll << 31)) return 1;
+    SkUpParams p;
+    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.HW = d->H * d->W;
+    p.GW = d->W + 1; p.P = (d->H + 1) * (d->W + 1); p.OH = 2 * d->H + 1; p.OW = 2 * d->W + 1;
+    p.PW = d->W + 2; p.tps = (p.P + 31) / 32; p.tiles_m = d->O / 32;
+    p.x_bytes = (int)x_bytes;
+    p.xbs = xbs; p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.OH * p.OW;
+    p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
+    N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.style_stride = d->style_stride ? d->style_stride : d->I;
+    p.epi = d->epi;
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
+    const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    hipLaunchKernelGGL(conv2d_up_sk_bf16x3_kernel, dim3((unsigned)(d->N * p.tps * p.tiles_m)), dim3(512), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}

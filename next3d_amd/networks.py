@@ -49,7 +49,8 @@ class _Block:
         """conv0 on the pre-split transposed kernel writing float32 NCHW: the few-position layers (conv1 not a pre-split layer) with at
         least 1024 positions in the batch — 16 x 16 at batch 4: 43 us against 58 for the register-staged kernel + split-K reduction."""
         return bool(L.UP_PRESPLIT and L.UP_PS_NCHW and xshape[1] % 16 == 0 and self._ps_base(xshape, fir, noise_mode) and
-                    not self._presplit(n, xshape, fir, noise_mode) and n * xshape[2] * xshape[3] >= 1024)
+                    not self._presplit(n, xshape, fir, noise_mode) and n * xshape[2] * xshape[3] >= 1024 and
+                    not L.cg.up_sk_eligible(n, xshape[1], self.conv0.out_channels, xshape[2], xshape[3]))
 
     def takes_split8(self, n, xshape, fir, noise_mode):
         """Does conv0 read its [n, I, h, w] input in the split8 layout (layers.synthesis_layer, the transposed pre-split kernel)?"""

@@ -79,6 +79,11 @@ def bf16x3_eligible(i, h, w, ksize, mode):
     return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
+def up_sk_eligible(n, i, o, h, w):
+    """Does the one-launch few-position kernel take this transposed 3x3 layer (float32 NCHW in / out; n3d_conv2d_up_sk_eligible)?"""
+    return bool(_lib.lib().n3d_conv2d_up_sk_eligible(n, i, o, h, w))
+
+
 def split8_eligible(n, i, o, h, w):
     """True when the 3x3 stride-1 layer [n,i,h,w] -> o channels is taken by the pre-split kernel (its producer may then write
     the split8 layout): the library's own rule (n3d_conv2d_split8_eligible)."""
@@ -214,6 +219,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and _lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w):
         ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
+    if bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and up_sk_eligible(n, i, o, h, w):
+        ksplit = 1                                       # ... and so does its transposed twin (few-position up-sampling layers)
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None
