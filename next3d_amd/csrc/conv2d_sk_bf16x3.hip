@@ -373,8 +373,7 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
 }
 
 static bool sk_up_plan(int N, int I, int O, int H, int W) {
-    static const bool enabled = n3d_tune("N3D_CONV_SK", 1) != 0;
-    if (!enabled) return false;
+    if (n3d_tune("N3D_CONV_SK", 1) == 0 || n3d_tune("N3D_CONV_UP_SK", 1) == 0) return false;      // (tuning builds: A/B)
     if (N < 1 || I % 128 != 0 || I > 1024 || O % 32 != 0 || O < 32 || H < 2 || W < 2 || W > 32) return false;
     const int P = (H + 1) * (W + 1);
     // every 32-position tile re-reads the layer's weights from L2: measured (layer trace inside a forward) 4 x 4 at batch 4 53 -> 44 us, 8 x 8 56 -> 41,
