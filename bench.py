@@ -326,7 +326,9 @@ def main():
         # ---- strict-fp32 arithmetic (N3D_PRECISION=fp32): the same K steps on v_mfma_f32_32x32x2_f32
         if layers.PRECISION == 'bf16x3':
             layers.set_precision('fp32')
-            step(); step(); torch.cuda.synchronize()
+            for _ in range(len(lanes) + 1):       # every lane once (its allocator pool, this mode's kernels), then one more
+            step()
+        torch.cuda.synchronize()
             k32 = max(3, args.steps // 2)
             t32 = timed(step, k32)
             p32 = conv_profile(k32)['conv2d']
@@ -340,7 +342,9 @@ def main():
         # ---- the reference's DEFAULT super-resolution mode (sr_num_fp16_res = 4, no force_fp32: float16 storage in the SR blocks,
         # superresolution.py:210-217) on the same workload
         sr_fp32[0] = False
-        step(); step(); torch.cuda.synchronize()
+        for _ in range(len(lanes) + 1):       # every lane once (its allocator pool, this mode's kernels), then one more
+            step()
+        torch.cuda.synchronize()
         k16 = max(3, args.steps // 2)
         t16 = timed(step, k16)
         p16 = conv_profile(k16)
@@ -364,7 +368,9 @@ def main():
         # every block of resolution >= 32 of the five networks runs as a float16 block on the f16 matrix cores
         G16, _ = demo.build_generator(dev, force_fp16=True)
         gen[0] = G16
-        step(); step(); torch.cuda.synchronize()
+        for _ in range(len(lanes) + 1):       # every lane once (its allocator pool, this mode's kernels), then one more
+            step()
+        torch.cuda.synchronize()
         tbb = timed(step, k16)
         pbb = conv_profile(k16)
         fbb = pbb['conv2d_f16']

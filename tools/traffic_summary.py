@@ -5,7 +5,7 @@ Usage: traffic_summary.py fetch.db write.db out.json [calib_fetch.db calib_write
 (MI355X_MICROARCH.md §HBM: separate passes; FETCH_SIZE / WRITE_SIZE come in KiB; gfx950 FETCH_SIZE under-reports wide reads)"""
 import collections, json, re, sqlite3, sys
 
-FAMILY = re.compile(r'^(void )?conv2d(_up|_s2|_p|_ps|_ps1|_ps2|_ps1_rgb|_ps2_rgb|_ps2_rgbs|_sk|_up_ps|_up_ps32|_up_ps32w|_s2_ps)?_bf16x3(_pair)?_kernel')      # every 3x3 split-bf16 kernel (not conv1x1 / split-K reduce)
+FAMILY = re.compile(r'^(void )?conv2d(_up|_up_sk|_s2|_p|_ps|_ps1|_ps2|_ps1_rgb|_ps2_rgb|_ps2_rgbs|_sk|_up_ps|_up_ps32|_up_ps32w|_s2_ps)?_bf16x3(_pair)?_kernel')      # every 3x3 split-bf16 kernel (not conv1x1 / split-K reduce)
 LAUNCHES_PER_STEP = 67          # bench.py configs[1], force_fp32 route (roofline.launches_per_step); 60 with N3D_PAIR_BACKBONES=1 (7 layer pairs as one launch each)
 CALIB_BYTES = float(1 << 30)
 
