@@ -327,8 +327,8 @@ def main():
         if layers.PRECISION == 'bf16x3':
             layers.set_precision('fp32')
             for _ in range(len(lanes) + 1):       # every lane once (its allocator pool, this mode's kernels), then one more
-            step()
-        torch.cuda.synchronize()
+                step()
+            torch.cuda.synchronize()
             k32 = max(3, args.steps // 2)
             t32 = timed(step, k32)
             p32 = conv_profile(k32)['conv2d']
