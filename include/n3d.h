@@ -199,7 +199,8 @@ typedef struct {
     void* side_split8;    /* NULL, or (1x1 n3d_conv2d_bf16x3 with O <= 128, I % 32 == 0 — the toRGB layers) a second output: the INPUT x
                              multiplied by side_style [N,I] in the dense split8 layout, i.e. exactly n3d_split8_from_nchw(x, side_style):
                              a block's feature map has two readers (toRGB, and the next block's transposed convolution with ITS
-                             styles, networks_stylegan2.py:469-475) and is read from HBM once for both */
+                             styles, networks_stylegan2.py:469-475) and is read from HBM once for both.  With rgb_partial (below) on the 3x3
+                             stride-1 kernel it is instead that layer's own OUTPUT times side_style [N,O] (O % 8 == 0) */
     const float* side_style;
     int64_t side_style_stride; /* floats between samples of side_style (0 = I) */
     int64_t wt_batch_stride;   /* BYTES between consecutive samples' prepared weights (a multiple of 16), 0 = one weight tensor shared by
@@ -214,7 +215,9 @@ typedef struct {
      *      layer epilogue to its tile and multiplies it, in float32, with rgb_weight [rgb_channels][O] (the toRGB layer's 1x1 weights) times
      *      rgb_style [N][O] (its styles, weight_gain included) — the partial colours of each 64-channel workgroup go to
      *      rgb_partial [N][ceil(O/64)][rgb_channels][H][W]; n3d_rgb_combine sums them and applies toRGB's own epilogue (bias, clamp, the skip image).
-     *      y may then be NULL: the feature map itself (537 MB per step for the 512 x 512 layer at batch 4) is neither written nor read back. */
+     *      y may then be NULL: the feature map itself (537 MB per step for the 512 x 512 layer at batch 4) is neither written nor read back.
+     *      n3d_conv2d_f16 (mode 0) takes the same fields for a float16 block: rgb_weight = per-sample float16 toRGB weights [N][rgb_channels][O]
+     *      (n3d_modulate_weights_f16, demodulate 0), rgb_style NULL; n3d_rgb_combine with epi.round_f16 applies n3d_torgb_h8's float16 epilogue. */
     const float* rgb_weight;   /* NULL (with rgb_partial NULL) = off */
     const float* rgb_style;
     float* rgb_partial;
