@@ -136,6 +136,7 @@ class TriPlaneGenerator(torch.nn.Module):
         self._identity_cache = None
         self._cache_gen = getattr(self, '_cache_gen', 0) + 1      # generation of the two caches above (synthesis_graph keys on it)
         self._param_stamp = None
+        self._ptensors = None           # (cached parameter / buffer list of _check_params)
         self._graphs = None             # captured HIP graphs (synthesis_graph): they hold pointers into the prepared weights and caches
 
     def _set_cache(self, name, value):
@@ -178,10 +179,23 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def _check_params(self):
         """In-place updates (misc.copy_params_and_buffers after a first forward, an optimizer step) bump the tensors' version
-        counters: a changed sum invalidates the prepared weights and the caches.  Called once per mapping / synthesis call."""
-        stamp = sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        counters: a changed sum invalidates the prepared weights and the caches.  Called once per mapping / synthesis call.
+        The list of tensors is cached (walking the 674-entry module tree costs ~0.4 ms, twice per frame: at batch 1 the eager call is
+        bound by the host) and re-walked when the model is moved / reloaded (`_drop_derived`) and every 256th call, which also catches a
+        parameter OBJECT that was replaced by assignment."""
+        ts = self.__dict__.get('_ptensors')
+        self._check_calls = self.__dict__.get('_check_calls', 0) + 1
+        if ts is None or (self._check_calls & 255) == 0:
+            fresh = list(self.parameters()) + list(self.buffers())
+            if ts is not None and (len(fresh) != len(ts) or any(a is not b for a, b in zip(fresh, ts))):
+                self._drop_derived()
+            ts = self._ptensors = fresh
+        stamp = 0
+        for t in ts:
+            stamp += t._version
         if self._param_stamp is not None and stamp != self._param_stamp:
             self._drop_derived()
+            self._ptensors = ts
         self._param_stamp = stamp
 
     def _prep(self):
