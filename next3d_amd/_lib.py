@@ -174,11 +174,11 @@ def ptr(t):
     stream).  One mechanism instead of a hand-kept `x = x.contiguous()` discipline at every call site."""
     if t is None:
         return None
-    held = getattr(_tls, 'held', None)
-    if held is None:
-        held = _tls.held = []
-    held.append(t)
-    return c_void_p(t.data_ptr())
+    try:
+        _tls.held.append(t)
+    except AttributeError:
+        _tls.held = [t]
+    return t.data_ptr()             # (a plain int: ctypes converts it for c_void_p arguments and struct fields; ~1500 calls per forward)
 
 
 def require_device(*tensors):

@@ -257,7 +257,7 @@ def fused_torgb_ok(conv, torgb, x, noise_mode):
     super-resolution's last block (537 MB per step at batch 4) is then neither written nor read back."""
     return (FUSED_TORGB and PRECISION == 'bf16x3' and isinstance(x, _lib.Split8) and noise_mode != 'random' and conv.wt16 is not None and
             torgb.out_channels <= 4 and torgb.ksize == 1 and torgb.in_channels == conv.out_channels and
-            _lib.lib().n3d_conv2d_split8_ksplit(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
+            cg.split8_ksplit(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
 
 
 def torgb_combine(L, partial, conv_clamp=None, residual=None, residual_up_filter=None):

@@ -79,11 +79,50 @@ def bf16x3_eligible(i, h, w, ksize, mode):
     return ksize == 3 and i % 16 == 0 and mode in (0, 2) and w >= 4 and h >= 4
 
 
+# The library's kernel-selection queries are pure functions of the shape for the shipped library: memoised (a generator forward asks ~15 of them per
+# layer call, each a ctypes round trip; at batch 1 the eager call is bound by the host).  Not with N3D_LIB set: tuning builds re-read their switches.
+import os as _os
+_MEMO_OK = 'N3D_LIB' not in _os.environ
+
+
+def _memo(fn):
+    cache = {}
+
+    def wrapped(*args):
+        if not _MEMO_OK:
+            return fn(*args)
+        r = cache.get(args)
+        if r is None:
+            r = cache[args] = fn(*args)
+        return r
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
+@_memo
+def split8_ksplit(n, i, o, h, w):
+    """n3d_conv2d_split8_ksplit: the split-K factor the pre-split stride-1 kernel uses for this shape (0 = not its layer)."""
+    return int(_lib.lib().n3d_conv2d_split8_ksplit(n, i, o, h, w))
+
+
+@_memo
+def sk_eligible(n, i, o, h, w):
+    """n3d_conv2d_sk_eligible: the one-launch few-pixel kernel takes this stride-1 3x3 layer."""
+    return bool(_lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w))
+
+
+@_memo
+def _bf16x3_blocks(n, o, h, w, mode):
+    return int(_lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode))
+
+
+@_memo
 def up_sk_eligible(n, i, o, h, w):
     """Does the one-launch few-position kernel take this transposed 3x3 layer (float32 NCHW in / out; n3d_conv2d_up_sk_eligible)?"""
     return bool(_lib.lib().n3d_conv2d_up_sk_eligible(n, i, o, h, w))
 
 
+@_memo
 def split8_eligible(n, i, o, h, w):
     """True when the 3x3 stride-1 layer [n,i,h,w] -> o channels is taken by the pre-split kernel (its producer may then write
     the split8 layout): the library's own rule (n3d_conv2d_split8_eligible)."""
@@ -132,7 +171,7 @@ def pick_ksplit(n, i, o, gh, gw, ksize, mode=0):
 
 def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
     """Split-K factor for the split-bf16 kernels from the library's own tile plan (n3d_conv2d_bf16x3_blocks)."""
-    blocks = _lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode)
+    blocks = _bf16x3_blocks(n, o, h, w, mode)
     # transposed: 8-wave workgroups, one per CU -> split only until ~2/3 of the CUs have one (measured: 160 blocks are
     # faster unsplit); stride-1: smaller 4-wave workgroups, several per CU
     want = 512 if mode == 0 else 160       # modes 1 / 2: 8-wave workgroups, one per CU
@@ -165,7 +204,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         xs = x
         x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only
         if mode == 0:                                                          # the library's own split-K factor for this shape (few tiles, deep K)
-            ksplit = max(1, _lib.lib().n3d_conv2d_split8_ksplit(n, i, out_channels, h, w))
+            ksplit = max(1, split8_ksplit(n, i, out_channels, h, w))
         elif mode == 2:
             ksplit = 1                                                         # (the stride-2 kernel keeps the caller's split-K for its small grids)
     _lib.require_device(None if split8 else x, wt, style, out)
@@ -217,7 +256,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=wt.device)
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
-    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and _lib.lib().n3d_conv2d_sk_eligible(n, i, o, h, w):
+    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and sk_eligible(n, i, o, h, w):
         ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
     if bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and up_sk_eligible(n, i, o, h, w):
         ksplit = 1                                       # ... and so does its transposed twin (few-position up-sampling layers)
@@ -369,7 +408,7 @@ def _launch_prepared(x, wt, wbs, kind, ksize, mode, n, i, o, h, w, row_pitch=Fal
     bf16x3 = kind == 1
     ksplit = 1
     if split8:
-        ksplit = max(1, _lib.lib().n3d_conv2d_split8_ksplit(n, i, o, h, w)) if mode == 0 else 1
+        ksplit = max(1, split8_ksplit(n, i, o, h, w)) if mode == 0 else 1
     else:
         if bf16x3:
             ksplit = 1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)

@@ -357,7 +357,7 @@ def test_ptr_keepalive_window():
     r = weakref.ref(t)
     p = _lib.ptr(t)
     del t
-    assert r() is not None and p.value == r().data_ptr()          # a temporary survives until the call it was marshalled for
+    assert r() is not None and int(p) == r().data_ptr()            # a temporary survives until the call it was marshalled for
     _lib.check(0)
     assert r() is None
     with pytest.raises(RuntimeError):
