@@ -348,6 +348,35 @@ def test_layout_grid_tiling():
         frames.layout_grid(img.float(), grid_w=3, grid_h=2)          # CPU tensor: no fallback for the conversion
 
 
+def test_parameter_update_check_uses_a_cached_tensor_list():
+    """TriPlaneGenerator._check_params (called by every mapping / synthesis): an in-place update of any parameter or buffer drops the prepared
+    weights and caches — detected through version counters of a CACHED tensor list (walking the 674-entry module tree cost 0.4 ms per call, which
+    bound the eager batch-1 call: DESIGN.md 3.1h); a parameter OBJECT replaced by assignment is caught when the tree is re-walked (every 256th call)."""
+    import torch
+    from next3d_amd import demo
+    G, _ = demo.build_generator(torch.device('cpu'))
+    G._check_params()
+    assert len(G._ptensors) == 674
+    marker = object()
+    G._prepared = marker
+    for _ in range(3):
+        G._check_params()
+    assert G._prepared is marker                                            # nothing changed: nothing dropped
+    with torch.no_grad():
+        G._ptensors[100].mul_(1.0)                                          # in-place update (misc.copy_params_and_buffers, an optimizer step)
+    G._check_params()
+    assert G._prepared is None
+    G._prepared = marker
+    name, old = next((n, p) for n, p in G.named_parameters() if n.endswith('decoder.net.0.bias'))
+    mod = G
+    for part in name.split('.')[:-1]:
+        mod = getattr(mod, part)
+    setattr(mod, name.split('.')[-1], torch.nn.Parameter(old.detach().clone(), requires_grad=False))     # a NEW object, same values, version 0
+    for _ in range(257):
+        G._check_params()
+    assert G._prepared is None and any(t is getattr(mod, name.split('.')[-1]) for t in G._ptensors)
+
+
 def test_ptr_keepalive_window():
     """`_lib.ptr()` holds every tensor whose pointer crosses the C ABI until `check()` (the launch is enqueued by then)."""
     import weakref
