@@ -329,13 +329,18 @@ int n3d_fc_multi(const n3d_fc_job* jobs, const int* rows, int total_rows, const 
  *        psi (MappingNetwork.forward :255-267; w_avg NULL or psi == 1 => plain broadcast).
  *      n3d_fma: y = a*b + c over a [NC,P] with b, c addressed as [nc*stride_nc + p*stride_p] (0 strides broadcast)
  *        (torch_utils/ops/fma.py:17-28 — only the non-fused modulated-conv branch uses it).
- *      n3d_to_uint8: (x*127.5+128).clamp(0,255) -> uint8 (gen_samples_next3d.py:201), layout preserved. */
+ *      n3d_to_uint8: (x*127.5+128).clamp(0,255) -> uint8 (gen_samples_next3d.py:201), layout preserved.
+ *      n3d_layout_grid_u8: the video scripts' `layout_grid` helper in one pass (gen_videos_next3d.py:35-49, reenact_avatar_next3d.py:56-70:
+ *        uint8 conversion, tiling and CHW -> HWC): frames [B,C,H,W] float32 (W % 4 == 0, B == cols * rows) -> uint8 canvas
+ *        [rows*H, cols*W, C] (hwc = 1) or [C, rows*H, cols*W] (hwc = 0), frame b at tile row b / cols, tile column b % cols. */
 int n3d_normalize_2nd_moment(const float* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream);
 int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int num_ws, int D, int cutoff, float psi,
                     n3d_stream_t stream);
 int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p,
             int64_t c_nc, int64_t c_p, n3d_stream_t stream);
 int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t stream);
+int n3d_layout_grid_u8(const float* frames, unsigned char* canvas, int B, int C, int H, int W, int cols, int rows, int hwc,
+                       n3d_stream_t stream);
 /* n3d_cast: float16 <-> float32 (N3D_F16 / N3D_F32), round to nearest even — the `x.to(dtype)` conversions at the
  * boundaries of the reference's fp16 blocks (tat/networks_stylegan2.py:548-552; tat/superresolution.py:210-217).  The
  * operator layer uses it to run fp16 tensors through the fp32-accumulating kernels: fp16 storage between operators,

@@ -102,6 +102,7 @@ _SIGNATURES = {
     'n3d_truncate_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'n3d_fma': (c_int, [c_void_p] * 4 + [c_int64] * 6 + [c_void_p]),
     'n3d_to_uint8': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'n3d_layout_grid_u8': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'n3d_cast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'n3d_modulate_weights_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'n3d_conv2d_f16': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),

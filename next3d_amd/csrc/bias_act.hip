@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bias_act_rows_kernel(const T* __restrict_
     const float bias = b ? ld(&b[row % size_b]) : 0.f;
     const V* xr = reinterpret_cast<const V*>(x) + row * row_vecs;
     V* yr = reinterpret_cast<V*>(y) + row * row_vecs;
-    const float cl = clamp >= 0.f ? clamp : INFINITY;
+    const bool clamped = clamp >= 0.f;          // (wave-uniform; without a clamp a NaN activation must stay NaN, as in bias_act_kernel and the reference: fminf / fmaxf drop NaNs)
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < row_vecs; v += (int64_t)gridDim.x * 256) {
         V in = xr[v];
         T* e = reinterpret_cast<T*>(&in);
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void bias_act_rows_kernel(const T* __restrict_
             float f = ld(&e[k]) + bias;
             if (ACT == N3D_ACT_LRELU) f = (f > 0.f ? f : f * alpha);
             else if (ACT != N3D_ACT_LINEAR) f = n3d_act(f, act, alpha);
-            st(&oe[k], fminf(fmaxf(f * gain, -cl), cl));
+            f *= gain;
+            if (clamped) f = fminf(fmaxf(f, -clamp), clamp);
+            st(&oe[k], f);
         }
         yr[v] = out;
     }

@@ -58,6 +58,31 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__
     }
 }
 
+// The video scripts' frame grid in ONE pass (gen_videos_next3d.py:35-49 does conversion, reshape, two permutes and a copy):
+// frames [B,C,H,W] float32 -> uint8 canvas, frame b at tile row b / cols, tile column b % cols.  One thread per 4 consecutive x of one
+// (frame, y): a 16-byte load per channel; hwc = 1 writes [rows*H, cols*W, C] (4 pixels x C bytes contiguous per thread), hwc = 0 writes [C, rows*H, cols*W].
+__global__ __launch_bounds__(256) void layout_grid_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int B, int C, int H, int W4,
+                                                             int cols, int rows, int hwc) {
+    const int64_t total = (int64_t)B * H * W4;
+    const int W = W4 * 4, CW = cols * W;
+    const int64_t CH = (int64_t)rows * H;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xq = (int)(i % W4), yy = (int)((i / W4) % H), b = (int)(i / ((int64_t)W4 * H));
+        const int64_t oy = (int64_t)(b / cols) * H + yy, ox = (int64_t)(b % cols) * W + xq * 4;
+        const float* src = x + ((int64_t)b * C * H + yy) * W + xq * 4;
+        for (int c = 0; c < C; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)c * H * W);
+            const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned char u = (unsigned char)fminf(fmaxf(f[k] * 127.5f + 128.f, 0.f), 255.f);
+                if (hwc) y[(oy * CW + ox + k) * C + c] = u;
+                else y[((int64_t)c * CH + oy) * CW + ox + k] = u;
+            }
+        }
+    }
+}
+
 // 8 elements per thread (16-byte accesses on the half side, 2 x 16 on the float side); the tail is done element-wise
 template <typename SRC, typename DST>
 __global__ __launch_bounds__(256) void cast_kernel(const SRC* __restrict__ x, DST* __restrict__ y, int64_t n) {
@@ -148,6 +173,19 @@ int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t s
     N3D_CHECK(x && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 3) == 0, "to_uint8: null or misaligned tensor");
     N3dProfScope prof(N3D_K_MISC, stream, 2.0 * numel, 5.0 * numel);
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, stream, x, y, numel / 4);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_layout_grid_u8(const float* frames, unsigned char* canvas, int B, int C, int H, int W, int cols, int rows, int hwc, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(B >= 0 && C >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && cols >= 1 && rows >= 1, "layout_grid_u8: bad shape (W %% 4 == 0)");
+    N3D_CHECK((int64_t)cols * rows == B, "layout_grid_u8: %d frames do not fill a %d x %d grid", B, cols, rows);
+    if (B == 0) return 0;
+    N3D_CHECK(frames && canvas && ((uintptr_t)frames & 15) == 0, "layout_grid_u8: null or misaligned tensor");
+    const int64_t numel = (int64_t)B * C * H * W;
+    N3dProfScope prof(N3D_K_MISC, stream, 2.0 * numel, 5.0 * numel);
+    hipLaunchKernelGGL(layout_grid_u8_kernel, dim3(grid_for(numel / (4 * C))), dim3(256), 0, stream, frames, canvas, B, C, H, W / 4, cols, rows, hwc);
     N3D_LAUNCH_CHECK();
     return 0;
 }

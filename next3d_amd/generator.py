@@ -39,7 +39,33 @@ def _require_hip(dev):
                            '(no CPU fallback; the CPU restatement is oracle/, test infrastructure)')
 
 
-class _Node(torch.nn.Module):
+_STRUCT_GEN = [0]        # bumped whenever a parameter / buffer OBJECT is (re)assigned anywhere in a generator's module tree
+
+
+class _Tracked(torch.nn.Module):
+    """Module whose parameter / buffer assignments bump `_STRUCT_GEN` (O(1) check per forward in `_check_params`: a parameter replaced by
+    assignment or a re-registered buffer invalidates the prepared weights, caches and captured graphs on the NEXT call)."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor) or name in self.__dict__.get('_parameters', ()) or name in self.__dict__.get('_buffers', ()):
+            _STRUCT_GEN[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name in self.__dict__.get('_parameters', ()) or name in self.__dict__.get('_buffers', ()):
+            _STRUCT_GEN[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _STRUCT_GEN[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _STRUCT_GEN[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
+
+
+class _Node(_Tracked):
     """Anonymous container used to reproduce the reference's dotted parameter names."""
 
 
@@ -56,7 +82,7 @@ def _attach(root, dotted, tensor, is_buffer):
         mod.register_parameter(parts[-1], torch.nn.Parameter(tensor, requires_grad=False))
 
 
-class TriPlaneGenerator(torch.nn.Module):
+class TriPlaneGenerator(_Tracked):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path, sr_num_fp16_res=0,
                  mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, uv_face_mask=None, **synthesis_kwargs):
         super().__init__()
@@ -138,6 +164,9 @@ class TriPlaneGenerator(torch.nn.Module):
         self._param_stamp = None
         self._ptensors = None           # (cached parameter / buffer list of _check_params)
         self._graphs = None             # captured HIP graphs (synthesis_graph): they hold pointers into the prepared weights and caches
+        self._tree_stamp = None         # (cheap structure stamp of _check_params)
+        from .torch_utils.ops import conv2d_gradfix
+        conv2d_gradfix.clear_prep_cache()     # the operator boundary's per-tensor cache cannot see `.data` updates: refresh() covers them
 
     def _set_cache(self, name, value):
         """(Re)assign a cross-call cache (`_last_planes` / `_identity_cache`).  Captured graphs bake in the device pointers of the
@@ -181,21 +210,23 @@ class TriPlaneGenerator(torch.nn.Module):
         """In-place updates (misc.copy_params_and_buffers after a first forward, an optimizer step) bump the tensors' version
         counters: a changed sum invalidates the prepared weights and the caches.  Called once per mapping / synthesis call.
         The list of tensors is cached (walking the 674-entry module tree costs ~0.4 ms, twice per frame: at batch 1 the eager call is
-        bound by the host) and re-walked when the model is moved / reloaded (`_drop_derived`) and every 256th call, which also catches a
-        parameter OBJECT that was replaced by assignment."""
+        bound by the host).  A parameter / buffer OBJECT replaced by assignment bumps `_STRUCT_GEN` (`_Tracked`), which is compared on
+        every call; every 256th call the tree is re-walked anyway (assignments that bypass the module API, `m._parameters[k] = ...`).
+        `p.data.copy_()` bypasses the version counter: call refresh()."""
         ts = self.__dict__.get('_ptensors')
         self._check_calls = self.__dict__.get('_check_calls', 0) + 1
-        if ts is None or (self._check_calls & 255) == 0:
+        if ts is None or self.__dict__.get('_tree_stamp') != _STRUCT_GEN[0] or (self._check_calls & 255) == 0:
             fresh = list(self.parameters()) + list(self.buffers())
             if ts is not None and (len(fresh) != len(ts) or any(a is not b for a, b in zip(fresh, ts))):
                 self._drop_derived()
             ts = self._ptensors = fresh
+            self._tree_stamp = _STRUCT_GEN[0]
         stamp = 0
         for t in ts:
             stamp += t._version
         if self._param_stamp is not None and stamp != self._param_stamp:
             self._drop_derived()
-            self._ptensors = ts
+            self._ptensors, self._tree_stamp = ts, _STRUCT_GEN[0]
         self._param_stamp = stamp
 
     def _prep(self):
@@ -509,14 +540,23 @@ class TriPlaneGenerator(torch.nn.Module):
         self._prep()
         rk = self.rendering_kwargs
         tensors = {k: synthesis_kwargs[k] for k in ('depth_jitter', 'importance_u') if synthesis_kwargs.get(k) is not None}
-        plain = {k: val for k, val in synthesis_kwargs.items() if k not in tensors and k != 'graph_slot'}
+        draws = synthesis_kwargs.get('density_noise_draws')
+        if draws is not None:             # (coarse, fine) normal draws: static copies like the other random inputs, never the caller's pointers
+            tensors['density_noise_coarse'], tensors['density_noise_fine'] = draws
+        plain = {k: val for k, val in synthesis_kwargs.items() if k not in tensors and k not in ('graph_slot', 'density_noise_draws')}
         # graph_slot: independent instances of the same signature (own static buffers): a serving loop replays slot k on stream k so
         # that several single-frame requests are in flight at once (bench.py config1b)
         slot = int(synthesis_kwargs.get('graph_slot', 0))
         sig = (tuple(ws.shape), tuple(c.shape), tuple(v.shape), tuple((k, tuple(t.shape)) for k, t in sorted(tensors.items())),
                tuple(sorted((k, repr(val)) for k, val in plain.items())), plain.get('neural_rendering_resolution') or self.neural_rendering_resolution,
-               rk['depth_resolution'], rk['depth_resolution_importance'], rk.get('superresolution_noise_mode', 'none'), layers.PRECISION,
-               layers.PRESPLIT, layers.F16_REF_CPU_ROUNDING, self.overlap_static, slot)
+               rk['depth_resolution'], rk['depth_resolution_importance'], rk.get('superresolution_noise_mode', 'none'),
+               # everything render() bakes into the launch arguments (a change between calls must not replay the old graph)
+               tuple(repr(rk.get(k)) for k in ('ray_start', 'ray_end', 'white_back', 'density_noise', 'disparity_space_sampling', 'box_warp',
+                                                'clamp_mode', 'decoder_lr_mul', 'c_gen_conditioning_zero', 'c_scale')),
+               # ... and every module switch that selects kernels
+               layers.PRECISION, layers.PRESPLIT, layers.S2_PRESPLIT, layers.UP_PRESPLIT, layers.TORGB_SIDE, layers.FUSED_TORGB, layers.DIRECT_SPLIT8,
+               layers.UP_PS_NCHW, layers.NCHW_FIR_SPLIT8, layers.CONVERT_MAX_BYTES, layers.F16_REF_CPU_ROUNDING, layers.uf.FIR_SEP, RASTER_ON_SIDE_STREAM,
+               self.overlap_static, slot)
         uses_cache = bool((plain.get('use_cached_backbone') and self._last_planes is not None) or
                           (plain.get('use_cached_identity') and self._identity_cache is not None))
         if uses_cache:
@@ -529,7 +569,11 @@ class TriPlaneGenerator(torch.nn.Module):
             _require_hip(dev)
             st = dict(ws=ws.to(dev, torch.float32).clone(), c=c.to(dev, torch.float32).clone(), v=v.to(dev, torch.float32).clone())
             st.update({k: t.to(dev).clone() for k, t in tensors.items()})
-            call = lambda: self.synthesis(st['ws'], st['c'], st['v'], **plain, **{k: st[k] for k in tensors})
+            def call():
+                kw = {k: st[k] for k in tensors if not k.startswith('density_noise_')}
+                if 'density_noise_coarse' in tensors:
+                    kw['density_noise_draws'] = (st['density_noise_coarse'], st['density_noise_fine'])
+                return self.synthesis(st['ws'], st['c'], st['v'], **plain, **kw)
             cur = torch.cuda.current_stream()
             warm = torch.cuda.Stream(device=dev)
             warm.wait_stream(cur)

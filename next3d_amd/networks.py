@@ -116,11 +116,28 @@ def _f16_block(blk, xh, img, fir, noise_mode, w16):
     return xh, img
 
 
-def _f16_blocks_ok(blocks, fir, noise_mode, in_res):
-    """Can these blocks (res -> _Block, each fed an [*, I, res/2, res/2] input) run on the f16 kernels?"""
-    return (noise_mode in ('const', 'none') and tuple(fir.shape) == (4, 4) and
-            all(b.conv0 is not None and L.f16_layer_ok(b.conv0, r // 2, r // 2, 2) and L.f16_layer_ok(b.conv1, r, r, 1) and
-                b.torgb.in_channels <= 512 and b.torgb.in_channels % 8 == 0 for r, b in blocks.items()))
+def _f16_block_ok(r, b):
+    return (b.conv0 is not None and L.f16_layer_ok(b.conv0, r // 2, r // 2, 2) and L.f16_layer_ok(b.conv1, r, r, 1) and
+            b.torgb.in_channels <= 512 and b.torgb.in_channels % 8 == 0)
+
+
+def _f16_eligible(blocks, fir, noise_mode, owner, what):
+    """Which of the reference's float16 blocks (res -> _Block, each fed an [*, I, res/2, res/2] input) run on the f16 kernels: the
+    highest-resolution run of eligible blocks (per block, not all-or-nothing).  The blocks below it that the kernels do not
+    take — 8 x 8 / 16 x 16 blocks with num_fp16_res >= 5: the stride-1 f16 kernel needs W >= 32 — run in float32 (a superset in accuracy of
+    the reference's float16 arithmetic, NOT its rounding: documented in INTEGRATION.md), with a one-time warning naming them.  Random noise
+    or a non-4x4 filter rule the f16 kernels out altogether."""
+    if not blocks:
+        return {}
+    ok = {}
+    if noise_mode in ('const', 'none') and tuple(fir.shape) == (4, 4):
+        for r in sorted(blocks, reverse=True):
+            if not _f16_block_ok(r, blocks[r]):
+                break
+            ok[r] = blocks[r]
+    if len(ok) < len(blocks):
+        _warn_f16_once(owner, what, sorted(set(blocks) - set(ok)))
+    return ok
 
 
 def _f16_weights(blocks, bank, n):
@@ -136,12 +153,13 @@ def _f16_weights(blocks, bank, n):
     return {r: tuple(flat[3 * k:3 * k + 3]) for k, r in enumerate(sorted(blocks))}
 
 
-def _warn_f16_once(obj, what):
+def _warn_f16_once(obj, what, which=None):
     import warnings
     if not getattr(obj, '_warned32', False):
         obj._warned32 = True
-        warnings.warn(f'float16 blocks of {what} are not available for this configuration (random noise / filter / shapes): running them in '
-                      'float32 (the force_fp32=True arithmetic)')
+        blocks = 'the float16 blocks' if which is None else 'float16 blocks ' + ', '.join(f'b{r}' for r in which)
+        warnings.warn(f'{blocks} of {what} are not available on the f16 kernels for this configuration (random noise / filter / shapes): running '
+                      'them in float32 (the force_fp32=True arithmetic); the other float16 blocks stay float16')
 
 
 def _first_slots(block_resolutions):
@@ -181,10 +199,8 @@ class SynthesisNet:
         ws = _ws3(ws)
         if bank is None:
             bank = self.bank.compute(ws)
-        f16 = {r: self.blocks[r] for r in self.block_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32}
-        if f16 and not _f16_blocks_ok(f16, self.fir, noise_mode, None):
-            _warn_f16_once(self, self.prefix)
-            f16 = {}
+        f16 = _f16_eligible({r: self.blocks[r] for r in self.block_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32},
+                            self.fir, noise_mode, self, self.prefix)
         w16 = _f16_weights(f16, bank, ws.shape[0]) if f16 else {}
         x = img = xs = xh = None
         for k, res in enumerate(self.block_res):
@@ -241,10 +257,8 @@ class StyleUNet:
         ws = _ws3(ws)
         if bank is None:
             bank = self.bank.compute(ws)
-        f16 = {r: self.blocks[r] for r in self.used_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32}
-        if f16 and not _f16_blocks_ok(f16, self.fir, noise_mode, None):
-            _warn_f16_once(self, self.prefix)
-            f16 = {}
+        f16 = _f16_eligible({r: self.blocks[r] for r in self.used_res if self.fp16_resolution and r >= self.fp16_resolution and not force_fp32},
+                            self.fir, noise_mode, self, self.prefix)
         w16 = _f16_weights(f16, bank, ws.shape[0]) if f16 else {}
         cat_copy = _CAT_COPY or bool(f16)          # float16 blocks hand their feature map over as h8: the concatenation is a copy then
         # The decoder concatenates its feature map with the encoder's condition before every fusion conv (reference

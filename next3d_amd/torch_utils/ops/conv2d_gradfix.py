@@ -366,16 +366,37 @@ def prep_weight_grouped(weight, groups, transposed, kind):
     return out, per, o, i
 
 
+def _tensor_version(t):
+    """`t._version`, or None where autograd keeps no version counter (inference tensors: everything created under
+    `torch.inference_mode()`, e.g. Conv2dLayer's `self.weight * self.weight_gain` temporary) — such a tensor is never cached."""
+    if t.is_inference():
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def clear_prep_cache():
+    """Forget every cached prepared weight.  The cache follows the tensor OBJECT and its version counter; an update that bypasses the
+    counter (`p.data.copy_(...)`, `p.data.mul_(...)`: `.data` detaches the counter) is invisible to it — call this after such an update
+    (generator.refresh() / load_state_dict() / .to() do)."""
+    _PREP_CACHE.clear()
+
+
 def _prepared(weight, groups, transposed, kind):
     """prep_weight_grouped with the per-tensor-object cache for groups == 1 (module docstring)."""
     if groups != 1:
         return prep_weight_grouped(weight, groups, transposed, kind)
+    version = _tensor_version(weight)
+    if version is None:                                  # no version counter: nothing a later call could be validated against
+        return prep_weight_grouped(weight, 1, transposed, kind)
     import weakref
     key, sub = id(weight), (kind, transposed)
     ent = _PREP_CACHE.get(key)
     if ent is not None:
         hit = ent.get(sub)
-        if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        if hit is not None and hit[0]() is weight and hit[1] == version and hit[2] == weight.data_ptr():
             return hit[3]
         if not any(h[0]() is weight for h in ent.values()):
             ent.clear()                                  # the id was recycled by another tensor
@@ -383,7 +404,7 @@ def _prepared(weight, groups, transposed, kind):
     if ent is None:
         ent = _PREP_CACHE[key] = {}
         weakref.finalize(weight, lambda k=key: _PREP_CACHE.pop(k, None) if all(h[0]() is None for h in _PREP_CACHE.get(k, {}).values()) else None)
-    ent[sub] = (weakref.ref(weight), weight._version, weight.data_ptr(), res)
+    ent[sub] = (weakref.ref(weight), version, weight.data_ptr(), res)
     return res
 
 

@@ -94,9 +94,11 @@ def fir_factor(fir):
     The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (:96-116): the separable kernels
     (n3d_fir4_split8_sep, n3d_fir4_h8) evaluate the same float32 sum with half the multiply-adds."""
     import weakref
+    from .conv2d_gradfix import _tensor_version
     key = id(fir)
+    version = _tensor_version(fir)            # None for inference tensors (no version counter): decided again on every call
     hit = _FIR1D.get(key)
-    if hit is not None and hit[0]() is fir and hit[1] == fir._version:
+    if version is not None and hit is not None and hit[0]() is fir and hit[1] == version:
         return hit[2]
     f = fir.detach().to('cpu', torch.float64)
     a = None
@@ -104,7 +106,9 @@ def fir_factor(fir):
         v = f.sum(1) / f.sum().sqrt()
         if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
             a = v.to(torch.float32).to(fir.device).contiguous()
-    _FIR1D[key] = (weakref.ref(fir), fir._version, a)
+    if version is None:
+        return a
+    _FIR1D[key] = (weakref.ref(fir), version, a)
     weakref.finalize(fir, lambda k=key: _FIR1D.pop(k, None) if (_FIR1D.get(k) and _FIR1D[k][0]() is None) else None)
     return a
 

@@ -351,7 +351,8 @@ def test_layout_grid_tiling():
 def test_parameter_update_check_uses_a_cached_tensor_list():
     """TriPlaneGenerator._check_params (called by every mapping / synthesis): an in-place update of any parameter or buffer drops the prepared
     weights and caches — detected through version counters of a CACHED tensor list (walking the 674-entry module tree cost 0.4 ms per call, which
-    bound the eager batch-1 call: DESIGN.md 3.1h); a parameter OBJECT replaced by assignment is caught when the tree is re-walked (every 256th call)."""
+    bound the eager batch-1 call: DESIGN.md 3.1h); a parameter OBJECT replaced by assignment / a re-registered buffer is caught on the NEXT call
+    (generator._Tracked bumps a structure counter: ADVICE r4), and the tree is re-walked every 256th call for assignments that bypass the module API."""
     import torch
     from next3d_amd import demo
     G, _ = demo.build_generator(torch.device('cpu'))
@@ -372,9 +373,37 @@ def test_parameter_update_check_uses_a_cached_tensor_list():
     for part in name.split('.')[:-1]:
         mod = getattr(mod, part)
     setattr(mod, name.split('.')[-1], torch.nn.Parameter(old.detach().clone(), requires_grad=False))     # a NEW object, same values, version 0
+    G._check_params()                                                      # the very next call sees it
+    assert G._prepared is None and any(t is getattr(mod, name.split('.')[-1]) for t in G._ptensors)
+    G._prepared = marker
+    G.backbone.mapping.register_buffer('w_avg', G.backbone.mapping.w_avg.detach().clone())        # a re-registered buffer
+    G._check_params()
+    assert G._prepared is None
+    G._prepared = marker
+    mod._parameters[name.split('.')[-1]] = torch.nn.Parameter(old.detach().clone(), requires_grad=False)    # bypasses the module API
     for _ in range(257):
         G._check_params()
-    assert G._prepared is None and any(t is getattr(mod, name.split('.')[-1]) for t in G._ptensors)
+    assert G._prepared is None
+
+
+def test_prepared_weight_cache_skips_inference_tensors_and_can_be_cleared():
+    """conv2d_gradfix._prepared: tensors created under torch.inference_mode() have no version counter (`._version` raises) — they
+    are never cached and never crash the operator boundary; `.data` updates bypass the counter, `clear_prep_cache()` (called by
+    generator.refresh()) is the documented way to drop the cache."""
+    import torch
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    from next3d_amd.torch_utils.ops import upfirdn2d as uf
+    with torch.inference_mode():
+        w = torch.randn(4, 4, 3, 3) * 0.5
+        f = uf.setup_filter([1, 3, 3, 1])
+        assert cg._tensor_version(w) is None
+        a = uf.fir_factor(f)                                                # must not raise; not cached
+        assert a is not None and id(f) not in uf._FIR1D
+    p = torch.nn.Parameter(torch.randn(4, 4, 3, 3))
+    assert cg._tensor_version(p) == p._version
+    cg._PREP_CACHE[12345] = {}
+    cg.clear_prep_cache()
+    assert not cg._PREP_CACHE
 
 
 def test_ptr_keepalive_window():

@@ -46,6 +46,19 @@ def test_bias_act_f16_and_errors(dev):
     assert bias_act.bias_act(torch.empty(0, 4, device=dev), None).numel() == 0
 
 
+def test_bias_act_propagates_nan_without_clamp(dev):
+    """without a clamp a NaN activation stays NaN on BOTH kernels (the 2-D row form serves contiguous NCHW tensors; fminf / fmaxf
+    against +-inf would turn it into -inf), as the reference's bias_act does (bias_act.cu: the clamp is applied only when clamp >= 0)."""
+    from next3d_amd.torch_utils.ops import bias_act
+    for shape in ((2, 8, 16, 16), (2, 8, 5, 5)):                      # row kernel (inner extent 256) / generic kernel (25)
+        x = torch.zeros(shape)
+        x[1, 3, 2, 1] = float('nan')
+        b = _gen((shape[1],), 5)
+        for act in ('linear', 'lrelu'):
+            y = bias_act.bias_act(x.to(dev), b.to(dev), act=act).cpu()
+            assert torch.isnan(y[1, 3, 2, 1]) and int(torch.isnan(y).sum()) == 1, (shape, act)
+
+
 def test_operator_layer_matches_reference_ref_ops(dev):
     """The B1 operator layer on libn3d.so against the REFERENCE's own _bias_act_ref / _upfirdn2d_ref / _filtered_lrelu_ref
     outputs (tests/golden/ref_ops.npz): every activation, separable / asymmetric filters, per-axis up x down, negative

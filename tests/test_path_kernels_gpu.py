@@ -460,6 +460,14 @@ def test_layout_grid_uint8_frames(dev):
     for b in range(4):
         gy, gx = b // 2, b % 2
         assert np.array_equal(out[gy * 16:(gy + 1) * 16, gx * 24:(gx + 1) * 24], ref[b].permute(1, 2, 0).numpy())
+    # channels-first canvas, kept on the device (one n3d_layout_grid_u8 launch as well); 1 x 4 strip with the width inferred
+    chw = frames.layout_grid(img.to(dev), grid_h=1, chw_to_hwc=False, to_numpy=False)
+    assert chw.is_cuda and tuple(chw.shape) == (3, 16, 96) and chw.dtype == torch.uint8
+    assert all(torch.equal(chw[:, :, b * 24:(b + 1) * 24].cpu(), ref[b]) for b in range(4))
+    # a width the one-pass kernel does not take (W % 4 != 0): conversion kernel + copy tiling, same result
+    odd = _gen((2, 3, 8, 10), 91, 0.8)
+    out = frames.layout_grid(odd.to(dev), grid_w=1, grid_h=2)
+    assert np.array_equal(out, (odd * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).reshape(16, 10, 3).numpy())
 
 
 # ------------------------------------------------------------------------------------------------ third-party shims (boundary B1)
