@@ -49,6 +49,7 @@ struct ConvPsParams {
     bf16x8* side; const float* side_style; int64_t side_style_stride;
 };
 
+constexpr int PS_RGB32_MAX = 32;                                                       // ... on the matrix cores (RGB == 2)
 constexpr int PS_RGB_MAX = 4, PS_RGB_PITCH = 16 * 32 + 4;                               // fused toRGB: colours, floats per staged channel row
 constexpr int PS_BM = 64, PS_TH = 16, PS_TW = 32, PS_TAPS = 9;
 constexpr int PS_PH = PS_TH + 2, PS_PW = PS_TW + 2, PS_PPIX = PS_PH * PS_PW;          // 18 x 34 = 612 patch pixels
@@ -65,7 +66,9 @@ constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                               
 //           workgroup fills the gaps: its MFMAs run while this one waits for its DMA or writes its tile.  With one workgroup per
 //           CU every chunk's DMA wait, every barrier skew and the whole epilogue (a 128 KB tile written while every other CU
 //           writes its own: ~7 us at the chip's ~4.7 TB/s of store bandwidth) leave the matrix pipe idle.
-template <int NBUF, bool RGB, bool SIDE = false>
+// RGB: 0 = plain layer; 1 = fused toRGB of at most PS_RGB_MAX colours on the VALU (the super-resolution's 3-colour layers); 2 = fused toRGB of up to
+// 32 colours on the matrix cores (the backbones' 32-channel toRGB layers).  SIDE (with RGB): the split8 side output for the layer's second reader.
+template <int NBUF, int RGB, bool SIDE = false>
 __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf16x8* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
         s_bs[tid] = E.bias ? E.bias[o] : 0.f;
     }
     float* s_cw = s_bs + PS_BM;                                           // RGB: [colour][64 channels] toRGB weight x style of this sample
-    if (RGB && tid < PS_RGB_MAX * PS_BM) {
+    if (RGB == 1 && tid < PS_RGB_MAX * PS_BM) {
         const int j = tid / PS_BM, o = m0 + tid % PS_BM;
         s_cw[tid] = (j < p.rgb_channels && o < p.O) ? p.rgb_weight[(int64_t)j * p.O + o] * p.rgb_style[(int64_t)n * p.rgb_style_stride + o] : 0.f;
     }
@@ -244,7 +247,126 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
     const float nstr = E.noise ? E.noise_strength[0] : 0.f;
     const bool lrelu = E.act == N3D_ACT_LRELU;
     const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
-    if constexpr (RGB) {
+    if constexpr (RGB == 2) {
+        // Fused toRGB with up to 32 colours (round 5: the 32-channel toRGB layers of the texture / mouth / blending networks,
+        // tat/networks_stylegan2.py:575-584) as an EPILOGUE CONTRACTION on the matrix cores.  The activated tile is staged through LDS 32 channels at
+        // a time exactly as in the <= 4-colour form; a lane then reads 8 consecutive channels of one pixel — which IS a first-operand fragment of
+        // v_mfma_f32_32x32x16_bf16 (pixels as rows) — splits them into bf16 hi / lo and multiplies them with the toRGB weights times the sample's
+        // toRGB styles (formed and split once per workgroup into the free chunk buffer): colour[p][j] += x_hi w_lo + x_lo w_hi + x_hi w_hi, float32
+        // accumulation, the arithmetic of the separate 1x1 split-bf16 kernel.  24 MFMAs per wave — a quarter of ONE 16-channel chunk of the K loop.
+        // The result has the main accumulators' layout (lane = colour, 4 runs of 4 consecutive pixels): 16-byte stores of the partial colour image
+        // of this workgroup's 64 channels; n3d_rgb_combine adds the O/64 partial images in index order.  With SIDE the same fragments, times the next
+        // layer's styles, are also the split8 units of the side output (n3d_split8_from_nchw's arithmetic).
+        float* stage = reinterpret_cast<float*>(smem);
+        bf16x8* s_bw = smem + (32 * PS_RGB_PITCH * 4 + 15) / 16;           // behind the stage: [k step 4][hi|lo][k half][32 colours] = 8 KB
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int tid_e = wn * 64 + lane_e, l31_e = lane_e & 31, half_e = lane_e >> 5;
+        __syncthreads();                                                  // every wave is past its last fragment read: the chunk buffers are free
+        {
+            const int colour = tid_e & 31, cg = tid_e >> 5;               // this thread: 4 consecutive channels cg * 4 .. + 3 of the workgroup's 64
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 wh, wl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = m0 + cg * 4 + k;
+                const float wv = (colour < p.rgb_channels && o < p.O) ? p.rgb_weight[(int64_t)colour * p.O + o] * p.rgb_style[(int64_t)n * p.rgb_style_stride + o] : 0.f;
+                const __bf16 h = (__bf16)wv;
+                wh[k] = h;
+                wl[k] = (__bf16)(wv - (float)h);
+            }
+            const int slot = (cg >> 2) * 128 + ((cg >> 1) & 1) * 32 + colour;             // [k step][hi|lo][k half][colour]: + 64 for lo
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot) + (cg & 1) * 4) = wh;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot + 64) + (cg & 1) * 4) = wl;
+        }
+        f32x16 racc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) racc[nt][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t r_side = __builtin_amdgcn_make_buffer_rsrc((void*)(p.side + (int64_t)n * 2 * (p.O / 8) * HW), 0, (SIDE && p.side) ? 2 * (p.O / 8) * HW * 16 : 0, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float rs = s_rs[mt * 32 + l31_e], bs = s_bs[mt * 32 + l31_e];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oy = min(y0 + wn * 2 + nt, p.H - 1);
+                const float* nrow = E.noise ? E.noise + (int64_t)oy * p.W : nullptr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = x0 + 8 * g + 4 * half_e;
+                    f32x4 out;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = acc[mt][nt][4 * g + k] * rs + (nrow ? nrow[min(ox + k, p.W - 1)] * nstr : 0.f) + bs;
+                        t = fmaxf(t, t * alpha_eff) * E.gain;
+                        out[k] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                    }
+                    *reinterpret_cast<f32x4*>(stage + l31_e * PS_RGB_PITCH + (wn * 2 + nt) * 32 + 8 * g + 4 * half_e) = out;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                 // 16-channel k steps of this 32-channel group
+                const bf16x8 bw_hi = s_bw[(mt * 2 + j) * 128 + half_e * 32 + l31_e], bw_lo = s_bw[(mt * 2 + j) * 128 + 64 + half_e * 32 + l31_e];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int prow = wn * 2 + nt;                          // tile row of this wave
+                    bf16x8 xh, xl, sh, sl;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) {
+                        const int c = 16 * j + 8 * half_e + cc;
+                        const float xv = stage[c * PS_RGB_PITCH + prow * 32 + l31_e];
+                        const __bf16 h = (__bf16)xv;
+                        xh[cc] = h;
+                        xl[cc] = (__bf16)(xv - (float)h);
+                        if constexpr (SIDE) {
+                            const float t = xv * s_sd[mt * 32 + c];        // n3d_split8_from_nchw's arithmetic
+                            const __bf16 th = (__bf16)t;
+                            sh[cc] = th;
+                            sl[cc] = (__bf16)(t - (float)th);
+                        }
+                    }
+                    racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bw_lo, racc[nt], 0, 0, 0);
+                    racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bw_hi, racc[nt], 0, 0, 0);
+                    racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bw_hi, racc[nt], 0, 0, 0);
+                    if constexpr (SIDE) {
+                        const int oy_s = y0 + prow, ox_s = x0 + l31_e;
+                        const int unit = (m0 + mt * 32) / 8 + 2 * j + half_e;
+                        if (p.side != nullptr) {
+                            typedef int i32x4 __attribute__((ext_vector_type(4)));
+                            // (the unit is lane-dependent here — the two k halves are two units — so it goes into the per-lane offset; out-of-image pixels
+                            // and channels beyond O get an offset beyond the descriptor's range: dropped by the hardware)
+                            const bool ok = oy_s < p.H && ox_s < p.W && unit * 8 < p.O;
+                            const int voff = ok ? (unit * HW + oy_s * p.W + ox_s) * 16 : (int)0x80000000;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sh), r_side, voff, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sl), r_side, ok ? voff + (p.O / 8) * HW * 16 : voff, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // partial colours: lane = colour, 4 runs of 4 consecutive pixels per tile row (the accumulator layout of the main loop)
+        if (l31_e < p.rgb_channels) {
+            float* dst = p.rgb_partial + (((int64_t)n * p.tiles_m + m0 / PS_BM) * p.rgb_channels + l31_e) * (int64_t)p.H * p.W;
+            const bool vec4 = (p.W & 3) == 0;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int oy = y0 + wn * 2 + nt;
+                if (oy >= p.H) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = x0 + 8 * g + 4 * half_e;
+                    if (ox >= p.W) continue;
+                    if (vec4) *reinterpret_cast<f32x4*>(dst + (int64_t)oy * p.W + ox) = f32x4{racc[nt][4 * g], racc[nt][4 * g + 1], racc[nt][4 * g + 2], racc[nt][4 * g + 3]};
+                    else
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (ox + k < p.W) dst[(int64_t)oy * p.W + ox + k] = racc[nt][4 * g + k];
+                }
+            }
+        }
+    } else if constexpr (RGB == 1) {
         // Fused toRGB.  The layer epilogue runs on the accumulators exactly as below; instead of going to HBM the activated tile is staged in
         // LDS 32 channels at a time ([channel][16 x 32 pixels], the chunk buffers are free now) and every thread sums ITS pixel over the
         // channels in float32: colour j += x[c] * (w[j][c] * style[n][c]).  The two 64-channel workgroups of a 128-channel layer write separate
@@ -371,25 +493,35 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
 constexpr int ps_smem_slots(int nbuf, bool rgb) { return nbuf * PS_BUF + (2 + (rgb ? PS_RGB_MAX + 1 : 0)) * PS_BM * 4 / 16; }
 __global__ __launch_bounds__(512, 4) void conv2d_ps1_bf16x3_kernel(ConvPsParams p) {         // one buffer, two workgroups per CU
     __shared__ bf16x8 smem[ps_smem_slots(1, false)];
-    conv2d_ps_bf16x3_body<1, false>(p, smem);
+    conv2d_ps_bf16x3_body<1, 0>(p, smem);
 }
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_bf16x3_kernel(ConvPsParams p) {         // two buffers, one workgroup per CU
     __shared__ bf16x8 smem[ps_smem_slots(2, false)];
-    conv2d_ps_bf16x3_body<2, false>(p, smem);
+    conv2d_ps_bf16x3_body<2, 0>(p, smem);
 }
 __global__ __launch_bounds__(512, 4) void conv2d_ps1_rgb_bf16x3_kernel(ConvPsParams p) {     // + fused toRGB (a network's last layer)
     __shared__ bf16x8 smem[ps_smem_slots(1, true)];
-    conv2d_ps_bf16x3_body<1, true>(p, smem);
+    conv2d_ps_bf16x3_body<1, 1>(p, smem);
 }
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_rgb_bf16x3_kernel(ConvPsParams p) {
     __shared__ bf16x8 smem[ps_smem_slots(2, true)];
-    conv2d_ps_bf16x3_body<2, true>(p, smem);
+    conv2d_ps_bf16x3_body<2, 1>(p, smem);
+}
+// + fused toRGB of up to 32 colours on the matrix cores (the backbones' toRGB layers), without / with the split8 side output.  One workgroup per CU
+// (the epilogue holds the 64 main and 32 colour accumulators: beyond the 128-register cap of the two-per-CU form)
+__global__ __launch_bounds__(512, 2) void conv2d_ps2_rgb32_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[ps_smem_slots(2, true)];
+    conv2d_ps_bf16x3_body<2, 2>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_ps2_rgb32s_bf16x3_kernel(ConvPsParams p) {
+    __shared__ bf16x8 smem[ps_smem_slots(2, true)];
+    conv2d_ps_bf16x3_body<2, 2, true>(p, smem);
 }
 // + the split8 side output for the layer's second reader.  Two buffers / one workgroup per CU only: the epilogue needs ~160 VGPRs, and under the
 // 128-register cap of the two-workgroups-per-CU form hipcc spills ACCUMULATORS inside the K loop
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_rgbs_bf16x3_kernel(ConvPsParams p) {
     __shared__ bf16x8 smem[ps_smem_slots(2, true)];
-    conv2d_ps_bf16x3_body<2, true, true>(p, smem);
+    conv2d_ps_bf16x3_body<2, 1, true>(p, smem);
 }
 
 // Layers this kernel takes (the host asks before it lets a producer write split8): 3x3 stride 1, I % 16 == 0, images of at
@@ -433,7 +565,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.epi = d->epi;
     const bool rgb = d->rgb_partial != nullptr;
     if (rgb) {
-        N3D_CHECK(d->rgb_weight && d->rgb_style && d->rgb_channels >= 1 && d->rgb_channels <= PS_RGB_MAX, "conv2d_bf16x3: fused toRGB needs rgb_weight, rgb_style and 1..4 colours");
+        N3D_CHECK(d->rgb_weight && d->rgb_style && d->rgb_channels >= 1 && d->rgb_channels <= PS_RGB32_MAX, "conv2d_bf16x3: fused toRGB needs rgb_weight, rgb_style and 1..32 colours");
         N3D_CHECK(p.ksplit == 1 && !E.residual && !E.round_f16, "conv2d_bf16x3: fused toRGB on a layer without split-K, residual or float16 rounding");
     }
     N3D_CHECK(d->y != nullptr || rgb, "conv2d_bf16x3: y is NULL");
@@ -454,7 +586,9 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     // workgroups: equal; 1024+: 174 vs 182 us, 697 vs 735 us).  Starting every other batch of workgroups late to de-phase the
     // CUs' store bursts was measured too: no effect.
     { const int nbuf = n3d_tune("N3D_PS_NBUF", nblk >= 768 ? 1 : 2);
-      if (rgb && d->side_split8) hipLaunchKernelGGL(conv2d_ps2_rgbs_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      if (rgb && d->rgb_channels > PS_RGB_MAX && d->side_split8) hipLaunchKernelGGL(conv2d_ps2_rgb32s_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (rgb && d->rgb_channels > PS_RGB_MAX) hipLaunchKernelGGL(conv2d_ps2_rgb32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (rgb && d->side_split8) hipLaunchKernelGGL(conv2d_ps2_rgbs_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (rgb) hipLaunchKernelGGL(conv2d_ps1_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);

@@ -37,7 +37,8 @@ PRESPLIT = True
 S2_PRESPLIT = True         # stride-2 encoder layers on split8 input
 UP_PRESPLIT = True         # the transposed convolution's input (a block output with two consumers) converted once, LDS-DMA staging
 TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
-FUSED_TORGB = True        # a network's last 3x3 layer evaluates its <= 4-colour toRGB in its epilogue (fused_torgb_ok)
+FUSED_TORGB = True        # a block's conv1 evaluates its toRGB (<= 32 colours) in its epilogue where x has no float32 reader (fused_torgb_ok)
+FUSED_TORGB_MAX = 32      # colours (module constant; tools flip it to 4 for A/B runs: only the super-resolution's toRGB layers fuse then)
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 UP_PS_NCHW = True          # few-position up-sampling layers on the pre-split transposed kernel writing NCHW (networks._Block._ps_nchw)
 NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)
@@ -252,11 +253,13 @@ def _conv1x1(L, x, style=None, epilogue=None, out=None, out_split8=False, side_s
 
 
 def fused_torgb_ok(conv, torgb, x, noise_mode):
-    """Can `conv` (the LAST 3x3 layer of a network, input `x`) evaluate `torgb` — its result's only reader — in its own epilogue
-    (n3d_conv2d_desc.rgb_*: at most 4 colours, the pre-split stride-1 kernel without split-K)?  The 512 x 512 x 128-channel feature map of the
-    super-resolution's last block (537 MB per step at batch 4) is then neither written nor read back."""
+    """Can `conv` (a block's conv1, input `x`) evaluate `torgb` in its own epilogue (n3d_conv2d_desc.rgb_*: at most 32 colours — up to 4 on the
+    VALU, the backbones' 32-channel toRGB layers as an epilogue contraction on the matrix cores —, the pre-split stride-1 kernel without
+    split-K)?  The caller has established that x has no other float32 reader (a network's last block, or a next block that takes the split8
+    side output).  The 512 x 512 x 128-channel feature map of the super-resolution's last block (537 MB per step at batch 4) and the 256 x 256 x
+    128-channel maps of the texture / mouth / blending networks' last blocks (134 MB each) are then neither written nor read back."""
     return (FUSED_TORGB and PRECISION == 'bf16x3' and isinstance(x, _lib.Split8) and noise_mode != 'random' and conv.wt16 is not None and
-            torgb.out_channels <= 4 and torgb.ksize == 1 and torgb.in_channels == conv.out_channels and
+            torgb.out_channels <= FUSED_TORGB_MAX and torgb.ksize == 1 and torgb.in_channels == conv.out_channels and
             cg.split8_ksplit(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
 
 

@@ -210,7 +210,7 @@ class SynthesisNet:
                 xh, img = _f16_block(self.blocks[res], xh, img, self.fir, noise_mode, w16[res])
                 continue
             nxt = self.blocks[self.block_res[k + 1]] if (k + 1 < len(self.block_res) and self.block_res[k + 1] not in f16) else None
-            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, next_block=nxt)
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, next_block=nxt, last=(k + 1 == len(self.block_res)))
         return img
 
 
@@ -300,7 +300,8 @@ class StyleUNet:
             # the next block reads this x directly unless a fusion layer (or the concatenation buffer's channel-slice view) is in between
             nb = self.blocks[self.used_res[idx + 1]] if (idx + 1 < len(self.used_res) and idx + 1 >= len(self.fusion) and x_out is None and
                                                          self.used_res[idx + 1] not in f16) else None
-            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_out=x_out, x_split8=xs, next_block=nb)
+            x, img, xs = self.blocks[res](x, img, bank, ws.shape[0], self.fir, noise_mode, x_out=x_out, x_split8=xs, next_block=nb,
+                                          last=(idx + 1 == len(self.used_res)))
             if nxt is not None and x_out is None:                 # shapes did not line up: fall back to a copy
                 nxt[:, :self.cd[res]].copy_(x)
         return img

@@ -146,12 +146,23 @@ def _seed_for(name, seed):
     return int.from_bytes(h[:7], 'little')
 
 
-def synthetic_state_dict(seed=0, only=None):
+_WIDE_STYLE, _WIDE_TORGB = 3.0, 1.0 / 3.0
+
+
+def synthetic_state_dict(seed=0, only=None, profile='unit'):
     """Seeded synthetic weights (CPU fp32).  Distributions follow the reference initialisers
     (randn weights, affine bias 1) except that biases, noise_strength and w_avg — zero at init in
     the reference — get small seeded non-zero values so those code paths are exercised
     (SURVEY.md §8c).  Each tensor has its own generator, so any subset is reproducible.
-    Mesh buffers are NOT produced here (see next3d_amd.mesh.mesh_buffers)."""
+    Mesh buffers are NOT produced here (see next3d_amd.mesh.mesh_buffers).
+
+    profile='wide' (VERDICT r4 item 4a): statistics closer to a TRAINED StyleGAN2 than unit-variance randn — heavy-tailed convolution /
+    fully-connected weights (a normal draw times a log-normal factor, sigma 0.6, rescaled to unit variance: kurtosis ~ 12 instead of 3),
+    style magnitudes x 3 (affine weights and biases; toRGB is not demodulated, so image magnitudes follow), noise strengths ~ 0.3,
+    biases ~ 0.3 — a second, independent test of the split-bf16 arithmetic's error (the unit profile's 8.8e-5 is one draw)."""
+    if profile not in ('unit', 'wide'):
+        raise ValueError(profile)
+    wide = profile == 'wide'
     out = OrderedDict()
     for name, (shape, kind) in build_spec().items():
         if kind == 'mesh' or (only is not None and not only(name)):
@@ -159,18 +170,25 @@ def synthetic_state_dict(seed=0, only=None):
         if kind == 'fir':
             out[name] = _fir()
             continue
-        g = torch.Generator().manual_seed(_seed_for(name, seed))
+        g = torch.Generator().manual_seed(_seed_for(name if not wide else f'wide:{name}', seed))
         r = torch.randn(shape, generator=g, dtype=torch.float32)
+        if wide and kind in ('randn', 'randn_lr'):
+            tail = torch.exp(0.6 * torch.randn(shape, generator=g, dtype=torch.float32)) / float(np.exp(0.6 ** 2))       # E[(r e^{0.6 g})^2] = e^{0.72}
+            r = r * tail
+            if name.endswith('.affine.weight'):
+                r = _WIDE_STYLE * r
+            elif '.torgb.weight' in name:
+                r = _WIDE_TORGB * r
         if kind == 'randn':
             t = r
         elif kind == 'randn_lr':
             t = r / 0.01
         elif kind == 'bias':
-            t = 0.1 * r
+            t = (0.3 if wide else 0.1) * r
         elif kind == 'affine_bias':
-            t = 1.0 + 0.1 * r
+            t = _WIDE_STYLE * (1.0 + 0.3 * r) if wide else 1.0 + 0.1 * r
         elif kind == 'noise_strength':
-            t = 0.1 * r
+            t = (0.3 if wide else 0.1) * r
         elif kind == 'w_avg':
             t = 0.25 * r
         else:

@@ -192,7 +192,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     split-bf16 layer, O <= 128): returns (y, `_lib.Split8` of x * side_style) — n3d_conv2d_desc.side_split8.
     _wt_batch_stride (bytes; `wt` is then the flat per-sample tensor of prep_weight_grouped, _wt_flat=True): per-sample weights,
     n3d_conv2d_desc.wt_batch_stride — the operator boundary's grouped calls.
-    rgb = (weight [C,O] float32, styles [N,O]) (split8 input, mode 0, no split-K, C <= 4): the toRGB layer that is this layer's ONLY reader is
+    rgb = (weight [C,O] float32, styles [N,O]) (split8 input, mode 0, no split-K, C <= 32: up to 4 colours on the VALU, more on the matrix cores): the toRGB layer that is this layer's ONLY reader is
     evaluated in the epilogue (n3d_conv2d_desc.rgb_*): returns the partial colour images [N, ceil(O/64), C, H, W] for rgb_combine; the feature
     map itself is not written; with side_style [N,O] as well: returns (partial, `_lib.Split8` of the layer's output * side_style) — the operand
     image of the layer's second reader (the next block's transposed convolution), exactly split8_from_nchw(y, side_style)."""
@@ -278,8 +278,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     if rgb is not None:
         rw, rs = rgb
         if not (split8 and bf16x3 and ksize == 3 and mode == 0 and ksplit == 1 and out is None and not row_pitch and c8 is None and s8 is None and rw.dtype == rs.dtype == torch.float32 and
-                rw.is_contiguous() and tuple(rw.shape[1:]) == (o,) and rw.shape[0] <= 4 and tuple(rs.shape) == (n, o) and rs.stride(1) == 1):
-            raise RuntimeError('conv2d: the fused toRGB is an option of the pre-split 3x3 stride-1 kernel without split-K (weights [C<=4, O], styles [N, O])')
+                rw.is_contiguous() and tuple(rw.shape[1:]) == (o,) and rw.shape[0] <= 32 and tuple(rs.shape) == (n, o) and rs.stride(1) == 1):
+            raise RuntimeError('conv2d: the fused toRGB is an option of the pre-split 3x3 stride-1 kernel without split-K (weights [C<=32, O], styles [N, O])')
         _lib.require_device(rw, rs)
         partial = torch.empty([n, (o + 63) // 64, rw.shape[0], h, w], dtype=torch.float32, device=wt.device)
         d.rgb_weight, d.rgb_style, d.rgb_partial, d.rgb_channels, d.rgb_style_stride = _lib.ptr(rw), _lib.ptr(rs), _lib.ptr(partial), rw.shape[0], rs.stride(0)

@@ -62,6 +62,12 @@ CASES = {
     # BASELINE.json configs[3]'s per-GPU share: 8 seeds in ONE call (other kernels are selected at batch 8: split-K factors, pre-split
     # eligibility, grid shapes), demo_batch's yaw pattern; `lean`: only what the parity test reads is stored (file size)
     'case_r64_s48_b8': dict(seeds=list(range(8)), yaws=[0.4, 0.0, -0.4, 0.4, 0.0, -0.4, 0.4, 0.0], R=64, Sc=48, Sf=48, psi=0.7, lean=True),
+    # round 5: the benched configuration on a SECOND, trained-like weight draw — spec.synthetic_state_dict(1, profile='wide'):
+    # heavy-tailed weights, styles x 3, noise / bias 0.3 (activations of 10^2 in the blending network) — the split-bf16 error on another draw
+    'case_r64_s48_b4_w1': dict(seeds=[0, 1, 2, 3], yaws=[0.4, 0.0, -0.4, 0.4], R=64, Sc=48, Sf=48, psi=0.7, lean=True, weights=(1, 'wide')),
+    # round 5 (item 4c): BASELINE.json configs[2] / bench.py config3 — README.md:48's seeds as ONE 2x2-grid frame at gen_videos' default sampling
+    # multiplier 2 (96 + 96 samples), four cameras of the orbit (yaw_range 0.35, gen_videos_next3d.py:131-137)
+    'case_r64_s96_v4': dict(seeds=[10720, 12374, 13393, 17099], yaws=[0.35, 0.0, -0.35, 0.2], R=64, Sc=96, Sf=96, psi=0.7, lean=True),
 }
 
 
@@ -169,9 +175,109 @@ def fp16_backbones():
     return 0 if ok else 1
 
 
+def fp16_blocks():
+    """--fp16-blocks (round 5): TEACHER-FORCED per-block goldens of the reference's float16 blocks — one per network and
+    resolution.  The `force_fp16` reference (as --fp16-backbones) runs case_r32_s24 once with hooks on every float16 SynthesisBlock of the four
+    backbones; then each block is evaluated ALONE by the reference on a stated input: its own captured input where that is small (the 16 x 16
+    inputs of the first float16 block of the texture / static / mouth networks, stored), else a seeded input with the captured activation's
+    per-channel rms (oracle.cases.block_inputs: regenerated identically by the test, not stored).  Stored: the network's latents, the block's
+    outputs (x float16, img float32; sub-sampled).  One block deep, two float16 implementations agree bit for bit except where the accumulation
+    order flips a rounding — a bound the float32 route cannot meet (tests/test_generator_gpu.py::test_fp16_blocks_teacher_forced)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    uv_mask = n3d_mesh.synthetic_uv_face_mask()
+    ref_shims.install(uv_mask[0, 0].numpy())
+    import camera_utils as ref_cam
+    G = ref_shims.build_reference_generator(RENDERING_KWARGS, num_fp16_res=4, conv_clamp=256)
+    sd = n3d_spec.synthetic_state_dict(seed=0)
+    verts, faces, uvs, uvfaces = n3d_mesh.parse_obj(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    sd.update(n3d_mesh.mesh_buffers(faces, uvs, uvfaces))
+    G.load_state_dict(sd, strict=True)
+    v_demo = n3d_mesh.parse_obj_vertices(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    lms = n3d_mesh.parse_landmarks(os.path.join(ref_shims.REF, 'data/demo/demo_kpt2d.txt'))
+    for mn in ('training.networks_stylegan2', 'training_avatar_texture.networks_stylegan2', 'training_avatar_texture.networks_stylegan2_styleunet'):
+        enable_reference_fp16_on_cpu(mn)
+    nets = {'texture': G.texture_backbone.synthesis, 'static': G.backbone.synthesis, 'mouth': G.mouth_backbone.synthesis, 'blend': G.neural_blending.synthesis}
+    cap, net_ws = {}, {}
+    for nname, net in nets.items():
+        def net_pre(mod, args, kwargs, nname=nname):
+            ws = kwargs['ws'] if 'ws' in kwargs else [a for a in args if torch.is_tensor(a) and a.ndim == 3][0]
+            net_ws[nname] = ws.detach().clone()
+        net.register_forward_pre_hook(net_pre, with_kwargs=True)
+        for bname, blk in net.named_children():
+            if not (bname.startswith('b') and bname[1:].isdigit() and getattr(blk, 'use_fp16', False)):
+                continue
+            key = (nname, int(bname[1:]))
+
+            def pre(mod, args, kwargs, key=key):
+                cap[key] = dict(x=args[0].detach().clone(), img=None if args[1] is None else args[1].detach().clone(), ws=args[2].detach().clone(),
+                                kw={k: v for k, v in kwargs.items()})
+
+            def post(mod, args, kwargs, out, key=key):
+                cap[key]['x_out'], cap[key]['img_out'] = out[0].detach().clone(), out[1].detach().clone()
+            blk.register_forward_pre_hook(pre, with_kwargs=True)
+            blk.register_forward_hook(post, with_kwargs=True)
+    cfg = CASES['case_r32_s24']
+    N, R, Sc, Sf = 1, cfg['R'], cfg['Sc'], cfg['Sf']
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    z = torch.from_numpy(np.concatenate([np.random.RandomState(s).randn(1, 512) for s in cfg['seeds']], 0))
+    pivot = torch.tensor(RENDERING_KWARGS['avg_camera_pivot'])
+    K = ref_cam.FOV_to_intrinsics(18.837)
+    c2w = ref_cam.LookAtPoseSampler.sample(np.pi / 2 + cfg['yaws'][0], np.pi / 2 - 0.2, pivot, radius=2.7)
+    cnd = ref_cam.LookAtPoseSampler.sample(np.pi / 2, np.pi / 2, pivot, radius=2.7)
+    c, c_cond = torch.cat([c2w.reshape(-1, 16), K.reshape(-1, 9)], 1), torch.cat([cnd.reshape(-1, 16), K.reshape(-1, 9)], 1)
+    v = torch.cat((v_demo, lms), 1)
+    ws_ref = G.mapping(z, c_cond, truncation_psi=cfg['psi'], truncation_cutoff=14)
+    G.synthesis(ws_ref, c, v, neural_rendering_resolution=R, noise_mode='const')
+    full = dict(cap)                                                       # (the hooks keep firing on the stand-alone calls below)
+    out = {}
+    from oracle import networks as onet
+    for (nname, res), e in sorted(full.items()):
+        blk = getattr(nets[nname], f'b{res}')
+        real_in = e['x'].shape[-1] <= 16
+        tag = f'fp16blk:{nname}:b{res}'
+        x_rms = e['x'].float().pow(2).mean(dim=(0, 2, 3)).sqrt()
+        has_img = e['img'] is not None                                   # (a StyleUNet's first decoder block starts the skip image: img is None)
+        img_rms = e['img'].float().pow(2).mean(dim=(0, 2, 3)).sqrt() if has_img else torch.zeros(1)
+        if real_in:
+            x_in, img_in = e['x'].to(torch.float16), (e['img'].float() if has_img else None)
+            out[f'{nname}_b{res}_x_in'] = x_in.numpy()
+            if has_img:
+                out[f'{nname}_b{res}_img_in'] = img_in.numpy()
+        else:
+            x_in, img_in = cases.block_inputs(tag, tuple(e['x'].shape), tuple(e['img'].shape) if has_img else (1, 1, 1, 1), x_rms, img_rms)
+            img_in = img_in if has_img else None
+            out[f'{nname}_b{res}_x_rms'] = x_rms.numpy()
+            if has_img:
+                out[f'{nname}_b{res}_img_rms'] = img_rms.numpy()
+        t0 = time.time()
+        clone = lambda t: None if t is None else t.clone()
+        x_out, img_out = blk(x_in.clone(), clone(img_in), e['ws'], **e['kw'])
+        assert x_out.dtype == torch.float16 and img_out.dtype == torch.float32
+        step = max(2, res // 16)
+        out[f'{nname}_b{res}_x_out'], out[f'{nname}_b{res}_img_out'] = sub(x_out, step), sub(img_out, step)
+        out[f'{nname}_b{res}_step'] = step
+        # what the float32 route gives on the same input (the bound the test states must separate the two)
+        x32, img32 = blk(x_in.clone(), clone(img_in), e['ws'], force_fp32=True, **e['kw'])
+        ulp = lambda t: torch.exp2(torch.floor(torch.log2(t.abs().float().clamp_min(6.1e-5))) - 10)
+        d32 = (x32.to(torch.float16).float() - x_out.float()).abs() / ulp(x_out)
+        same32 = float((x32.to(torch.float16) == x_out).float().mean())
+        out[f'{nname}_b{res}_fp32_route'] = np.array([same32, float(d32.mean()), float((img32 - img_out).abs().max())])
+        print(f'[{nname} b{res}] input {"captured" if real_in else "seeded"} {tuple(x_in.shape)} |x| max {float(x_in.abs().max()):.1f}; reference block {time.time() - t0:.1f}s; '
+              f'out |x| max {float(x_out.abs().max()):.1f}, img max {float(img_out.abs().max()):.1f}; float32 route: {100 * same32:.1f}% of x bit-equal, '
+              f'mean {float(d32.mean()):.2f} ulp, img max-abs {float((img32 - img_out).abs().max()):.2e}')
+    for nname, ws in net_ws.items():
+        out[f'{nname}_ws'] = ws.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, 'fp16_blocks.npz'), **out)
+    print('PIN fp16 blocks done:', os.path.getsize(os.path.join(GOLDEN, 'fp16_blocks.npz')) // 1024, 'KB')
+    return 0
+
+
 def main():
     if '--fp16-backbones' in sys.argv:
         return fp16_backbones()
+    if '--fp16-blocks' in sys.argv:
+        return fp16_blocks()
     only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
     do_fp16 = '--fp16' in sys.argv
     timings = {}
@@ -222,9 +328,15 @@ def main():
     hooks.append(G.superresolution.register_forward_hook(lambda m, i, o: stages.__setitem__('sr_in', tuple(t.clone() for t in i[:3]))))
 
     overall_ok = True
+    loaded = (0, 'unit')
     for cname, cfg in CASES.items():
         if only is not None and cname != only:
             continue
+        if cfg.get('weights', (0, 'unit')) != loaded:                      # another weight draw: both sides reload it
+            loaded = cfg.get('weights', (0, 'unit'))
+            sd = n3d_spec.synthetic_state_dict(seed=loaded[0], profile=loaded[1])
+            sd.update(mb)
+            G.load_state_dict(sd, strict=True)
         N = len(cfg['seeds'])
         R, Sc, Sf = cfg['R'], cfg['Sc'], cfg['Sf']
         G.rendering_kwargs['depth_resolution'] = Sc
@@ -303,7 +415,10 @@ def main():
                 ws=ws_ref.numpy(), image_raw=out_ref['image_raw'].numpy(), image_depth=out_ref['image_depth'].numpy(),
                 image_sub4=sub(out_ref['image'], 4), image_mean=out_ref['image'].mean(dim=(2, 3)).numpy(),
                 textures_sub8=sub(stages['textures'], 8), static_plane_sub8=sub(stages['static_plane'], 8),
-                alpha=(st['alpha'].numpy() * 255).round().astype(np.uint8), mouth_mask=st['mouth_mask'].numpy())
+                alpha=(st['alpha'].numpy() * 255).round().astype(np.uint8), mouth_mask=st['mouth_mask'].numpy(),
+                weights_seed=loaded[0], weights_profile=loaded[1],
+                stage_absmax=np.array([float(stages[k].abs().max()) for k in ('textures', 'mouths_plane', 'rendering_stitch', 'static_plane')] +
+                                      [float(out_ref['image'].abs().max())]))
             continue
         np.savez_compressed(
             os.path.join(GOLDEN, f'{cname}.npz'),

@@ -20,8 +20,8 @@ def _check_conv_desc(name, d):
     bf16x3 = name == 'n3d_conv2d_bf16x3'
     assert d.N >= 0 and d.I > 0 and d.O > 0 and d.H > 0 and d.W > 0, (name, d.N, d.I, d.O, d.H, d.W)
     assert d.x and d.wt and (d.y or d.rgb_partial), name
-    if d.rgb_partial:                                    # toRGB fused into a network's last 3x3 layer: pre-split stride-1 kernel, no split-K, <= 4 colours
-        assert bf16x3 and d.x_layout == 1 and d.ksize == 3 and d.mode == 0 and d.ksplit <= 1 and d.rgb_weight and d.rgb_style and 1 <= d.rgb_channels <= 4
+    if d.rgb_partial:                                    # toRGB fused into a network's last 3x3 layer: pre-split stride-1 kernel, no split-K, <= 32 colours
+        assert bf16x3 and d.x_layout == 1 and d.ksize == 3 and d.mode == 0 and d.ksplit <= 1 and d.rgb_weight and d.rgb_style and 1 <= d.rgb_channels <= 32
         assert not d.epi.residual and not d.epi.round_f16
     assert d.ksize in (1, 3) and 0 <= d.mode <= 2
     assert d.x_layout in (0, 1) and d.y_layout in (0, 1, 2)

@@ -1,0 +1,62 @@
+"""Loader of the teacher-forced float16-block goldens (tests/golden/fp16_blocks.npz, written by oracle/pin_against_reference.py --fp16-blocks:
+the REFERENCE's SynthesisBlock.forward, float16 branch, evaluated alone on a stated input — one block per network and resolution).
+Shared by the CPU test (oracle vs golden) and the GPU test (HIP kernels vs golden)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import cases
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'fp16_blocks.npz')
+PREFIX = {'texture': 'texture_backbone.synthesis', 'static': 'backbone.synthesis', 'mouth': 'mouth_backbone.synthesis', 'blend': 'neural_blending.synthesis'}
+# Bounds of the teacher-forced comparison, ONE block deep (x: the block's float16 feature map, img: its float32 skip image):
+#   at least MIN_EQUAL of x's elements BIT-equal to the reference's, mean |difference| at most MAX_MEAN_ULP float16 ulps (of the element's own
+#   magnitude, floored at the smallest normal), img within IMG_TOL_ULP float16 ulps of its largest value.
+# Measured (oracle/pin_against_reference.py --fp16-blocks, tests/test_cpu_oracle.py): a float16 implementation with the reference's off-GPU
+# bias_act rounding reaches 95.6 - 99.9 % / 0.002 - 0.29 ulp (what is left is the accumulation order inside the half convolutions); the reference's
+# OWN float32 route on the same inputs reaches 28 - 30 % / 4.9 - 6.7 ulp — it FAILS these bounds by a factor of 3 / 10, which is what makes the test
+# tell the float16 route from the float32 one.
+MIN_EQUAL, MAX_MEAN_ULP, IMG_TOL_ULP = 0.93, 0.6, 2.0
+
+
+def ulp16(t):
+    return torch.exp2(torch.floor(torch.log2(t.abs().float().clamp_min(6.1e-5))) - 10)
+
+
+def blocks():
+    """-> list of dicts: net, res, prefix, ws (the NETWORK's latents [1, num_ws, 512]), block_ws [1, 3, 512], x float16 [1,I,res/2,res/2],
+    img float32 or None, step, x_out (float16, sub-sampled), img_out, fp32_route (bit-equal fraction, mean ulp, img max-abs of the reference's
+    own float32 route)."""
+    g = np.load(GOLDEN)
+    out = []
+    for key in sorted(k for k in g.files if k.endswith('_x_out')):
+        net, b = key.split('_')[:2]
+        res = int(b[1:])
+        p = f'{net}_b{res}_'
+        ws = torch.from_numpy(g[f'{net}_ws'])
+        k = int(np.log2(res)) - 2                                     # b4 holds one conv + toRGB, every later block two + toRGB (networks_stylegan2.py:632-640)
+        has_img = (p + 'img_in') in g.files or (p + 'img_rms') in g.files
+        x_out, img_out = torch.from_numpy(g[p + 'x_out']), torch.from_numpy(g[p + 'img_out'])
+        if (p + 'x_in') in g.files:                                   # the reference's own captured input
+            x = torch.from_numpy(g[p + 'x_in'])
+            img = torch.from_numpy(g[p + 'img_in']) if has_img else None
+        else:                                                         # seeded input with the captured activation's per-channel rms
+            ci, cimg = len(g[p + 'x_rms']), img_out.shape[1]
+            x, img = cases.block_inputs(f'fp16blk:{net}:b{res}', (1, ci, res // 2, res // 2), (1, cimg, res // 2, res // 2) if has_img else (1, 1, 1, 1),
+                                        g[p + 'x_rms'], g[p + 'img_rms'] if has_img else np.zeros(1))
+            img = img if has_img else None
+        out.append(dict(net=net, res=res, prefix=f'{PREFIX[net]}.b{res}', ws=ws, block_ws=ws[:, 2 * k - 1:2 * k + 2], x=x, img=img, step=int(g[p + 'step']),
+                        x_out=x_out, img_out=img_out, fp32_route=g[p + 'fp32_route']))
+    return out
+
+
+def compare(x16, img, blk):
+    """x16 float16 [1,O,res,res], img float32 -> (bit-equal fraction, mean ulp, img error in float16 ulps of img's largest value)."""
+    st = blk['step']
+    xs = x16[..., ::st, ::st].cpu()
+    ref = blk['x_out']
+    same = float((xs == ref).float().mean())
+    mean_ulp = float(((xs.float() - ref.float()).abs() / ulp16(ref)).mean())
+    ie = float((img[..., ::st, ::st].cpu() - blk['img_out']).abs().max() / ulp16(blk['img_out'].abs().max()))
+    return same, mean_ulp, ie

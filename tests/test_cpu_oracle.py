@@ -249,3 +249,25 @@ def test_oracle_fp16_backbones_against_reference_fp16_run():
     out, st = ogen.synthesis(sd, ws, t('c'), t('v'), mesh.synthetic_uv_face_mask(), rk, jitter, u, neural_rendering_resolution=R, return_stages=True,
                              force_fp32=False, net_kw=dict(fp16_resolution=32, conv_clamp=256, cpu_rounding=True))
     check_fp16_backbone_outputs(g, st, out, 'oracle')
+
+
+def test_fp16_blocks_teacher_forced_oracle_vs_reference():
+    """tests/golden/fp16_blocks.npz (round 5): every float16 block of the four backbones evaluated ALONE by the reference on a stated input.  The
+    oracle's float16 emulation with the reference's off-GPU bias_act rounding reproduces each block almost bit for bit; the same emulation with
+    bias_act.cu's single rounding and the reference's own float32 route both FAIL the bound — one block deep the comparison tells the arithmetic
+    apart (the end-to-end float16 tolerances cannot: FP16_BB_IMAGE_TOL)."""
+    import _fp16_blocks as fb
+    from next3d_amd import spec
+    from oracle import networks as onet
+    sd = spec.synthetic_state_dict(0)
+    blocks = fb.blocks()
+    assert len(blocks) == 15 and {b['net'] for b in blocks} == set(fb.PREFIX)
+    for b in blocks:
+        x, img = onet.synthesis_block_fp16(sd, b['prefix'], b['x'].float(), b['img'], b['block_ws'], conv_clamp=256, cpu_rounding=True, noise_mode='const')
+        same, mean_ulp, ie = fb.compare(x.half(), img, b)
+        assert same >= fb.MIN_EQUAL and mean_ulp <= fb.MAX_MEAN_ULP and ie <= fb.IMG_TOL_ULP, (b['net'], b['res'], same, mean_ulp, ie)
+        assert b['fp32_route'][0] < 0.5 and b['fp32_route'][1] > 5 * fb.MAX_MEAN_ULP, (b['net'], b['res'], b['fp32_route'])       # the float32 route fails it
+    b = blocks[0]
+    x, img = onet.synthesis_block_fp16(sd, b['prefix'], b['x'].float(), b['img'], b['block_ws'], conv_clamp=256, cpu_rounding=False, noise_mode='const')
+    same, mean_ulp, _ = fb.compare(x.half(), img, b)
+    assert same < 0.5 and mean_ulp > fb.MAX_MEAN_ULP                      # bias_act.cu's single rounding is ANOTHER arithmetic than this off-GPU golden
