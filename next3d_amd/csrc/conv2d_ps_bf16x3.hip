@@ -157,9 +157,15 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
                 for (int nt = 0; nt < 2; ++nt) {
                     // pixels are the matrix ROWS here (first operand), channels the columns: the accumulator then holds, per lane, ONE
                     // channel and 16 pixels in 4 runs of 4 consecutive x -> the epilogue stores 16 bytes at a time (see below)
+                    if constexpr (RGB == 2) {   // weights as rows: a lane then holds 16 CHANNELS of one pixel — the epilogue contraction's operand (below)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bl[s][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mt], bh[s][nt], acc[mt][nt], 0, 0, 0);
+                    } else {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][nt], al[s][mt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s][nt], ah[s][mt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][nt], ah[s][mt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -219,7 +225,7 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
     // the channel-per-register form was 10-17 % of the kernel, store-issue bound: tools/conv_ps_abl.py), and the per-channel
     // factors are two registers per lane instead of 32.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (p.ksplit > 1) {                                                   // split-K: raw partial sums, dense [ks][n][o][H][W]; the reduce pass applies the epilogue
+    if (RGB != 2 && p.ksplit > 1) {                                       // split-K: raw partial sums, dense [ks][n][o][H][W]; the reduce pass applies the epilogue
         float* part = p.partial + (((int64_t)ks * p.N + n) * p.O) * (int64_t)p.H * p.W;
         const bool vec4 = (p.W & 3) == 0;
 #pragma unroll
@@ -249,105 +255,101 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
     const float alpha_eff = lrelu ? E.alpha : 1.f, clamp_eff = E.clamp >= 0.f ? E.clamp : INFINITY;
     if constexpr (RGB == 2) {
         // Fused toRGB with up to 32 colours (round 5: the 32-channel toRGB layers of the texture / mouth / blending networks,
-        // tat/networks_stylegan2.py:575-584) as an EPILOGUE CONTRACTION on the matrix cores.  The activated tile is staged through LDS 32 channels at
-        // a time exactly as in the <= 4-colour form; a lane then reads 8 consecutive channels of one pixel — which IS a first-operand fragment of
-        // v_mfma_f32_32x32x16_bf16 (pixels as rows) — splits them into bf16 hi / lo and multiplies them with the toRGB weights times the sample's
-        // toRGB styles (formed and split once per workgroup into the free chunk buffer): colour[p][j] += x_hi w_lo + x_lo w_hi + x_hi w_hi, float32
-        // accumulation, the arithmetic of the separate 1x1 split-bf16 kernel.  24 MFMAs per wave — a quarter of ONE 16-channel chunk of the K loop.
-        // The result has the main accumulators' layout (lane = colour, 4 runs of 4 consecutive pixels): 16-byte stores of the partial colour image
-        // of this workgroup's 64 channels; n3d_rgb_combine adds the O/64 partial images in index order.  With SIDE the same fragments, times the next
-        // layer's styles, are also the split8 units of the side output (n3d_split8_from_nchw's arithmetic).
-        float* stage = reinterpret_cast<float*>(smem);
-        bf16x8* s_bw = smem + (32 * PS_RGB_PITCH * 4 + 15) / 16;           // behind the stage: [k step 4][hi|lo][k half][32 colours] = 8 KB
+        // tat/networks_stylegan2.py:575-584) as an EPILOGUE CONTRACTION on the matrix cores, straight from the accumulators.  This variant multiplies
+        // with the weights as matrix ROWS (mfma_block), so a lane's 16 values per accumulator are 4 runs of 4 consecutive CHANNELS of ONE pixel:
+        //     channel = 32 mt + (r & 3) + 8 (r >> 2) + 4 half,    pixel = (tile row 2 wn + nt, column lane & 31).
+        // Eight of them (r = 8 s .. 8 s + 7) are, after the layer epilogue and the hi / lo split, a first-operand fragment of
+        // v_mfma_f32_32x32x16_bf16 (pixels as rows) — the K index of that instruction is just a NAME for "which channel": the toRGB weights times the
+        // sample's toRGB styles are laid out in LDS in the same permuted order, so no data moves between lanes and nothing is staged:
+        //     colour[p][j] += x_hi w_lo + x_lo w_hi + x_hi w_hi   (float32 accumulation: the arithmetic of the separate 1x1 split-bf16 kernel),
+        // 24 MFMAs per wave — a quarter of ONE 16-channel chunk of the K loop.  The result has lane = colour and 4 runs of 4 consecutive pixels:
+        // 16-byte stores of the partial colour image of this workgroup's 64 channels; n3d_rgb_combine adds the O/64 partial images in index order.
+        // SIDE: a run of 4 channels times the next layer's styles is half a split8 unit (n3d_split8_from_nchw's arithmetic): 8-byte stores, the
+        // lanes l and l + 32 complete each 16-byte unit.  The feature map itself is never written (y must be NULL).
+        bf16x8* s_bw = smem;                                              // [k step 4 = (mt, s)][hi|lo][half][32 colours] = 8 KB of the free chunk buffers
         int lane_e;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int tid_e = wn * 64 + lane_e, l31_e = lane_e & 31, half_e = lane_e >> 5;
         __syncthreads();                                                  // every wave is past its last fragment read: the chunk buffers are free
         {
-            const int colour = tid_e & 31, cg = tid_e >> 5;               // this thread: 4 consecutive channels cg * 4 .. + 3 of the workgroup's 64
+            const int colour = tid_e & 31, grp = tid_e >> 5;              // grp = (mt, s, half, element quad): 4 consecutive channels
+            const int gmt = grp >> 3, gs = (grp >> 2) & 1, gh = (grp >> 1) & 1, gq = grp & 1;
+            const int c0 = gmt * 32 + 8 * (2 * gs + gq) + 4 * gh;         // fragment elements 4 gq .. 4 gq + 3 of (k step (gmt, gs), half gh)
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 wh, wl;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int o = m0 + cg * 4 + k;
+                const int o = m0 + c0 + k;
                 const float wv = (colour < p.rgb_channels && o < p.O) ? p.rgb_weight[(int64_t)colour * p.O + o] * p.rgb_style[(int64_t)n * p.rgb_style_stride + o] : 0.f;
                 const __bf16 h = (__bf16)wv;
                 wh[k] = h;
                 wl[k] = (__bf16)(wv - (float)h);
             }
-            const int slot = (cg >> 2) * 128 + ((cg >> 1) & 1) * 32 + colour;             // [k step][hi|lo][k half][colour]: + 64 for lo
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot) + (cg & 1) * 4) = wh;
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot + 64) + (cg & 1) * 4) = wl;
+            const int slot = (gmt * 2 + gs) * 128 + gh * 32 + colour;     // + 64 for lo
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot) + gq * 4) = wh;
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(s_bw + slot + 64) + gq * 4) = wl;
         }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t r_side = __builtin_amdgcn_make_buffer_rsrc((void*)(p.side + (int64_t)n * 2 * (p.O / 8) * HW), 0, (SIDE && p.side) ? 2 * (p.O / 8) * HW * 16 : 0, 0x00020000);
+        const int ox_e = x0 + l31_e;
         f32x16 racc[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) racc[nt][r] = 0.f;
-        const __amdgpu_buffer_rsrc_t r_side = __builtin_amdgcn_make_buffer_rsrc((void*)(p.side + (int64_t)n * 2 * (p.O / 8) * HW), 0, (SIDE && p.side) ? 2 * (p.O / 8) * HW * 16 : 0, 0x00020000);
+            const int oy = y0 + wn * 2 + nt;
+            const float nz = E.noise ? E.noise[(int64_t)min(oy, p.H - 1) * p.W + min(ox_e, p.W - 1)] * nstr : 0.f;
+            const bool px_ok = oy < p.H && ox_e < p.W;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float rs = s_rs[mt * 32 + l31_e], bs = s_bs[mt * 32 + l31_e];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int oy = min(y0 + wn * 2 + nt, p.H - 1);
-                const float* nrow = E.noise ? E.noise + (int64_t)oy * p.W : nullptr;
+            for (int mt = 0; mt < 2; ++mt) {
+                float v[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ox = x0 + 8 * g + 4 * half_e;
-                    f32x4 out;
+                    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(s_rs + mt * 32 + 8 * g + 4 * half_e), bs4 = *reinterpret_cast<const f32x4*>(s_bs + mt * 32 + 8 * g + 4 * half_e);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float t = acc[mt][nt][4 * g + k] * rs + (nrow ? nrow[min(ox + k, p.W - 1)] * nstr : 0.f) + bs;
+                    for (int q = 0; q < 4; ++q) {
+                        float t = acc[mt][nt][4 * g + q] * rs4[q] + nz + bs4[q];
                         t = fmaxf(t, t * alpha_eff) * E.gain;
-                        out[k] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
+                        v[4 * g + q] = fminf(fmaxf(t, -clamp_eff), clamp_eff);
                     }
-                    *reinterpret_cast<f32x4*>(stage + l31_e * PS_RGB_PITCH + (wn * 2 + nt) * 32 + 8 * g + 4 * half_e) = out;
-                }
-            }
-            __syncthreads();
+                    if constexpr (SIDE) {
+                        const f32x4 sd4 = *reinterpret_cast<const f32x4*>(s_sd + mt * 32 + 8 * g + 4 * half_e);
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 sh, sl;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {                                 // 16-channel k steps of this 32-channel group
-                const bf16x8 bw_hi = s_bw[(mt * 2 + j) * 128 + half_e * 32 + l31_e], bw_lo = s_bw[(mt * 2 + j) * 128 + 64 + half_e * 32 + l31_e];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int prow = wn * 2 + nt;                          // tile row of this wave
-                    bf16x8 xh, xl, sh, sl;
-#pragma unroll
-                    for (int cc = 0; cc < 8; ++cc) {
-                        const int c = 16 * j + 8 * half_e + cc;
-                        const float xv = stage[c * PS_RGB_PITCH + prow * 32 + l31_e];
-                        const __bf16 h = (__bf16)xv;
-                        xh[cc] = h;
-                        xl[cc] = (__bf16)(xv - (float)h);
-                        if constexpr (SIDE) {
-                            const float t = xv * s_sd[mt * 32 + c];        // n3d_split8_from_nchw's arithmetic
+                        for (int q = 0; q < 4; ++q) {
+                            const float t = v[4 * g + q] * sd4[q];             // n3d_split8_from_nchw's arithmetic
                             const __bf16 th = (__bf16)t;
-                            sh[cc] = th;
-                            sl[cc] = (__bf16)(t - (float)th);
+                            sh[q] = th;
+                            sl[q] = (__bf16)(t - (float)th);
+                        }
+                        if (p.side != nullptr) {
+                            typedef int i32x2 __attribute__((ext_vector_type(2)));
+                            const int unit = (m0 + mt * 32) / 8 + g;
+                            // (out-of-image pixels and channels beyond O get an offset beyond the descriptor's range: dropped by the hardware)
+                            const int voff = (px_ok && unit * 8 < p.O) ? (unit * HW + oy * p.W + ox_e) * 16 + 8 * half_e : (int)0x80000000;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, sh), r_side, voff, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, sl), r_side, voff, (p.O / 8) * HW * 16, 0);
                         }
                     }
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 xh, xl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 h = (__bf16)v[8 * st + e];
+                        xh[e] = h;
+                        xl[e] = (__bf16)(v[8 * st + e] - (float)h);
+                    }
+                    const bf16x8 bw_hi = s_bw[(mt * 2 + st) * 128 + half_e * 32 + l31_e], bw_lo = s_bw[(mt * 2 + st) * 128 + 64 + half_e * 32 + l31_e];
                     racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bw_lo, racc[nt], 0, 0, 0);
                     racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bw_hi, racc[nt], 0, 0, 0);
                     racc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bw_hi, racc[nt], 0, 0, 0);
-                    if constexpr (SIDE) {
-                        const int oy_s = y0 + prow, ox_s = x0 + l31_e;
-                        const int unit = (m0 + mt * 32) / 8 + 2 * j + half_e;
-                        if (p.side != nullptr) {
-                            typedef int i32x4 __attribute__((ext_vector_type(4)));
-                            // (the unit is lane-dependent here — the two k halves are two units — so it goes into the per-lane offset; out-of-image pixels
-                            // and channels beyond O get an offset beyond the descriptor's range: dropped by the hardware)
-                            const bool ok = oy_s < p.H && ox_s < p.W && unit * 8 < p.O;
-                            const int voff = ok ? (unit * HW + oy_s * p.W + ox_s) * 16 : (int)0x80000000;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sh), r_side, voff, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, sl), r_side, ok ? voff + (p.O / 8) * HW * 16 : voff, 0, 0);
-                        }
-                    }
                 }
             }
-            __syncthreads();
         }
-        // partial colours: lane = colour, 4 runs of 4 consecutive pixels per tile row (the accumulator layout of the main loop)
+        // partial colours: lane = colour, 4 runs of 4 consecutive pixels per tile row
         if (l31_e < p.rgb_channels) {
             float* dst = p.rgb_partial + (((int64_t)n * p.tiles_m + m0 / PS_BM) * p.rgb_channels + l31_e) * (int64_t)p.H * p.W;
             const bool vec4 = (p.W & 3) == 0;
@@ -438,7 +440,7 @@ __device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf1
                 if (j < p.rgb_channels) dst[(int64_t)j * p.H * p.W] = col[j];
         }
     }
-    const bool store_y = !RGB || p.y != nullptr;          // (an early `return` here makes hipcc wrap every LDS-DMA copy of the K loop into a waterfall loop)
+    const bool store_y = RGB != 2 && (!RGB || p.y != nullptr);      // (RGB == 2: other accumulator layout, y is NULL by contract)          // (an early `return` here makes hipcc wrap every LDS-DMA copy of the K loop into a waterfall loop)
     const int64_t plane = (int64_t)p.H * p.W, yplane = (int64_t)p.H * p.yrs;
     const bool vec = ((p.W | p.yrs | p.ybs) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
                      (!E.residual || ((E.residual_batch_stride & 3) == 0 && ((uintptr_t)E.residual & 15) == 0)) && (!E.noise || ((uintptr_t)E.noise & 15) == 0);
@@ -569,6 +571,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
         N3D_CHECK(p.ksplit == 1 && !E.residual && !E.round_f16, "conv2d_bf16x3: fused toRGB on a layer without split-K, residual or float16 rounding");
     }
     N3D_CHECK(d->y != nullptr || rgb, "conv2d_bf16x3: y is NULL");
+    N3D_CHECK(!(rgb && d->rgb_channels > PS_RGB_MAX) || d->y == nullptr, "conv2d_bf16x3: the fused toRGB with more than 4 colours does not write the feature map (y must be NULL)");
     N3D_CHECK(!d->side_split8 || (rgb && d->side_style && d->O % 8 == 0 && ((uintptr_t)d->side_split8 & 15) == 0 && (int64_t)2 * (d->O / 8) * d->H * d->W * 16 < (1ll << 31)),
               "conv2d_bf16x3 (split8 input): the split8 side output is an option of the fused toRGB (rgb_partial, side_style, O %% 8 == 0)");
     p.side = (bf16x8*)d->side_split8; p.side_style = d->side_style; p.side_style_stride = d->side_style_stride ? d->side_style_stride : d->O;
@@ -599,25 +602,40 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
 }
 
 // The second half of the fused toRGB: sum the workgroups' partial colour images in index order and apply the toRGB layer's epilogue.
+// blockIdx.y = (sample, colour) plane, blockIdx.x walks the plane's VEC-pixel vectors (VEC = 4: 16-byte loads of the M partial images and a 16-byte
+// store; VEC = 1 for widths that are not a multiple of 4): no 64-bit division per element, bias / clamp are per-plane scalars.  With 32 colours
+// (round 5: the backbones' toRGB layers) this kernel moves 100 MB per 256 x 256 block at batch 4 — it has to stream, not crawl.
+template <int VEC>
 __global__ __launch_bounds__(256) void rgb_combine_kernel(const float* __restrict__ partial, float* __restrict__ y, int N, int M, int C, int H, int W, n3d_epilogue E) {
-    const int64_t plane = (int64_t)H * W, total = (int64_t)N * C * plane;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t pix = i % plane; const int c = (int)((i / plane) % C), n = (int)(i / (plane * C));
-        float v = 0.f;
-        for (int m = 0; m < M; ++m) v += partial[(((int64_t)n * M + m) * C + c) * plane + pix];
-        if (E.round_f16) {        // ToRGBLayer of a float16 block (n3d_torgb_h8's order): the float32 sum rounds to float16, bias_act on float16, float32 skip image
-            const float t = (float)(_Float16)v + (E.bias ? (float)(_Float16)E.bias[c] : 0.f);
-            const float cl = E.clamp >= 0.f ? E.clamp : INFINITY;
-            v = (float)(_Float16)fminf(fmaxf(t, -cl), cl);
-            if (E.residual) {
-                const int oy = (int)(pix / W), ox = (int)(pix % W);
-                if (E.residual_up_filter) v += n3d_up2_apply(n3d_up2_setup(E.residual_up_filter, oy, ox, H >> 1, W >> 1), E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)c * (plane >> 2));
-                else v += E.residual[(int64_t)n * E.residual_batch_stride + (int64_t)c * plane + pix];
+    const int nc = blockIdx.y, n = nc / C, c = nc % C;
+    const int plane = H * W, nvec = plane / VEC, WV = W / VEC;
+    const float* p0 = partial + ((int64_t)n * M * C + c) * plane;
+    const int64_t mstride = (int64_t)C * plane;
+    float* yp = y + (int64_t)nc * plane;
+    const float* rplane = E.residual ? E.residual + (int64_t)n * E.residual_batch_stride + (int64_t)c * (E.residual_up_filter ? (plane >> 2) : plane) : nullptr;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        vec_t s = *reinterpret_cast<const vec_t*>(p0 + (int64_t)i * VEC);
+        for (int m = 1; m < M; ++m) s += *reinterpret_cast<const vec_t*>(p0 + m * mstride + (int64_t)i * VEC);
+        const int oy = i / WV, ox = (i - oy * WV) * VEC;
+        vec_t out;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float v = s[k];
+            if (E.round_f16) {    // ToRGBLayer of a float16 block (n3d_torgb_h8's order): the float32 sum rounds to float16, bias_act on float16, float32 skip image
+                const float t = (float)(_Float16)v + (E.bias ? (float)(_Float16)E.bias[c] : 0.f);
+                const float cl = E.clamp >= 0.f ? E.clamp : INFINITY;
+                v = (float)(_Float16)fminf(fmaxf(t, -cl), cl);
+                if (rplane) {
+                    if (E.residual_up_filter) v += n3d_up2_apply(n3d_up2_setup(E.residual_up_filter, oy, ox + k, H >> 1, W >> 1), rplane);
+                    else v += rplane[(int64_t)i * VEC + k];
+                }
+            } else {
+                v = n3d_apply_epilogue(v, E, n, c, C, oy, ox + k, H, W);
             }
-            y[i] = v;
-            continue;
+            out[k] = v;
         }
-        y[i] = n3d_apply_epilogue(v, E, n, c, C, (int)(pix / W), (int)(pix % W), H, W);
+        *reinterpret_cast<vec_t*>(yp + (int64_t)i * VEC) = out;
     }
 }
 extern "C" int n3d_rgb_combine(const float* partial, float* y, int N, int M, int C, int H, int W, const n3d_epilogue* epi, n3d_stream_t stream_) {
@@ -630,7 +648,12 @@ extern "C" int n3d_rgb_combine(const float* partial, float* y, int N, int M, int
     N3D_CHECK(!epi->residual_up_filter || (epi->residual && H % 2 == 0 && W % 2 == 0), "rgb_combine: residual_up_filter needs a residual and an even output size");
     const int64_t total = (int64_t)N * C * H * W;
     N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * total * (M + 1));
-    hipLaunchKernelGGL(rgb_combine_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, stream, partial, y, N, M, C, H, W, *epi);
+    N3D_CHECK((int64_t)H * W < (1ll << 31) && (int64_t)N * C <= 65535, "rgb_combine: plane or plane count too large");
+    const bool vec = (W & 3) == 0 && (((uintptr_t)partial | (uintptr_t)y) & 15) == 0;
+    const int nvec = H * W / (vec ? 4 : 1);
+    const dim3 grid((unsigned)std::min((nvec + 255) / 256, 64), (unsigned)(N * C));
+    if (vec) hipLaunchKernelGGL(rgb_combine_kernel<4>, grid, dim3(256), 0, stream, partial, y, N, M, C, H, W, *epi);
+    else hipLaunchKernelGGL(rgb_combine_kernel<1>, grid, dim3(256), 0, stream, partial, y, N, M, C, H, W, *epi);
     N3D_LAUNCH_CHECK();
     return 0;
 }

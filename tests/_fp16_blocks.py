@@ -18,6 +18,11 @@ PREFIX = {'texture': 'texture_backbone.synthesis', 'static': 'backbone.synthesis
 # OWN float32 route on the same inputs reaches 28 - 30 % / 4.9 - 6.7 ulp — it FAILS these bounds by a factor of 3 / 10, which is what makes the test
 # tell the float16 route from the float32 one.
 MIN_EQUAL, MAX_MEAN_ULP, IMG_TOL_ULP = 0.93, 0.6, 2.0
+# The HIP kernels accumulate a whole 9 x I product chain in float32 on the matrix cores and round once; ATen's off-GPU half convolution (what the
+# reference and the oracle both call) rounds elsewhere inside its blocking, so fewer elements are bit-equal than oracle-vs-reference — calibrated on
+# hardware (15 blocks: 85.0 - 93.7 % bit-equal, mean 0.26 - 0.92 ulp; this library's float32 route on the same inputs: 27.8 - 30.5 %, 4.4 - 8.4 ulp,
+# the reference's own float32 route 27.9 - 30.5 % / 4.9 - 6.7 ulp): the bound sits 2.7x / 3.4x away from what any float32 route reaches.
+MIN_EQUAL_HIP, MAX_MEAN_ULP_HIP = 0.78, 1.3
 
 
 def ulp16(t):

@@ -215,12 +215,47 @@ def test_pipelined_steps_are_bitwise_reproducible(G, dev):
 
 
 @pytest.mark.gpu
+def test_fused_backbone_torgb_equals_separate_torgb(G, dev, monkeypatch):
+    """Round 5 (layers.FUSED_TORGB_MAX = 32): the 32-colour toRGB layers of the texture / mouth / blending networks evaluated in their conv1's
+    epilogue on the matrix cores (blocks whose feature map has no float32 reader: n3d_conv2d_desc.rgb_*, partial colours + n3d_rgb_combine)
+    against the same forward with separate 1x1 toRGB launches (FUSED_TORGB_MAX = 4).  Both forms are split-bf16 products with float32
+    accumulation in different orders: the stage tensors agree to the 1x1 kernel's own accuracy, the rasterised geometry bit for bit."""
+    from next3d_amd import layers
+    layers.set_precision('bf16x3')
+    d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
+    R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
+    jitter, u = cases.rng_inputs(4, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(d[k]).to(dev)
+    ws = G.mapping(t('z'), t('c_cond'), truncation_psi=0.7, truncation_cutoff=14)
+    kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
+    G.keep_stages = True
+    got = {}
+    try:
+        for mx in (32, 4):
+            monkeypatch.setattr(layers, 'FUSED_TORGB_MAX', mx)
+            o = G.synthesis(ws, t('c'), t('v'), **kw)
+            got[mx] = dict({k: G._debug[k].clone() for k in ('textures', 'mouths', 'stitch', 'static', 'alpha', 'bbox')}, image=o['image'].clone(), image_raw=o['image_raw'].clone())
+    finally:
+        G.keep_stages = False
+    assert torch.equal(got[32]['alpha'], got[4]['alpha']) and torch.equal(got[32]['bbox'], got[4]['bbox']) and torch.equal(got[32]['static'], got[4]['static'])
+    rep = {k: _md(got[32][k], got[4][k]) for k in ('textures', 'mouths', 'stitch', 'image_raw', 'image')}
+    print('fused vs separate 32-colour toRGB:', ' '.join(f'{k}={v:.3e}' for k, v in rep.items()), '| stage |max|', ' '.join(f"{k}={float(got[4][k].abs().max()):.1f}" for k in ('textures', 'mouths', 'stitch')))
+    assert rep['textures'] > 0                                              # the fused layers do run
+    for k in ('textures', 'mouths', 'stitch'):
+        assert rep[k] <= 2e-5 * max(1.0, float(got[4][k].abs().max())), (k, rep[k])
+    assert rep['image_raw'] <= 1e-4 and rep['image'] <= 1e-4
+
+
+@pytest.mark.gpu
 def test_fused_last_layer_torgb_equals_separate_torgb(G, dev, monkeypatch):
     """layers.FUSED_TORGB: the super-resolution's last 3x3 layer (128 channels at 512 x 512) evaluates its toRGB in the epilogue and never
     writes its feature map.  Against the same forward with the two layers separate: equal to the accuracy of the separate 1x1 kernel
-    (split-bf16: 2^-17 relative per product); everything in front of that layer is bit-identical."""
+    (split-bf16: 2^-17 relative per product); everything in front of that layer is bit-identical.  (FUSED_TORGB_MAX = 4 here: the super-resolution's
+    3-colour layers only, as in round 4; the backbones' 32-colour layers: test_fused_backbone_torgb_equals_separate_torgb.)"""
     from next3d_amd import layers
     layers.set_precision('bf16x3')
+    monkeypatch.setattr(layers, 'FUSED_TORGB_MAX', 4)
     d = np.load(os.path.join(GOLDEN, 'case_r64_s48_b4.npz'))
     R, Sc, Sf = 64, int(d['Sc']), int(d['Sf'])
     G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf
@@ -547,7 +582,7 @@ def test_fp16_blocks_teacher_forced(G16, dev, monkeypatch):
     layers.set_precision('bf16x3')
     S = G16._prep()
     nets = {'texture': S.texture, 'static': S.static, 'mouth': S.mouth, 'blend': S.blend}
-    worst = [1.0, 0.0, 0.0]
+    worst, bad = [1.0, 0.0, 0.0], []
     for b in fb.blocks():
         net = nets[b['net']]
         blk = net.blocks[b['res']]
@@ -563,10 +598,11 @@ def test_fp16_blocks_teacher_forced(G16, dev, monkeypatch):
         same32, mean32, _ = fb.compare(x32.half(), img32, b)
         print(f"{b['net']} b{b['res']}: f16 kernels {100 * same:.2f} % bit-equal, mean {mean_ulp:.3f} ulp, img {ie:.2f} ulp | float32 route {100 * same32:.1f} %, {mean32:.2f} ulp "
               f"(the reference's own float32 route: {100 * b['fp32_route'][0]:.1f} %, {b['fp32_route'][1]:.2f} ulp)")
-        assert same >= fb.MIN_EQUAL and mean_ulp <= fb.MAX_MEAN_ULP and ie <= fb.IMG_TOL_ULP, (b['net'], b['res'], same, mean_ulp, ie)
-        assert same32 < 0.6 and mean32 > 3 * fb.MAX_MEAN_ULP, (b['net'], b['res'], same32, mean32)        # the float32 route FAILS the bound
+        bad += [(b['net'], b['res'], 'f16', same, mean_ulp, ie)] if not (same >= fb.MIN_EQUAL_HIP and mean_ulp <= fb.MAX_MEAN_ULP_HIP and ie <= fb.IMG_TOL_ULP) else []
+        bad += [(b['net'], b['res'], 'f32 passes', same32, mean32)] if not (same32 < 0.5 * fb.MIN_EQUAL_HIP and mean32 > 3 * fb.MAX_MEAN_ULP_HIP) else []    # the float32 route FAILS the bound
         worst = [min(worst[0], same), max(worst[1], mean_ulp), max(worst[2], ie)]
     print('worst block: %.2f %% bit-equal, mean %.3f ulp, img %.2f ulp' % (100 * worst[0], worst[1], worst[2]))
+    assert not bad, bad
 
 
 @pytest.fixture(scope='module')

@@ -16,6 +16,6 @@ python - <<PY
 import json
 d=json.loads(open('gpurun_out/r5_ab_rgb$mode.json').read().strip().splitlines()[-1])
 f=d['roofline']['family_ms_per_step']
-print('FUSED_TORGB_MAX $mode  frames/s',round(d['value'],1),'ms/step',round(d['ms_per_step'],3),'single_stream',round(d.get('single_stream',{}).get('value',0),1),'frac',round(d['roofline']['frac'],4), 'conv3x3',f['conv2d_bf16x3'], 'conv1x1',f['conv1x1_bf16x3'], 'fir', f.get('upfirdn2d'), 'misc', f['misc'])
+print('FUSED_TORGB_MAX $mode  frames/s',round(d['value'],1),'ms/step',round(d['ms_per_step'],3),'single_stream',round((d.get('single_stream') or {}).get('value',0),1),'frac',round(d['roofline']['frac'],4), 'conv3x3',f['conv2d_bf16x3'], 'conv1x1',f['conv1x1_bf16x3'], 'fir', f.get('upfirdn2d'), 'misc', f['misc'])
 PY
 done; done
