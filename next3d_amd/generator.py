@@ -634,6 +634,43 @@ class TriPlaneGenerator(_Tracked):
                               cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
 
 
+class _DecoderFC(torch.nn.Module):
+    """weight [O,I] / bias [O] with the reference's equalised-learning-rate scaling (FullyConnectedLayer, tat/networks_stylegan2.py:95-127)."""
+
+    def __init__(self, in_features, out_features, lr_multiplier=1.0):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(out_features, in_features) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.zeros(out_features))
+        self.weight_gain, self.bias_gain = lr_multiplier / np.sqrt(in_features), lr_multiplier
+
+    def forward(self, x):
+        return torch.addmm((self.bias * self.bias_gain).unsqueeze(0), x, (self.weight * self.weight_gain).t())
+
+
+class OSGDecoder(torch.nn.Module):
+    """The un-pickling target `training_avatar_texture.triplane_next3d.OSGDecoder`.  The reference's decoder is NOT a persistent class
+    (tat/triplane_next3d.py:348-371 has no @persistence.persistent_class), so a network pickle stores `G.decoder` BY REFERENCE to that module path —
+    the path `install_dropin(model=True)` aliases to this module: without this class `legacy.load_network_pkl` fails before `--reload_modules`
+    is even looked at (found by tests/_e2e_scripts.py, round 5).  An un-pickled instance carries the pickle's `net` (the reference's own
+    FullyConnectedLayer modules, which ARE persistent); with `--reload_modules=True` it only donates its parameters to
+    misc.copy_params_and_buffers, without it (boundary B1: the pickled reference generator keeps running) `forward` is what that generator calls.
+    This package's own generator never instantiates it: its decoder runs inside n3d_render_rays."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        lr = options['decoder_lr_mul']
+        self.net = torch.nn.Sequential(_DecoderFC(n_features, self.hidden_dim, lr), torch.nn.Softplus(),
+                                       _DecoderFC(self.hidden_dim, 1 + options['decoder_output_dim'], lr))
+
+    def forward(self, sampled_features, ray_directions, sampled_embeddings=None):
+        feats = sampled_features.mean(dim=1)                              # [N, planes, M, C] -> [N, M, C]: the three planes' features averaged
+        batch, points = feats.shape[:2]
+        raw = self.net(feats.reshape(batch * points, -1)).reshape(batch, points, -1)
+        return {'rgb': torch.sigmoid(raw[..., 1:]) * 1.002 - 0.001,         # MipNeRF's widened sigmoid (:369)
+                'sigma': raw[..., :1]}
+
+
 def _resize_aa(x, size):
     """F.interpolate(x, (size,size), mode='bilinear', align_corners=False, antialias=True) on libn3d.so."""
     n, c, h, w = x.shape

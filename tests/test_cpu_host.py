@@ -527,3 +527,46 @@ print('LAUNCHER_OK')
 """ % (repo, script)
     r = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'LAUNCHER_OK' in r.stdout and '--network' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/gen_samples_next3d.py'), reason='needs the reference tree (build container only)')
+def test_reference_scripts_run_end_to_end_through_the_launcher(tmp_path_factory):
+    """"drop in unchanged", once, end to end.  The reference's OWN generator is pickled by the reference's own persistence
+    ({'G_ema': G}), then gen_samples_next3d.py (1 seed), gen_videos_next3d.py (2x2 grid, 2 frames) and reenact_avatar_next3d.py (2 frames of a
+    synthetic driving sequence) are executed UNCHANGED by `next3d_amd.run` with --reload_modules=True against the recording stand-in of
+    libn3d.so (tests/_e2e_scripts.py): legacy.load_network_pkl -> TriPlaneGenerator(*G.init_args, **G.init_kwargs) -> misc.copy_params_and_buffers
+    -> the scripts' image loops -> PNG / video frames.  Every G.synthesis call lands in next3d_amd.generator, carries the pickle's weights and issues
+    exactly the launch sequence of a direct call (156 launches on the scripts' default float16 super-resolution route)."""
+    import json
+    work = tmp_path_factory.mktemp('e2e')
+    pkl = str(work / 'synthetic_next3d.pkl')
+    harness = os.path.join(os.path.dirname(__file__), '_e2e_scripts.py')
+    try:
+        r = subprocess.run([sys.executable, harness, 'write-pickle', pkl], cwd='/tmp', capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and 'PICKLE_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        r = subprocess.run([sys.executable, harness, 'run', pkl, str(work)], cwd='/tmp', capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0 and 'E2E_OK' in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+    finally:
+        if os.path.exists(pkl):
+            os.remove(pkl)                                            # 0.7 GB
+    rep = json.loads(r.stdout[r.stdout.index('E2E_OK') + 7:].splitlines()[0])
+    assert rep['gen_samples_next3d.py']['synthesis_calls'] == 3 and rep['gen_samples_next3d.py']['mapping_calls'] == 3          # three views of one seed
+    assert rep['gen_videos_next3d.py']['synthesis_calls'] == 1 + 2 * 4 and rep['reenact_avatar_next3d.py']['synthesis_calls'] == 2
+    assert all(v['launches_per_synthesis'] == rep['gen_samples_next3d.py']['launches_per_synthesis'] and v['sequences_checked'] >= 1 for v in rep.values())
+
+
+def test_osg_decoder_unpickling_target_matches_oracle():
+    """generator.OSGDecoder: the class a network pickle names by reference (tat/triplane_next3d.py:348 is not a persistent class) — constructor
+    signature, parameter names (decoder.net.{0,2}.{weight,bias}) and forward against the oracle's restatement of the reference decoder."""
+    import torch
+    from next3d_amd import generator, spec
+    from oracle import renderer as orend
+    dec = generator.OSGDecoder(32, {'decoder_lr_mul': 1.0, 'decoder_output_dim': 32})
+    assert sorted(k for k, _ in dec.named_parameters()) == ['net.0.bias', 'net.0.weight', 'net.2.bias', 'net.2.weight']
+    sd = spec.synthetic_state_dict(0, only=lambda n: n.startswith('decoder.'))
+    dec.load_state_dict({k[len('decoder.'):]: v for k, v in sd.items()}, strict=True)
+    feats = torch.randn(2, 3, 50, 32, generator=torch.Generator().manual_seed(3))
+    out = dec(feats, None)
+    rgb, sigma = orend.osg_decoder(sd, 'decoder', feats)
+    assert tuple(out['rgb'].shape) == (2, 50, 32) and tuple(out['sigma'].shape) == (2, 50, 1)
+    assert float((out['rgb'] - rgb).abs().max()) <= 1e-6 and float((out['sigma'] - sigma).abs().max()) <= 1e-5
