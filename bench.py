@@ -43,6 +43,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+PEAK_L2_TBPS = 34.5                 # aggregate L2 bandwidth, /opt/skills/guides/MI355X_MICROARCH.md (L2 per XCD)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
 TRAFFIC_PROFILE = os.path.join(REPO, "profiles", "r04_traffic_pmc.json")
@@ -200,7 +201,7 @@ def main():
     lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.lanes))]
     for s_ in lanes:
         s_.wait_stream(torch.cuda.current_stream())
-    counter, one_lane, sr_fp32, gen = [0], [False], [not args.sr_fp16], [G]
+    counter, one_lane, sr_fp32, gen, draw_rng = [0], [False], [not args.sr_fp16], [G], [False]
 
     def step():
         if args.serial_gather:
@@ -209,8 +210,10 @@ def main():
         counter[0] += 1
         with torch.cuda.stream(lane):
             ws = gen[0].mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
-            img = gen[0].synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u,
-                                   force_fp32=sr_fp32[0])['image']              # the fp32 path (the one the goldens pin)
+            # the renderer's two random inputs are INJECTED in the timed loop (the reference draws them per call with torch.rand, vr/renderer.py:205,252:
+            # two launches); `rng_default_path` on the line times the same steps with the draws inside the call
+            rnd = dict() if draw_rng[0] else dict(depth_jitter=jitter, importance_u=u)
+            img = gen[0].synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const', force_fp32=sr_fp32[0], **rnd)['image']   # the fp32 path (the one the goldens pin)
             frames = to_frames(img)
             gatherer.submit(frames)      # joins the PREVIOUS step's gather, then starts this one (runs under the next step's compute)
         return frames
@@ -244,10 +247,22 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = [args.steps * B / elapsed]
+    rccl = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)                               # each rank's own clock: per-rank frames/s on the line (did RCCL see N ranks?)
+        per_rank = [args.steps * B / float(e.item()) for e in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        try:
+            ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:                                           # noqa: BLE001
+            ver = None
+        rccl = {'rccl_world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'rccl_version': ver,
+                'per_rank_frames_per_s': [round(x, 2) for x in per_rank]}
 
     # the inputs do not change between steps, so pipelined steps must return identical frames — and the frames of a step issued ALONE
     # on one stream with nothing else in flight: a cheap guard against stream races in exactly the configuration that was timed
@@ -318,10 +333,30 @@ def main():
                     'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
                     'all_conv_tflops': sum(prof[k]['flops'] for k in convs) / (sum(prof[k]['ms'] for k in convs) * 1e-3) / 1e12,
                     'family_ms_per_step': {k: round(p['ms'] / args.steps, 4) for k, p in prof.items()}}
+        # ---- the volume renderer (n3d_render_rays_ex: depth-bounds pre-pass + render_rays_kernel) against what bounds it: the texel gathers.
+        # Algorithmic bytes = 12 texels x 128 B per sample point (3 planes x 4 bilinear taps x 32 float32 channels; nothing is shared between
+        # points in the accounting) over the HIP-event time of the entry point.  The planes (25 MB per sample) are L2 / Infinity-Cache resident:
+        # the bound is the L2 -> L1 -> register gather path, not HBM.  PMC of this kernel: profiles/r05_render_pmc.txt.
+        rr = prof.get('render_rays')
+        if rr and rr['ms'] > 0:
+            tb = rr['bytes'] / (rr['ms'] * 1e-3) / 1e12
+            roofline['render_rays'] = {'bound': 'l2 gather', 'achieved': tb, 'peak': PEAK_L2_TBPS, 'unit': 'TB/s', 'frac': tb / PEAK_L2_TBPS,
+                                       'ms_per_launch': rr['ms'] / max(rr['launches'], 1), 'algorithmic_bytes_per_launch': rr['bytes'] / max(rr['launches'], 1),
+                                       'decoder_tflops': rr['flops'] / (rr['ms'] * 1e-3) / 1e12,
+                                       'note': 'achieved = 12 texels x 128 B per sample point / HIP-event time of n3d_render_rays_ex (batch of rays: N x 64 x 64 x (48 + 48)); '
+                                               'peak = aggregate L2 bandwidth of /opt/skills/guides/MI355X_MICROARCH.md (34.5 TB/s); measured L1 / L2 request rates and the '
+                                               'reason the kernel sits where it does: profiles/r05_render_pmc.txt, DESIGN.md 3.2'}
 
     extras = {}
     frames_total, elapsed_total = args.steps * B * world, elapsed
     if single and not args.no_extras:
+        # ---- the same K steps with the renderer's random inputs drawn INSIDE the call (torch.rand on the device, as the reference does)
+        draw_rng[0] = True
+        step(); step(); torch.cuda.synchronize()
+        t_rng = timed(step, args.steps)
+        draw_rng[0] = False
+        extras['rng_default_path'] = {'value': args.steps * B / t_rng, 'unit': 'frames/s', 'ms_per_step': 1e3 * t_rng / args.steps,
+                                      'note': 'depth jitter / importance u drawn per call by torch.rand (vr/renderer.py:205,252) instead of injected: the headline injects them'}
         kw = dict(neural_rendering_resolution=R, noise_mode='const', depth_jitter=jitter, importance_u=u, force_fp32=True)
         # ---- strict-fp32 arithmetic (N3D_PRECISION=fp32): the same K steps on v_mfma_f32_32x32x2_f32
         if layers.PRECISION == 'bf16x3':
@@ -480,7 +515,23 @@ def main():
                 torch.cuda.synchronize()
                 return float('nan')
         t_1bpg = lanes_graph_timed()
-        extras['config1b'] = {'workload': 'batch 1 (one G.synthesis call per frame, as gen_samples_next3d.py / gen_videos_next3d.py issue them), 512² output, '
+        # ... and on the route the scripts actually take (no force_fp32: float16 super-resolution blocks; gen_videos_next3d.py:155)
+        kw1d = {k: val for k, val in kw1b.items() if k != 'force_fp32'}
+        one_d = lambda fn: to_frames(fn(ws1, c1, v1, **kw1d)['image'])
+        one_d(G.synthesis); one_d(G.synthesis); torch.cuda.synchronize()
+        t_1de = timed(lambda: one_d(G.synthesis), 60)
+        t_1dg = graph_timed(lambda: one_d(G.synthesis_graph), 60)
+
+        def request_d():
+            lane = lanes[req[0] % len(lanes)]; req[0] += 1
+            with torch.cuda.stream(lane):
+                w_ = G.mapping(z1, c1_cond, truncation_psi=0.7, truncation_cutoff=14)
+                return to_frames(G.synthesis(w_, c1, v1, **kw1d)['image'])
+        request_d(); request_d(); request_d(); torch.cuda.synchronize()
+        t_1dp = timed(request_d, 120)
+        extras['config1b'] = {
+                              'default_route': {'eager_ms_per_frame': 1e3 * t_1de / 60, 'hip_graph_ms_per_frame': 1e3 * t_1dg / 60, 'pipelined_frames_per_s': 120 / t_1dp,
+                                                'note': "no force_fp32: the scripts' own call (float16 super-resolution blocks on the f16 matrix cores)"},'workload': 'batch 1 (one G.synthesis call per frame, as gen_samples_next3d.py / gen_videos_next3d.py issue them), 512² output, '
                                           '64² neural render, 48 + 48 samples, force_fp32=True',
                               'eager_ms_per_frame': 1e3 * t_1be / 60, 'hip_graph_ms_per_frame': 1e3 * t_1bg / 60,
                               'pipelined_frames_per_s': 120 / t_1bp, 'pipelined_hip_graph_frames_per_s': 240 / t_1bpg, 'lanes': len(lanes),
@@ -576,6 +627,8 @@ def main():
                        'streams': f'{len(lanes)} (consecutive steps alternate between them)',
                        'gather': 'RCCL gather of uint8 frames to rank 0, overlapped with the next step' if use_dist else 'none',
                        'prewarm_seconds': args.prewarm_seconds},
+            'rng_inputs': 'depth_jitter / importance_u injected (resident tensors); rng_default_path = the same steps with the draws inside the call',
+            'multi_gpu': rccl if rccl is not None else {'rccl_world_size': 1, 'per_rank_frames_per_s': [round(per_rank[0], 2)], 'note': 'single process, no process group'},
             'frames_bitwise_reproducible': reproducible, 'single_stream': single_stream, 'roofline': roofline, **extras,
             'cpu_baseline': cpu}))
         if not reproducible:

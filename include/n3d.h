@@ -43,7 +43,8 @@ const char* n3d_last_error(void);
 enum { N3D_K_BIAS_ACT = 0, N3D_K_UPFIRDN2D = 1, N3D_K_CONV2D = 2, N3D_K_FC = 3, N3D_K_RENDER = 4, N3D_K_RASTER = 5,
        N3D_K_MISC = 6, N3D_K_CONV2D_BF16X3 = 7 /* 3x3 split-bf16 kernels: MFMA-bound */,
        N3D_K_CONV1X1_BF16X3 = 8 /* 1x1 split-bf16 kernels (and the float16 toRGB): HBM-bound */,
-       N3D_K_CONV2D_F16 = 9 /* 3x3 float16 kernels of the fp16 blocks (n3d_conv2d_f16): MFMA / HBM */, N3D_K_COUNT = 10 };
+       N3D_K_CONV2D_F16 = 9 /* 3x3 float16 kernels of the fp16 blocks (n3d_conv2d_f16): MFMA / HBM */,
+       N3D_K_RENDER_RAYS = 10 /* n3d_render_rays(_ex): depth-bounds pre-pass + render_rays_kernel (texel gathers through L1 / L2 + the decoder) */, N3D_K_COUNT = 11 };
 int n3d_prof_enable(int on);
 int n3d_prof_reset(void);
 int n3d_prof_read(int family, double* total_ms, int64_t* launches, double* flops, double* bytes);

@@ -19,7 +19,7 @@ c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, cty
 
 ACT_IDS = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
 K_BIAS_ACT, K_UPFIRDN2D, K_CONV2D, K_FC, K_RENDER, K_RASTER, K_MISC, K_CONV2D_BF16X3 = range(8)
-FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'misc', 'conv2d_bf16x3', 'conv1x1_bf16x3', 'conv2d_f16']
+FAMILY_NAMES = ['bias_act', 'upfirdn2d', 'conv2d', 'fc', 'render', 'raster', 'misc', 'conv2d_bf16x3', 'conv1x1_bf16x3', 'conv2d_f16', 'render_rays']
 
 
 class Epilogue(ctypes.Structure):

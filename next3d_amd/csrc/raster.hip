@@ -36,13 +36,30 @@
 #ifndef RASTER_VARIANT
 #define RASTER_VARIANT 15
 #endif
+#if RASTER_VARIANT & 64
+__device__ unsigned int* g_raster_dbg = nullptr;        // probe build only: raw gathered words of raster_resolve_kernel
+__device__ unsigned int* g_raster_dbg2 = nullptr;       // ... and of raster_faces_kernel
+extern "C" int n3d_raster_debug_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_raster_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+extern "C" int n3d_raster_debug_buffer_faces(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_raster_dbg2), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
 template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 //   bit 5 (probe only): plain single-dword vertex loads the compiler cannot merge into 12-byte dwordx3 loads
-template <typename T> __device__ __forceinline__ T ld_tab(const T* p) { return (RASTER_VARIANT & 4) ? ld_agent(p) : *p; }
+//   bit 8 of the high byte (256, probe only): EVERY table load as a plain single-dword load the compiler cannot merge (no global_load_dwordx3 anywhere,
+//   still L1-served) — separates "96-bit loads" from "L1-served loads" as the property the failing builds share
+template <typename T> __device__ __forceinline__ T ld_plain1(const T* p) {
+    static_assert(sizeof(T) == 4, "dword tables");
+    unsigned v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return __builtin_bit_cast(T, v);
+}
+template <typename T> __device__ __forceinline__ T ld_tab(const T* p) {
+    if (RASTER_VARIANT & 4) return ld_agent(p);
+    if constexpr (sizeof(T) == 4) { if (RASTER_VARIANT & 256) return ld_plain1(p); }
+    return *p;
+}
 __device__ __forceinline__ float ld_vert(const float* p) {
     if (RASTER_VARIANT & 4) return ld_agent(p);
-    if (RASTER_VARIANT & 32) { float v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+    if (RASTER_VARIANT & (32 | 256)) { float v; asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
     return *p;
 }
 struct XfParams { const float* verts; const float* rot; int V, views; float sx, sy, sz, scale; };
@@ -111,9 +128,18 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
     const float* vn = tv + (int64_t)nv * V * 3;
     // the reference rasterises faces[..., [0,2,1]] (triplane_next3d.py:207): `faces` is passed already swapped
     float x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 0), x0, y0, z0);
-    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 1), x1, y1, z1);
-    get_vertex(vn, xf, nv, ld_tab(faces + 3 * f + 2), x2, y2, z2);
+    const int i0 = ld_tab(faces + 3 * f + 0), i1 = ld_tab(faces + 3 * f + 1), i2 = ld_tab(faces + 3 * f + 2);
+    get_vertex(vn, xf, nv, i0, x0, y0, z0);
+    get_vertex(vn, xf, nv, i1, x1, y1, z1);
+    get_vertex(vn, xf, nv, i2, x2, y2, z2);
+#if RASTER_VARIANT & 64
+    if (g_raster_dbg2) {                               // probe build only: the RAW words this lane gathered for its face, 12 per (view, face)
+        unsigned int* o = g_raster_dbg2 + i * 12;
+        o[0] = (unsigned)i0; o[1] = (unsigned)i1; o[2] = (unsigned)i2;
+        const float w[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+        for (int k = 0; k < 9; ++k) o[3 + k] = __float_as_uint(w[k]);
+    }
+#endif
     const float zmax = fmaxf(z0, fmaxf(z1, z2));
     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
     const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
@@ -127,6 +153,9 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
     int yi_hi = (int)ceilf((float)(H - 1) - ((ymin + 1.0f) * (float)H - 1.0f) * 0.5f) + 1;
     xi_lo = max(xi_lo, 0); yi_lo = max(yi_lo, 0); xi_hi = min(xi_hi, W - 1); yi_hi = min(yi_hi, H - 1);
     const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+#if RASTER_VARIANT & 64
+    unsigned int n_atomics = 0, key_xor = 0;           // probe build: how many z-buffer updates this lane ISSUED, and a checksum of their keys
+#endif
     for (int yi = yi_lo; yi <= yi_hi; ++yi) {
         const float yf = pix_to_ndc(H - 1 - yi, H);
         for (int xi = xi_lo; xi <= xi_hi; ++xi) {
@@ -140,8 +169,14 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
             if (!((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f))) continue;
             const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
             atomicMin(&zbuf[((int64_t)nv * H + yi) * W + xi], key);
+#if RASTER_VARIANT & 64
+            ++n_atomics; key_xor ^= __float_as_uint(pz) * 2654435761u + (unsigned)(yi * W + xi);
+#endif
         }
     }
+#if RASTER_VARIANT & 64
+    if (g_raster_dbg2) { g_raster_dbg2[(int64_t)NV * F * 12 + i * 2] = n_atomics; g_raster_dbg2[(int64_t)NV * F * 12 + i * 2 + 1] = key_xor; }
+#endif
 }
 
 __device__ __forceinline__ float bilinear_1ch(const float* __restrict__ img, int H, int W, float gx, float gy) {
@@ -215,18 +250,29 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float* tv, co
         const int f = (int)(key & 0xFFFFFFFFull);
         const float* vn = tv + (int64_t)nv * V * 3;
         float ax, ay, az, bx, by, bz, cx, cy, cz;
-        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 0), ax, ay, az);
-        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 1), bx, by, bz);
-        get_vertex(vn, xfp, nv, ld_tab(faces + 3 * f + 2), cx, cy, cz);
+        const int i0 = ld_tab(faces + 3 * f + 0), i1 = ld_tab(faces + 3 * f + 1), i2 = ld_tab(faces + 3 * f + 2);
+        get_vertex(vn, xfp, nv, i0, ax, ay, az);
+        get_vertex(vn, xfp, nv, i1, bx, by, bz);
+        get_vertex(vn, xfp, nv, i2, cx, cy, cz);
         const float xf = pix_to_ndc(W - 1 - xi, W), yf = pix_to_ndc(H - 1 - yi, H);
         const float area = edge_fn(cx, cy, ax, ay, bx, by) + K_EPS;
         const float w0 = edge_fn(xf, yf, bx, by, cx, cy) / area;
         const float w1 = edge_fn(xf, yf, cx, cy, ax, ay) / area;
         const float w2 = edge_fn(xf, yf, ax, ay, bx, by) / area;
         const float* a = face_uv + (int64_t)f * 9;
-        u = (w0 * ld_tab(a + 0) + w1 * ld_tab(a + 3)) + w2 * ld_tab(a + 6);
-        v = (w0 * ld_tab(a + 1) + w1 * ld_tab(a + 4)) + w2 * ld_tab(a + 7);
+        const float u0 = ld_tab(a + 0), u1 = ld_tab(a + 3), u2 = ld_tab(a + 6), v0 = ld_tab(a + 1), v1 = ld_tab(a + 4), v2 = ld_tab(a + 7);
+        u = (w0 * u0 + w1 * u1) + w2 * u2;
+        v = (w0 * v0 + w1 * v1) + w2 * v2;
         vis = 1.f;
+#if RASTER_VARIANT & 64
+        // probe build only (tools/probe/raster_coresidency_repro.cpp, RASTER_CLASSIFY): the RAW words this lane gathered, 18 per pixel
+        if (g_raster_dbg) {
+            unsigned int* o = g_raster_dbg + i * 18;
+            o[0] = (unsigned)i0; o[1] = (unsigned)i1; o[2] = (unsigned)i2;
+            const float w[15] = {ax, ay, az, bx, by, bz, cx, cy, cz, u0, v0, u1, v1, u2, v2};
+            for (int k = 0; k < 15; ++k) o[3 + k] = __float_as_uint(w[k]);
+        }
+#endif
     }
     grid[i * 2 + 0] = u; grid[i * 2 + 1] = v;
     alpha[i] = bilinear_1ch(uv_mask, MH, MW, u, v) * vis;

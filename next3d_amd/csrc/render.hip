@@ -849,8 +849,8 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     const size_t lds = image + wpb * per_wave;
     const void* kfn = (const void*)render_rays_kernel;
     const double pts = (double)N * R * R * M;
-    N3dProfScope prof(N3D_K_RENDER, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
-                      pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));
+    N3dProfScope prof(N3D_K_RENDER_RAYS, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
+                      pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));          // bytes: 12 texels x 128 B gathered per point + the outputs
     if (lds > 48 * 1024)
         N3D_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, "render_rays: %zu bytes of LDS refused", lds);
     hipLaunchKernelGGL(render_depth_bounds_init_kernel, dim3(1), dim3(1), 0, stream, keys);

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/n3d.h"
@@ -165,6 +166,7 @@ int main(int argc, char** argv) {
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(ref_g.data(), grid, npix * 8, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(ref_a.data(), alpha, npix * 4, hipMemcpyDeviceToHost));
     int bad_runs = 0; long long bad_words = 0;
+    if (getenv("RASTER_CLASSIFY")) { printf("--- rocm-smi --showrasinfo all (before) ---\n"); fflush(stdout); if (system("rocm-smi --showrasinfo all 2>&1 | grep -v '^$' | head -60") != 0) printf("(rocm-smi failed)\n"); }
     float4* d_dst; HIPCHECK(hipMalloc(&d_dst, (size_t)64 << 20));
     auto corun = [&]() {
         if (mode == 0) { if (conv(&cd, sb) != 0) { fprintf(stderr, "conv failed\n"); exit(1); } }
@@ -196,6 +198,73 @@ int main(int argc, char** argv) {
         printf("victim_gather, co-runner mode %d: %d of %d co-resident runs differ (%lld words)\n", mode, bad, runs, words);
         return 0;
     }
+    // round 5: WHICH stage goes wrong, and WHAT the wrong words are.  n3d_rasterize_views leaves its intermediates in
+    // caller-owned buffers: tv (transformed vertices: raster_transform_kernel's output, the z-buffer kernel's gather table) and zbuf (64-bit
+    // z|face keys: raster_faces_kernel's atomicMin target, raster_resolve_kernel's input) — both are compared with the solo run's, and every
+    // differing word is classified: equal to ANOTHER entry of the reference table (a mis-addressed / stale gather), one bit flipped (an SRAM
+    // upset), the cleared value, or something else.
+    const bool classify = getenv("RASTER_CLASSIFY") != nullptr;
+    std::vector<uint32_t> ref_tv(NV * V * 3), got_tv(NV * V * 3);
+    std::vector<unsigned long long> ref_z(npix), got_z(npix);
+    HIPCHECK(hipMemcpy(ref_tv.data(), tv, ref_tv.size() * 4, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(ref_z.data(), zbuf, npix * 8, hipMemcpyDeviceToHost));
+    long long tv_bad = 0, z_bad = 0, z_face = 0, z_zonly = 0, z_cleared = 0, z_to_cleared = 0, z_face_invalid = 0, z_onebit = 0, z_neighbour = 0, z_got_closer = 0, z_got_farther = 0;
+    long long ga_runs_without_z = 0, printed = 0;
+    // raw gathered words of raster_resolve_kernel (libraster_v64 / v79: n3d_raster_debug_buffer): 18 per pixel = 3 vertex indices, 9 vertex
+    // coordinates, 6 uv coordinates of the winning face
+    typedef int (*dbg_fn)(void*);
+    auto set_dbg = (dbg_fn)dlsym(hr, "n3d_raster_debug_buffer");
+    uint32_t* d_dbg = nullptr;
+    std::vector<uint32_t> ref_dbg, got_dbg;
+    std::unordered_set<uint32_t> tv_words, fuv_words;
+    long long w_total = 0, w_idx = 0, w_vert = 0, w_fuv = 0, w_other_entry = 0, w_onebit = 0, w_zero = 0, w_else = 0, px_bad = 0, px_idx_consistent = 0, px_whole_vertex_of_other_index = 0, dbg_printed = 0;
+    long long w_idx_valid = 0, w_idx_same_face_rotated = 0;
+    if (classify && set_dbg) {
+        HIPCHECK(hipMalloc(&d_dbg, npix * 18 * 4)); HIPCHECK(hipMemset(d_dbg, 0, npix * 18 * 4));
+        if (set_dbg(d_dbg) != 0) { fprintf(stderr, "n3d_raster_debug_buffer failed\n"); return 1; }
+        if (raster(sa) != 0) return 1;
+        HIPCHECK(hipDeviceSynchronize());
+        ref_dbg.resize(npix * 18); got_dbg.resize(npix * 18);
+        HIPCHECK(hipMemcpy(ref_dbg.data(), d_dbg, npix * 18 * 4, hipMemcpyDeviceToHost));
+        for (uint32_t w : ref_tv) tv_words.insert(w);
+        for (float f : face_uv) { uint32_t w; memcpy(&w, &f, 4); fuv_words.insert(w); }
+        // sanity: the solo dump equals what the host reads from the reference tables
+        long long host_bad = 0;
+        for (size_t i = 0; i < npix; ++i) {
+            if (ref_z[i] == ~0ull) continue;
+            const uint32_t f = (uint32_t)ref_z[i]; const size_t nv = i / ((size_t)H * W);
+            for (int k = 0; k < 3; ++k) {
+                const int vi = faces[3 * f + k];
+                host_bad += ref_dbg[i * 18 + k] != (uint32_t)vi;
+                for (int c = 0; c < 3; ++c) host_bad += ref_dbg[i * 18 + 3 + 3 * k + c] != ref_tv[(nv * V + vi) * 3 + c];
+            }
+        }
+        printf("raw-word dump: solo run vs the tables read on the host: %lld words differ\n", host_bad);
+    }
+    // ... and of raster_faces_kernel (the z-buffer pass): 12 words per (view, face) = 3 vertex indices + 9 vertex coordinates
+    auto set_dbg2 = (dbg_fn)dlsym(hr, "n3d_raster_debug_buffer_faces");
+    uint32_t* d_dbg2 = nullptr;
+    const size_t nfr = NV * (size_t)F, nfw = nfr * 14;     // 12 gathered words per record, then (updates issued, checksum of their keys) per record
+    std::vector<uint32_t> ref_f2, got_f2;
+    long long f_bad = 0, fw_total = 0, fw_idx = 0, fw_coord = 0, fw_zero = 0, fw_other = 0, fw_onebit = 0, fw_else = 0, f_consistent = 0, f_printed = 0, f_idx_valid = 0, f_all_words_wrong = 0;
+    long long f_run_lanes = 0, f_runs_count = 0, issued_total = 0, issued_count_bad = 0, issued_keys_bad = 0;
+    if (classify && set_dbg2) {
+        HIPCHECK(hipMalloc(&d_dbg2, nfw * 4)); HIPCHECK(hipMemset(d_dbg2, 0, nfw * 4));
+        if (set_dbg2(d_dbg2) != 0) return 1;
+        if (raster(sa) != 0) return 1;
+        HIPCHECK(hipDeviceSynchronize());
+        ref_f2.resize(nfw); got_f2.resize(nfw);
+        HIPCHECK(hipMemcpy(ref_f2.data(), d_dbg2, nfw * 4, hipMemcpyDeviceToHost));
+        long long host_bad = 0;
+        for (size_t nvf = 0; nvf < NV * (size_t)F; ++nvf) {
+            const size_t nv = nvf / F, f = nvf % F;
+            for (int k = 0; k < 3; ++k) {
+                const int vi = faces[3 * f + k];
+                host_bad += ref_f2[nvf * 12 + k] != (uint32_t)vi;
+                for (int c = 0; c < 3; ++c) host_bad += ref_f2[nvf * 12 + 3 + 3 * k + c] != ref_tv[(nv * V + vi) * 3 + c];
+            }
+        }
+        printf("raw-word dump of raster_faces_kernel: solo run vs the tables read on the host: %lld words differ\n", host_bad);
+    }
     for (int r = 0; r < runs; ++r) {
         for (int k = 0; k < nco; ++k) corun();                                   // keeps the CUs full of 8-wave workgroups
         if (raster(sa) != 0) return 1;
@@ -207,7 +276,136 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < npix; ++i) d += got_a[i] != ref_a[i];
         printf("run %2d: %lld words differ from the solo rasterisation\n", r, d);
         bad_runs += d != 0; bad_words += d;
+        if (classify) {
+            HIPCHECK(hipMemcpy(got_tv.data(), tv, got_tv.size() * 4, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(got_z.data(), zbuf, npix * 8, hipMemcpyDeviceToHost));
+            long long t = 0, z = 0;
+            for (size_t i = 0; i < got_tv.size(); ++i) t += got_tv[i] != ref_tv[i];
+            for (size_t i = 0; i < npix; ++i) {
+                if (got_z[i] == ref_z[i]) continue;
+                ++z;
+                const unsigned long long g = got_z[i], e = ref_z[i];
+                const uint32_t gf = (uint32_t)g, ef = (uint32_t)e, gz = (uint32_t)(g >> 32), ez = (uint32_t)(e >> 32);
+                if (e == ~0ull) ++z_cleared;                                     // solo: no face here; co-resident: some face won
+                if (g == ~0ull) ++z_to_cleared;                                  // co-resident: NO face won where one should have
+                if (gf != ef) ++z_face; else ++z_zonly;
+                if (g != ~0ull && gf >= (uint32_t)F) ++z_face_invalid;
+                if (__builtin_popcountll(g ^ e) == 1) ++z_onebit;
+                if (g != ~0ull && e != ~0ull) { if (gz < ez) ++z_got_closer; else if (gz > ez) ++z_got_farther; }
+                // is the winning key of a NEIGHBOURING pixel (the face that should have lost here, or that pixel's own result)?
+                const size_t x = i % W, y = (i / W) % H;
+                bool nb = false;
+                for (int dy = -1; dy <= 1 && !nb; ++dy) for (int dx = -1; dx <= 1 && !nb; ++dx) {
+                    if ((!dx && !dy) || (int)x + dx < 0 || (int)x + dx >= W || (int)y + dy < 0 || (int)y + dy >= H) continue;
+                    nb = (uint32_t)ref_z[i + dy * W + dx] == gf;
+                }
+                z_neighbour += nb;
+                if (printed < 24) { printf("  zbuf[%zu] (view %zu, y %zu, x %zu): solo %016llx  co-resident %016llx%s\n", i, i / ((size_t)H * W), y, x, e, g, nb ? "  (face of a neighbouring pixel)" : ""); ++printed; }
+            }
+            tv_bad += t; z_bad += z;
+            ga_runs_without_z += (d != 0 && z == 0);
+            if (d_dbg2) {
+                HIPCHECK(hipMemcpy(got_f2.data(), d_dbg2, nfw * 4, hipMemcpyDeviceToHost));
+                long long prev_bad = -2, run_len = 0;
+                for (size_t nvf = 0; nvf < NV * (size_t)F; ++nvf) {
+                    const uint32_t* g = &got_f2[nvf * 12]; const uint32_t* e = &ref_f2[nvf * 12];
+                    if (!memcmp(g, e, 48)) continue;
+                    ++f_bad;
+                    if ((long long)nvf == prev_bad + 1) ++run_len; else { if (run_len) { f_run_lanes += run_len; ++f_runs_count; } run_len = 1; }
+                    prev_bad = (long long)nvf;
+                    const size_t nv = nvf / F;
+                    bool consistent = true, allwrong = true;
+                    for (int k = 0; k < 3; ++k)
+                        for (int c = 0; c < 3; ++c) consistent &= g[k] < (uint32_t)V && g[3 + 3 * k + c] == ref_tv[(nv * V + g[k]) * 3 + c];
+                    f_consistent += consistent;
+                    for (int k = 0; k < 12; ++k) {
+                        if (g[k] == e[k]) { allwrong = false; continue; }
+                        ++fw_total;
+                        if (k < 3) { ++fw_idx; f_idx_valid += g[k] < (uint32_t)V; } else ++fw_coord;
+                        if (g[k] == 0) ++fw_zero;
+                        else if (k >= 3 && tv_words.count(g[k])) ++fw_other;
+                        else if (__builtin_popcount(g[k] ^ e[k]) == 1) ++fw_onebit;
+                        else if (k >= 3) ++fw_else;
+                    }
+                    f_all_words_wrong += allwrong;
+                    if (f_printed < 16) {
+                        printf("  face record %zu (view %zu, face %zu):", nvf, nv, nvf % F);
+                        for (int k = 0; k < 12; ++k) if (g[k] != e[k]) printf(" [%d] %08x -> %08x", k, e[k], g[k]);
+                        printf("\n"); ++f_printed;
+                    }
+                }
+                if (run_len) { f_run_lanes += run_len; ++f_runs_count; }
+                for (size_t nvf = 0; nvf < nfr; ++nvf) {
+                    issued_total += got_f2[nfr * 12 + nvf * 2];
+                    if (got_f2[nfr * 12 + nvf * 2] != ref_f2[nfr * 12 + nvf * 2]) ++issued_count_bad;
+                    else if (got_f2[nfr * 12 + nvf * 2 + 1] != ref_f2[nfr * 12 + nvf * 2 + 1]) ++issued_keys_bad;
+                }
+            }
+            if (d_dbg) {
+                HIPCHECK(hipMemcpy(got_dbg.data(), d_dbg, npix * 18 * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < npix; ++i) {
+                    if (got_z[i] != ref_z[i] || ref_z[i] == ~0ull) continue;             // same winning face: the resolve kernel's own gathers
+                    const uint32_t* g = &got_dbg[i * 18]; const uint32_t* e = &ref_dbg[i * 18];
+                    if (!memcmp(g, e, 72)) continue;
+                    ++px_bad;
+                    const size_t nv = i / ((size_t)H * W);
+                    bool consistent = true;                                            // do the vertex words match the (possibly wrong) index words?
+                    for (int k = 0; k < 3; ++k)
+                        for (int c = 0; c < 3; ++c) consistent &= g[k] < (uint32_t)V && g[3 + 3 * k + c] == ref_tv[(nv * V + g[k]) * 3 + c];
+                    px_idx_consistent += consistent && (g[0] != e[0] || g[1] != e[1] || g[2] != e[2]);
+                    for (int k = 0; k < 18; ++k) {
+                        if (g[k] == e[k]) continue;
+                        ++w_total;
+                        if (k < 3) { ++w_idx; w_idx_valid += g[k] < (uint32_t)V; w_idx_same_face_rotated += (g[k] == e[0] || g[k] == e[1] || g[k] == e[2]); }
+                        else if (k < 12) ++w_vert; else ++w_fuv;
+                        const bool other = k < 3 ? false : (k < 12 ? tv_words.count(g[k]) > 0 : fuv_words.count(g[k]) > 0);
+                        if (other) ++w_other_entry;
+                        else if (__builtin_popcount(g[k] ^ e[k]) == 1) ++w_onebit;
+                        else if (g[k] == 0) ++w_zero;
+                        else if (k >= 3) ++w_else;
+                    }
+                    // a whole vertex (3 words) replaced by ANOTHER vertex of the table?
+                    for (int k = 0; k < 3; ++k) {
+                        if (!memcmp(g + 3 + 3 * k, e + 3 + 3 * k, 12)) continue;
+                        bool found = false;
+                        for (size_t vi = 0; vi < (size_t)NV * V && !found; ++vi) found = !memcmp(g + 3 + 3 * k, &ref_tv[vi * 3], 12);
+                        px_whole_vertex_of_other_index += found;
+                    }
+                    if (dbg_printed < 12) {
+                        printf("  pixel %zu (face %u): idx solo %u %u %u | got %u %u %u;  differing words:", i, (uint32_t)ref_z[i], e[0], e[1], e[2], g[0], g[1], g[2]);
+                        for (int k = 3; k < 18; ++k) if (g[k] != e[k]) printf(" [%d] %08x -> %08x", k, e[k], g[k]);
+                        printf("\n"); ++dbg_printed;
+                    }
+                }
+            }
+            printf("        transformed-vertex words differing: %lld; z-buffer keys differing: %lld\n", t, z);
+        }
     }
     printf("%s, co-runner mode %d: %d of %d co-resident runs differ (%lld words)\n", argv[1], mode, bad_runs, runs, bad_words);
+    if (classify) { printf("--- rocm-smi --showrasinfo all (after) ---\n"); fflush(stdout); if (system("rocm-smi --showrasinfo all 2>&1 | grep -v '^$' | head -60") != 0) printf("(rocm-smi failed)\n"); }
+    if (classify) {
+        printf("classification over %d runs: transformed vertices (raster_transform_kernel's output) differing: %lld words\n", runs, tv_bad);
+        printf("  z-buffer keys differing: %lld — another FACE won: %lld, same face / other depth: %lld; face index out of range: %lld; exactly one bit flipped: %lld\n",
+               z_bad, z_face, z_zonly, z_face_invalid, z_onebit);
+        printf("  solo had no face, co-resident has one: %lld; solo had a face, co-resident has none: %lld; winning depth closer / farther than solo: %lld / %lld\n",
+               z_cleared, z_to_cleared, z_got_closer, z_got_farther);
+        printf("  the co-resident winner is the solo winner of one of the 8 neighbouring pixels: %lld of %lld\n", z_neighbour, z_bad);
+        printf("  runs whose grid / alpha differ although every z-buffer key equals the solo run's: %lld\n", ga_runs_without_z);
+        if (d_dbg2) {
+            printf("raw gathered words of raster_faces_kernel (one record per view and face): %lld records with a wrong word, %lld wrong words\n", f_bad, fw_total);
+            printf("  vertex-index words %lld (valid index: %lld), coordinate words %lld; zero: %lld; another entry of the vertex table: %lld; one bit flipped: %lld; anything else: %lld\n",
+                   fw_idx, f_idx_valid, fw_coord, fw_zero, fw_other, fw_onebit, fw_else);
+            printf("  records whose coordinate words equal the vertices of the index words READ (a wrong index, followed faithfully): %lld; records with all 12 words wrong: %lld\n", f_consistent, f_all_words_wrong);
+            printf("  wrong records come in runs of consecutive lanes: %lld runs, mean length %.1f\n", f_runs_count, f_runs_count ? (double)f_run_lanes / f_runs_count : 0.0);
+            printf("  z-buffer updates ISSUED by raster_faces_kernel (atomicMin calls): %lld in all; lanes that issued another NUMBER of updates than solo: %lld; same number, other keys: %lld\n",
+                   issued_total, issued_count_bad, issued_keys_bad);
+        }
+        if (d_dbg) {
+            printf("raw gathered words of raster_resolve_kernel on pixels whose z-buffer key is RIGHT: %lld pixels with a wrong word, %lld wrong words\n", px_bad, w_total);
+            printf("  by table: vertex indices %lld (of them a valid index: %lld, another corner of the SAME face: %lld), vertex coordinates %lld, face uv %lld\n", w_idx, w_idx_valid, w_idx_same_face_rotated, w_vert, w_fuv);
+            printf("  wrong coordinate / uv words that are ANOTHER entry of the same table: %lld; one bit flipped: %lld; zero: %lld; anything else: %lld\n", w_other_entry, w_onebit, w_zero, w_else);
+            printf("  pixels whose wrong index words are consistent with the vertex words read (the INDEX gather went wrong, the vertex gather followed it): %lld\n", px_idx_consistent);
+            printf("  wrong vertices that are, as a whole (x, y, z), another vertex of the table: %lld\n", px_whole_vertex_of_other_index);
+        }
+    }
     return 0;
 }
