@@ -340,6 +340,11 @@ int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int nu
 int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p,
             int64_t c_nc, int64_t c_p, n3d_stream_t stream);
 int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t stream);
+/* n3d_unpack_inputs: synthesis' input hand-over in one launch (tat/triplane_next3d.py:119-133: `v[:, :5023]`, `v[:, 5023:]`, `c[:, :16]`, `c[:, 16:25]`):
+ * v [N][V + L][3] with batch stride v_batch_stride floats -> verts [N][V][3], lms [N][L][3]; c [N][>=25] with batch stride c_batch_stride ->
+ * cam2world [N][16], intrinsics [N][9] — the dense tensors n3d_rasterize_views / n3d_render_rays_ex read. */
+int n3d_unpack_inputs(const float* v, int64_t v_batch_stride, const float* c, int64_t c_batch_stride, float* verts, float* lms, float* cam2world,
+                      float* intrinsics, int N, int V, int L, n3d_stream_t stream);
 int n3d_layout_grid_u8(const float* frames, unsigned char* canvas, int B, int C, int H, int W, int cols, int rows, int hwc,
                        n3d_stream_t stream);
 /* n3d_cast: float16 <-> float32 (N3D_F16 / N3D_F32), round to nearest even — the `x.to(dtype)` conversions at the
@@ -353,6 +358,10 @@ int n3d_cast(const void* x, void* y, int64_t numel, int src_dtype, int dst_dtype
  *      front/side/top [N,32,H,W], stat [N,96,H,W], alpha [N,3,H,W]. */
 int n3d_blend_planes(const float* front, const float* side, const float* top, const float* stat, const float* alpha,
                      float* planes_cl, int N, int H, int W, n3d_stream_t stream);
+/* ... with alpha as the rasteriser leaves it: alpha_views [N,views,H,W] (n3d_rasterize_views' alpha4), plane p blended with the alpha image of view
+ * v_p (front, side, top = views 0, 1, 3 of tat/triplane_next3d.py:140-145,226) — no index_select copy in between. */
+int n3d_blend_planes_views(const float* front, const float* side, const float* top, const float* stat, const float* alpha_views,
+                           float* planes_cl, int N, int H, int W, int views, int v_front, int v_side, int v_top, n3d_stream_t stream);
 /* NCHW planes [N,3,32,H,W] -> channels-last, for callers holding blended planes in the reference layout. */
 int n3d_planes_to_channels_last(const float* planes, float* planes_cl, int N, int H, int W, n3d_stream_t stream);
 

@@ -86,6 +86,8 @@ _SIGNATURES = {
     'n3d_conv2d_bf16x3': (c_int, [ctypes.POINTER(Conv2dDesc), c_void_p]),
     'n3d_conv2d_bf16x3_blocks': (c_int, [c_int] * 5),
     'n3d_blend_planes': (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    'n3d_blend_planes_views': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    'n3d_unpack_inputs': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     'n3d_planes_to_channels_last': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'n3d_render_rays': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, c_void_p]),
     'n3d_render_rays_ex': (c_int, [c_void_p] * 14 + [c_int] * 6 + [c_float, c_float, ctypes.POINTER(RenderOpts), c_void_p]),

@@ -177,6 +177,35 @@ int n3d_to_uint8(const float* x, unsigned char* y, int64_t numel, n3d_stream_t s
     return 0;
 }
 
+// synthesis' input hand-over in ONE launch: v [N][V + L][3] (vertices then landmarks, any batch stride) -> verts [N][V][3], lms [N][L][3];
+// c [N][25] -> cam2world [N][16], intrinsics [N][9] (the dense tensors n3d_rasterize_views / n3d_render_rays read) — four torch copies before
+__global__ __launch_bounds__(256) void unpack_inputs_kernel(const float* __restrict__ v, int64_t v_bs, const float* __restrict__ c, int64_t c_bs,
+                                                            float* __restrict__ verts, float* __restrict__ lms, float* __restrict__ cam, float* __restrict__ intr,
+                                                            int N, int V, int L) {
+    const int per = (V + L) * 3 + 25;
+    const int64_t total = (int64_t)N * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / per), e = (int)(i % per);
+        if (e < V * 3) verts[(int64_t)n * V * 3 + e] = v[n * v_bs + e];
+        else if (e < (V + L) * 3) lms[(int64_t)n * L * 3 + (e - V * 3)] = v[n * v_bs + e];
+        else if (e < (V + L) * 3 + 16) cam[n * 16 + (e - (V + L) * 3)] = c[n * c_bs + (e - (V + L) * 3)];
+        else intr[n * 9 + (e - (V + L) * 3 - 16)] = c[n * c_bs + (e - (V + L) * 3)];
+    }
+}
+
+int n3d_unpack_inputs(const float* v, int64_t v_batch_stride, const float* c, int64_t c_batch_stride, float* verts, float* lms, float* cam2world,
+                      float* intrinsics, int N, int V, int L, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && V >= 1 && L >= 0, "unpack_inputs: bad shape");
+    if (N == 0) return 0;
+    N3D_CHECK(v && c && verts && (lms || L == 0) && cam2world && intrinsics, "unpack_inputs: null tensor");
+    const int64_t total = (int64_t)N * ((V + L) * 3 + 25);
+    N3dProfScope prof(N3D_K_MISC, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(unpack_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, v_batch_stride, c, c_batch_stride, verts, lms, cam2world, intrinsics, N, V, L);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int n3d_layout_grid_u8(const float* frames, unsigned char* canvas, int B, int C, int H, int W, int cols, int rows, int hwc, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     N3D_CHECK(B >= 0 && C >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && cols >= 1 && rows >= 1, "layout_grid_u8: bad shape (W %% 4 == 0)");

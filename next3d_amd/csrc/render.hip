@@ -735,12 +735,13 @@ __global__ __launch_bounds__(256) void ray_limits_fixup_kernel(float* __restrict
 __global__ __launch_bounds__(256) void blend_planes_kernel(const float* __restrict__ front, const float* __restrict__ side,
                                                            const float* __restrict__ top, const float* __restrict__ stat,
                                                            const float* __restrict__ alpha, float* __restrict__ out, int N,
-                                                           int H, int W) {
+                                                           int H, int W, int views, int v0, int v1, int v2) {
     __shared__ float tile[RN_C][65];
     const int x0 = blockIdx.x * 64, y = blockIdx.y, np = blockIdx.z, n = np / 3, pl = np % 3;
     const float* dyn = (pl == 0 ? front : (pl == 1 ? side : top)) + (int64_t)n * RN_C * H * W;
     const float* st = stat + ((int64_t)n * 3 + pl) * RN_C * H * W;
-    const float* al = alpha + ((int64_t)n * 3 + pl) * H * W + (int64_t)y * W;
+    // alpha [N][views][H][W]: plane pl blends with the alpha image of view v_pl (views = 3, (0, 1, 2): the dense [N,3,H,W] form)
+    const float* al = alpha + ((int64_t)n * views + (pl == 0 ? v0 : (pl == 1 ? v1 : v2))) * H * W + (int64_t)y * W;
     for (int e = threadIdx.x; e < RN_C * 64; e += 256) {
         const int c = e / 64, xx = e % 64, x = x0 + xx;
         float v = 0.f;
@@ -784,7 +785,21 @@ extern "C" int n3d_blend_planes(const float* front, const float* side, const flo
     N3D_CHECK(front && side && top && stat && alpha && planes_cl, "blend_planes: null tensor");
     N3dProfScope prof(N3D_K_RENDER, stream, 3.0 * N * 3 * RN_C * (double)H * W, 4.0 * N * 3 * (double)H * W * (3 * RN_C + 1));
     hipLaunchKernelGGL(blend_planes_kernel, dim3(cdiv(W, 64), H, N * 3), dim3(256), 0, stream, front, side, top, stat, alpha,
-                       planes_cl, N, H, W);
+                       planes_cl, N, H, W, 3, 0, 1, 2);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int n3d_blend_planes_views(const float* front, const float* side, const float* top, const float* stat, const float* alpha_views,
+                                      float* planes_cl, int N, int H, int W, int views, int v_front, int v_side, int v_top, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(N >= 0 && H > 0 && W > 0 && H <= 65535, "blend_planes: bad shape");
+    N3D_CHECK(views >= 1 && v_front >= 0 && v_front < views && v_side >= 0 && v_side < views && v_top >= 0 && v_top < views, "blend_planes_views: view index out of range");
+    if (N == 0) return 0;
+    N3D_CHECK(front && side && top && stat && alpha_views && planes_cl, "blend_planes: null tensor");
+    N3dProfScope prof(N3D_K_RENDER, stream, 3.0 * N * 3 * RN_C * (double)H * W, 4.0 * N * 3 * (double)H * W * (3 * RN_C + 1));
+    hipLaunchKernelGGL(blend_planes_kernel, dim3(cdiv(W, 64), H, N * 3), dim3(256), 0, stream, front, side, top, stat, alpha_views,
+                       planes_cl, N, H, W, views, v_front, v_side, v_top);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -267,6 +267,7 @@ class TriPlaneGenerator(_Tracked):
         S.side_streams = {}         # launch stream -> its side stream (callers may pipeline calls on several streams)
         S.alpha_views = torch.tensor([0, 1, 3], dtype=torch.int64, device=dev)
         S.tlin = {}
+        S.zero_c = {}               # batch size -> zeros [N, 25] (mapping with c_gen_conditioning_zero)
         self._prepared = S
         return S
 
@@ -276,17 +277,25 @@ class TriPlaneGenerator(_Tracked):
         self._check_params()
         S = self._prep()
         P = S.P
-        if self.rendering_kwargs['c_gen_conditioning_zero']:
-            c = torch.zeros_like(c)
-        c = c[:, :25] * self.rendering_kwargs.get('c_scale', 0)
         z = z.to(device=self.device, dtype=torch.float32)
-        c = c.to(device=self.device, dtype=torch.float32)
-        pre = 'backbone.mapping'
         n = z.shape[0]
+        scale = float(self.rendering_kwargs.get('c_scale', 0))
+        if self.rendering_kwargs['c_gen_conditioning_zero'] or scale == 0.0:
+            # zeros_like(c)[:, :25] * c_scale (:112-114): one cached zero tensor per batch size instead of a fill + a multiply launch per call
+            c = S.zero_c.get(n)
+            if c is None:
+                c = S.zero_c[n] = torch.zeros(n, 25, dtype=torch.float32, device=self.device)
+            scale = 1.0
+        else:
+            c = c[:, :25].to(device=self.device, dtype=torch.float32)
+        pre = 'backbone.mapping'
         L = _lib.lib()
         x = torch.empty(n, 1024, dtype=torch.float32, device=self.device)          # cat([norm(z), norm(embed(c))], 1)
         z = z.contiguous()              # (never pass a temporary to _lib.ptr: it is freed before the launch and its block can be re-used)
         _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(z), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
+        if scale != 1.0:                 # (c * c_scale is exact for c_scale = 1, the ffhq configuration; any other scale: libn3d.so's fma, not a torch multiply)
+            from .torch_utils.ops import fma as _fma
+            c = _fma.fma(c.contiguous(), torch.full((1, 1), scale, dtype=torch.float32, device=self.device).expand(n, 25).contiguous(), torch.zeros(n, 25, dtype=torch.float32, device=self.device))
         y = layers.fc(c.contiguous(), P[f'{pre}.embed.weight'], P[f'{pre}.embed.bias'], wgain=1 / np.sqrt(25))
         _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(y), _lib.c_void_p(x.data_ptr() + 512 * 4), n, 512, 1024, 1e-8, _lib.stream()))
         for i in range(2):
@@ -300,10 +309,11 @@ class TriPlaneGenerator(_Tracked):
                                      cutoff if trunc else 0, float(truncation_psi), _lib.stream()))
         return ws
 
-    def raster_geometry(self, v, lms):
+    def raster_geometry(self, v, lms, _all_views=False):
         """The texture-independent half of `rasterize` (reference triplane_next3d.py:190-222): z-buffer the four orthographic
         views of the mesh -> (uv sampling grid [N*4,256,256,2], alpha [N,3,256,256], mouth box [N,4] int32).  It depends only
-        on the vertices, so `_planes` runs it first."""
+        on the vertices, so `_planes` runs it first.  `_all_views`: alpha as the kernels leave it, [N,4,256,256] (n3d_blend_planes_views picks
+        views 0 / 1 / 3 itself: no index_select copy on the forward path)."""
         S = self._prep()
         dev, N, V, Lm, F = v.device, v.shape[0], v.shape[1], lms.shape[1], S.faces.shape[0]
         views, H, W = len(RENDERING_VIEWS), 256, 256
@@ -325,6 +335,8 @@ class TriPlaneGenerator(_Tracked):
                                          1 if self.fill_mouth else 0, 1, _lib.stream()))
         bbox = torch.empty(N, 4, dtype=torch.int32, device=dev)
         _lib.check(L.n3d_mouth_bbox(_lib.ptr(lm2d), _lib.ptr(bbox), N, Lm, _lib.stream()))
+        if _all_views:
+            return grid, alpha4, bbox
         alpha = alpha4.index_select(1, S.alpha_views)          # views 0 (front), 1 (side; view 2's alpha is unused, :226), 3 (top)
         return grid, alpha, bbox
 
@@ -346,17 +358,30 @@ class TriPlaneGenerator(_Tracked):
         grid, alpha, bbox = self.raster_geometry(v, lms)
         return self.project_textures(textures, grid), alpha, bbox
 
-    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False, bank=None, force_fp32=False):
+    def _unpack(self, v, c):
+        """v [N, 5023 + 68, 3], c [N, 25] (device float32, unit inner strides) -> dense (verts, lms, cam2world [N,16], intrinsics [N,9]) in ONE launch
+        (n3d_unpack_inputs) instead of four torch copies."""
+        n = v.shape[0]
+        f32 = dict(dtype=torch.float32, device=v.device)
+        verts, lms = torch.empty(n, 5023, 3, **f32), torch.empty(n, v.shape[1] - 5023, 3, **f32)
+        cam, intr = torch.empty(n, 16, **f32), torch.empty(n, 9, **f32)
+        _lib.check(_lib.lib().n3d_unpack_inputs(_lib.ptr(v), v.stride(0), _lib.ptr(c), c.stride(0), _lib.ptr(verts), _lib.ptr(lms), _lib.ptr(cam), _lib.ptr(intr),
+                                                n, 5023, v.shape[1] - 5023, _lib.stream()))
+        return verts, lms, cam, intr
+
+    def _planes(self, ws, v, noise_mode, cache_identity=False, use_cached_identity=False, bank=None, force_fp32=False, _unpacked=None):
         """Everything up to the blended tri-planes (channels-last [N,3,256,256,32]).  `cache_identity` keeps the two
         latent-only results (neural texture, static tri-planes); `use_cached_identity` re-uses them for a new mesh `v` (the
         reenactment loop, reenact_avatar_next3d.py:139-160: one identity, one mesh per frame)."""
         S = self._prep()
         L = _lib.lib()
-        v = v.to(device=self.device, dtype=torch.float32)
-        if self.load_lms:
-            v, lms = v[:, :5023], v[:, 5023:]
-        else:
+        if not self.load_lms:
             raise RuntimeError('load_lms=False is not supported: the mouth branch needs the 68 landmarks')
+        if _unpacked is not None:
+            v, lms = _unpacked
+        else:
+            v = v.to(device=self.device, dtype=torch.float32)
+            v, lms = v[:, :5023], v[:, 5023:]
         N = ws.shape[0]
         nw = S.texture.num_ws
         eg3d_ws, texture_ws = ws[:, :nw], ws[:, nw:]
@@ -373,7 +398,7 @@ class TriPlaneGenerator(_Tracked):
         ident = self._identity_cache if use_cached_identity else None
         static = None
         if ident is not None:                       # reenactment: same latents, new mesh -> only the mesh-dependent half runs
-            grid, alpha, bbox = self.raster_geometry(v, lms)
+            grid, alpha, bbox = self.raster_geometry(v, lms, _all_views=True)
             textures, static = ident
         elif self.overlap_static:
             sstream = S.side_streams.get(cur.cuda_stream)
@@ -382,11 +407,11 @@ class TriPlaneGenerator(_Tracked):
             sstream.wait_stream(cur)
             side_raster = N <= RASTER_ON_SIDE_STREAM
             if not side_raster:
-                grid, alpha, bbox = self.raster_geometry(v, lms)
+                grid, alpha, bbox = self.raster_geometry(v, lms, _all_views=True)
                 sstream.wait_stream(cur)
             with torch.cuda.stream(sstream):
                 if side_raster:
-                    grid, alpha, bbox = self.raster_geometry(v, lms)
+                    grid, alpha, bbox = self.raster_geometry(v, lms, _all_views=True)
                     raster_done = sstream.record_event()
                 static = S.static(eg3d_ws, noise_mode, bank=bank, force_fp32=force_fp32)
             static.record_stream(cur)
@@ -396,7 +421,7 @@ class TriPlaneGenerator(_Tracked):
                     t.record_stream(cur)
                 cur.wait_event(raster_done)
         else:
-            grid, alpha, bbox = self.raster_geometry(v, lms)
+            grid, alpha, bbox = self.raster_geometry(v, lms, _all_views=True)
             textures = S.texture(texture_ws, noise_mode, bank=bank, force_fp32=force_fp32)
         front, side, top = self.project_textures(textures, grid)
         f32 = dict(dtype=torch.float32, device=ws.device)
@@ -415,13 +440,16 @@ class TriPlaneGenerator(_Tracked):
         if cache_identity:
             self._set_cache('_identity_cache', (textures, static))
         planes = torch.empty(N, 3, 256, 256, 32, **f32)
-        _lib.check(L.n3d_blend_planes(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
-                                      _lib.ptr(planes), N, 256, 256, _lib.stream()))
+        # alpha [N, 4 views, 256, 256]: front / side / top = views 0 / 1 / 3 (view 2's alpha is unused, :226)
+        _lib.check(L.n3d_blend_planes_views(_lib.ptr(stitch), _lib.ptr(side), _lib.ptr(top), _lib.ptr(static), _lib.ptr(alpha),
+                                            _lib.ptr(planes), N, 256, 256, alpha.shape[1], 0, 1, 3, _lib.stream()))
+        if getattr(self, 'keep_stages', False):
+            alpha = alpha.index_select(1, S.alpha_views)
         self._debug = dict(textures=textures, front=front, side=side, top=top, alpha=alpha, bbox=bbox, grid=grid, crop=crop, mouths=mouths,
                            stitch_in=stitch_in, stitch=stitch, static=static) if getattr(self, 'keep_stages', False) else None
         return planes, eg3d_ws
 
-    def render(self, planes_cl, c, neural_rendering_resolution, depth_jitter=None, importance_u=None, density_noise_draws=None):
+    def render(self, planes_cl, c, neural_rendering_resolution, depth_jitter=None, importance_u=None, density_noise_draws=None, _camera=None):
         """RaySampler + ImportanceRenderer on channels-last planes -> (feature_image [N,32,R,R], depth_image [N,1,R,R]).
         rendering_kwargs as the reference reads them (vr/renderer.py:95-147, vr/ray_marcher.py:27-66): fixed `ray_start` / `ray_end` or
         both 'auto' (per-ray box limits), `disparity_space_sampling`, `white_back`, `density_noise` (the normal draws come from the
@@ -466,9 +494,12 @@ class TriPlaneGenerator(_Tracked):
         if key not in S.tlin:
             S.tlin[key] = torch.linspace(lo, hi, Sc).to(dev)
         t0, t1 = lo, hi
-        c = c.to(device=dev, dtype=torch.float32)
-        cam2world = c[:, :16].contiguous()
-        intrinsics = c[:, 16:25].contiguous()
+        if _camera is not None:              # (synthesis: already dense, n3d_unpack_inputs)
+            cam2world, intrinsics = _camera
+        else:
+            c = c.to(device=dev, dtype=torch.float32)
+            cam2world = c[:, :16].contiguous()
+            intrinsics = c[:, 16:25].contiguous()
         jitter = (torch.rand((N, R * R, Sc, 1), device=dev) if depth_jitter is None else depth_jitter.to(dev)).contiguous()
         u = (torch.rand((N * R * R, Sf), device=dev) if importance_u is None else importance_u.to(dev)).contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
@@ -506,15 +537,21 @@ class TriPlaneGenerator(_Tracked):
             if not (ws.stride(2) == 1 and ws.stride(1) == 512):
                 ws = ws.contiguous()
             bank = S.all_bank.compute(ws)
+        # the call's two small inputs -> the dense tensors the kernels read, in one launch (v: vertices + landmarks, c: camera label)
+        vd, cd = v.to(device=self.device, dtype=torch.float32), c.to(device=self.device, dtype=torch.float32)
+        unpacked = camera = None
+        if vd.dim() == 3 and vd.shape[1] > 5023 and vd.shape[2] == 3 and vd.stride()[1:] == (3, 1) and cd.dim() == 2 and cd.shape[1] >= 25 and cd.stride(1) == 1 and cd.shape[0] == vd.shape[0]:
+            verts, lms, cam, intr = self._unpack(vd, cd)
+            unpacked, camera = (verts, lms), (cam, intr)
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes, _ = self._planes(ws, v, noise_mode, cache_identity, use_cached_identity, bank=bank,
-                                     force_fp32=bool(synthesis_kwargs.get('force_fp32', False)))
+            planes, _ = self._planes(ws, vd, noise_mode, cache_identity, use_cached_identity, bank=bank,
+                                     force_fp32=bool(synthesis_kwargs.get('force_fp32', False)), _unpacked=unpacked)
         if cache_backbone:
             self._set_cache('_last_planes', planes)
-        feature_image, depth_image = self.render(planes, c, neural_rendering_resolution, depth_jitter, importance_u,
-                                                 synthesis_kwargs.get('density_noise_draws'))
+        feature_image, depth_image = self.render(planes, cd, neural_rendering_resolution, depth_jitter, importance_u,
+                                                 synthesis_kwargs.get('density_noise_draws'), _camera=camera)
         rgb_image = feature_image[:, :3]
         sr_noise = self.rendering_kwargs.get('superresolution_noise_mode', 'none')     # triplane_next3d.py:182
         # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is

@@ -47,7 +47,8 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     # the launch count does not depend on the batch: one launch per layer, whatever N — plus the split8 conversion passes of
     # the pre-split path, whose number follows the layers' eligibility (n3d_conv2d_split8_eligible: batch and size dependent)
     assert full['n3d_fc_multi'] == 2                             # every style affine / demodulation coefficient of the five networks: two launches
-    assert n_full - full['n3d_split8_from_nchw'] == 145 + (0 if R == 128 else 2), full
+    assert n_full - full['n3d_split8_from_nchw'] == 146 + (0 if R == 128 else 2), full        # (round 5: + n3d_unpack_inputs, which replaced four torch copies)
+    assert full['n3d_unpack_inputs'] == 1 and full['n3d_blend_planes_views'] == 1
     assert full['n3d_fir4_split8'] <= 14 and full['n3d_split8_from_nchw'] <= 24
     dry.clear()
     G.synthesis(ws, c, v, use_cached_backbone=True, **kw)        # camera orbit: renderer + super-resolution only
@@ -79,7 +80,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')      # no force_fp32: the reference's default, fp16
     half = Counter(dry)                                                          # super-resolution blocks (sr_num_fp16_res = 4)
     assert sr16(half, nb) == (1, 1, 4, 2, 2)
-    assert sum(half.values()) - half['n3d_split8_from_nchw'] == 145 + (0 if R == 128 else 2) - 8 + 10
+    assert sum(half.values()) - half['n3d_split8_from_nchw'] == 146 + (0 if R == 128 else 2) - 8 + 10
     # the switches that once made the default call raise: strict-fp32 arithmetic, no pre-split hand-off -> the float16
     # blocks run on their own kernels whatever the float32 layers use; random super-resolution noise -> float32 blocks, never an error
     import warnings

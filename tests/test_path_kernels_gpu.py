@@ -297,6 +297,26 @@ def test_blend_planes_and_layout(dev):
     refd = ref.contiguous().to(dev)
     _lib.check(L.n3d_planes_to_channels_last(_lib.ptr(refd), _lib.ptr(cl), N, H, W, _lib.stream()))
     assert torch.equal(cl.permute(0, 1, 4, 2, 3).cpu(), ref)
+    # n3d_blend_planes_views: alpha as the rasteriser leaves it, [N, 4 views, H, W], planes blended with views 0 / 1 / 3 — bit-equal to index_select + blend
+    alpha4 = torch.stack([alpha[:, 0], alpha[:, 1], _rand((N, H, W), 56), alpha[:, 2]], 1).contiguous().to(dev)
+    out4 = torch.empty_like(out)
+    _lib.check(L.n3d_blend_planes_views(*[_lib.ptr(t) for t in d[:4]], _lib.ptr(alpha4), _lib.ptr(out4), N, H, W, 4, 0, 1, 3, _lib.stream()))
+    assert torch.equal(out4, out)
+    assert L.n3d_blend_planes_views(*[_lib.ptr(t) for t in d[:4]], _lib.ptr(alpha4), _lib.ptr(out4), N, H, W, 4, 0, 1, 4, _lib.stream()) != 0      # view index out of range
+
+
+def test_unpack_inputs(dev):
+    """n3d_unpack_inputs: synthesis' v [N, V + L, 3] / c [N, 25] -> dense verts / landmarks / cam2world / intrinsics in one launch (a batch-strided
+    v: the reenactment loop hands over slices of a longer sequence) — pure data movement, bit-equal to the four torch slices it replaces."""
+    from next3d_amd import _lib
+    N, V, Lm = 3, 5023, 68
+    seq = _gen((N, V + Lm + 7, 3), 57).to(dev)
+    v = seq[:, :V + Lm]                                   # batch stride (V + L + 7) * 3
+    c = _gen((N, 27), 58).to(dev)[:, :25]
+    f32 = dict(dtype=torch.float32, device=dev)
+    verts, lms, cam, intr = torch.empty(N, V, 3, **f32), torch.empty(N, Lm, 3, **f32), torch.empty(N, 16, **f32), torch.empty(N, 9, **f32)
+    _lib.check(_lib.lib().n3d_unpack_inputs(_lib.ptr(v), v.stride(0), _lib.ptr(c), c.stride(0), _lib.ptr(verts), _lib.ptr(lms), _lib.ptr(cam), _lib.ptr(intr), N, V, Lm, _lib.stream()))
+    assert torch.equal(verts, v[:, :V]) and torch.equal(lms, v[:, V:]) and torch.equal(cam, c[:, :16]) and torch.equal(intr, c[:, 16:25])
 
 
 def _decoder(seed):
