@@ -4,7 +4,7 @@
 // The plain kernel runs one 64-channel x (16 x 32)-pixel tile per workgroup and, at 152 KB of LDS, one workgroup per CU: when
 // a tile ends, the matrix pipe idles through the epilogue (per-channel factors fetched, 64 stores per wave drained), the
 // dispatch of the next workgroup and its prologue (first patch fetched from HBM, converted, stored, barrier) — measured at
-// ~18 % of the kernel.  Here one workgroup per CU walks its own sequence of tiles and the K loop simply
+// ~18 % of the kernel (docs/history/DESIGN_rounds1-4.md 3.1b).  Here one workgroup per CU walks its own sequence of tiles and the K loop simply
 // continues across tile boundaries: (tile, 16-channel chunk) pairs form ONE software pipeline — while the last chunks of
 // tile k are multiplied, the first chunks of tile k+1 are already being fetched, converted and stored into the other LDS
 // buffer.  The epilogue of a finished tile runs under the other wave role's MFMA block: waves 4-7 (MFMA first) store their

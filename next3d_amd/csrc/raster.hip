@@ -23,14 +23,15 @@
 
 // RASTER_VARIANT — how the rasteriser's kernels read and hand over their small, heavily re-read tables.
 // Round-1 finding: while an 8-wave split-bf16 convolution workgroup of ANOTHER stream is resident on the same
-// CUs, raster_faces / raster_resolve returned different results from run to run (12 of 12 runs).  Round-2 bisection
-// (tools/dbg_race3.py, gpurun_out r2a): the damage is in loads served by the per-CU VECTOR L1 — it persists when the kernels
-// read only IMMUTABLE inputs (variant 16: vertices transformed in place from `verts`, no inter-kernel hand-off left), it
-// persists with un-merged single-dword loads (variant 32), with write-through stores on the producers (1, 2) and with an
-// L1-bypassing z-buffer read (8); it disappears (0 of 12, co-resident stride-1, stride-2 and fill runs) as soon as the vertex
-// loads are agent-scope (sc1: served by L2, bypassing the L1) — variant 4.  So it is not a software coherence bug of this
-// file; the shipped configuration reads every gathered table through sc1 loads and hands the z-buffer / vertices over with
-// write-through stores, which costs nothing on a few hundred KB and is right under any stream schedule.
+// CUs, raster_faces / raster_resolve built with plain table loads return different results from run to run (12 of 12 runs); with
+// agent-scope (sc1) dword loads (variant 4 and up) never.  Rounds 2-4 read that as "wrong words from vector-L1-served gathers".  Round 5
+// (profiles/r05_raster_coresidency_classified.txt; probe bit 64 dumps every gathered word and the number of z-buffer updates a lane issues):
+// the GATHERED WORDS ARE RIGHT in the failing runs (0 wrong of ~46 M per run; RAS counters clean; never a bit flip) — what differs is how
+// many atomicMin updates ~0.2 % of the lanes issue, so faces go missing from the z-buffer; and a build whose table loads are PLAIN,
+// L1-served single-dword loads (bit 256) never fails either.  What every failing build shares is per-lane 96-bit gathers
+// (global_load_dwordx3 on 12-byte records) in flight in these two kernels, not the cache that serves them; the mechanism below the
+// instruction level is still unknown.  The shipped configuration keeps dword sc1 loads for every gathered table and write-through hand-overs
+// (no 96-bit gather, nothing measurable in cost on a few hundred KB), and the co-residency test keeps it that way.
 //   bit 0: z-buffer clear stores sc1   bit 1: vertex (tv) stores sc1   bit 2: vertex / index / uv-table loads sc1
 //   bit 3: z-buffer loads in resolve sc1   bit 4: (probe) faces / resolve transform their vertices themselves from `verts`
 #ifndef RASTER_VARIANT

@@ -308,7 +308,7 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     assert down == 2 and L.ksize == 3
     if PRECISION == 'bf16x3' and L.wt16 is not None and S2_PRESPLIT and x.shape[1] % 16 == 0 and x.shape[2] >= 32 and epi.act in (1, 3):
         # FIR writing split8 -> the LDS-DMA stride-2 kernel (the register-staged one pays a stride-1 chunk's
-        # staging for a quarter of its MFMAs per stage)
+        # staging for a quarter of its MFMAs per stage; docs/history/DESIGN_rounds1-4.md 3.1c)
         x = uf._fir4_split8_nchw(x, fir, 2) if x.shape[1] % 8 == 0 and tuple(fir.shape) == (4, 4) else cg.split8_from_nchw(uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2]))
         return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
     if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2] + 1, x.shape[3] + 1, 3, 1):

@@ -351,7 +351,7 @@ def test_layout_grid_tiling():
 def test_parameter_update_check_uses_a_cached_tensor_list():
     """TriPlaneGenerator._check_params (called by every mapping / synthesis): an in-place update of any parameter or buffer drops the prepared
     weights and caches — detected through version counters of a CACHED tensor list (walking the 674-entry module tree cost 0.4 ms per call, which
-    bound the eager batch-1 call: DESIGN.md 3.1h); a parameter OBJECT replaced by assignment / a re-registered buffer is caught on the NEXT call
+    bound the eager batch-1 call: docs/history/DESIGN_rounds1-4.md 3.1h); a parameter OBJECT replaced by assignment / a re-registered buffer is caught on the NEXT call
     (generator._Tracked bumps a structure counter: ADVICE r4), and the tree is re-walked every 256th call for assignments that bypass the module API."""
     import torch
     from next3d_amd import demo

@@ -1,4 +1,4 @@
-// tools/probe/conv_presplit_probe.hip — COMPILE-ONLY study for DESIGN.md §7 item 1 (not part of libn3d.so, never launched by
+// tools/probe/conv_presplit_probe.hip — COMPILE-ONLY study for docs/history/DESIGN_rounds1-4.md §7 item 1 (not part of libn3d.so, never launched by
 // the product or the tests): what the stride-1 3x3 K loop of conv2d_bf16x3.hip looks like when the activations arrive ALREADY
 // split (bf16 hi / lo planes in the consumer's fragment layout, [I/8][H][W][8] = 16-byte units) and the style has been folded
 // into per-sample weights.  Staging is then a pure copy, done by LDS-DMA (`buffer_load_dwordx4 ... lds`): no landing registers,

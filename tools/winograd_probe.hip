@@ -1,5 +1,5 @@
 // Winograd F(2x2, 3x3) for the 64 x 64 x 512 -> 512 layer at batch 4: a TRAFFIC-MODEL probe, not a convolution.  It issues exactly the
-// memory traffic, LDS traffic, MFMA count and barriers the fused split-bf16 Winograd kernel of DESIGN.md 3.1h would issue — per workgroup 64 output channels x
+// memory traffic, LDS traffic, MFMA count and barriers the fused split-bf16 Winograd kernel of docs/history/DESIGN_rounds1-4.md 3.1h would issue — per workgroup 64 output channels x
 // 64 tiles (= 8 x 32 output pixels) with all 16 transform-domain accumulators resident (8 waves x 2 positions x 2 x 2 blocks of 32 x 32 = 128 accumulator
 // registers per lane), per 16-channel chunk 64 KB of transformed input V by LDS-DMA (double-buffered) and 8 x 1 KB of transformed-weight fragments U per wave straight
 // from global memory, 24 MFMAs per wave (3 per product: hi*hi, hi*lo, lo*hi), one barrier — on operands of the right size and layout with random contents, and
