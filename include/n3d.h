@@ -151,6 +151,9 @@ int n3d_split8_from_nchw(const float* x, const float* scale, void* y_split8, int
 /* 1 when n3d_conv2d_bf16x3 runs this 3x3 stride-1 float32-NCHW layer on the few-pixel kernel (conv2d_sk_bf16x3.hip: the whole K inside
  * one workgroup, one launch): ksplit / workspace are then ignored, the caller need not allocate one.  (N3D_CONV_SK=0: never.) */
 int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W);
+/* the same question for the few-pixel STRIDE-2 layers (ksize 3, mode 1, float32 NCHW in / out, dense rows, H x W = the INPUT image, odd): the <= 17 x 17
+ * down-sampling layers of the mouth encoder (Conv2dLayer down = 2 behind its FIR, conv2d_resample.py:108-111) */
+int n3d_conv2d_sk_s2_eligible(int N, int I, int O, int H, int W);
 /* the same question for the few-position TRANSPOSED layers (ksize 3, mode 2, float32 NCHW in and out, one weight tensor for the batch): 1 = the one-launch
  * kernel takes the layer whatever `ksplit` says (no workspace needed) */
 int n3d_conv2d_up_sk_eligible(int N, int I, int O, int H, int W);

@@ -75,6 +75,7 @@ _SIGNATURES = {
     'n3d_fir4_split8_nchw_sep': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
     'n3d_fir4_split8_nchw': (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_int64, c_int64, c_int, c_int, c_float, ctypes.POINTER(Epilogue), c_void_p, c_int64, c_void_p]),
     'n3d_conv2d_sk_eligible': (c_int, [c_int] * 5),
+    'n3d_conv2d_sk_s2_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_up_sk_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_split8_eligible': (c_int, [c_int] * 5),
     'n3d_conv2d_split8_ksplit': (c_int, [c_int] * 5),

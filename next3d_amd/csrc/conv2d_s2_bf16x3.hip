@@ -271,8 +271,14 @@ int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, in
                                   const n3d_epilogue& epi, hipStream_t stream);
 
 // called by n3d_conv2d_bf16x3 for ksize == 3, mode == 1 (descriptor already validated for the common fields)
+int conv2d_sk_s2_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream);   // conv2d_sk_bf16x3.hip (few-pixel stride-2 layers; 1 = not its layer)
+
 int conv2d_s2_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(d->H >= 3 && d->W >= 3, "conv2d_bf16x3: stride-2 input smaller than the kernel");
+    {                                                                      // few-pixel layers (<= 17 x 17 inputs at batch 4): K split inside the workgroup, one launch
+        const int r = conv2d_sk_s2_bf16x3_try_launch(d, stream);
+        if (r <= 0) return r;
+    }
     ConvS2Params p;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y; p.partial = d->workspace;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;

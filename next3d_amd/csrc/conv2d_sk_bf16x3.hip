@@ -25,7 +25,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct SkParams {
     const float* x; const bf16x8* wt16; const float* style; float* y;
-    int N, I, O, OP64, H, W, HW;
+    int N, I, O, OP64, H, W, HW;         // H, W: OUTPUT image (= the input image for stride 1)
+    int IH, IW, HWin;                    // input image (stride 2: IH = 2 H + 1, IW = 2 W + 1, no padding: conv2d_resample.py:108-111 pads in the FIR)
     int R, NS, PR, PW, nslots, tps;      // tile rows per sample, samples per tile, patch rows / pitch, patch pixels, tiles per sample (NS == 1)
     int tiles_p, tiles_m;
     int x_bytes;                          // size of the whole input tensor (buffer descriptor range)
@@ -33,12 +34,17 @@ struct SkParams {
     n3d_epilogue epi;
 };
 
-constexpr int SK_SLOTS = 128;                                              // patch pixels per wave region
+constexpr int SK_SLOTS = 128;                                              // patch pixels per wave region (stride 1; the transposed twin below)
 constexpr int SK_WAVE_SLOTS = 2 * 2 * SK_SLOTS;                            // [hi|lo][half][pixel] 16-byte slots = 8 KB
 
-template <int PT>                                                          // 32-pixel groups per workgroup tile
+// S = 1: stride 1, padding 1.  S = 2 (round 5): stride 2, padding 0 — the <= 17 x 17 down-sampling layers of the mouth encoder (Conv2dLayer
+// down = 2 behind its FIR, conv2d_resample.py:108-111), which ran on the fp32-MFMA kernel with split-K 16 + a reduce launch (58 us each): the patch
+// of a 32-pixel output tile is (2 R + 1) x (2 W + 1) <= 192 input pixels (three per lane), tap (ky, kx) of output (oy, ox) reads patch pixel
+// (2 oy + ky, 2 ox + kx) — the same shifted-fragment scheme with a doubled pitch.
+template <int PT, int S = 1>                                               // 32-pixel groups per workgroup tile; stride
 __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
-    __shared__ bf16x8 smem[8 * SK_WAVE_SLOTS];                             // 64 KB: the waves' patch regions; afterwards the partial sums
+    constexpr int NJ = S == 1 ? 2 : 3, SLOTS = 64 * NJ, WAVE_SLOTS = 4 * SLOTS, PAD = S == 1 ? 1 : 0;
+    __shared__ bf16x8 smem[8 * WAVE_SLOTS];                                // 64 KB (96 KB for S = 2): the waves' patch regions; afterwards the partial sums
     __shared__ float s_style[2 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -61,15 +67,15 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
         s_style[i] = (p.style && n0 + s < p.N) ? p.style[(int64_t)(n0 + s) * p.style_stride + ch] : 1.f;
     }
 
-    // this lane's two patch pixels: byte offset of (sample, channel 0, y, x) in x, or out of range (halo, beyond the batch)
-    int voff[2], srow[2];
+    // this lane's NJ patch pixels: byte offset of (sample, channel 0, y, x) in x, or out of range (halo, beyond the batch)
+    int voff[NJ], srow[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int pp = lane + 64 * j;
         const int s = pp / PRW, rem = pp - s * PRW, pr = rem / p.PW, pc = rem - pr * p.PW;
-        const int n = n0 + s, yy = y0 - 1 + pr, xx = pc - 1;
-        const bool ok = pp < p.nslots && n < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        voff[j] = ok ? (int)(((int64_t)n * p.xbs + yy * p.W + xx) * 4) : (int)0x80000000;
+        const int n = n0 + s, yy = S * y0 - PAD + pr, xx = pc - PAD;
+        const bool ok = pp < p.nslots && n < p.N && yy >= 0 && yy < p.IH && xx >= 0 && xx < p.IW;
+        voff[j] = ok ? (int)(((int64_t)n * p.xbs + yy * p.IW + xx) * 4) : (int)0x80000000;
         srow[j] = min(s, p.NS - 1) * p.I;
     }
     // this lane's output pixels (one per 32-pixel group) and the patch slot of their centre tap
@@ -78,11 +84,11 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
     for (int g = 0; g < PT; ++g) {
         const int q = g * 32 + l31;
         const int s = p.NS == 1 ? 0 : q / p.HW, rem = q - s * p.HW, ry = rem / p.W, x = rem - ry * p.W;
-        centre[g] = s * PRW + (ry + 1) * p.PW + (x + 1);
+        centre[g] = s * PRW + (S * ry + PAD) * p.PW + (S * x + PAD);
         on[g] = n0 + s; oy[g] = y0 + ry; ox[g] = x;
     }
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    bf16x8* Bw = smem + wn * SK_WAVE_SLOTS;                                // this wave's patch region
+    bf16x8* Bw = smem + wn * WAVE_SLOTS;                                   // this wave's patch region
 
     // several accumulators per pixel group — one per product of the operand split (lo*hi, hi*lo, hi*hi; PT = 2: the two cross terms share
     // one, register budget) — so that consecutive MFMAs do not wait for each other's results (27 dependent MFMAs per chunk otherwise);
@@ -99,14 +105,14 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
 
     // software pipeline over the wave's chunks: the activations of chunk c + 1 are requested as soon as chunk c's are converted, and every
     // tap's weight fragments are re-requested for chunk c + 1 right after the MFMAs that consumed them (same registers)
-    float raw[2][16];
+    float raw[NJ][16];
     bf16x8 ah[9], al[9];
     auto load_raw = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int ch = 0; ch < 16; ++ch)
-                raw[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[j], (c * 16 + ch) * p.HW * 4, 0));
+                raw[j][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[j], (c * 16 + ch) * p.HWin * 4, 0));
     };
     const bf16x8* a0 = p.wt16 + (int64_t)half * p.OP64 + m0 + l31;
     const int64_t a_tap = (int64_t)KC * 4 * p.OP64, a_chunk = (int64_t)4 * p.OP64;
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
 
     for (int c = c_begin; c < c_begin + nc; ++c) {
         const bool more = c + 1 < c_begin + nc;
-        // modulation + operand split, once per patch pixel, into the wave's own region (2 patch pixels x 16 channels per lane)
+        // modulation + operand split, once per patch pixel, into the wave's own region (NJ patch pixels x 16 channels per lane)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const float* st = s_style + srow[j] + c * 16;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -130,19 +136,19 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
                     hi[k] = h;
                     lo[k] = (__bf16)(v - (float)h);
                 }
-                Bw[(0 * 2 + hf) * SK_SLOTS + lane + 64 * j] = hi;
-                Bw[(1 * 2 + hf) * SK_SLOTS + lane + 64 * j] = lo;
+                Bw[(0 * 2 + hf) * SLOTS + lane + 64 * j] = hi;
+                Bw[(1 * 2 + hf) * SLOTS + lane + 64 * j] = lo;
             }
         }
         if (more) load_raw(c + 1);
         // 9 taps: shifted pixel fragments from the patch (LDS operations of one wave complete in order: no barrier)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int off = (t / 3 - 1) * p.PW + (t % 3 - 1);
+            const int off = (t / 3 - PAD) * p.PW + (t % 3 - PAD);
 #pragma unroll
             for (int g = 0; g < PT; ++g) {
-                const bf16x8 bh = Bw[(0 * 2 + half) * SK_SLOTS + centre[g] + off];
-                const bf16x8 bl = Bw[(1 * 2 + half) * SK_SLOTS + centre[g] + off];
+                const bf16x8 bh = Bw[(0 * 2 + half) * SLOTS + centre[g] + off];
+                const bf16x8 bl = Bw[(1 * 2 + half) * SLOTS + centre[g] + off];
                 acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[g][0], 0, 0, 0);
                 acc[g][NA - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[g][NA - 2], 0, 0, 0);
                 acc[g][NA - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[g][NA - 1], 0, 0, 0);
@@ -209,6 +215,53 @@ static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_ou
 
 extern "C" int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W) { return sk_plan(N, I, O, H, W, nullptr, nullptr) ? 1 : 0; }
 
+// stride 2 (mode 1): input IH x IW = (2 OH + 1) x (2 OW + 1), 32-pixel output tiles of R rows (or two whole samples), patch <= 192 input pixels
+static bool sk_s2_plan(int N, int I, int O, int IH, int IW, SkParams* out) {
+    static const bool enabled = n3d_tune("N3D_CONV_SK_S2", 1) != 0;
+    if (!enabled) return false;
+    if (N < 1 || I % 128 != 0 || I > 512 || O % 32 != 0 || O < 32 || IH < 5 || IW < 5 || (IH & 1) == 0 || (IW & 1) == 0) return false;
+    const int H = (IH - 3) / 2 + 1, W = (IW - 3) / 2 + 1, HW = H * W;
+    if (W > 16 || (int64_t)N * HW > 1024) return false;                    // (every pixel tile re-reads the layer's weights from L2)
+    SkParams q;
+    const int TP = 32;
+    if (HW >= TP) { if (TP % W != 0 || HW % TP != 0) return false; q.NS = 1; q.R = TP / W; q.tps = HW / TP; q.tiles_p = N * q.tps; }
+    else { if (TP % HW != 0) return false; q.NS = TP / HW; q.R = H; q.tps = 1; q.tiles_p = (N + q.NS - 1) / q.NS; }
+    if (q.NS > 2) return false;
+    q.PR = 2 * q.R + 1; q.PW = 2 * W + 1; q.nslots = q.NS * q.PR * q.PW;
+    if (q.nslots > 192) return false;
+    if (out) { out->NS = q.NS; out->R = q.R; out->tps = q.tps; out->tiles_p = q.tiles_p; out->PR = q.PR; out->PW = q.PW; out->nslots = q.nslots; out->H = H; out->W = W; out->HW = HW; }
+    return true;
+}
+/* 1 when n3d_conv2d_bf16x3 (ksize 3, mode 1, float32 NCHW in / out, dense input rows) runs this stride-2 layer on the one-launch few-pixel kernel: ksplit / workspace ignored */
+extern "C" int n3d_conv2d_sk_s2_eligible(int N, int I, int O, int H, int W) { return sk_s2_plan(N, I, O, H, W, nullptr) ? 1 : 0; }
+
+// called by the stride-2 launcher (conv2d_s2_bf16x3.hip) first; returns 1 when the layer is not this kernel's
+int conv2d_sk_s2_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
+    SkParams p;
+    if (d->epi.round_f16 || d->epi.residual_up_filter || d->side_split8 || d->y_layout != N3D_LAYOUT_NCHW_F32 || d->x_layout != N3D_LAYOUT_NCHW_F32 || d->wt_batch_stride) return 1;
+    if (d->x_row_stride != 0 && d->x_row_stride != d->W) return 1;        // (pitched FIR output: the general stride-2 kernel)
+    if (!sk_s2_plan(d->N, d->I, d->O, d->H, d->W, &p)) return 1;
+    const int64_t xbs = d->x_batch_stride;
+    const int64_t x_bytes = ((int64_t)(d->N - 1) * xbs + (int64_t)d->I * d->H * d->W) * 4;
+    if (x_bytes >= (1ll << 31)) return 1;
+    p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y;
+    p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64;
+    p.IH = d->H; p.IW = d->W; p.HWin = d->H * d->W;
+    p.tiles_m = d->O / 32;
+    p.x_bytes = (int)x_bytes;
+    p.xbs = xbs; p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * p.HW;
+    p.yrs = d->y_row_stride ? d->y_row_stride : p.W;
+    N3D_CHECK(p.yrs >= p.W, "conv2d_bf16x3: y_row_stride smaller than the output width");
+    p.style_stride = d->style_stride ? d->style_stride : d->I;
+    p.epi = d->epi;
+    const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.HW;
+    const double bytes = 4.0 * ((double)d->N * d->I * p.HWin + (double)d->N * d->O * p.HW + (double)d->O * d->I * 9);
+    N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
+    hipLaunchKernelGGL((conv2d_sk_bf16x3_kernel<1, 2>), dim3((unsigned)(p.tiles_p * p.tiles_m)), dim3(512), 0, stream, p);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
 // called by n3d_conv2d_bf16x3 for ksize 3 / mode 0 / float32 NCHW in and out (common fields validated there); returns 1 when the layer is
 // not this kernel's (the caller goes on to the general kernels), 0 after a launch, -1 on error
 int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
@@ -221,6 +274,7 @@ int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     if (x_bytes >= (1ll << 31)) return 1;
     p.x = d->x; p.wt16 = (const bf16x8*)d->wt; p.style = d->style; p.y = d->y;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W; p.HW = d->H * d->W;
+    p.IH = d->H; p.IW = d->W; p.HWin = p.HW;
     p.tiles_m = d->O / 32;
     p.x_bytes = (int)x_bytes;
     p.xbs = xbs; p.ybs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->O * d->H * d->W;

@@ -42,6 +42,8 @@ FUSED_TORGB_MAX = 32      # colours (module constant; tools flip it to 4 for A/B
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 UP_PS_NCHW = True          # few-position up-sampling layers on the pre-split transposed kernel writing NCHW (networks._Block._ps_nchw)
 NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)
+SK_S2 = True               # few-pixel stride-2 layers on conv2d_sk_bf16x3_kernel<1, 2> (conv2d_layer)
+SK_S2_MAX_IN = 16          # ... up to this input size (before the FIR); 32 would take the 32 x 32 -> 16 x 16 layer from the pre-split stride-2 kernel too (A/B: tools/ab_switch.py)
 CONVERT_MAX_BYTES = int(70e6)     # see _conv3x3
 
 
@@ -306,16 +308,21 @@ def conv2d_layer(L, x, fir, activation='linear', down=1, conv_clamp=None, gain=1
     if down == 1:
         return cg.conv_launch(x, L.wt, L.ksize, 0, L.out_channels, epilogue=epi, out=out)
     assert down == 2 and L.ksize == 3
-    if PRECISION == 'bf16x3' and L.wt16 is not None and S2_PRESPLIT and x.shape[1] % 16 == 0 and x.shape[2] >= 32 and epi.act in (1, 3):
+    sk_s2 = (SK_S2 and PRECISION == 'bf16x3' and L.wt16 is not None and x.dtype == torch.float32 and x.shape[2] <= SK_S2_MAX_IN and
+             cg.sk_s2_eligible(x.shape[0], x.shape[1], L.out_channels, x.shape[2] + 1, x.shape[3] + 1))
+    if not sk_s2 and PRECISION == 'bf16x3' and L.wt16 is not None and S2_PRESPLIT and x.shape[1] % 16 == 0 and x.shape[2] >= 32 and epi.act in (1, 3):
         # FIR writing split8 -> the LDS-DMA stride-2 kernel (the register-staged one pays a stride-1 chunk's
         # staging for a quarter of its MFMAs per stage; docs/history/DESIGN_rounds1-4.md 3.1c)
         x = uf._fir4_split8_nchw(x, fir, 2) if x.shape[1] % 8 == 0 and tuple(fir.shape) == (4, 4) else cg.split8_from_nchw(uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2]))
         return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
-    if PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2] + 1, x.shape[3] + 1, 3, 1):
+    if not sk_s2 and PRECISION == 'bf16x3' and L.wt16 is not None and cg.bf16x3_eligible(x.shape[1], x.shape[2] + 1, x.shape[3] + 1, 3, 1):
         # the (W+1)-wide FIR output goes to the stride-2 kernel with rows padded to 16 bytes (aligned float4 FIR stores)
         x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2], _row_pitch=True)
         return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
     x = uf.upfirdn2d(x, fir, padding=[2, 2, 2, 2])
+    if sk_s2:
+        # few-pixel stride-2 layers (<= 17 x 17 behind the FIR): the one-launch split-bf16 kernel instead of fp32 MFMA + split-K 16 + reduce launch
+        return cg.conv_launch(x, L.wt16, 3, 1, L.out_channels, epilogue=epi, out=out, bf16x3=True)
     return cg.conv_launch(x, L.wt, 3, 1, L.out_channels, epilogue=epi, out=out)
 
 

@@ -112,6 +112,12 @@ def sk_eligible(n, i, o, h, w):
 
 
 @_memo
+def sk_s2_eligible(n, i, o, h, w):
+    """n3d_conv2d_sk_s2_eligible: the one-launch few-pixel kernel takes this STRIDE-2 3x3 layer (h x w = the input image)."""
+    return bool(_lib.lib().n3d_conv2d_sk_s2_eligible(n, i, o, h, w))
+
+
+@_memo
 def _bf16x3_blocks(n, o, h, w, mode):
     return int(_lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode))
 
@@ -260,6 +266,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
     if bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and up_sk_eligible(n, i, o, h, w):
         ksplit = 1                                       # ... and so does its transposed twin (few-position up-sampling layers)
+    if bf16x3 and ksize == 3 and mode == 1 and not split8 and not pitched_in and not _wt_batch_stride and out_dtype == torch.float32 and sk_s2_eligible(n, i, o, h, w):
+        ksplit = 1                                       # ... and the few-pixel stride-2 layers
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None

@@ -71,7 +71,7 @@ def patches():
     class Recorder:
         def __getattr__(self, name):
             res, argtypes = _lib._SIGNATURES[name]
-            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_split8_ksplit', 'n3d_conv2d_sk_eligible', 'n3d_conv2d_up_sk_eligible', 'n3d_abi_version', 'n3d_last_error'):
+            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_split8_ksplit', 'n3d_conv2d_sk_eligible', 'n3d_conv2d_sk_s2_eligible', 'n3d_conv2d_up_sk_eligible', 'n3d_abi_version', 'n3d_last_error'):
                 return getattr(real, name)                       # pure host functions: the real ones
 
             def fn(*args):

@@ -277,6 +277,39 @@ def test_conv2d_bf16x3_few_pixel_kernel(dev, N, I, OC, H, W):
     assert torch.equal(ye, cg.conv_launch(xe.contiguous(), wt16, 3, 0, OC, style=t(s), bf16x3=True))
 
 
+@pytest.mark.parametrize('N,I,OC,H,W', [(4, 512, 512, 17, 17), (4, 512, 512, 9, 9), (1, 512, 512, 17, 17), (3, 128, 96, 9, 9), (2, 256, 64, 33, 33), (1, 512, 512, 9, 9)])
+def test_conv2d_sk_stride2_few_pixel_layers(dev, N, I, OC, H, W):
+    """conv2d_sk_bf16x3_kernel<1, 2> (round 5): the few-pixel STRIDE-2 layers — the mouth encoder's 17 x 17 -> 8 x 8 and 9 x 9 -> 4 x 4 convolutions behind
+    their FIR (Conv2dLayer down = 2, conv2d_resample.py:108-111), which ran on the fp32-MFMA kernel with split-K 16 + a reduce launch — in one launch on the
+    split-bf16 matrix-core path, against float32 ATen: plain, with the full epilogue + residual into a strided output view, odd batch / two samples per
+    tile, channel counts that do not divide by the XCDs, run-to-run bitwise equality; the library's own eligibility answer decides the route."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    assert _lib.lib().n3d_conv2d_sk_s2_eligible(N, I, OC, H, W) == 1 and cg.sk_s2_eligible(N, I, OC, H, W)
+    assert _lib.lib().n3d_conv2d_sk_s2_eligible(N, I, OC, H + 1, W) == 0 and _lib.lib().n3d_conv2d_sk_s2_eligible(N, I + 16, OC, H, W) == 0
+    OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    x, w = _gen((N, I, H, W), 170), _gen((OC, I, 3, 3), 171) / np.sqrt(I * 9)
+    b, res = _gen((OC,), 172), _gen((N, OC, OH, OW), 173)
+    ref_plain = F.conv2d(x, w, stride=2)
+    ref_full = O.bias_act(ref_plain * 0.7, b, act='lrelu', gain=1.3, clamp=2.0) + res
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    y = cg.conv_launch(t(x), wt16, 3, 1, OC, bf16x3=True)
+    assert tuple(y.shape) == (N, OC, OH, OW)
+    err = float((y.cpu() - ref_plain).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_plain.abs().max())), err
+    epi = _lib.make_epilogue(bias=t(b), const_scale=0.7, act='lrelu', gain=1.3, clamp=2.0, residual=t(res))
+    out = torch.zeros(N, OC + 8, OH, OW, device=dev)[:, 8:]              # a channel-slice view (the U-Net's concatenation buffers)
+    y2 = cg.conv_launch(t(x), wt16, 3, 1, OC, epilogue=epi, bf16x3=True, out=out)
+    err = float((y2.cpu() - ref_full).abs().max())
+    assert err <= 1e-4 * max(1.0, float(ref_full.abs().max())), err
+    assert torch.equal(y2, cg.conv_launch(t(x), wt16, 3, 1, OC, epilogue=epi, bf16x3=True))
+    # against the fp32-MFMA route these layers took before (split-K + reduce launch): same result to the split-bf16 accuracy
+    y32 = cg.conv_launch(t(x), cg.prep_weight(t(w)), 3, 1, OC, epilogue=epi)
+    assert float((y2 - y32).abs().max()) <= 1e-4 * max(1.0, float(ref_full.abs().max()))
+
+
 @pytest.mark.parametrize('N,I,OC,H,W', [(2, 64, 128, 256, 256), (3, 48, 256, 144, 160), (3, 32, 128, 250, 200), (1, 128, 128, 512, 512),
                                        (4, 512, 256, 128, 128)])
 def test_conv2d_bf16x3_persistent(dev, N, I, OC, H, W):
