@@ -591,7 +591,8 @@ class TriPlaneGenerator(_Tracked):
                tuple(repr(rk.get(k)) for k in ('ray_start', 'ray_end', 'white_back', 'density_noise', 'disparity_space_sampling', 'box_warp',
                                                 'clamp_mode', 'decoder_lr_mul', 'c_gen_conditioning_zero', 'c_scale')),
                # ... and every module switch that selects kernels
-               layers.PRECISION, layers.PRESPLIT, layers.S2_PRESPLIT, layers.UP_PRESPLIT, layers.TORGB_SIDE, layers.FUSED_TORGB, layers.DIRECT_SPLIT8,
+               layers.PRECISION, layers.PRESPLIT, layers.S2_PRESPLIT, layers.UP_PRESPLIT, layers.TORGB_SIDE, layers.FUSED_TORGB, layers.FUSED_TORGB_MAX, layers.FUSED_TORGB_MID,
+               layers.SK_S2, layers.SK_S2_MAX_IN, layers.DIRECT_SPLIT8,
                layers.UP_PS_NCHW, layers.NCHW_FIR_SPLIT8, layers.CONVERT_MAX_BYTES, layers.F16_REF_CPU_ROUNDING, layers.uf.FIR_SEP, RASTER_ON_SIDE_STREAM,
                self.overlap_static, slot)
         uses_cache = bool((plain.get('use_cached_backbone') and self._last_planes is not None) or

@@ -39,6 +39,7 @@ UP_PRESPLIT = True         # the transposed convolution's input (a block output 
 TORGB_SIDE = True          # toRGB also writes its input as split8 for the next block's conv0 (torgb_layer)
 FUSED_TORGB = True        # a block's conv1 evaluates its toRGB (<= 32 colours) in its epilogue where x has no float32 reader (fused_torgb_ok)
 FUSED_TORGB_MAX = 32      # colours (module constant; tools flip it to 4 for A/B runs: only the super-resolution's toRGB layers fuse then)
+FUSED_TORGB_MID = True     # ... also in blocks whose x feeds the next block (split8 side output from the same epilogue); False: last blocks only (A/B)
 DIRECT_SPLIT8 = True       # 1x1 layers write split8 for their sole 3x3 consumer (conv2d_layer)
 UP_PS_NCHW = True          # few-position up-sampling layers on the pre-split transposed kernel writing NCHW (networks._Block._ps_nchw)
 NCHW_FIR_SPLIT8 = True     # up-sampling layers on the register-staged transposed kernel: their FIR writes split8 for conv1 (synthesis_layer)

@@ -80,7 +80,7 @@ class _Block:
             # x's only readers are this block's toRGB (<= 4 colours) and, unless `last`, the next block's transposed convolution on split8 input:
             # conv1 evaluates the toRGB in its epilogue and writes that operand image itself — x is never written in float32 (layers.fused_torgb_ok)
             nb_split8 = next_block is not None and self.conv1.out_channels % 8 == 0 and next_block.takes_split8(n, (n, self.conv1.out_channels, x.shape[2], x.shape[3]), fir, noise_mode)
-            if (last or nb_split8) and x_out is None and L.fused_torgb_ok(self.conv1, self.torgb, x, noise_mode):
+            if (last or (nb_split8 and (L.FUSED_TORGB_MID or self.torgb.out_channels <= 4))) and x_out is None and L.fused_torgb_ok(self.conv1, self.torgb, x, noise_mode):
                 t = self.torgb
                 part = L.synthesis_layer(self.conv1, x, None, fir, noise_mode=noise_mode, conv_clamp=self.conv_clamp,
                                          rgb=(t.weight.reshape(t.out_channels, t.in_channels), bank[t.prefix][0]),
