@@ -96,6 +96,7 @@ def _gpu_views(dev, v, lms, faces, face_uv, mask, size, fill, binarize_view):
                                               _lib.ptr(lm2d), N, V, Lm, Fn, nv, size, size, sh[0], sh[1], sh[2], float(ogen.ORTH_SCALE.item()),
                                               1 if fill else 0, binarize_view, _lib.stream()))
     torch.cuda.synchronize()
+    _gpu_views.tv = tv.reshape(N, nv, V, 3).cpu()                       # the transformed vertices the z-buffer pass read (PyTorch3D NDC: x, y negated)
     return grid.reshape(N, nv, size, size, 2).cpu(), alpha.cpu(), lm2d.cpu()
 
 
@@ -103,7 +104,8 @@ def _gpu_views(dev, v, lms, faces, face_uv, mask, size, fill, binarize_view):
 def test_rasterize_views_triangle_soup(dev, size):
     """Coverage, z order, tie rule and barycentric uv of random overlapping triangles against oracle/raster_ref.c.  The
     vertex transform is evaluated in a different order on the two sides, so a pixel whose centre sits within rounding of an
-    edge (or of two equally deep faces) may resolve differently: at most 0.1 % of the pixels may disagree."""
+    edge (or of two equally deep faces) may resolve differently: at most 0.1 % of the pixels may disagree end to end.  The second half of the test removes
+    that slack: the transforms agree to 4e-7 relative, and the oracle rasterising the kernel's own transformed vertices agrees at EVERY pixel, bit for bit."""
     v0, faces, uv = _soup(11 + size)
     v = torch.cat([v0, v0.flip(1) * 0.9], 0)                                       # batch of 2 different meshes
     lms = _rand((2, 68, 3), 5, -0.1, 0.1)
@@ -121,6 +123,21 @@ def test_rasterize_views_triangle_soup(dev, size):
     assert cov_bad <= 1e-3 and uv_bad <= 1e-3
     assert float((a - a_ref).abs()[same].max()) <= 1e-4
     assert _md(l, l_ref) <= 1e-6
+    # ... and STRICTLY: the two sides' vertex transforms agree to rounding (ATen's bmm vs the kernel's fixed-order sum), and with the
+    # oracle rasterising the kernel's OWN transformed vertices every pixel agrees — coverage, winning face and barycentric uv bit for bit
+    tv = _gpu_views.tv
+    N = v.shape[0]
+    for k, view in enumerate(VIEWS):
+        t_or = raster.orth_project(v, raster.angle2matrix(view), ogen.ORTH_SHIFT, ogen.ORTH_SCALE)
+        t_or[:, :, 2] = t_or[:, :, 2] + 10
+        back = tv[:, k].clone()
+        back[..., :2] = -back[..., :2]                                              # undo Pytorch3dRasterizer.forward's sign flip (exact)
+        assert float((back - t_or).abs().max()) <= 4e-7 * max(1.0, float(t_or.abs().max()))
+        rendering = raster.pytorch3d_rasterizer(back, faces, uv, size)
+        grid_k = rendering[:, :-1].permute(0, 2, 3, 1)[:, :, :, :2]
+        alpha_k = (F.grid_sample(mask[None, None].expand(N, -1, -1, -1), grid_k, align_corners=False) * rendering[:, -1:])[:, 0]
+        assert torch.equal(g[:, k], grid_k), (size, k, int((g[:, k] != grid_k).sum()))
+        assert torch.equal(a[:, k] > 0, alpha_k > 0) and float((a[:, k] - alpha_k).abs().max()) <= 1e-6
 
 
 def test_rasterize_views_tie_rule_and_empty_batch(dev):
