@@ -86,8 +86,12 @@ class TriPlaneGenerator(_Tracked):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path, sr_num_fp16_res=0,
                  mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={}, uv_face_mask=None, **synthesis_kwargs):
         super().__init__()
-        if (z_dim, c_dim, w_dim, img_resolution, img_channels) != (512, 25, 512, 512, 3):
-            raise RuntimeError('this build implements the next3d_ffhq_512 configuration (z=w=512, c=25, 512x512x3)')
+        # the super-resolution module decides the output resolution (tat/triplane_next3d.py:66: construct_class_by_name(superresolution_module, img_resolution=...);
+        # every module asserts its own img_resolution): 8XDC (ffhq-512) / 8X -> 512, 4X -> 256, 2X -> 128 (spec.SR_MODULES)
+        self.sr_class, (sr_res, _, _, _, _) = spec.sr_module(rendering_kwargs.get('superresolution_module'))
+        if (z_dim, c_dim, w_dim, img_channels) != (512, 25, 512, 3) or img_resolution != sr_res:
+            raise RuntimeError(f'this build implements the next3d configuration z = w = 512, c = 25, 3 colours at the resolution of the super-resolution module '
+                               f'({self.sr_class}: {sr_res} x {sr_res}); got z={z_dim} c={c_dim} w={w_dim} {img_resolution}x{img_resolution}x{img_channels}')
         if mapping_kwargs.get('num_layers', 2) != 2:
             raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
         if synthesis_kwargs.get('channel_base', 32768) != 32768 or synthesis_kwargs.get('channel_max', 512) != 512:
@@ -115,7 +119,7 @@ class TriPlaneGenerator(_Tracked):
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
-        for name, (shape, kind) in spec.build_spec().items():
+        for name, (shape, kind) in spec.build_spec(self.sr_class).items():
             leaf = name.rsplit('.', 1)[-1]
             if kind == 'mesh':
                 t = mb[name]
@@ -141,15 +145,12 @@ class TriPlaneGenerator(_Tracked):
             if hasattr(node, 'mapping'):
                 node.mapping.num_ws = 28 if net == 'backbone' else 14
                 node.mapping.z_dim, node.mapping.c_dim, node.mapping.w_dim, node.mapping.num_layers = z_dim, c_dim, w_dim, 2
-        self.superresolution.input_resolution = 128
+        self.superresolution.input_resolution = spec.SR_MODULES[self.sr_class][1]
 
         if uv_face_mask is None:      # reference: cv2.imread('data/ffhq/uv_face_eye_mask.png') (triplane_next3d.py:91)
             uv_face_mask = self._load_uv_mask('data/ffhq/uv_face_eye_mask.png')
         self.uv_face_mask = torch.nn.functional.interpolate(uv_face_mask.float(), [256, 256])
         # super-resolution settings the reference derives in its constructors (superresolution.py:264-278, triplane_next3d.py:181-183)
-        sr_module = rendering_kwargs.get('superresolution_module', 'training_avatar_texture.superresolution.SuperresolutionHybrid8XDC')
-        if not str(sr_module).endswith('SuperresolutionHybrid8XDC'):
-            raise RuntimeError(f'superresolution_module {sr_module!r}: only SuperresolutionHybrid8XDC (512x512) is implemented')
         self.sr_conv_clamp = 256 if sr_num_fp16_res > 0 else None        # (256 if use_fp16 else None); kept under force_fp32
         self.sr_use_fp16 = sr_num_fp16_res > 0                           # superresolution.py:269: the SR blocks run in fp16 unless force_fp32
         self._drop_derived()
@@ -244,7 +245,7 @@ class TriPlaneGenerator(_Tracked):
         S.static = networks.SynthesisNet(P, 'backbone.synthesis', **bk)
         S.mouth = networks.StyleUNet(P, 'mouth_backbone.synthesis', in_size=64, final_size=4, num_cond_res=64, **bk)
         S.blend = networks.StyleUNet(P, 'neural_blending.synthesis', in_size=256, final_size=32, num_cond_res=256, **bk)
-        S.sr = networks.SuperRes8XDC(P, 'superresolution', conv_clamp=self.sr_conv_clamp)
+        S.sr = networks.SuperRes8XDC(P, 'superresolution', conv_clamp=self.sr_conv_clamp, sr_class=self.sr_class)
         # every style affine and demodulation coefficient of the five networks in TWO launches per forward (layers.StyleBank over the
         # full [N, 28, 512] latents: the texture backbone reads slots 14-27, the others 0-13, the super-resolution slot 13)
         nw = S.texture.num_ws

@@ -307,13 +307,33 @@ class StyleUNet:
         return img
 
 
+class _BlockNoUp(_Block):
+    """SynthesisBlockNoUp (tat/superresolution.py:158-254: the first block of SuperresolutionHybrid4X / 2X): conv0 WITHOUT up-sampling, conv1, toRGB; the skip
+    image is added as it is (the upsample2d of SynthesisBlock.forward is commented out there, :244-246).  Plain layer calls: these two modules are outside the
+    benchmarked configuration, what matters is that the reference's architectures run and match."""
+
+    def takes_split8(self, n, xshape, fir, noise_mode):
+        return False
+
+    def __call__(self, x, img, bank, n, fir, noise_mode, x_out=None, x_split8=None, next_block=None, last=False):
+        sl = lambda layer: dict(zip(('styles', 'dcoef'), bank[layer.prefix]))
+        x = L.synthesis_layer(self.conv0, x, None, fir, up=1, noise_mode=noise_mode, conv_clamp=self.conv_clamp, **sl(self.conv0))
+        x = L.synthesis_layer(self.conv1, x, None, fir, up=1, noise_mode=noise_mode, conv_clamp=self.conv_clamp, out=x_out, **sl(self.conv1))
+        img = L.torgb_layer(self.torgb, x, None, conv_clamp=self.conv_clamp, residual=img, styles=bank[self.torgb.prefix][0])
+        return x, img, None
+
+
 class SuperRes8XDC:
-    def __init__(self, P, prefix, conv_clamp=256):
+    """The reference's super-resolution modules (tat/superresolution.py; spec.SR_MODULES): SuperresolutionHybrid8XDC — the ffhq-512 configuration, the class
+    name this one keeps — and, round 5, SuperresolutionHybrid8X (other channel counts), 4X and 2X (a SynthesisBlockNoUp first, 256 x 256 / 128 x 128 output)."""
+
+    def __init__(self, P, prefix, conv_clamp=256, sr_class=S.DEFAULT_SR):
         """conv_clamp: 256 when the model was built with sr_num_fp16_res > 0, else None (superresolution.py:273-278)."""
-        self.block0 = _Block(P, f'{prefix}.block0', 32, conv_clamp=conv_clamp)
-        self.block1 = _Block(P, f'{prefix}.block1', 256, conv_clamp=conv_clamp)
+        _, self.input_resolution, self.resize_rule, blocks, _ = S.SR_MODULES[sr_class]
+        mk = lambda bi: (_Block if blocks[bi][0] == 'up' else _BlockNoUp)(P, f'{prefix}.block{bi}', blocks[bi][1], conv_clamp=conv_clamp)
+        self.block0, self.block1 = mk(0), mk(1)
+        self.all_up = all(b[0] == 'up' for b in blocks)
         self.fir = P[f'{prefix}.block0.resample_filter']
-        self.input_resolution = 128
         self._banks = {}
         uf.fir_factor(self.fir)
 
@@ -323,7 +343,7 @@ class SuperRes8XDC:
         a one-time warning, never an error: the reference's default `synthesis(ws, c, v)` call must run."""
         import warnings
         h = x.shape[2]
-        ok = (noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and
+        ok = (self.all_up and noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and      # (a SynthesisBlockNoUp has no float16 form here: 4X / 2X run in float32)
               all(L.f16_layer_ok(b.conv0, hh, hh, 2) and L.f16_layer_ok(b.conv1, 2 * hh, 2 * hh, 1) and b.torgb.in_channels <= 512
                   for b, hh in ((self.block0, h), (self.block1, 2 * h))))
         if not ok and not getattr(self, '_warned32', False):
@@ -366,7 +386,7 @@ class SuperRes8XDC:
             if last not in self._banks:
                 self._banks[last] = L.StyleBank(self.bank_entries(last), self.fir.device)
             bank = self._banks[last].compute(ws)
-        if x.shape[-1] != self.input_resolution:
+        if (x.shape[-1] != self.input_resolution) if self.resize_rule == 'ne' else (x.shape[-1] < self.input_resolution):     # (4X resizes only a SMALLER render, :82)
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
         if fp16 and self._f16_ok(x, noise_mode):

@@ -98,8 +98,29 @@ def _styleunet(spec, p, img_channels, cond_channels, in_size, final_size):
         _conv2d_layer(spec, f'{p}.fusion.{i}', nc * 2 if res > final_size else nc, nc, 3)
 
 
-def build_spec():
-    """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator."""
+# The reference's super-resolution modules (tat/superresolution.py): class name -> (img_resolution, input_resolution, resize rule of forward —
+# 'ne': resize when the render differs from input_resolution (:48,127,282), 'lt': only when it is smaller (4X, :82) —,
+# [(block kind, in channels, out channels, block resolution)]: 'up' = SynthesisBlock, 'noup' = SynthesisBlockNoUp (:158), module-level resample_filter buffer?)
+SR_MODULES = {
+    'SuperresolutionHybrid8XDC': (512, 128, 'ne', [('up', 32, 256, 256), ('up', 256, 128, 512)], False),     # :264-290 (next3d_ffhq_512)
+    'SuperresolutionHybrid8X': (512, 128, 'ne', [('up', 32, 128, 256), ('up', 128, 64, 512)], True),          # :29-58
+    'SuperresolutionHybrid4X': (256, 128, 'lt', [('noup', 32, 128, 128), ('up', 128, 64, 256)], True),        # :62-91
+    'SuperresolutionHybrid2X': (128, 64, 'ne', [('noup', 32, 128, 64), ('up', 128, 64, 128)], True),          # :95-124
+}
+DEFAULT_SR = 'SuperresolutionHybrid8XDC'
+
+
+def sr_module(name):
+    """`rendering_kwargs['superresolution_module']` (a dotted class path) -> (class name, SR_MODULES entry); RuntimeError for anything else
+    (SuperresolutionHybridDeepfp32 / 2XDC ...: not implemented)."""
+    cls = str(name or DEFAULT_SR).rsplit('.', 1)[-1]
+    if cls not in SR_MODULES:
+        raise RuntimeError(f'superresolution_module {name!r}: implemented are ' + ', '.join(SR_MODULES))
+    return cls, SR_MODULES[cls]
+
+
+def build_spec(sr=DEFAULT_SR):
+    """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator (`sr`: the super-resolution class, SR_MODULES)."""
     spec = OrderedDict()
     # texture_backbone: StyleGAN2 256², 32 ch (triplane_next3d.py:63)
     _synthesis(spec, 'texture_backbone.synthesis', 32)
@@ -110,15 +131,15 @@ def build_spec():
     # backbone: StyleGAN2 256², 96 ch, mapping broadcasts to 28 ws (:65)
     _synthesis(spec, 'backbone.synthesis', 96)
     _mapping(spec, 'backbone.mapping', 28)
-    # superresolution: SuperresolutionHybrid8XDC (superresolution.py:264-277)
-    spec['superresolution.block0.resample_filter'] = ((4, 4), 'fir')
-    _synth_layer(spec, 'superresolution.block0.conv0', 32, 256, 256)
-    _synth_layer(spec, 'superresolution.block0.conv1', 256, 256, 256)
-    _torgb(spec, 'superresolution.block0.torgb', 256, 3)
-    spec['superresolution.block1.resample_filter'] = ((4, 4), 'fir')
-    _synth_layer(spec, 'superresolution.block1.conv0', 256, 128, 512)
-    _synth_layer(spec, 'superresolution.block1.conv1', 128, 128, 512)
-    _torgb(spec, 'superresolution.block1.torgb', 128, 3)
+    # superresolution (superresolution.py:29-124, :264-277): two blocks, every layer a SynthesisLayer of the block's resolution, toRGB to 3 colours
+    _, (_, _, _, sr_blocks, sr_filter) = sr_module(sr)
+    for bi, (_, ic, oc, res) in enumerate(sr_blocks):
+        spec[f'superresolution.block{bi}.resample_filter'] = ((4, 4), 'fir')
+        _synth_layer(spec, f'superresolution.block{bi}.conv0', ic, oc, res)
+        _synth_layer(spec, f'superresolution.block{bi}.conv1', oc, oc, res)
+        _torgb(spec, f'superresolution.block{bi}.torgb', oc, 3)
+    if sr_filter:
+        spec['superresolution.resample_filter'] = ((4, 4), 'fir')
     # decoder: OSGDecoder (triplane_next3d.py:353-357)
     spec['decoder.net.0.weight'] = ((64, 32), 'randn')
     spec['decoder.net.0.bias'] = ((64,), 'bias')
@@ -149,7 +170,7 @@ def _seed_for(name, seed):
 _WIDE_STYLE, _WIDE_TORGB = 3.0, 1.0 / 3.0
 
 
-def synthetic_state_dict(seed=0, only=None, profile='unit'):
+def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR):
     """Seeded synthetic weights (CPU fp32).  Distributions follow the reference initialisers
     (randn weights, affine bias 1) except that biases, noise_strength and w_avg — zero at init in
     the reference — get small seeded non-zero values so those code paths are exercised
@@ -164,7 +185,7 @@ def synthetic_state_dict(seed=0, only=None, profile='unit'):
         raise ValueError(profile)
     wide = profile == 'wide'
     out = OrderedDict()
-    for name, (shape, kind) in build_spec().items():
+    for name, (shape, kind) in build_spec(sr).items():
         if kind == 'mesh' or (only is not None and not only(name)):
             continue
         if kind == 'fir':

@@ -226,18 +226,38 @@ def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, fin
     return img
 
 
-def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False):
-    """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward), noise_mode='none'; fp32 path (what the reference
-    runs off-GPU and what the goldens pin) or, with force_fp32=False, its fp16 blocks emulated (synthesis_block_fp16).
-    conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275)."""
+def synthesis_block_noup(P, prefix, x, img, ws, noise_mode='const', conv_clamp=None):
+    """tat/superresolution.py:210-254 (SynthesisBlockNoUp.forward, 'skip' architecture, fp32): conv0 without up-sampling, conv1, toRGB; the skip
+    image is added WITHOUT upsample2d (the two lines are commented out in the reference, :244-246)."""
+    w0, w1, w2 = ws.unbind(dim=1)
+    x = synthesis_layer(P, f'{prefix}.conv0', x, w0, noise_mode=noise_mode, conv_clamp=conv_clamp)
+    x = synthesis_layer(P, f'{prefix}.conv1', x, w1, noise_mode=noise_mode, conv_clamp=conv_clamp)
+    y = torgb_layer(P, f'{prefix}.torgb', x, w2, conv_clamp=conv_clamp)
+    return x, (img + y if img is not None else y)
+
+
+# class name -> (input_resolution, resize rule, first block is a SynthesisBlockNoUp) — tat/superresolution.py:29-124, :264-290
+_SR = {'SuperresolutionHybrid8XDC': (128, 'ne', False), 'SuperresolutionHybrid8X': (128, 'ne', False),
+       'SuperresolutionHybrid4X': (128, 'lt', True), 'SuperresolutionHybrid2X': (64, 'ne', True)}
+
+
+def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False, sr_class='SuperresolutionHybrid8XDC'):
+    """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward; :46-58 8X, :79-91 4X, :113-124 2X), noise_mode='none'; fp32 path (what the
+    reference runs off-GPU and what the goldens pin) or, with force_fp32=False (8XDC / 8X), its fp16 blocks emulated (synthesis_block_fp16).
+    conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275).  Channel counts come from the parameters' shapes."""
     ws = ws[:, -1:, :].repeat(1, 3, 1)
-    if x.shape[-1] != 128:
-        x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
-        rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
+    res_in, rule, noup = _SR[sr_class]
+    if (x.shape[-1] != res_in) if rule == 'ne' else (x.shape[-1] < res_in):
+        x = F.interpolate(x, size=(res_in, res_in), mode='bilinear', align_corners=False, antialias=True)
+        rgb = F.interpolate(rgb, size=(res_in, res_in), mode='bilinear', align_corners=False, antialias=True)
     if not force_fp32:      # the reference's default on a GPU (use_fp16 = sr_num_fp16_res > 0): emulated float16 storage
+        assert not noup, 'float16 emulation of SynthesisBlockNoUp is not restated'
         x, rgb = synthesis_block_fp16(P, f'{prefix}.block0', x, rgb, ws, cpu_rounding=cpu_rounding)
         x, rgb = synthesis_block_fp16(P, f'{prefix}.block1', x, rgb, ws, cpu_rounding=cpu_rounding)
         return rgb
-    x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, 32, noise_mode='none', conv_clamp=256)
-    x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, 256, noise_mode='none', conv_clamp=256)
+    if noup:
+        x, rgb = synthesis_block_noup(P, f'{prefix}.block0', x, rgb, ws, noise_mode='none', conv_clamp=256)
+    else:
+        x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, P[f'{prefix}.block0.conv0.weight'].shape[1], noise_mode='none', conv_clamp=256)
+    x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, P[f'{prefix}.block1.conv0.weight'].shape[1], noise_mode='none', conv_clamp=256)
     return rgb

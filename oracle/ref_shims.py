@@ -112,8 +112,9 @@ def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.ob
     from training_avatar_texture.triplane_next3d import TriPlaneGenerator
     rk = dict(rendering_kwargs)
     rk.setdefault('superresolution_module', 'training_avatar_texture.superresolution.SuperresolutionHybrid8XDC')
+    img_resolution = {'8XDC': 512, '8X': 512, '4X': 256, '2X': 128}[rk['superresolution_module'].rsplit('Hybrid', 1)[-1]]      # every module asserts its own
     G = TriPlaneGenerator(
-        z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, topology_path=topology_path,
+        z_dim=512, c_dim=25, w_dim=512, img_resolution=img_resolution, img_channels=3, topology_path=topology_path,
         sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
         sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
         channel_base=32768, channel_max=512, fused_modconv_default='inference_only', num_fp16_res=num_fp16_res,

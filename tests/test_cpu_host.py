@@ -43,9 +43,17 @@ def test_generator_module_state_dict_names():
     topo = (d['faces'], d['uvs'], d['uvfaces'])
     with pytest.raises(RuntimeError, match='uv_face_eye_mask.png not found'):     # as the reference (cv2.imread -> None -> crash): no silent stand-in
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS))
-    with pytest.raises(RuntimeError, match='superresolution_module'):
+    with pytest.raises(RuntimeError, match='superresolution_module'):            # a module this build does not implement
+        TriPlaneGenerator(512, 25, 512, 256, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
+                          rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybridDeepfp32'))
+    with pytest.raises(RuntimeError, match='256 x 256'):                          # every module has its own output resolution (the reference's modules assert it)
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
                           rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybrid4X'))
+    for cls, res in (('SuperresolutionHybrid8X', 512), ('SuperresolutionHybrid4X', 256), ('SuperresolutionHybrid2X', 128)):      # round 5: the other modules
+        g = TriPlaneGenerator(512, 25, 512, res, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
+                              rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.' + cls))
+        assert set(g.state_dict()) == set(spec.build_spec(cls)) and 'superresolution.resample_filter' in g.state_dict()
+        assert tuple(g.state_dict()['superresolution.block1.conv1.weight'].shape) == (64, 64, 3, 3)
     G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask())
     assert G.sr_conv_clamp is None                                           # sr_num_fp16_res == 0 -> no clamp (superresolution.py:273)
     assert set(G.state_dict()) == set(spec.build_spec())
