@@ -638,9 +638,9 @@ class TriPlaneGenerator(_Tracked):
         gen_samples_next3d.py:208-246) -> {'rgb' [N,M,32], 'sigma' [N,M,1]}.  `directions` is accepted and ignored exactly as
         OSGDecoder ignores it (:359).  The reference rebuilds all planes for every chunk of points; `cache_backbone` /
         `use_cached_backbone` (same flags as `synthesis`) keep them across calls."""
-        noise_mode = synthesis_kwargs.get('noise_mode', 'random')
-        if noise_mode == 'random':
-            raise RuntimeError("noise_mode='random' is the training default; the inference scripts pass noise_mode='const'")
+        noise_mode = synthesis_kwargs.get('noise_mode', 'random')       # the reference's default (networks_stylegan2.py:311): per-sample noise draws, as in `synthesis`
+        if noise_mode not in ('random', 'const', 'none'):
+            raise RuntimeError(f'noise_mode {noise_mode!r}: random / const / none')
         self._check_params()
         S = self._prep()
         ws = ws.to(device=self.device, dtype=torch.float32)

@@ -63,6 +63,9 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     smp = G.sample_mixed(pts, None, ws, v, noise_mode='const', use_cached_backbone=True)
     assert tuple(smp['rgb'].shape) == (N, 1000, 32) and tuple(smp['sigma'].shape) == (N, 1000, 1) and dry == ['n3d_sample_points']
     dry.clear()
+    smp = G.sample_mixed(pts, None, ws, v)                        # noise_mode defaults to 'random' as in the reference (triplane_next3d.py:278 -> :311): runs, rebuilding the planes
+    assert tuple(smp['sigma'].shape) == (N, 1000, 1) and dry[-1] == 'n3d_sample_points' and len(dry) > 100
+    dry.clear()
     G.synthesis(ws, c, v, neural_rendering_resolution=R)         # noise_mode defaults to 'random' (the reference's default,
     rnd = Counter(dry)                                           # networks_stylegan2.py:311): noisy layers run sample by sample
     # the default call runs the float16 super-resolution blocks on the f16 kernels: 10 launches (cast to h8, one weight
