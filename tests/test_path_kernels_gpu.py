@@ -334,6 +334,13 @@ def test_unpack_inputs(dev):
     verts, lms, cam, intr = torch.empty(N, V, 3, **f32), torch.empty(N, Lm, 3, **f32), torch.empty(N, 16, **f32), torch.empty(N, 9, **f32)
     _lib.check(_lib.lib().n3d_unpack_inputs(_lib.ptr(v), v.stride(0), _lib.ptr(c), c.stride(0), _lib.ptr(verts), _lib.ptr(lms), _lib.ptr(cam), _lib.ptr(intr), N, V, Lm, _lib.stream()))
     assert torch.equal(verts, v[:, :V]) and torch.equal(lms, v[:, V:]) and torch.equal(cam, c[:, :16]) and torch.equal(intr, c[:, 16:25])
+    # empty batch: a no-op (return code 0, nothing dereferenced); null tensors with N > 0: an error code + message, no launch
+    L = _lib.lib()
+    assert L.n3d_unpack_inputs(None, 0, None, 0, None, None, None, None, 0, V, Lm, _lib.stream()) == 0
+    assert L.n3d_unpack_inputs(None, 0, _lib.ptr(c), 25, _lib.ptr(verts), _lib.ptr(lms), _lib.ptr(cam), _lib.ptr(intr), 1, V, Lm, _lib.stream()) != 0
+    assert b'null tensor' in L.n3d_last_error()
+    assert L.n3d_layout_grid_u8(None, None, 0, 3, 8, 8, 1, 1, 1, _lib.stream()) != 0          # 0 frames do not fill a 1 x 1 grid
+    assert L.n3d_blend_planes_views(None, None, None, None, None, None, 0, 8, 8, 4, 0, 1, 3, _lib.stream()) == 0
 
 
 def _decoder(seed):
