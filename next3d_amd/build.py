@@ -58,6 +58,10 @@ def build(force=False, verbose=True):
         # a library that links but cannot be loaded (hipcc's host pass silently drops the launch stub of some __global__ templates:
         # an undefined __device_stub__ symbol) must fail HERE, on the build machine, not on the GPU box
         import ctypes
+        try:
+            import torch                               # noqa: F401  (torch's HIP runtime first: see __graft_entry__.build)
+        except ImportError:
+            pass
         ctypes.CDLL(LIB)
     return LIB
 
