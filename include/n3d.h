@@ -458,6 +458,10 @@ int n3d_mouth_bbox(const float* lm2d, int* bbox, int N, int Lm, n3d_stream_t str
  * s = y1-y0, as the reference's paste at :161).  NULL box = whole tensor. */
 int n3d_resize_aa(const float* src, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW,
                   int DH, int DW, int dst_square, n3d_stream_t stream);
+/* ... with an explicit batch stride of `src` in floats (0 = dense): a channel-slice view — the first 3 of the renderer's 32 feature channels as the RGB input of the
+ * super-resolution module, tat/triplane_next3d.py:179-181 — is resized without a copy. */
+int n3d_resize_aa_strided(const float* src, int64_t src_batch_stride, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW,
+                          int DH, int DW, int dst_square, n3d_stream_t stream);
 
 #ifdef __cplusplus
 }

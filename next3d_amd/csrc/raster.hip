@@ -460,6 +460,7 @@ struct ResizeParams {
     const int* src_box; const int* dst_box;      // [N,4] device ints or NULL (= full tensor)
     int N, C, SH, SW, DH, DW;
     int dst_square;                              // paste mode: destination box is (y0, y0+s, x0, x0+s), s = y1-y0
+    int64_t src_bs;                              // floats between consecutive samples of src (C * SH * SW when dense): a channel-slice view needs no copy
 };
 
 __device__ __forceinline__ float tri_filter(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
     float cyc, cxc, yinv, xinv, ytot, xtot;
     aa_range(ry, sh, oh, ymin, ysize, cyc, yinv, ytot);
     aa_range(rx, sw, ow, xmin, xsize, cxc, xinv, xtot);
-    const float* s = p.src + ((int64_t)n * p.C + c) * p.SH * p.SW;
+    const float* s = p.src + (int64_t)n * p.src_bs + (int64_t)c * p.SH * p.SW;
     float acc = 0.f;
     constexpr int MAXT = 16;
     if (xsize <= MAXT) {            // the horizontal weights do not depend on the row: compute (and divide) them once
@@ -721,15 +722,23 @@ int n3d_mouth_bbox(const float* lm2d, int* bbox, int N, int Lm, n3d_stream_t str
     return 0;
 }
 
+int n3d_resize_aa_strided(const float* src, int64_t src_batch_stride, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW, int DH,
+                          int DW, int dst_square, n3d_stream_t stream_);
 int n3d_resize_aa(const float* src, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW, int DH,
                   int DW, int dst_square, n3d_stream_t stream_) {
+    return n3d_resize_aa_strided(src, 0, dst, src_box, dst_box, N, C, SH, SW, DH, DW, dst_square, stream_);
+}
+int n3d_resize_aa_strided(const float* src, int64_t src_batch_stride, float* dst, const int* src_box, const int* dst_box, int N, int C, int SH, int SW, int DH,
+                          int DW, int dst_square, n3d_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(src_batch_stride == 0 || src_batch_stride >= (int64_t)C * SH * SW, "resize_aa: source batch stride smaller than one sample");
     N3D_CHECK(N >= 0 && C > 0 && SH > 0 && SW > 0 && DH > 0 && DW > 0, "resize_aa: bad shape");
     if (N == 0) return 0;
     N3D_CHECK(src && dst, "resize_aa: null tensor");
     ResizeParams p;
     p.src = src; p.dst = dst; p.src_box = src_box; p.dst_box = dst_box; p.N = N; p.C = C; p.SH = SH; p.SW = SW; p.DH = DH; p.DW = DW;
     p.dst_square = dst_square;
+    p.src_bs = src_batch_stride ? src_batch_stride : (int64_t)C * SH * SW;
     N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * N * C * ((double)SH * SW + (double)DH * DW));
     hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)cdiv64((int64_t)N * C * DH * DW, 256)), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();

@@ -558,7 +558,7 @@ class TriPlaneGenerator(_Tracked):
         # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is
         # the float32 path its CPU run takes (networks_stylegan2.py:548) and the one the golden fixtures pin
         sr_fp16 = self.sr_use_fp16 and not synthesis_kwargs.get('force_fp32', False)
-        sr_image = S.sr(rgb_image.contiguous(), feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16, bank=bank)
+        sr_image = S.sr(rgb_image, feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16, bank=bank)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
     # ------------------------------------------------------------------ HIP-graph replay of the steady-state loops
@@ -714,6 +714,7 @@ def _resize_aa(x, size):
     """F.interpolate(x, (size,size), mode='bilinear', align_corners=False, antialias=True) on libn3d.so."""
     n, c, h, w = x.shape
     y = torch.empty(n, c, size, size, dtype=torch.float32, device=x.device)
-    x = x.contiguous()
-    _lib.check(_lib.lib().n3d_resize_aa(_lib.ptr(x), _lib.ptr(y), None, None, n, c, h, w, size, size, 0, _lib.stream()))
+    if x.stride()[1:] != (h * w, w, 1) or x.stride(0) < c * h * w:        # dense planes with any batch stride (a channel-slice view) need no copy
+        x = x.contiguous()
+    _lib.check(_lib.lib().n3d_resize_aa_strided(_lib.ptr(x), x.stride(0), _lib.ptr(y), None, None, n, c, h, w, size, size, 0, _lib.stream()))
     return y

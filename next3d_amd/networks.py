@@ -389,6 +389,8 @@ class SuperRes8XDC:
         if (x.shape[-1] != self.input_resolution) if self.resize_rule == 'ne' else (x.shape[-1] < self.input_resolution):     # (4X resizes only a SMALLER render, :82)
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
+        if not rgb.is_contiguous():                                  # (no resize: the caller's channel-slice view of the feature image)
+            rgb = rgb.contiguous()
         if fp16 and self._f16_ok(x, noise_mode):
             return self._forward_f16(x, rgb, bank, noise_mode)
         x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, next_block=self.block1)

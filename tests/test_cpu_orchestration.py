@@ -42,7 +42,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert tuple(out['image_depth'].shape) == (N, 1, R, R)
     assert full['n3d_conv2d_prep_weight'] == 0 and full['n3d_conv2d_prep_weight_bf16x3'] == 0      # prepared once per model
     assert full['n3d_rasterize_views'] == 1 and full['n3d_render_rays_ex'] == 1 and full['n3d_texture_project_planes'] == 1
-    assert full['n3d_resize_aa'] == (2 if R == 128 else 4)       # mouth crop + paste (+ feature / rgb resize unless R == 128)
+    assert full['n3d_resize_aa'] == 2 and full['n3d_resize_aa_strided'] == (0 if R == 128 else 2)       # mouth crop + paste (+ feature / rgb resize unless R == 128: rgb is a channel-slice view, no copy)
     n_full = sum(full.values())
     # the launch count does not depend on the batch: one launch per layer, whatever N — plus the split8 conversion passes of
     # the pre-split path, whose number follows the layers' eligibility (n3d_conv2d_split8_eligible: batch and size dependent)

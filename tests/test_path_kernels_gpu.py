@@ -273,6 +273,21 @@ def test_resize_aa_matches_aten(dev, shape, out):
     assert _md(y, ref) <= 5e-6
 
 
+def test_resize_aa_strided_channel_slice(dev):
+    """n3d_resize_aa_strided: a channel-slice view (the first 3 of the renderer's 32 feature channels = the super-resolution's RGB input,
+    triplane_next3d.py:179-181) resized straight from the 32-channel tensor — bit-equal to the resize of its contiguous copy."""
+    from next3d_amd import _lib, generator
+    feat = _gen((3, 32, 64, 64), 45).to(dev)
+    rgb = feat[:, :3]
+    assert not rgb.is_contiguous()
+    y = generator._resize_aa(rgb, 128)
+    y_ref = generator._resize_aa(rgb.contiguous(), 128)
+    assert torch.equal(y, y_ref)
+    assert _md(y, F.interpolate(rgb.cpu(), size=(128, 128), mode='bilinear', align_corners=False, antialias=True)) <= 5e-6
+    p = _lib.ptr(feat)
+    assert _lib.lib().n3d_resize_aa_strided(p, 100, p, None, None, 1, 3, 64, 64, 8, 8, 0, _lib.stream()) != 0       # batch stride smaller than one sample
+
+
 def test_resize_aa_crop_and_paste_boxes(dev):
     """The mouth crop (triplane_next3d.py:151-152: per-sample box -> 64²) and the paste back (:156-163: 256² -> s×s into the
     box, everything else untouched), boxes of different sizes per sample."""
