@@ -46,7 +46,7 @@ sys.path.insert(0, REPO)
 PEAK_L2_TBPS = 34.5                 # aggregate L2 bandwidth, /opt/skills/guides/MI355X_MICROARCH.md (L2 per XCD)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
-TRAFFIC_PROFILE = os.path.join(REPO, "profiles", "r04_traffic_pmc.json")
+TRAFFIC_PROFILE = os.path.join(REPO, "profiles", "r05_traffic_pmc.json")
 CPU_REFERENCE_PROFILE = os.path.join(REPO, 'profiles', 'r03_cpu_reference.json')
 # what the bf16 matrix pipe sustains with the kernels' instruction mix and RANDOM operands (tools/mfma_peak.hip, profiles/r02_mfma_peak_probe.txt:
 # 1850-1950 TFLOP/s bf16 = 617-650 fp32-equivalent; the chip power-limits to ~1.8 GHz under this load)

@@ -5,8 +5,8 @@ Usage: traffic_summary.py fetch.db write.db out.json [calib_fetch.db calib_write
 (MI355X_MICROARCH.md §HBM: separate passes; FETCH_SIZE / WRITE_SIZE come in KiB; gfx950 FETCH_SIZE under-reports wide reads)"""
 import collections, json, re, sqlite3, sys
 
-FAMILY = re.compile(r'^(void )?conv2d(_up|_up_sk|_s2|_p|_ps|_ps1|_ps2|_ps1_rgb|_ps2_rgb|_ps2_rgbs|_sk|_up_ps|_up_ps32|_up_ps32w|_s2_ps)?_bf16x3(_pair)?_kernel')      # every 3x3 split-bf16 kernel (not conv1x1 / split-K reduce)
-LAUNCHES_PER_STEP = 67          # bench.py configs[1], force_fp32 route (roofline.launches_per_step); 60 with N3D_PAIR_BACKBONES=1 (7 layer pairs as one launch each)
+FAMILY = re.compile(r'^(void )?conv2d(_[a-z0-9_]+)?_bf16x3(_pair)?_kernel')      # every 3x3 split-bf16 kernel, whatever its variant suffix (not conv1x1_* / conv16_splitk_* / rgb_combine)
+LAUNCHES_PER_STEP = 69          # bench.py configs[1], force_fp32 route (roofline.launches_per_step): 67 until round 4, + the two few-pixel stride-2 layers that were fp32-MFMA launches
 CALIB_BYTES = float(1 << 30)
 
 
@@ -27,7 +27,7 @@ f, w = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZ
 sel = lambda d: {k: v for k, v in d.items() if FAMILY.match(k)}
 f, w = sel(f), sel(w)
 nl, nlw = sum(len(v) for v in f.values()), sum(len(v) for v in w.values())
-assert nl > 0 and (nl % LAUNCHES_PER_STEP == 0 or nl % 60 == 0) and nlw == nl, f'family launches counted: fetch pass {nl}, write pass {nlw} — expected a multiple of {LAUNCHES_PER_STEP} (run bench.py with --no-extras --lanes 1)'
+assert nl > 0 and (nl % LAUNCHES_PER_STEP == 0 or nl % 67 == 0 or nl % 60 == 0) and nlw == nl, f'family launches counted: fetch pass {nl}, write pass {nlw} — expected a multiple of {LAUNCHES_PER_STEP} (run bench.py with --no-extras --lanes 1)'
 fetch_kb = sum(sum(v) for v in f.values()) / nl
 write_kb = sum(sum(v) for v in w.values()) / nl
 out = {
@@ -35,7 +35,7 @@ out = {
               'averaged over ALL launches of the 3x3 split-bf16 conv family (bench.py\'s roofline family; kernel names below)',
     'per_kernel_avg_KB': {'FETCH_SIZE': {k: sum(v) / len(v) for k, v in f.items()}, 'WRITE_SIZE': {k: sum(v) / len(v) for k, v in w.items()}},
     'per_kernel_launches': {k: len(v) for k, v in f.items()},
-    'launches_counted': nl, 'steps_counted': nl // (LAUNCHES_PER_STEP if nl % LAUNCHES_PER_STEP == 0 else 60),
+    'launches_counted': nl, 'steps_counted': nl // (LAUNCHES_PER_STEP if nl % LAUNCHES_PER_STEP == 0 else (67 if nl % 67 == 0 else 60)),
     'fetch_KB_per_launch_raw': fetch_kb, 'write_KB_per_launch_raw': write_kb,
     'traffic_bytes_per_launch_raw': (fetch_kb + write_kb) * 1024.0,
 }
