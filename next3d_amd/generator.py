@@ -94,8 +94,10 @@ class TriPlaneGenerator(_Tracked):
                                f'({self.sr_class}: {sr_res} x {sr_res}); got z={z_dim} c={c_dim} w={w_dim} {img_resolution}x{img_resolution}x{img_channels}')
         if mapping_kwargs.get('num_layers', 2) != 2:
             raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
-        if synthesis_kwargs.get('channel_base', 32768) != 32768 or synthesis_kwargs.get('channel_max', 512) != 512:
-            raise RuntimeError('channel_base=32768 / channel_max=512 expected')
+        # the backbones' widths: channels_dict of `channel_base` / `channel_max` (tat/networks_stylegan2.py:614; ffhq-512: 32768 / 512) — RuntimeError for
+        # widths the matrix-core kernels do not tile (spec.check_channels)
+        self.channel_base, self.channel_max = int(synthesis_kwargs.get('channel_base', 32768)), int(synthesis_kwargs.get('channel_max', 512))
+        spec.check_channels(self.channel_base, self.channel_max)
         # float16 blocks in the four StyleGAN2 / StyleUNet backbones: num_fp16_res > 0 — what legacy.load_network_pkl(force_fp16=True)
         # sets (legacy.py:49-59: num_fp16_res = 4, conv_clamp = 256; the ffhq-512 pickle itself has 0).  The blocks of resolution >=
         # fp16_resolution run on the f16 matrix-core kernels unless force_fp32 is passed (tat/networks_stylegan2.py:615-621, :548-562)
@@ -119,7 +121,7 @@ class TriPlaneGenerator(_Tracked):
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
-        for name, (shape, kind) in spec.build_spec(self.sr_class).items():
+        for name, (shape, kind) in spec.build_spec(self.sr_class, self.channel_base, self.channel_max).items():
             leaf = name.rsplit('.', 1)[-1]
             if kind == 'mesh':
                 t = mb[name]

@@ -176,12 +176,18 @@ def _ws3(ws):
     return ws if (ws.stride(2) == 1 and ws.stride(1) == ws.shape[2]) else ws.contiguous()
 
 
+def _channels_of(P, prefix, img_resolution):
+    """resolution -> channels of the network's blocks, read off the weights (the reference's channels_dict, tat/networks_stylegan2.py:614:
+    min(channel_base // res, channel_max) — 32768 / 512 in the ffhq-512 pickle, any other `--cbase` / `--cmax` of train_next3d.py:199-200 arrives here as shapes)."""
+    return {r: int(P[f'{prefix}.b{r}.conv1.weight'].shape[0]) for r in sorted(S.channels_dict(img_resolution))}
+
+
 class SynthesisNet:
     def __init__(self, P, prefix, img_resolution=256, fp16_resolution=None, conv_clamp=None):
         """fp16_resolution: blocks of that resolution and up are the reference's float16 blocks (`num_fp16_res` > 0: fp16_resolution =
         max(2 ** (log2(img_resolution) + 1 - num_fp16_res), 8), tat/networks_stylegan2.py:615-621; legacy.load_network_pkl(force_fp16=True)
         sets num_fp16_res = 4, conv_clamp = 256, legacy.py:49-59); conv_clamp applies to every block."""
-        self.cd = S.channels_dict(img_resolution)
+        self.cd = _channels_of(P, prefix, img_resolution)
         self.block_res = sorted(self.cd)
         self.prefix, self.fp16_resolution = prefix, fp16_resolution
         self.blocks = {r: _Block(P, f'{prefix}.b{r}', self.cd[r // 2] if r > 4 else 0, conv_clamp=conv_clamp) for r in self.block_res}
@@ -236,7 +242,7 @@ class _EncoderBlock:
 class StyleUNet:
     def __init__(self, P, prefix, img_resolution=256, in_size=64, final_size=4, num_cond_res=64, fp16_resolution=None, conv_clamp=None):
         self.prefix, self.fp16_resolution = prefix, fp16_resolution
-        self.cd = S.channels_dict(img_resolution)
+        self.cd = _channels_of(P, prefix, img_resolution)
         self.block_res = sorted(self.cd)
         self.final_log2 = int(np.log2(final_size))
         self.num_cond_res = num_cond_res

@@ -77,15 +77,15 @@ def _conv2d_layer(spec, p, ic, oc, k, bias=True):
     spec[f'{p}.resample_filter'] = ((4, 4), 'fir')
 
 
-def _synthesis(spec, p, img_channels, img_resolution=PLANE_RES):
-    cd = channels_dict(img_resolution)
+def _synthesis(spec, p, img_channels, img_resolution=PLANE_RES, channel_base=32768, channel_max=512):
+    cd = channels_dict(img_resolution, channel_base, channel_max)
     for res in sorted(cd):
         _block(spec, f'{p}.b{res}', cd[res // 2] if res > 4 else 0, cd[res], res, img_channels)
     return cd
 
 
-def _styleunet(spec, p, img_channels, cond_channels, in_size, final_size):
-    cd = _synthesis(spec, p, img_channels)
+def _styleunet(spec, p, img_channels, cond_channels, in_size, final_size, channel_base=32768, channel_max=512):
+    cd = _synthesis(spec, p, img_channels, PLANE_RES, channel_base, channel_max)
     enc_res = [2 ** i for i in range(int(np.log2(in_size)), int(np.log2(final_size)) - 1, -1)]
     for i, res in enumerate(enc_res[:-1]):
         e = f'{p}.encoder.{i}'
@@ -119,17 +119,29 @@ def sr_module(name):
     return cls, SR_MODULES[cls]
 
 
-def build_spec(sr=DEFAULT_SR):
-    """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator (`sr`: the super-resolution class, SR_MODULES)."""
+def check_channels(channel_base=32768, channel_max=512):
+    """The four 256 x 256 backbones' channels_dict for `channel_base` / `channel_max` (train_next3d.py:199-200 --cbase / --cmax; ffhq-512: 32768 / 512).
+    The split-bf16 / f16 matrix-core kernels tile 64 output channels per workgroup: every width must be a multiple of 64, at most 512."""
+    cd = channels_dict(PLANE_RES, int(channel_base), int(channel_max))
+    if any(c % 64 or not 64 <= c <= 512 for c in cd.values()):
+        raise RuntimeError(f'channel_base={channel_base} / channel_max={channel_max} gives block widths {cd}: this build runs widths that are multiples of 64 in 64..512 '
+                           '(e.g. channel_base 32768 or 16384, channel_max 512 or 256)')
+    return cd
+
+
+def build_spec(sr=DEFAULT_SR, channel_base=32768, channel_max=512):
+    """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator (`sr`: the super-resolution class, SR_MODULES; channel_base /
+    channel_max: the `synthesis_kwargs` every backbone receives, triplane_next3d.py:63-65,109 — the super-resolution modules ignore theirs)."""
+    cb, cm = int(channel_base), int(channel_max)
     spec = OrderedDict()
     # texture_backbone: StyleGAN2 256², 32 ch (triplane_next3d.py:63)
-    _synthesis(spec, 'texture_backbone.synthesis', 32)
+    _synthesis(spec, 'texture_backbone.synthesis', 32, PLANE_RES, cb, cm)
     _mapping(spec, 'texture_backbone.mapping', 14)
     # mouth_backbone: StyleUNet 64² -> 256², final 4 (:64)
-    _styleunet(spec, 'mouth_backbone.synthesis', 32, 32, 64, 4)
+    _styleunet(spec, 'mouth_backbone.synthesis', 32, 32, 64, 4, cb, cm)
     _mapping(spec, 'mouth_backbone.mapping', 14)
     # backbone: StyleGAN2 256², 96 ch, mapping broadcasts to 28 ws (:65)
-    _synthesis(spec, 'backbone.synthesis', 96)
+    _synthesis(spec, 'backbone.synthesis', 96, PLANE_RES, cb, cm)
     _mapping(spec, 'backbone.mapping', 28)
     # superresolution (superresolution.py:29-124, :264-277): two blocks, every layer a SynthesisLayer of the block's resolution, toRGB to 3 colours
     _, (_, _, _, sr_blocks, sr_filter) = sr_module(sr)
@@ -154,7 +166,7 @@ def build_spec(sr=DEFAULT_SR):
     spec['uvfaces'] = ((1, N_FACES, 3), 'mesh')
     spec['face_uvcoords'] = ((1, N_FACES, 3, 3), 'mesh')
     # neural_blending: StyleUNet 256² -> 256², final 32 (:109)
-    _styleunet(spec, 'neural_blending.synthesis', 32, 32, 256, 32)
+    _styleunet(spec, 'neural_blending.synthesis', 32, 32, 256, 32, cb, cm)
     _mapping(spec, 'neural_blending.mapping', 14)
     return spec
 
@@ -170,7 +182,7 @@ def _seed_for(name, seed):
 _WIDE_STYLE, _WIDE_TORGB = 3.0, 1.0 / 3.0
 
 
-def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR):
+def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR, channel_base=32768, channel_max=512):
     """Seeded synthetic weights (CPU fp32).  Distributions follow the reference initialisers
     (randn weights, affine bias 1) except that biases, noise_strength and w_avg — zero at init in
     the reference — get small seeded non-zero values so those code paths are exercised
@@ -185,7 +197,7 @@ def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR):
         raise ValueError(profile)
     wide = profile == 'wide'
     out = OrderedDict()
-    for name, (shape, kind) in build_spec(sr).items():
+    for name, (shape, kind) in build_spec(sr, channel_base, channel_max).items():
         if kind == 'mesh' or (only is not None and not only(name)):
             continue
         if kind == 'fir':

@@ -170,7 +170,7 @@ def synthesis_network(P, prefix, ws, img_resolution=256, noise_mode='const', ret
                       cpu_rounding=False):
     """tat/networks_stylegan2.py:630-645 (SynthesisNetwork.forward).  fp16_resolution (num_fp16_res > 0, :615-621): the blocks of that
     resolution and up are float16 blocks (emulated, synthesis_block_fp16); conv_clamp applies to every block."""
-    cd = channels_dict(img_resolution)
+    cd = {r: int(P[f'{prefix}.b{r}.conv1.weight'].shape[0]) for r in channels_dict(img_resolution)}     # (any channel_base / channel_max: read off the weights)
     block_res = sorted(cd.keys())
     x = img = None
     for res, cur_ws in zip(block_res, _split_ws(ws.to(torch.float32), block_res)):
@@ -197,7 +197,7 @@ def encoder_res_block(P, prefix, inp, skip, downsample):
 def styleunet_synthesis(P, prefix, x_in, ws, img_resolution=256, in_size=64, final_size=4, num_cond_res=64,
                         noise_mode='const', fp16_resolution=None, conv_clamp=None, cpu_rounding=False):
     """tat/networks_stylegan2_styleunet.py:554-588 (conditional SynthesisNetwork.forward)."""
-    cd = channels_dict(img_resolution)
+    cd = {r: int(P[f'{prefix}.b{r}.conv1.weight'].shape[0]) for r in channels_dict(img_resolution)}     # (any channel_base / channel_max: read off the weights)
     block_res = sorted(cd.keys())
     block_ws = _split_ws(ws.to(torch.float32), block_res)
     enc_res = [2 ** i for i in range(int(np.log2(in_size)), int(np.log2(final_size)) - 1, -1)]

@@ -106,7 +106,7 @@ def install(uv_face_mask_np, third_party=True):
     os.chdir(REF)  # TriPlaneGenerator.__init__ opens data/ffhq/uv_face_eye_mask.png by relative path
 
 
-def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.obj', num_fp16_res=0, conv_clamp=None):
+def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.obj', num_fp16_res=0, conv_clamp=None, channel_base=32768, channel_max=512):
     """Construct the reference TriPlaneGenerator with the kwargs train_next3d.py would pass
     (train_next3d.py:250-411)."""
     from training_avatar_texture.triplane_next3d import TriPlaneGenerator
@@ -117,6 +117,6 @@ def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.ob
         z_dim=512, c_dim=25, w_dim=512, img_resolution=img_resolution, img_channels=3, topology_path=topology_path,
         sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
         sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
-        channel_base=32768, channel_max=512, fused_modconv_default='inference_only', num_fp16_res=num_fp16_res,
+        channel_base=channel_base, channel_max=channel_max, fused_modconv_default='inference_only', num_fp16_res=num_fp16_res,
         conv_clamp=conv_clamp)        # (num_fp16_res = 4, conv_clamp = 256: what legacy.load_network_pkl(force_fp16=True) rebuilds the model with)
     return G.eval().requires_grad_(False)

@@ -251,6 +251,31 @@ def test_oracle_fp16_backbones_against_reference_fp16_run():
     check_fp16_backbone_outputs(g, st, out, 'oracle')
 
 
+@pytest.mark.parametrize('suffix', ['sr4X', 'cb16384', 'cb16384_cm256'])
+def test_oracle_reproduces_reference_golden_of_other_architectures(suffix):
+    """The reference's other architectures — super-resolution modules (tat/superresolution.py:29-124) and backbone widths (`--cbase` / `--cmax`,
+    train_next3d.py:199-200) — run by the reference's own constructors (oracle/pin_against_reference.py --sr-modules / --channel-widths): the oracle
+    restatement reproduces the committed outputs (the pin reported max-abs 0.0; here: the same comparison from the fixture)."""
+    import os
+    from next3d_amd import mesh, spec
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'case_r32_s24_{suffix}.npz'))
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'demo_inputs.npz'))
+    cls = str(g['sr_class'])
+    cb, cm = (int(g['channel_base']), int(g['channel_max'])) if 'channel_base' in g.files else (32768, 512)
+    sd = spec.synthetic_state_dict(0, sr=cls, channel_base=cb, channel_max=cm)
+    sd.update(mesh.mesh_buffers(d['faces'], d['uvs'], d['uvfaces']))
+    R, Sc, Sf = int(g['R']), int(g['Sc']), int(g['Sf'])
+    rk = dict(ogen.DEFAULT_RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, superresolution_module='training_avatar_texture.superresolution.' + cls)
+    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    t = lambda k: torch.from_numpy(g[k])
+    ws = ogen.mapping(sd, t('z'), t('c_cond'), rk, truncation_psi=float(g['psi']), truncation_cutoff=int(g['cutoff']))
+    assert float((ws - t('ws')).abs().max()) <= 1e-6
+    out = ogen.synthesis(sd, ws, t('c'), t('v'), mesh.synthetic_uv_face_mask(), rk, jitter, u, neural_rendering_resolution=R)
+    step = int(g['image_step'])
+    assert float((out['image_raw'] - t('image_raw')).abs().max()) <= 1e-5 and float((out['image_depth'] - t('image_depth')).abs().max()) <= 1e-5
+    assert float((out['image'][..., ::step, ::step] - t('image_sub')).abs().max()) <= 1e-5
+
+
 def test_fp16_blocks_teacher_forced_oracle_vs_reference():
     """tests/golden/fp16_blocks.npz (round 5): every float16 block of the four backbones evaluated ALONE by the reference on a stated input.  The
     oracle's float16 emulation with the reference's off-GPU bias_act rounding reproduces each block almost bit for bit; the same emulation with

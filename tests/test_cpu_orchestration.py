@@ -24,6 +24,30 @@ def dry(monkeypatch):
     return calls
 
 
+@pytest.mark.parametrize('cb,cm,widths', [(16384, 512, {32: 512, 64: 256, 128: 128, 256: 64}), (16384, 256, {32: 256, 64: 256, 128: 128, 256: 64})])
+def test_other_channel_widths_dry_run(dry, cb, cm, widths):
+    """`--cbase` / `--cmax` other than the ffhq-512 pickle's 32768 / 512 (train_next3d.py:199-200; every backbone gets them as synthesis_kwargs,
+    tat/networks_stylegan2.py:614): the constructor builds the reference's shapes, every launch of a forward marshals (the recorder checks pointers, sizes
+    and layouts), one launch per layer as for the default widths; widths the matrix-core kernels do not tile raise at construction."""
+    from next3d_amd import demo, spec
+    with pytest.raises(RuntimeError, match='multiples of 64'):
+        demo.build_generator(torch.device('cpu'), channel_base=8192)
+    G, sd = demo.build_generator(torch.device('cpu'), channel_base=cb, channel_max=cm)
+    G.overlap_static = False
+    for net in ('texture_backbone', 'backbone', 'mouth_backbone', 'neural_blending'):
+        for r, c in widths.items():
+            assert sd[f'{net}.synthesis.b{r}.conv1.weight'].shape[:2] == (c, c)
+    assert sd['superresolution.block0.conv0.weight'].shape[:2] == (256, 32)           # the super-resolution module ignores channel_base / channel_max
+    z, c, c_cond, v = demo.demo_batch([0, 1])
+    ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+    for kw in (dict(force_fp32=True), {}):
+        dry.clear()
+        out = G.synthesis(ws, c, v, neural_rendering_resolution=64, noise_mode='const', **kw)
+        cnt = Counter(dry)
+        assert tuple(out['image'].shape) == (2, 3, 512, 512) and cnt['n3d_render_rays_ex'] == 1 and cnt['n3d_rasterize_views'] == 1
+        assert sum(cnt.values()) - cnt['n3d_split8_from_nchw'] - cnt['n3d_conv2d_prep_weight'] - cnt['n3d_conv2d_prep_weight_bf16x3'] <= 160, cnt
+
+
 @pytest.mark.parametrize('N,R,Sc,Sf', [(1, 32, 24, 24), (3, 64, 48, 0), (8, 64, 48, 48), (2, 128, 96, 96)])
 def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     from next3d_amd import demo
