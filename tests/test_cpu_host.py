@@ -578,3 +578,24 @@ def test_osg_decoder_unpickling_target_matches_oracle():
     rgb, sigma = orend.osg_decoder(sd, 'decoder', feats)
     assert tuple(out['rgb'].shape) == (2, 50, 32) and tuple(out['sigma'].shape) == (2, 50, 1)
     assert float((out['rgb'] - rgb).abs().max()) <= 1e-6 and float((out['sigma'] - sigma).abs().max()) <= 1e-5
+
+
+def test_profile_tools_count_every_split_bf16_3x3_kernel():
+    """tools/traffic_summary.py selects "the 3x3 split-bf16 family" by kernel name: every such kernel defined in csrc/ must match (a new variant that
+    did not once left `roofline.traffic` on a stale profile), and nothing else may (1x1, split-K reduce, fp32-MFMA and f16 kernels are other families)."""
+    import glob
+    import importlib.util
+    import re
+    spec_ = importlib.util.spec_from_file_location('traffic_summary', os.path.join(REPO, 'tools', 'traffic_summary.py'))
+    src = open(spec_.origin).read()
+    fam = re.compile(re.search(r"FAMILY = re\.compile\(r'([^']+)'\)", src).group(1))
+    names = set()
+    for f in glob.glob(os.path.join(REPO, 'next3d_amd', 'csrc', '*.hip')):
+        names |= set(re.findall(r'__global__[^;{]*?void\s+(\w+_kernel)\s*\(', open(f).read()))
+    family = {n for n in names if re.fullmatch(r'conv2d(_\w+)?_bf16x3(_pair)?_kernel', n)}
+    assert len(family) >= 14 and 'conv2d_ps2_rgb32s_bf16x3_kernel' in family and 'conv2d_sk_bf16x3_kernel' in family
+    for n in sorted(names):
+        for shown in (n, 'void ' + n + '<1, 2>'):                       # (rocprofv3 prints template kernels as "void name<args>")
+            assert bool(fam.match(shown)) == (n in family), shown
+    import bench
+    assert os.path.isfile(bench.TRAFFIC_PROFILE) and os.path.basename(bench.TRAFFIC_PROFILE).startswith('r05_')
