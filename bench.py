@@ -349,7 +349,10 @@ def main():
 
     extras = {}
     frames_total, elapsed_total = args.steps * B * world, elapsed
-    if single and not args.no_extras:
+    precision0 = layers.PRECISION
+
+    def run_extras():
+        """Every figure below is optional: main() calls this under try / except — a failure is reported on the line ('extras_error'), it never costs the headline."""
         # ---- the same K steps with the renderer's random inputs drawn INSIDE the call (torch.rand on the device, as the reference does)
         draw_rng[0] = True
         step(); step(); torch.cuda.synchronize()
@@ -601,6 +604,23 @@ def main():
                              'cached_identity_frames_per_s': 32 * B / t_rc, 'cached_identity_hip_graph_frames_per_s': 32 * B / t_rg,
                              'uncached_frames_per_s': 16 * B / t_ru, 'unit': 'frames/s',
                              'frames_timed': [32 * B, 16 * B]}
+
+    if single and not args.no_extras:
+        try:
+            run_extras()
+        except Exception as e:                                          # noqa: BLE001
+            print(f'bench.py: extras stopped ({type(e).__name__}: {e})', file=sys.stderr)
+            extras['extras_error'] = f'{type(e).__name__}: {e}'
+            try:
+                torch.cuda.synchronize()
+            except Exception:                                           # noqa: BLE001
+                pass
+        finally:                                                        # (the legs switch these; nothing below depends on them, but leave the process as it was found)
+            draw_rng[0] = False
+            sr_fp32[0] = not args.sr_fp16
+            gen[0] = G
+            if layers.PRECISION != precision0:
+                layers.set_precision(precision0)
 
     cpu = None
     if rank == 0 and single and not args.no_cpu_baseline:
