@@ -225,8 +225,14 @@ class TriPlaneGenerator(_Tracked):
             ts = self._ptensors = fresh
             self._tree_stamp = _STRUCT_GEN[0]
         stamp = 0
-        for t in ts:
-            stamp += t._version
+        try:
+            for t in ts:
+                stamp += t._version
+        except RuntimeError:            # inference tensors (a model built or loaded under torch.inference_mode()) track no version: they cannot be
+            stamp = 0                   # updated in place either — only the tensors that do track one are summed
+            for t in ts:
+                if not t.is_inference():
+                    stamp += t._version
         if self._param_stamp is not None and stamp != self._param_stamp:
             self._drop_derived()
             self._ptensors, self._tree_stamp = ts, _STRUCT_GEN[0]

@@ -24,6 +24,25 @@ def dry(monkeypatch):
     return calls
 
 
+def test_generator_built_and_called_under_inference_mode(dry):
+    """A model constructed / loaded under torch.inference_mode() holds inference tensors, which track no version counter (`t._version` raises): the
+    per-call parameter-update check, the operator layer's prepared-weight cache and the filter cache all have to cope (the scripts themselves
+    run under torch.no_grad(), gen_samples_next3d.py:163)."""
+    from next3d_amd import demo
+    with torch.inference_mode():
+        G, _ = demo.build_generator(torch.device('cpu'))
+        G.overlap_static = False
+        assert next(G.parameters()).is_inference()
+        z, c, c_cond, v = demo.demo_batch([0])
+        for _ in range(2):
+            ws = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+            out = G.synthesis(ws, c, v, neural_rendering_resolution=32, noise_mode='const')
+        assert tuple(out['image'].shape) == (1, 3, 512, 512)
+    z, c, c_cond, v = demo.demo_batch([1])
+    ws = G.mapping(z, c_cond)                                       # ... and outside the mode afterwards
+    assert tuple(G.synthesis(ws, c, v, noise_mode='const')['image'].shape) == (1, 3, 512, 512)
+
+
 @pytest.mark.parametrize('cb,cm,widths', [(16384, 512, {32: 512, 64: 256, 128: 128, 256: 64}), (16384, 256, {32: 256, 64: 256, 128: 128, 256: 64})])
 def test_other_channel_widths_dry_run(dry, cb, cm, widths):
     """`--cbase` / `--cmax` other than the ffhq-512 pickle's 32768 / 512 (train_next3d.py:199-200; every backbone gets them as synthesis_kwargs,
