@@ -47,7 +47,8 @@ class _Tracked(torch.nn.Module):
     assignment or a re-registered buffer invalidates the prepared weights, caches and captured graphs on the NEXT call)."""
 
     def __setattr__(self, name, value):
-        if isinstance(value, torch.Tensor) or name in self.__dict__.get('_parameters', ()) or name in self.__dict__.get('_buffers', ()):
+        # (a Parameter value registers a parameter; a name already in _parameters / _buffers replaces one; a plain tensor under a new name is an ordinary attribute)
+        if isinstance(value, torch.nn.Parameter) or name in self.__dict__.get('_parameters', ()) or name in self.__dict__.get('_buffers', ()):
             _STRUCT_GEN[0] += 1
         super().__setattr__(name, value)
 
