@@ -112,7 +112,7 @@ DEFAULT_SR = 'SuperresolutionHybrid8XDC'
 
 def sr_module(name):
     """`rendering_kwargs['superresolution_module']` (a dotted class path) -> (class name, SR_MODULES entry); RuntimeError for anything else
-    (SuperresolutionHybridDeepfp32 / 2XDC ...: not implemented)."""
+    (SuperresolutionHybridDeepfp32 raises in the reference too: triplane_next3d.py:66 passes it `sr_antialias`, which it hands on to SynthesisLayer -> TypeError)."""
     cls = str(name or DEFAULT_SR).rsplit('.', 1)[-1]
     if cls not in SR_MODULES:
         raise RuntimeError(f'superresolution_module {name!r}: implemented are ' + ', '.join(SR_MODULES))

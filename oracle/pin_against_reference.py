@@ -275,6 +275,8 @@ def fp16_blocks():
 
 # (class, channel_base, channel_max, golden suffix): the reference's OTHER architectures, one small case each
 VARIANTS_SR = [('SuperresolutionHybrid8X', 32768, 512, 'sr8X'), ('SuperresolutionHybrid4X', 32768, 512, 'sr4X'), ('SuperresolutionHybrid2X', 32768, 512, 'sr2X')]
+# (SuperresolutionHybridDeepfp32, :127-154, cannot be constructed by the reference's own TriPlaneGenerator: triplane_next3d.py:66 passes sr_antialias=..., which that class does
+#  not take and forwards to SynthesisLayer -> TypeError.  Tried here in round 5; the generator of this package raises for it too.)
 VARIANTS_WIDTH = [('SuperresolutionHybrid8XDC', 16384, 512, 'cb16384'), ('SuperresolutionHybrid8XDC', 16384, 256, 'cb16384_cm256')]
 
 

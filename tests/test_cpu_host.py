@@ -43,7 +43,7 @@ def test_generator_module_state_dict_names():
     topo = (d['faces'], d['uvs'], d['uvfaces'])
     with pytest.raises(RuntimeError, match='uv_face_eye_mask.png not found'):     # as the reference (cv2.imread -> None -> crash): no silent stand-in
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS))
-    with pytest.raises(RuntimeError, match='superresolution_module'):            # a module this build does not implement
+    with pytest.raises(RuntimeError, match='superresolution_module'):            # (the reference cannot construct this one either: sr_antialias -> SynthesisLayer TypeError)
         TriPlaneGenerator(512, 25, 512, 256, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
                           rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybridDeepfp32'))
     with pytest.raises(RuntimeError, match='256 x 256'):                          # every module has its own output resolution (the reference's modules assert it)
