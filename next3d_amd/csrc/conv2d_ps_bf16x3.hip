@@ -69,12 +69,12 @@ constexpr int PS_BUF = 2 * PS_A_SZ + 2 * PS_B_SZ;                               
 // RGB: 0 = plain layer; 1 = fused toRGB of at most PS_RGB_MAX colours on the VALU (the super-resolution's 3-colour layers); 2 = fused toRGB of up to
 // 32 colours on the matrix cores (the backbones' 32-channel toRGB layers).  SIDE (with RGB): the split8 side output for the layer's second reader.
 template <int NBUF, int RGB, bool SIDE = false>
-__device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf16x8* smem) {
+__device__ __forceinline__ void conv2d_ps_bf16x3_body(const ConvPsParams& p, bf16x8* smem, int lb_in = -1) {
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware 1-D grid, M tile fastest (conv2d_bf16x3.hip): the O/64 workgroups reading one input patch share it in one L2
-    int lb;
-    {
+    int lb = lb_in;                                                       // (>= 0: the persistent form hands over the logical workgroup index)
+    if (lb_in < 0) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
@@ -497,6 +497,23 @@ __global__ __launch_bounds__(512, 4) void conv2d_ps1_bf16x3_kernel(ConvPsParams 
     __shared__ bf16x8 smem[ps_smem_slots(1, false)];
     conv2d_ps_bf16x3_body<1, 0>(p, smem);
 }
+// Persistent form (tuning builds: N3D_PS_PERSIST=1): 2 workgroups per CU walk the logical workgroups of their XCD's share in steps of the XCD's
+// resident workgroups — a tile's stores drain under the next tile's first DMA instead of holding the CU's slot until they are acknowledged.
+__device__ __forceinline__ void ps_persistent_range(int total, int& first, int& count, int& step) {
+    const int q = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    count = q + (xcd < r ? 1 : 0) - (blockIdx.x >> 3);                    // logical indices left in this XCD's share from `first` on
+    step = gridDim.x >> 3;                                                // (the grid is a multiple of 8)
+}
+__global__ __launch_bounds__(512, 4) void conv2d_ps1p_bf16x3_kernel(ConvPsParams p, int total) {
+    __shared__ bf16x8 smem[ps_smem_slots(1, false)];
+    int first, count, step;
+    ps_persistent_range(total, first, count, step);
+    for (int k = 0; k < count; k += step) {
+        conv2d_ps_bf16x3_body<1, 0>(p, smem, first + k);
+        __syncthreads();                                                  // the epilogue's LDS factors are rewritten by the next tile
+    }
+}
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_bf16x3_kernel(ConvPsParams p) {         // two buffers, one workgroup per CU
     __shared__ bf16x8 smem[ps_smem_slots(2, false)];
     conv2d_ps_bf16x3_body<2, 0>(p, smem);
@@ -595,6 +612,7 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
       else if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (rgb) hipLaunchKernelGGL(conv2d_ps1_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+      else if (n3d_tune("N3D_PS_PERSIST", 0) && p.ksplit == 1 && nblk > 512) hipLaunchKernelGGL(conv2d_ps1p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
       else hipLaunchKernelGGL(conv2d_ps1_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.H, p.W, p.ybs, p.yrs, p.epi, stream);
@@ -698,7 +716,7 @@ constexpr int up_ps_smem_slots(int nmt) { return 2 * up_ps_buf_slots(nmt) + 32 *
 // covers 64 positions x 32 channels, so the weight fragments it reads serve twice the MFMAs (34 fragment reads per 54 MFMAs instead
 // of 26 per 27: the <1, 8, 1> form keeps the LDS pipe ~96 % busy at the MFMA rate it reaches).
 template <int NMT, int NW, int PG>
-__device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x8* smem) {
+__device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x8* smem, int lb_in = -1) {
     static_assert(NW * PG == 8, "256 positions per tile");
     constexpr int BM = 32 * NMT, A_SZ = PS_TAPS * 2 * BM;                  // 16-byte slots per (buffer, hi|lo): [tap][half][row]
     constexpr int BUF = up_ps_buf_slots(NMT);                             // NMT = 2: 57,344 B, NMT = 1: 38,912 B per buffer
@@ -706,8 +724,8 @@ __device__ __forceinline__ void conv2d_up_ps_body(const ConvUpPsParams& p, bf16x
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    int lb;
-    {
+    int lb = lb_in;
+    if (lb_in < 0) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
@@ -878,6 +896,16 @@ __global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsP
     conv2d_up_ps_body<1, 8, 1>(p, smem);
 }
 
+__global__ __launch_bounds__(512, 4) void conv2d_up_ps32p_bf16x3_kernel(ConvUpPsParams p, int total) {      // persistent form (see conv2d_ps1p_bf16x3_kernel)
+    __shared__ bf16x8 smem[up_ps_smem_slots(1)];
+    int first, count, step;
+    ps_persistent_range(total, first, count, step);
+    for (int k = 0; k < count; k += step) {
+        conv2d_up_ps_body<1, 8, 1>(p, smem, first + k);
+        __syncthreads();
+    }
+}
+
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const bool nchw = d->y_layout == N3D_LAYOUT_NCHW_F32;
     N3D_CHECK(d->ksize == 3 && d->mode == 2 && (d->y_layout == N3D_LAYOUT_C8_F32 || nchw), "conv2d_bf16x3: a split8 input to the transposed kernel: c8 or float32 NCHW output");
@@ -909,7 +937,8 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    if (n3d_tune("N3D_PS_PERSIST", 0) && nblk > 512) hipLaunchKernelGGL(conv2d_up_ps32p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
+    else hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }
