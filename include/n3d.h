@@ -329,6 +329,8 @@ int n3d_fc_multi(const n3d_fc_job* jobs, const int* rows, int total_rows, const 
 /* ---- small element-wise pieces of the path.
  *      n3d_normalize_2nd_moment: y[r,:] = x[r,:] * rsqrt(mean(x[r,:]^2) + eps)  (tat/networks_stylegan2.py:27-29); y rows
  *        have pitch y_stride so two calls can fill the halves of the mapping network's concatenated input (:239-246).
+ *        n3d_normalize_2nd_moment_f64: the same for a float64 x — the scripts' z is float64 (gen_samples_next3d.py:165) and MappingNetwork.forward
+ *        converts it first (`z.to(torch.float32)`, :239): every element is rounded to float32, then the float32 arithmetic (bit-identical).
  *      n3d_truncate_ws: broadcast w [N,D] to ws [N,num_ws,D] and lerp the first `cutoff` latents towards w_avg with
  *        psi (MappingNetwork.forward :255-267; w_avg NULL or psi == 1 => plain broadcast).
  *      n3d_fma: y = a*b + c over a [NC,P] with b, c addressed as [nc*stride_nc + p*stride_p] (0 strides broadcast)
@@ -338,6 +340,7 @@ int n3d_fc_multi(const n3d_fc_job* jobs, const int* rows, int total_rows, const 
  *        uint8 conversion, tiling and CHW -> HWC): frames [B,C,H,W] float32 (W % 4 == 0, B == cols * rows) -> uint8 canvas
  *        [rows*H, cols*W, C] (hwc = 1) or [C, rows*H, cols*W] (hwc = 0), frame b at tile row b / cols, tile column b % cols. */
 int n3d_normalize_2nd_moment(const float* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream);
+int n3d_normalize_2nd_moment_f64(const double* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream);
 int n3d_truncate_ws(const float* w, const float* w_avg, float* ws, int N, int num_ws, int D, int cutoff, float psi,
                     n3d_stream_t stream);
 int n3d_fma(const float* a, const float* b, const float* c, float* y, int64_t NC, int64_t P, int64_t b_nc, int64_t b_p,

@@ -103,6 +103,7 @@ _SIGNATURES = {
     'n3d_resize_aa': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     'n3d_resize_aa_strided': (c_int, [c_void_p, c_int64] + [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     'n3d_normalize_2nd_moment': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),
+    'n3d_normalize_2nd_moment_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_void_p]),
     'n3d_truncate_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'n3d_fma': (c_int, [c_void_p] * 4 + [c_int64] * 6 + [c_void_p]),
     'n3d_to_uint8': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -8,20 +8,23 @@
 //                          training_avatar_texture/networks_stylegan2.py:548-552, :57-59)
 #include "common.h"
 
-// one wave per row
-__global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int D,
+// one wave per row.  T = double: the scripts' z (torch.from_numpy(np.random.RandomState(seed).randn(...)): float64) — every element is rounded to
+// float32 first, as MappingNetwork.forward does (`z.to(torch.float32)`, tat/networks_stylegan2.py:239), then the float32 arithmetic: bit-identical to
+// a separate conversion pass
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_2nd_moment_kernel(const T* __restrict__ x, float* __restrict__ y, int rows, int D,
                                                                    int64_t y_stride, float eps) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
-    const float* xr = x + (int64_t)r * D;
+    const T* xr = x + (int64_t)r * D;
     float s = 0.f;
-    for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+    for (int i = lane; i < D; i += 64) { const float v = (float)xr[i]; s += v * v; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float k = rsqrtf(s / (float)D + eps);
     float* yr = y + (int64_t)r * y_stride;
-    for (int i = lane; i < D; i += 64) yr[i] = xr[i] * k;
+    for (int i = lane; i < D; i += 64) yr[i] = (float)xr[i] * k;
 }
 
 // ws[n, j, :] = j < cutoff ? lerp(w_avg, w[n], psi) : w[n]
@@ -138,7 +141,18 @@ int n3d_normalize_2nd_moment(const float* x, float* y, int rows, int D, int64_t 
     if (rows == 0) return 0;
     N3D_CHECK(x && y, "normalize_2nd_moment: null tensor");
     N3dProfScope prof(N3D_K_MISC, stream, 3.0 * rows * D, 8.0 * rows * D);
-    hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, D, y_stride, eps);
+    hipLaunchKernelGGL(normalize_2nd_moment_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, D, y_stride, eps);
+    N3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int n3d_normalize_2nd_moment_f64(const double* x, float* y, int rows, int D, int64_t y_stride, float eps, n3d_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    N3D_CHECK(rows >= 0 && D > 0 && y_stride >= D, "normalize_2nd_moment_f64: bad shape");
+    if (rows == 0) return 0;
+    N3D_CHECK(x && y, "normalize_2nd_moment_f64: null tensor");
+    N3dProfScope prof(N3D_K_MISC, stream, 3.0 * rows * D, 12.0 * rows * D);
+    hipLaunchKernelGGL(normalize_2nd_moment_kernel<double>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, D, y_stride, eps);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -287,7 +287,8 @@ class TriPlaneGenerator(_Tracked):
         self._check_params()
         S = self._prep()
         P = S.P
-        z = z.to(device=self.device, dtype=torch.float32)
+        # the scripts' z is float64 (np.random.RandomState(seed).randn): the float32 conversion of :239 happens inside the normalisation kernel
+        z = z.to(device=self.device) if z.dtype == torch.float64 else z.to(device=self.device, dtype=torch.float32)
         n = z.shape[0]
         scale = float(self.rendering_kwargs.get('c_scale', 0))
         if self.rendering_kwargs['c_gen_conditioning_zero'] or scale == 0.0:
@@ -302,7 +303,7 @@ class TriPlaneGenerator(_Tracked):
         L = _lib.lib()
         x = torch.empty(n, 1024, dtype=torch.float32, device=self.device)          # cat([norm(z), norm(embed(c))], 1)
         z = z.contiguous()              # (never pass a temporary to _lib.ptr: it is freed before the launch and its block can be re-used)
-        _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(z), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
+        _lib.check((L.n3d_normalize_2nd_moment_f64 if z.dtype == torch.float64 else L.n3d_normalize_2nd_moment)(_lib.ptr(z), _lib.ptr(x), n, 512, 1024, 1e-8, _lib.stream()))
         if scale != 1.0:                 # (c * c_scale is exact for c_scale = 1, the ffhq configuration; any other scale: libn3d.so's fma, not a torch multiply)
             from .torch_utils.ops import fma as _fma
             c = _fma.fma(c.contiguous(), torch.full((1, 1), scale, dtype=torch.float32, device=self.device).expand(n, 25).contiguous(), torch.zeros(n, 25, dtype=torch.float32, device=self.device))

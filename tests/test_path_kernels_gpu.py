@@ -659,3 +659,31 @@ def test_third_party_shims_flood_fill_matches_oracle(dev, shims):
         assert np.array_equal(t.cpu().numpy(), ref)
     with pytest.raises(RuntimeError):
         cv2.floodFill(imgs[0].copy(), None, (3, 3), 255, 0, 254, cv2.FLOODFILL_FIXED_RANGE)
+
+
+@pytest.mark.parametrize('rows,D,pitch', [(1, 512, 1024), (5, 512, 1024), (3, 100, 100)])
+def test_normalize_2nd_moment_float32_and_float64_input(dev, rows, D, pitch):
+    """normalize_2nd_moment (tat/networks_stylegan2.py:27-29) on float32 rows, and on the scripts' float64 z (gen_samples_next3d.py:165), whose
+    `z.to(torch.float32)` (:239) happens inside the kernel: bit-identical to converting first; both against the torch expression."""
+    from next3d_amd import _lib
+    L = _lib.lib()
+    z64 = torch.from_numpy(np.random.RandomState(rows * 7 + D).randn(rows, D))                    # float64, as the scripts draw it
+    z32 = z64.float()
+    want = z32 * (z32.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    ya = torch.full((rows, pitch), -7.0, device=dev)
+    yb = torch.full((rows, pitch), -7.0, device=dev)
+    a, b = z32.to(dev), z64.to(dev)
+    _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(a), _lib.ptr(ya), rows, D, pitch, 1e-8, _lib.stream()))
+    _lib.check(L.n3d_normalize_2nd_moment_f64(_lib.ptr(b), _lib.ptr(yb), rows, D, pitch, 1e-8, _lib.stream()))
+    assert torch.equal(ya, yb)
+    assert _md(ya[:, :D], want) <= 2e-6 and (pitch == D or bool((ya[:, D:] == -7.0).all()))
+    assert L.n3d_normalize_2nd_moment_f64(None, _lib.ptr(yb), rows, D, pitch, 1e-8, _lib.stream()) != 0 and 'normalize_2nd_moment_f64' in L.n3d_last_error().decode()
+
+
+def test_mapping_takes_float64_latents_without_a_conversion_pass(dev):
+    """G.mapping(z float64) == G.mapping(z.float()) bit for bit (the conversion of MappingNetwork.forward :239 is folded into the first kernel)."""
+    from next3d_amd import demo
+    G, _ = demo.build_generator(dev)
+    z, c, c_cond, v = demo.demo_batch([0, 1, 2], device=dev)
+    assert z.dtype == torch.float64
+    assert torch.equal(G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14), G.mapping(z.float(), c_cond, truncation_psi=0.7, truncation_cutoff=14))
