@@ -246,6 +246,13 @@ class H8:
         n, c, h, w = self.shape
         return self.data.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).float()
 
+    def sample(self, i):
+        """Sample i as an H8 of batch 1 sharing this tensor's storage (a view: the layers that run sample by sample — per-sample random noise)."""
+        v = object.__new__(H8)
+        n, c, h, w = self.shape
+        v.shape, v.data, v.device, v._src = (1, c, h, w), self.data[i:i + 1], self.device, self
+        return v
+
     def to_nchw(self):
         """`x.to(torch.float32)`: dense float32 [N,C,H,W] on libn3d.so (n3d_cast_h8) — where a float16 block's feature map is read by
         float32 code (the StyleUNets' fusion layers concatenate it with the float32 encoder features)."""

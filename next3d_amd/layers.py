@@ -408,14 +408,38 @@ def modulate_weights_f16_multi(entries, styles_base, n):
     return outs
 
 
-def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=None, gain=1.0, w16=None, rgb=None):
+def synthesis_layer_f16(L, x, styles, fir, up=1, noise_mode='none', conv_clamp=None, gain=1.0, w16=None, rgb=None, _noise=None):
     """SynthesisLayer.forward of a float16 block (training/networks_stylegan2.py:311-330 with x.dtype == float16, fused_modconv):
-    x `_lib.H8` -> `_lib.H8`.  `w16`: the layer's per-sample weights when already formed (modulate_weights_f16_multi)."""
-    if noise_mode not in ('const', 'none'):
-        raise RuntimeError("float16 blocks: noise_mode 'const' or 'none'")
-    noise = L.noise_const if noise_mode == 'const' else None
+    x `_lib.H8` -> `_lib.H8`.  `w16`: the layer's per-sample weights when already formed (modulate_weights_f16_multi).
+    noise_mode 'random' (the reference's default, :318-319): a fresh N(0,1) image per sample, drawn with torch.randn from the device generator like the
+    reference; the kernels' epilogue takes one noise image per launch, so the noisy part of the layer runs sample by sample (as synthesis_layer does)."""
+    if noise_mode not in ('random', 'const', 'none'):
+        raise RuntimeError(f'noise_mode {noise_mode!r}: random / const / none')
+    if noise_mode == 'random' and L.noise_const is not None and _noise is None:
+        n = x.shape[0]
+        if w16 is None:
+            w16 = modulate_weights_f16(L, styles, demodulate=True)
+        draws = torch.randn([n, *L.noise_const.shape], dtype=torch.float32, device=L.noise_const.device)
+        kw = dict(up=up, noise_mode='random', conv_clamp=conv_clamp, gain=gain)
+        if up == 2:            # the transposed convolution carries no noise: one launch for the batch, the FIR + epilogue per sample
+            z = conv2d_f16(x, w16, L.out_channels, 2)
+            outs = [synthesis_layer_f16(L, z.sample(i), None, fir, w16=w16, _noise=(draws[i], True), **kw) for i in range(n)]
+        else:
+            per = w16.numel() // n
+            rw = None if rgb is None else rgb[0].reshape(n, -1)
+            outs = [synthesis_layer_f16(L, x.sample(i), None, fir, w16=w16[i * per:(i + 1) * per], rgb=None if rgb is None else (rw[i], rgb[1]),
+                                        _noise=(draws[i], False), **kw) for i in range(n)]
+        if rgb is not None:
+            return torch.cat(outs, 0)                                    # partial colours [N, O/64, C, H, W]
+        y = _lib.H8(n, L.out_channels, outs[0].shape[2], outs[0].shape[3], x.device)
+        for i, o in enumerate(outs):
+            y.data[i:i + 1].copy_(o.data)
+        return y
+    noise = _noise[0] if _noise is not None else (L.noise_const if noise_mode == 'const' else None)
     epi = _lib.make_epilogue(noise=noise, noise_strength=L.noise_strength if noise is not None else None, bias=L.bias, act='lrelu',
                              gain=_SQRT2 * gain, clamp=None if conv_clamp is None else conv_clamp * gain, round_f16=2 if F16_REF_CPU_ROUNDING else 0)
+    if _noise is not None and _noise[1]:                                  # (per-sample random noise, up = 2: x is this sample's transposed-convolution result)
+        return fir4_h8(x, fir, epi)
     if w16 is None:
         w16 = modulate_weights_f16(L, styles, demodulate=True)
     if up == 1:

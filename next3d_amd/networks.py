@@ -125,12 +125,12 @@ def _f16_eligible(blocks, fir, noise_mode, owner, what):
     """Which of the reference's float16 blocks (res -> _Block, each fed an [*, I, res/2, res/2] input) run on the f16 kernels: the
     highest-resolution run of eligible blocks (per block, not all-or-nothing).  The blocks below it that the kernels do not
     take — 8 x 8 / 16 x 16 blocks with num_fp16_res >= 5: the stride-1 f16 kernel needs W >= 32 — run in float32 (a superset in accuracy of
-    the reference's float16 arithmetic, NOT its rounding: documented in INTEGRATION.md), with a one-time warning naming them.  Random noise
-    or a non-4x4 filter rule the f16 kernels out altogether."""
+    the reference's float16 arithmetic, NOT its rounding: documented in INTEGRATION.md), with a one-time warning naming them.  A non-4x4 filter
+    rules the f16 kernels out altogether."""
     if not blocks:
         return {}
     ok = {}
-    if noise_mode in ('const', 'none') and tuple(fir.shape) == (4, 4):
+    if tuple(fir.shape) == (4, 4):                                  # (random noise: the noisy layers run sample by sample, layers.synthesis_layer_f16)
         for r in sorted(blocks, reverse=True):
             if not _f16_block_ok(r, blocks[r]):
                 break
@@ -158,7 +158,7 @@ def _warn_f16_once(obj, what, which=None):
     if not getattr(obj, '_warned32', False):
         obj._warned32 = True
         blocks = 'the float16 blocks' if which is None else 'float16 blocks ' + ', '.join(f'b{r}' for r in which)
-        warnings.warn(f'{blocks} of {what} are not available on the f16 kernels for this configuration (random noise / filter / shapes): running '
+        warnings.warn(f'{blocks} of {what} are not available on the f16 kernels for this configuration (filter / shapes): running '
                       'them in float32 (the force_fp32=True arithmetic); the other float16 blocks stay float16')
 
 
@@ -344,17 +344,17 @@ class SuperRes8XDC:
         uf.fir_factor(self.fir)
 
     def _f16_ok(self, x, noise_mode):
-        """Can the reference's float16 blocks run on the f16 kernels for this input (conv2d_f16.hip)?  When not (random SR noise, a
+        """Can the reference's float16 blocks run on the f16 kernels for this input (conv2d_f16.hip)?  When not (a
         non-4x4 resampling filter, odd shapes) they run in float32 — the force_fp32=True arithmetic, a superset in accuracy — with
         a one-time warning, never an error: the reference's default `synthesis(ws, c, v)` call must run."""
         import warnings
         h = x.shape[2]
-        ok = (self.all_up and noise_mode in ('const', 'none') and tuple(self.fir.shape) == (4, 4) and      # (a SynthesisBlockNoUp has no float16 form here: 4X / 2X run in float32)
+        ok = (self.all_up and noise_mode in ('random', 'const', 'none') and tuple(self.fir.shape) == (4, 4) and      # (a SynthesisBlockNoUp has no float16 form here: 4X / 2X run in float32)
               all(L.f16_layer_ok(b.conv0, hh, hh, 2) and L.f16_layer_ok(b.conv1, 2 * hh, 2 * hh, 1) and b.torgb.in_channels <= 512
                   for b, hh in ((self.block0, h), (self.block1, 2 * h))))
         if not ok and not getattr(self, '_warned32', False):
             self._warned32 = True
-            warnings.warn('float16 super-resolution blocks are not available for this configuration (random noise / filter / shapes): '
+            warnings.warn('float16 super-resolution blocks are not available for this configuration (filter / shapes): '
                           'running them in float32 (the force_fp32=True arithmetic)')
         return ok
 

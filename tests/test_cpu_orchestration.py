@@ -128,7 +128,8 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert sr16(half, nb) == (1, 1, 4, 2, 2)
     assert sum(half.values()) - half['n3d_split8_from_nchw'] == 146 + (0 if R == 128 else 2) - 8 + 10
     # the switches that once made the default call raise: strict-fp32 arithmetic, no pre-split hand-off -> the float16
-    # blocks run on their own kernels whatever the float32 layers use; random super-resolution noise -> float32 blocks, never an error
+    # blocks run on their own kernels whatever the float32 layers use; random super-resolution noise -> the float16 kernels with the noisy part of each
+    # layer sample by sample (one noise image per launch: conv1 + the FIR behind conv0 run N times, the transposed convolutions once), never an error
     import warnings
     from next3d_amd import layers
     for attr, val in (('PRECISION', 'fp32'), ('PRESPLIT', False)):
@@ -146,7 +147,7 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
         dry.clear()
         out = G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
     G.rendering_kwargs['superresolution_noise_mode'] = 'none'
-    assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry), nb) == (0, 0, 0, 0, 0)
+    assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry), nb) == (1, 1, 2 + 2 * N, 2 * N, 2)
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
 
@@ -384,5 +385,7 @@ def test_fp16_backbones_launch_sequence_dry_run(dry):
     cnt32 = Counter(dry)
     assert cnt32['n3d_conv2d_f16'] == 0 and cnt32['n3d_cast_h8'] == 0
     dry.clear()
-    G.synthesis(ws, c, v, neural_rendering_resolution=32, noise_mode='random')      # random noise: the float16 blocks fall back to float32 (warning), never an error
-    assert Counter(dry)['n3d_conv2d_f16'] == 4                                      # (the super-resolution blocks have noise_mode 'none': still float16)
+    G.synthesis(ws, c, v, neural_rendering_resolution=32, noise_mode='random')      # random noise (the reference's default): the float16 blocks stay on the f16 kernels,
+    rnd = Counter(dry)                                                              # their noisy parts sample by sample (one noise image per launch), never an error
+    # per block: the transposed convolution once for the batch + its FIR per sample, conv1 per sample; the super-resolution blocks have noise_mode 'none' (4 launches)
+    assert rnd['n3d_conv2d_f16'] == blocks * (1 + 2) + 4 and rnd['n3d_fir4_h8'] == blocks * 2 + 2, rnd

@@ -225,3 +225,38 @@ def test_cast_h8_round_trip(dev):
     y = torch.empty(2, 24, 9, 13, device=dev)
     _lib.check(_lib.lib().n3d_cast_h8(_lib.ptr(h.data), _lib.ptr(y), 2, 24, 9 * 13, 0, 0, _lib.stream()))
     assert torch.equal(y.cpu(), _q(x))
+
+
+@pytest.mark.parametrize('up,rgb', [(1, False), (2, False), (1, True)])
+def test_float16_layer_with_random_noise_runs_sample_by_sample(dev, up, rgb):
+    """noise_mode='random' (the reference's default, training/networks_stylegan2.py:318-319: randn([N,1,res,res]) * noise_strength added inside
+    modulated_conv2d) on a float16 layer: the kernels take one noise image per launch, so layers.synthesis_layer_f16 draws [N,res,res] with torch.randn
+    from the device generator and runs the noisy part of the layer sample by sample.  Checked against the 'const' path of the SAME layer called once per
+    sample with that sample's draw as its noise image (same device seed -> same draws): bit-identical; and different from the noise-free layer."""
+    N, I, O, H, W, C = 3, 32, 128, 32, 32, 3
+    fir = layers.uf.setup_filter([1, 3, 3, 1]).to(dev)
+    res = (2 * H, 2 * W) if up == 2 else (H, W)
+    x, w, s = _q(_g((N, I, H, W), 70)), _g((O, I, 3, 3), 71), _g((N, I), 72) + 1.0
+    L1 = _Layer(w.to(dev), _g((O,), 73, 0.1).to(dev), torch.zeros(res, device=dev), torch.tensor(0.5, device=dev))
+    w16 = layers.modulate_weights_f16(L1, s.to(dev))
+    xh = _lib.H8.from_nchw(x.to(dev))
+    kw = dict(up=up, conv_clamp=256, w16=w16)
+    if rgb:
+        LT = _Layer(_g((C, O, 1, 1), 74).to(dev), _g((C,), 75, 0.1).to(dev))
+        wt16 = layers.modulate_weights_f16(LT, ((_g((N, O), 76) + 1.0) / np.sqrt(O)).to(dev), demodulate=False)
+        kw['rgb'] = (wt16, C)
+    val = (lambda r: r) if rgb else (lambda r: r.data)
+    torch.manual_seed(1234)
+    got = val(layers.synthesis_layer_f16(L1, xh, None, fir, noise_mode='random', **kw))
+    torch.manual_seed(1234)
+    draws = torch.randn([N, *res], dtype=torch.float32, device=dev)
+    per = w16.numel() // N
+    for i in range(N):
+        Li = _Layer(L1.weight, L1.bias, draws[i].contiguous(), L1.noise_strength)
+        kwi = dict(kw, w16=w16[i * per:(i + 1) * per])
+        if rgb:
+            kwi['rgb'] = (wt16.reshape(N, -1)[i], C)
+        want = val(layers.synthesis_layer_f16(Li, xh.sample(i), None, fir, noise_mode='const', **kwi))
+        assert torch.equal(got[i:i + 1], want), (up, rgb, i)
+    quiet = val(layers.synthesis_layer_f16(L1, xh, None, fir, noise_mode='none', **kw))
+    assert float((got.float() - quiet.float()).abs().max()) > 1e-2                   # the noise is really added

@@ -571,6 +571,35 @@ def test_fp16_backbones_match_reference_fp16_run(G16, dev, case):
 
 
 @pytest.mark.gpu
+def test_default_call_of_a_force_fp16_generator_keeps_the_float16_blocks(G16, dev):
+    """`G.synthesis(ws, c, v)` with every default — noise_mode 'random' (tat/networks_stylegan2.py:311) — on the force_fp16 generator: the float16
+    blocks stay on the f16 kernels (their noisy layers run sample by sample: one noise image per launch), no warning, no float32 fallback; the draws come
+    from the device generator, so the same seed gives the same image; the image differs from the noise-free one by the noise and from the float32
+    route's by more than the noise-free float16 / float32 distance would explain nothing — it is checked to be finite and in range."""
+    import warnings
+    from next3d_amd import demo
+    z, c, c_cond, v = demo.demo_batch([0, 1], device=dev)
+    ws = G16.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+    jitter, u = cases.rng_inputs(2, 32, 24, 24)
+    G16.rendering_kwargs['depth_resolution'], G16.rendering_kwargs['depth_resolution_importance'] = 24, 24
+    kw = dict(neural_rendering_resolution=32, depth_jitter=jitter, importance_u=u)
+    G16.__dict__.pop('_warned32', None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        torch.manual_seed(7)
+        a = G16.synthesis(ws, c, v, **kw)['image']
+        torch.manual_seed(7)
+        b = G16.synthesis(ws, c, v, **kw)['image']
+    assert not [x for x in w if 'float16' in str(x.message)], [str(x.message) for x in w]
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    quiet = G16.synthesis(ws, c, v, noise_mode='none', **kw)['image']
+    const = G16.synthesis(ws, c, v, noise_mode='const', **kw)['image']
+    d_rand, d_const = _md(a, quiet), _md(const, quiet)
+    print(f'force_fp16 generator: |random - none| {d_rand:.3e}, |const - none| {d_const:.3e}')
+    assert d_rand > 1e-3 and d_rand < 50 * max(d_const, 1e-3)               # noise of the same strengths, another draw
+
+
+@pytest.mark.gpu
 def test_fp16_blocks_teacher_forced(G16, dev, monkeypatch):
     """every float16 block of the four backbones ONE BLOCK DEEP against the reference's own block output on a stated input
     (tests/golden/fp16_blocks.npz, tests/_fp16_blocks.py).  With the reference's off-GPU bias_act rounding (layers.F16_REF_CPU_ROUNDING: the fixture was
