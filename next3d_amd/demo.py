@@ -50,18 +50,18 @@ def demo_arrays():
     return np.load(DEMO_NPZ)
 
 
-def build_generator(device, seed=0, rendering_kwargs=None, force_fp16=False, channel_base=32768, channel_max=512):
+def build_generator(device, seed=0, rendering_kwargs=None, force_fp16=False, channel_base=32768, channel_max=512, mapping_layers=2):
     """channel_base / channel_max: the backbones' widths (train_next3d.py --cbase / --cmax; the ffhq-512 pickle: 32768 / 512).  force_fp16: the generator as legacy.load_network_pkl(force_fp16=True) rebuilds it (legacy.py:49-59): num_fp16_res = 4 and
     conv_clamp = 256 in all four backbones."""
     from .generator import TriPlaneGenerator
     d = demo_arrays()
     topo = (d['faces'], d['uvs'], d['uvfaces'])
-    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2),
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=mapping_layers),
                           rendering_kwargs=dict(rendering_kwargs or RENDERING_KWARGS),
                           sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
                           uv_face_mask=mesh.synthetic_uv_face_mask(), channel_base=channel_base, channel_max=channel_max,
                           fused_modconv_default='inference_only', num_fp16_res=4 if force_fp16 else 0, conv_clamp=256 if force_fp16 else None)
-    sd = spec.synthetic_state_dict(seed, channel_base=channel_base, channel_max=channel_max)
+    sd = spec.synthetic_state_dict(seed, channel_base=channel_base, channel_max=channel_max, mapping_layers=mapping_layers)
     sd.update(mesh.mesh_buffers(*topo))
     G.load_state_dict(sd, strict=True)
     return G.eval().requires_grad_(False).to(device), sd

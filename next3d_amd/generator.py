@@ -93,8 +93,10 @@ class TriPlaneGenerator(_Tracked):
         if (z_dim, c_dim, w_dim, img_channels) != (512, 25, 512, 3) or img_resolution != sr_res:
             raise RuntimeError(f'this build implements the next3d configuration z = w = 512, c = 25, 3 colours at the resolution of the super-resolution module '
                                f'({self.sr_class}: {sr_res} x {sr_res}); got z={z_dim} c={c_dim} w={w_dim} {img_resolution}x{img_resolution}x{img_channels}')
-        if mapping_kwargs.get('num_layers', 2) != 2:
-            raise RuntimeError('mapping_kwargs.num_layers must be 2 (train_next3d.py map_depth)')
+        # mapping depth: train_next3d.py passes map_depth = 2; without the key the reference's MappingNetwork builds its own default, 8 (tat/networks_stylegan2.py:207)
+        self.mapping_layers = int(mapping_kwargs.get('num_layers', 8))
+        if not 1 <= self.mapping_layers <= 16:
+            raise RuntimeError(f'mapping_kwargs.num_layers = {self.mapping_layers}: 1..16 expected')
         # the backbones' widths: channels_dict of `channel_base` / `channel_max` (tat/networks_stylegan2.py:614; ffhq-512: 32768 / 512) — RuntimeError for
         # widths the matrix-core kernels do not tile (spec.check_channels)
         self.channel_base, self.channel_max = int(synthesis_kwargs.get('channel_base', 32768)), int(synthesis_kwargs.get('channel_max', 512))
@@ -122,7 +124,7 @@ class TriPlaneGenerator(_Tracked):
 
         # parameters / buffers under the reference's names, reference init distributions (randn, affine bias 1, zeros)
         mb = mesh.mesh_buffers_from_obj(topology_path) if isinstance(topology_path, str) else mesh.mesh_buffers(*topology_path)
-        for name, (shape, kind) in spec.build_spec(self.sr_class, self.channel_base, self.channel_max).items():
+        for name, (shape, kind) in spec.build_spec(self.sr_class, self.channel_base, self.channel_max, self.mapping_layers).items():
             leaf = name.rsplit('.', 1)[-1]
             if kind == 'mesh':
                 t = mb[name]
@@ -147,7 +149,7 @@ class TriPlaneGenerator(_Tracked):
             node.synthesis.num_ws, node.synthesis.img_resolution, node.synthesis.img_channels = 14, res, ch
             if hasattr(node, 'mapping'):
                 node.mapping.num_ws = 28 if net == 'backbone' else 14
-                node.mapping.z_dim, node.mapping.c_dim, node.mapping.w_dim, node.mapping.num_layers = z_dim, c_dim, w_dim, 2
+                node.mapping.z_dim, node.mapping.c_dim, node.mapping.w_dim, node.mapping.num_layers = z_dim, c_dim, w_dim, self.mapping_layers
         self.superresolution.input_resolution = spec.SR_MODULES[self.sr_class][1]
 
         if uv_face_mask is None:      # reference: cv2.imread('data/ffhq/uv_face_eye_mask.png') (triplane_next3d.py:91)
@@ -309,7 +311,7 @@ class TriPlaneGenerator(_Tracked):
             c = _fma.fma(c.contiguous(), torch.full((1, 1), scale, dtype=torch.float32, device=self.device).expand(n, 25).contiguous(), torch.zeros(n, 25, dtype=torch.float32, device=self.device))
         y = layers.fc(c.contiguous(), P[f'{pre}.embed.weight'], P[f'{pre}.embed.bias'], wgain=1 / np.sqrt(25))
         _lib.check(L.n3d_normalize_2nd_moment(_lib.ptr(y), _lib.c_void_p(x.data_ptr() + 512 * 4), n, 512, 1024, 1e-8, _lib.stream()))
-        for i in range(2):
+        for i in range(self.mapping_layers):
             w = P[f'{pre}.fc{i}.weight']
             x = layers.fc(x, w, P[f'{pre}.fc{i}.bias'], wgain=0.01 / np.sqrt(w.shape[1]), bgain=0.01, act='lrelu')
         num_ws = 2 * S.texture.num_ws

@@ -33,14 +33,15 @@ def _fir():
     return f / f.sum()
 
 
-def _mapping(spec, p, num_ws):
+def _mapping(spec, p, num_ws, num_layers=2):
+    """MappingNetwork (tat/networks_stylegan2.py:200-231): embed, then `num_layers` FC layers 1024 -> 512 -> ... -> 512 (num_layers: `mapping_kwargs`, train_next3d.py
+    map_depth = 2 for every next3d configuration; the class's own default is 8)."""
     spec[f'{p}.w_avg'] = ((W_DIM,), 'w_avg')
     spec[f'{p}.embed.weight'] = ((W_DIM, C_DIM), 'randn')
     spec[f'{p}.embed.bias'] = ((W_DIM,), 'bias')
-    spec[f'{p}.fc0.weight'] = ((W_DIM, Z_DIM + W_DIM), 'randn_lr')     # stored / lr_multiplier (0.01)
-    spec[f'{p}.fc0.bias'] = ((W_DIM,), 'bias')
-    spec[f'{p}.fc1.weight'] = ((W_DIM, W_DIM), 'randn_lr')
-    spec[f'{p}.fc1.bias'] = ((W_DIM,), 'bias')
+    for i in range(num_layers):
+        spec[f'{p}.fc{i}.weight'] = ((W_DIM, Z_DIM + W_DIM if i == 0 else W_DIM), 'randn_lr')     # stored / lr_multiplier (0.01)
+        spec[f'{p}.fc{i}.bias'] = ((W_DIM,), 'bias')
 
 
 def _synth_layer(spec, p, ic, oc, res, k=3):
@@ -129,20 +130,20 @@ def check_channels(channel_base=32768, channel_max=512):
     return cd
 
 
-def build_spec(sr=DEFAULT_SR, channel_base=32768, channel_max=512):
+def build_spec(sr=DEFAULT_SR, channel_base=32768, channel_max=512, mapping_layers=2):
     """name -> (shape, kind) for every parameter and buffer of TriPlaneGenerator (`sr`: the super-resolution class, SR_MODULES; channel_base /
     channel_max: the `synthesis_kwargs` every backbone receives, triplane_next3d.py:63-65,109 — the super-resolution modules ignore theirs)."""
     cb, cm = int(channel_base), int(channel_max)
     spec = OrderedDict()
     # texture_backbone: StyleGAN2 256², 32 ch (triplane_next3d.py:63)
     _synthesis(spec, 'texture_backbone.synthesis', 32, PLANE_RES, cb, cm)
-    _mapping(spec, 'texture_backbone.mapping', 14)
+    _mapping(spec, 'texture_backbone.mapping', 14, mapping_layers)
     # mouth_backbone: StyleUNet 64² -> 256², final 4 (:64)
     _styleunet(spec, 'mouth_backbone.synthesis', 32, 32, 64, 4, cb, cm)
-    _mapping(spec, 'mouth_backbone.mapping', 14)
+    _mapping(spec, 'mouth_backbone.mapping', 14, mapping_layers)
     # backbone: StyleGAN2 256², 96 ch, mapping broadcasts to 28 ws (:65)
     _synthesis(spec, 'backbone.synthesis', 96, PLANE_RES, cb, cm)
-    _mapping(spec, 'backbone.mapping', 28)
+    _mapping(spec, 'backbone.mapping', 28, mapping_layers)
     # superresolution (superresolution.py:29-124, :264-277): two blocks, every layer a SynthesisLayer of the block's resolution, toRGB to 3 colours
     _, (_, _, _, sr_blocks, sr_filter) = sr_module(sr)
     for bi, (_, ic, oc, res) in enumerate(sr_blocks):
@@ -167,7 +168,7 @@ def build_spec(sr=DEFAULT_SR, channel_base=32768, channel_max=512):
     spec['face_uvcoords'] = ((1, N_FACES, 3, 3), 'mesh')
     # neural_blending: StyleUNet 256² -> 256², final 32 (:109)
     _styleunet(spec, 'neural_blending.synthesis', 32, 32, 256, 32, cb, cm)
-    _mapping(spec, 'neural_blending.mapping', 14)
+    _mapping(spec, 'neural_blending.mapping', 14, mapping_layers)
     return spec
 
 
@@ -182,7 +183,7 @@ def _seed_for(name, seed):
 _WIDE_STYLE, _WIDE_TORGB = 3.0, 1.0 / 3.0
 
 
-def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR, channel_base=32768, channel_max=512):
+def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR, channel_base=32768, channel_max=512, mapping_layers=2):
     """Seeded synthetic weights (CPU fp32).  Distributions follow the reference initialisers
     (randn weights, affine bias 1) except that biases, noise_strength and w_avg — zero at init in
     the reference — get small seeded non-zero values so those code paths are exercised
@@ -197,7 +198,7 @@ def synthetic_state_dict(seed=0, only=None, profile='unit', sr=DEFAULT_SR, chann
         raise ValueError(profile)
     wide = profile == 'wide'
     out = OrderedDict()
-    for name, (shape, kind) in build_spec(sr, channel_base, channel_max).items():
+    for name, (shape, kind) in build_spec(sr, channel_base, channel_max, mapping_layers).items():
         if kind == 'mesh' or (only is not None and not only(name)):
             continue
         if kind == 'fir':

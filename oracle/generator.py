@@ -24,8 +24,9 @@ def mapping(P, z, c, rendering_kwargs, truncation_psi=1.0, truncation_cutoff=Non
     if rendering_kwargs['c_gen_conditioning_zero']:
         c = torch.zeros_like(c)
     c = c[:, :25]
+    num_layers = sum(1 for k in P if k.startswith('backbone.mapping.fc') and k.endswith('.weight'))       # (mapping_kwargs.num_layers: read off the parameters)
     return networks.mapping_network(P, 'backbone.mapping', z, c * rendering_kwargs.get('c_scale', 0),
-                                    num_ws=2 * NUM_WS_HALF, truncation_psi=truncation_psi,
+                                    num_ws=2 * NUM_WS_HALF, num_layers=num_layers, truncation_psi=truncation_psi,
                                     truncation_cutoff=truncation_cutoff)
 
 

@@ -336,7 +336,43 @@ def sr_modules(variants=VARIANTS_SR, what='sr modules'):
     return 0 if ok else 1
 
 
+def mapping_depth():
+    """--mapping-depth: `mapping_kwargs.num_layers` other than train_next3d.py's map_depth = 2 — the MappingNetwork's own default of 8 (what the reference builds when the
+    key is absent, tat/networks_stylegan2.py:207) and 1: the reference's constructors with that depth, seeded synthetic weights, ws of four seeds compared with the
+    oracle (max-abs 0.0 expected) and committed as tests/golden/mapping_depth.npz."""
+    torch.manual_seed(0)
+    uv_mask = n3d_mesh.synthetic_uv_face_mask()
+    ref_shims.install(uv_mask[0, 0].numpy())
+    import camera_utils as ref_cam
+    verts, faces, uvs, uvfaces = n3d_mesh.parse_obj(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    mb = n3d_mesh.mesh_buffers(faces, uvs, uvfaces)
+    z = torch.from_numpy(np.concatenate([np.random.RandomState(s_).randn(1, 512) for s_ in (0, 1, 2, 3)], 0))
+    pivot = torch.tensor(RENDERING_KWARGS['avg_camera_pivot'])
+    K = ref_cam.FOV_to_intrinsics(18.837)
+    cnd = ref_cam.LookAtPoseSampler.sample(np.pi / 2, np.pi / 2, pivot, radius=2.7)
+    c_cond = torch.cat([cnd.reshape(-1, 16), K.reshape(-1, 9)], 1).repeat(4, 1)
+    out, ok = dict(z=z.numpy(), c_cond=c_cond.numpy(), psi=0.7, cutoff=14), True
+    for depth in (8, 1):
+        G = ref_shims.build_reference_generator(RENDERING_KWARGS, mapping_kwargs=dict(num_layers=depth) if depth != 8 else {})
+        sd = n3d_spec.synthetic_state_dict(seed=0, mapping_layers=depth)
+        sd.update(mb)
+        ref_sd = G.state_dict()
+        assert set(ref_sd) == set(sd) and all(tuple(ref_sd[k].shape) == tuple(sd[k].shape) for k in sd), (depth, set(ref_sd) ^ set(sd))
+        G.load_state_dict(sd, strict=True)
+        ws_ref = G.mapping(z, c_cond, truncation_psi=0.7, truncation_cutoff=14)
+        ws_or = ogen.mapping(sd, z, c_cond, RENDERING_KWARGS, truncation_psi=0.7, truncation_cutoff=14)
+        err = float((ws_ref - ws_or).abs().max())
+        print(f'[mapping depth {depth}] {sum(1 for k in ref_sd if "backbone.mapping.fc" in k and k.endswith("weight") and k.startswith("backbone"))} FC layers; max-abs(reference - oracle) ws = {err:.2e}')
+        ok &= err <= 1e-6
+        out[f'ws_depth{depth}'] = ws_ref.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, 'mapping_depth.npz'), **out)
+    print('PIN mapping depth', 'OK' if ok else 'FAILED')
+    return 0 if ok else 1
+
+
 def main():
+    if '--mapping-depth' in sys.argv:
+        return mapping_depth()
     if '--sr-modules' in sys.argv:
         return sr_modules()
     if '--channel-widths' in sys.argv:

@@ -106,7 +106,7 @@ def install(uv_face_mask_np, third_party=True):
     os.chdir(REF)  # TriPlaneGenerator.__init__ opens data/ffhq/uv_face_eye_mask.png by relative path
 
 
-def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.obj', num_fp16_res=0, conv_clamp=None, channel_base=32768, channel_max=512):
+def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.obj', num_fp16_res=0, conv_clamp=None, channel_base=32768, channel_max=512, mapping_kwargs=None):
     """Construct the reference TriPlaneGenerator with the kwargs train_next3d.py would pass
     (train_next3d.py:250-411)."""
     from training_avatar_texture.triplane_next3d import TriPlaneGenerator
@@ -115,7 +115,7 @@ def build_reference_generator(rendering_kwargs, topology_path='data/demo/demo.ob
     img_resolution = {'8XDC': 512, '8X': 512, '4X': 256, '2X': 128}[rk['superresolution_module'].rsplit('Hybrid', 1)[-1]]      # every module asserts its own
     G = TriPlaneGenerator(
         z_dim=512, c_dim=25, w_dim=512, img_resolution=img_resolution, img_channels=3, topology_path=topology_path,
-        sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+        sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2) if mapping_kwargs is None else mapping_kwargs, rendering_kwargs=rk,
         sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'),
         channel_base=channel_base, channel_max=channel_max, fused_modconv_default='inference_only', num_fp16_res=num_fp16_res,
         conv_clamp=conv_clamp)        # (num_fp16_res = 4, conv_clamp = 256: what legacy.load_network_pkl(force_fp16=True) rebuilds the model with)

@@ -50,11 +50,17 @@ def test_generator_module_state_dict_names():
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
                           rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.SuperresolutionHybrid4X'))
     for cls, res in (('SuperresolutionHybrid8X', 512), ('SuperresolutionHybrid4X', 256), ('SuperresolutionHybrid2X', 128)):      # round 5: the other modules
-        g = TriPlaneGenerator(512, 25, 512, res, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(),
+        g = TriPlaneGenerator(512, 25, 512, res, 3, topo, uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=2),
                               rendering_kwargs=dict(demo.RENDERING_KWARGS, superresolution_module='training_avatar_texture.superresolution.' + cls))
         assert set(g.state_dict()) == set(spec.build_spec(cls)) and 'superresolution.resample_filter' in g.state_dict()
         assert tuple(g.state_dict()['superresolution.block1.conv1.weight'].shape) == (64, 64, 3, 3)
-    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask())
+    # mapping depth: without mapping_kwargs.num_layers the reference's MappingNetwork builds its own default of 8 layers (tat/networks_stylegan2.py:207;
+    # pinned: oracle/pin_against_reference.py --mapping-depth); train_next3d.py passes map_depth = 2
+    G8 = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask())
+    assert set(G8.state_dict()) == set(spec.build_spec(mapping_layers=8)) and 'neural_blending.mapping.fc7.weight' in G8.state_dict() and G8.backbone.mapping.num_layers == 8
+    with pytest.raises(RuntimeError, match='num_layers'):
+        TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=0))
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=2))
     assert G.sr_conv_clamp is None                                           # sr_num_fp16_res == 0 -> no clamp (superresolution.py:273)
     assert set(G.state_dict()) == set(spec.build_spec())
     params = {n for n, _ in G.named_parameters()}

@@ -276,6 +276,18 @@ def test_oracle_reproduces_reference_golden_of_other_architectures(suffix):
     assert float((out['image'][..., ::step, ::step] - t('image_sub')).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize('depth', [8, 1])
+def test_oracle_mapping_depths_against_reference(depth):
+    """mapping_kwargs.num_layers = 8 (the MappingNetwork's own default: what the reference builds when the key is absent) and 1: the oracle's ws against the
+    reference's own (tests/golden/mapping_depth.npz, oracle/pin_against_reference.py --mapping-depth)."""
+    import os
+    from next3d_amd import spec
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mapping_depth.npz'))
+    sd = spec.synthetic_state_dict(0, only=lambda n: n.startswith('backbone.mapping'), mapping_layers=depth)
+    ws = ogen.mapping(sd, torch.from_numpy(g['z']), torch.from_numpy(g['c_cond']), ogen.DEFAULT_RENDERING_KWARGS, truncation_psi=float(g['psi']), truncation_cutoff=int(g['cutoff']))
+    assert float((ws - torch.from_numpy(g[f'ws_depth{depth}'])).abs().max()) <= 1e-6
+
+
 def test_fp16_blocks_teacher_forced_oracle_vs_reference():
     """tests/golden/fp16_blocks.npz (round 5): every float16 block of the four backbones evaluated ALONE by the reference on a stated input.  The
     oracle's float16 emulation with the reference's off-GPU bias_act rounding reproduces each block almost bit for bit; the same emulation with

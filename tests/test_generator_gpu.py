@@ -684,6 +684,24 @@ def test_second_weight_draw_matches_reference_golden(GW, dev, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('depth', [8, 1])
+def test_mapping_depths_match_reference_golden(dev, depth):
+    """mapping_kwargs.num_layers = 8 (the MappingNetwork's default, what a constructor call WITHOUT the key builds in the reference) and 1 against the reference's
+    own ws (tests/golden/mapping_depth.npz); the forward runs on such a model."""
+    from next3d_amd import demo
+    g = np.load(os.path.join(GOLDEN, 'mapping_depth.npz'))
+    G, _ = demo.build_generator(dev, mapping_layers=depth)
+    assert G.backbone.mapping.num_layers == depth
+    ws = G.mapping(torch.from_numpy(g['z']).to(dev), torch.from_numpy(g['c_cond']).to(dev), truncation_psi=float(g['psi']), truncation_cutoff=int(g['cutoff']))
+    err = _md(ws, g[f'ws_depth{depth}'])
+    print(f'mapping depth {depth}: ws max-abs vs reference {err:.3e}')
+    assert err <= 1e-4
+    z, c, c_cond, v = demo.demo_batch([0], device=dev)
+    out = G.synthesis(ws[:1], c, v, neural_rendering_resolution=32, noise_mode='const')
+    assert tuple(out['image'].shape) == (1, 3, 512, 512) and bool(torch.isfinite(out['image']).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('suffix', ['cb16384', 'cb16384_cm256'])
 def test_other_channel_widths_match_reference_golden(dev, suffix):
     """Backbone widths other than the ffhq-512 pickle's (`--cbase 16384`, `--cmax 256` of train_next3d.py:199-200: 64-channel blocks at 256 x 256, 256 at the
