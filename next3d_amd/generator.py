@@ -104,9 +104,21 @@ class TriPlaneGenerator(_Tracked):
         # float16 blocks in the four StyleGAN2 / StyleUNet backbones: num_fp16_res > 0 — what legacy.load_network_pkl(force_fp16=True)
         # sets (legacy.py:49-59: num_fp16_res = 4, conv_clamp = 256; the ffhq-512 pickle itself has 0).  The blocks of resolution >=
         # fp16_resolution run on the f16 matrix-core kernels unless force_fp32 is passed (tat/networks_stylegan2.py:615-621, :548-562)
-        nfp16 = int(synthesis_kwargs.get('num_fp16_res', 0) or 0)
+        # the block options this build implements are the next3d ones; anything else must not be ignored silently (the reference would build another network,
+        # or raise TypeError for a key its blocks do not take)
+        fixed = dict(architecture='skip', use_noise=True, activation='lrelu', resample_filter=[1, 3, 3, 1])
+        for key, want in fixed.items():
+            got = synthesis_kwargs.get(key, want)
+            if (list(got) if key == 'resample_filter' else got) != want:
+                raise RuntimeError(f'synthesis_kwargs[{key!r}] = {got!r}: this build implements {want!r} only')
+        unknown = set(synthesis_kwargs) - set(fixed) - {'channel_base', 'channel_max', 'num_fp16_res', 'conv_clamp', 'fused_modconv_default', 'fp16_channels_last'}
+        if unknown:
+            raise TypeError(f'TriPlaneGenerator: unexpected synthesis keyword arguments {sorted(unknown)} (the reference\'s SynthesisBlock takes none of them)')
+        # (absent keys take the reference classes' own defaults: SynthesisNetwork num_fp16_res = 4, SynthesisBlock conv_clamp = 256, tat/networks_stylegan2.py:603,376;
+        #  train_next3d.py writes num_fp16_res = 0 / conv_clamp = None into every next3d pickle's init_kwargs)
+        nfp16 = int(synthesis_kwargs.get('num_fp16_res', 4) or 0)
         self.backbone_fp16_resolution = max(2 ** (8 + 1 - nfp16), 8) if nfp16 > 0 else None            # the backbones are 256 x 256 networks
-        self.backbone_conv_clamp = synthesis_kwargs.get('conv_clamp', None)
+        self.backbone_conv_clamp = synthesis_kwargs.get('conv_clamp', 256)
         self.init_args = (z_dim, c_dim, w_dim, img_resolution, img_channels, topology_path)
         self.init_kwargs = dict(sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs,
                                 rendering_kwargs=rendering_kwargs, sr_kwargs=sr_kwargs, **synthesis_kwargs)

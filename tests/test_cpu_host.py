@@ -62,6 +62,15 @@ def test_generator_module_state_dict_names():
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=0))
     G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=2))
     assert G.sr_conv_clamp is None                                           # sr_num_fp16_res == 0 -> no clamp (superresolution.py:273)
+    # absent synthesis kwargs take the reference classes' defaults: float16 in the 4 highest resolutions of the backbones (fp16_resolution 32), conv_clamp 256
+    assert G.backbone_fp16_resolution == 32 and G.backbone_conv_clamp == 256
+    G0 = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), num_fp16_res=0, conv_clamp=None)
+    for bad in (dict(architecture='resnet'), dict(use_noise=False), dict(resample_filter=[1, 2, 1])):               # block options other than next3d's: refused, not ignored
+        with pytest.raises(RuntimeError, match='implements'):
+            TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), **bad)
+    with pytest.raises(TypeError, match='unexpected'):                                                              # (as the reference's SynthesisBlock would)
+        TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), magnitude_ema_beta=0.9)
+    assert G0.backbone_fp16_resolution is None and G0.backbone_conv_clamp is None
     assert set(G.state_dict()) == set(spec.build_spec())
     params = {n for n, _ in G.named_parameters()}
     assert 'backbone.synthesis.b4.conv1.noise_const' not in params and 'backbone.synthesis.b4.conv1.weight' in params

@@ -760,7 +760,7 @@ def test_other_superresolution_modules_match_reference_golden(dev, cls, res):
         TriPlaneGenerator(512, 25, 512, res * 2, 3, (d0['faces'], d0['uvs'], d0['uvfaces']), sr_num_fp16_res=4, rendering_kwargs=dict(rk), uv_face_mask=mesh.synthetic_uv_face_mask())
     g = TriPlaneGenerator(512, 25, 512, res, 3, (d0['faces'], d0['uvs'], d0['uvfaces']), sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=dict(rk),
                           sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only'), uv_face_mask=mesh.synthetic_uv_face_mask(),
-                          channel_base=32768, channel_max=512, fused_modconv_default='inference_only')
+                          channel_base=32768, channel_max=512, fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None)
     sd = spec.synthetic_state_dict(0, sr=cls)
     sd.update(mesh.mesh_buffers(d0['faces'], d0['uvs'], d0['uvfaces']))
     assert sorted(k for k in g.state_dict() if k.startswith('superresolution')) == list(d['state_dict_names'])
