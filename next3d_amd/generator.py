@@ -582,6 +582,12 @@ class TriPlaneGenerator(_Tracked):
         # the reference's default: fp16 super-resolution blocks (no inference script passes force_fp32); `force_fp32=True` is
         # the float32 path its CPU run takes (networks_stylegan2.py:548) and the one the golden fixtures pin
         sr_fp16 = self.sr_use_fp16 and not synthesis_kwargs.get('force_fp32', False)
+        # rendering_kwargs['sr_antialias'] (train_next3d.py:326: True in every next3d configuration) selects the antialiased resize of superresolution.py:282-286.
+        # False: an UP-scaling is the same two taps and weights either way (differences of a float32 ulp); a DOWN-scaling (render above the module's input
+        # resolution) would be plain bilinear, which this build has no kernel for — refused, not replaced silently
+        if not self.rendering_kwargs.get('sr_antialias', True) and feature_image.shape[-1] > S.sr.input_resolution:
+            raise RuntimeError(f"sr_antialias=False with a {feature_image.shape[-1]} x {feature_image.shape[-1]} render above the super-resolution input "
+                               f'({S.sr.input_resolution}): the non-antialiased down-scaling is not implemented')
         sr_image = S.sr(rgb_image, feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16, bank=bank)
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 

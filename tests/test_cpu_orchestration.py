@@ -150,6 +150,16 @@ def test_generator_launch_sequence_dry_run(dry, N, R, Sc, Sf):
     assert tuple(out['image'].shape) == (N, 3, 512, 512) and sr16(Counter(dry), nb) == (1, 1, 2 + 2 * N, 2 * N, 2)
     with pytest.raises(RuntimeError):
         G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='fancy')
+    # sr_antialias=False (never set by train_next3d.py): fine for an up-scaling resize (same taps), refused for a down-scaling one (no plain-bilinear kernel)
+    G.rendering_kwargs['sr_antialias'] = False
+    try:
+        if R <= 128:
+            G.synthesis(ws, c, v, neural_rendering_resolution=R, noise_mode='const')
+        with pytest.raises(RuntimeError, match='sr_antialias'):
+            G.synthesis(ws, c, v, neural_rendering_resolution=160, noise_mode='const')
+    finally:
+        G.rendering_kwargs['sr_antialias'] = True
+        G.neural_rendering_resolution = R
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/training_avatar_texture'), reason='needs the reference tree (build container only)')
