@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 6
+#define N3D_ABI_VERSION 7
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -157,6 +157,10 @@ int n3d_conv2d_sk_s2_eligible(int N, int I, int O, int H, int W);
 /* the same question for the few-position TRANSPOSED layers (ksize 3, mode 2, float32 NCHW in and out, one weight tensor for the batch): 1 = the one-launch
  * kernel takes the layer whatever `ksplit` says (no workspace needed) */
 int n3d_conv2d_up_sk_eligible(int N, int I, int O, int H, int W);
+/* Floats of `workspace` the few-pixel kernels (the three questions above; mode as n3d_conv2d_desc.mode, mode 1: H x W = the input image) use for this
+ * layer when the descriptor carries arrival counters (desc.tickets), and the number of counters they need (*tickets_needed): 0 / 0 = not their layer,
+ * or a layer whose grid covers the chip without slicing K. */
+int64_t n3d_conv2d_sk_workspace(int N, int I, int O, int H, int W, int mode, int* tickets_needed);
 /* 1 when n3d_conv2d_bf16x3 accepts a split8 input for this 3x3 stride-1 shape (x_layout = N3D_LAYOUT_SPLIT8), else 0.
  * n3d_conv2d_split8_ksplit: 0 = not accepted, 1 = accepted, > 1 = accepted and run with that split-K factor (layers whose pixel tiles
  * alone leave CUs idle: the caller then provides `workspace` = ksplit * N * O * H * W floats; desc.ksplit is ignored). */
@@ -227,6 +231,13 @@ typedef struct {
     float* rgb_partial;
     int rgb_channels;          /* 1 .. 4 */
     int64_t rgb_style_stride;  /* floats between samples of rgb_style (0 = O) */
+    /* ---- ABI 7: arrival counters for kernels that split K over WORKGROUPS and reduce inside the launch (the few-pixel 3x3 layers of
+     *      n3d_conv2d_bf16x3, conv2d_sk_bf16x3.hip): ticket_count zero-initialised 32-bit words owned by the caller, ONE pool per stream (launches of
+     *      a stream are serialised; every launch leaves the words zero, so the pool is zeroed once at allocation).  With tickets != NULL and
+     *      workspace = n3d_conv2d_sk_workspace(...) floats the layer's K is sliced over up to 256 workgroups and the last-arriving slice of an output
+     *      tile adds the slices' slabs in slice order and applies the epilogue (bitwise reproducible); NULL = the whole K inside one workgroup. */
+    unsigned int* tickets;
+    int ticket_count;
 } n3d_conv2d_desc;
 int n3d_conv2d(const n3d_conv2d_desc* desc, n3d_stream_t stream);
 

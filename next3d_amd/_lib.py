@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -36,7 +36,8 @@ class Conv2dDesc(ctypes.Structure):
                 ('x_batch_stride', c_int64), ('y_batch_stride', c_int64), ('style_stride', c_int64),
                 ('x_row_stride', c_int64), ('y_row_stride', c_int64), ('epi', Epilogue), ('x_layout', c_int), ('y_layout', c_int),
                 ('side_split8', c_void_p), ('side_style', c_void_p), ('side_style_stride', c_int64), ('wt_batch_stride', c_int64),
-                ('rgb_weight', c_void_p), ('rgb_style', c_void_p), ('rgb_partial', c_void_p), ('rgb_channels', c_int), ('rgb_style_stride', c_int64)]
+                ('rgb_weight', c_void_p), ('rgb_style', c_void_p), ('rgb_partial', c_void_p), ('rgb_channels', c_int), ('rgb_style_stride', c_int64),
+                ('tickets', c_void_p), ('ticket_count', c_int)]
 
 
 class RenderOpts(ctypes.Structure):
@@ -62,6 +63,7 @@ _SIGNATURES = {
     'n3d_prof_reset': (c_int, []),
     'n3d_prof_read': (c_int, [c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_double),
                               ctypes.POINTER(c_double)]),
+    'n3d_conv2d_sk_workspace': (c_int64, [c_int] * 6 + [ctypes.POINTER(c_int)]),
     'n3d_rgb_combine': (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [ctypes.POINTER(Epilogue), c_void_p]),
     'n3d_bias_act': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float,
                              c_float, c_void_p]),
@@ -185,6 +187,57 @@ def ptr(t):
     except AttributeError:
         _tls.held = [t]
     return t.data_ptr()             # (a plain int: ctypes converts it for c_void_p arguments and struct fields; ~1500 calls per forward)
+
+
+TICKET_COUNT = 4096
+_ticket_pools = {}
+
+
+def tickets():
+    """The current stream's pool of arrival counters (n3d_conv2d_desc.tickets): TICKET_COUNT zeroed int32 words.  Kernels that split K over
+    workgroups and reduce in the last-arriving one (csrc/conv2d_sk_bf16x3.hip) count arrivals per output tile here and leave every word zero, so
+    a pool is zeroed once, when it is created; launches of ONE stream are serialised and may share it, different streams (the side stream of the
+    static backbone, the bench's lanes) get their own.  A HIP graph replays on whatever stream its caller picks, possibly beside eager work of
+    the streams it was captured on: `ticket_pools(...)` gives a capture its own pools, allocated eagerly BEFORE the capture begins
+    (generator.synthesis_graph)."""
+    cur = torch.cuda.current_stream()
+    over = getattr(_tls, 'ticket_override', None)
+    if over is not None:
+        t = over.assigned.get(cur.cuda_stream)
+        if t is None and over.free:
+            t = over.assigned[cur.cuda_stream] = over.free.pop()
+        if t is not None:
+            return t
+    elif not torch.cuda.is_current_stream_capturing():
+        key = (cur.device.index, cur.cuda_stream)
+        t = _ticket_pools.get(key)
+        if t is None:
+            t = _ticket_pools[key] = torch.zeros(TICKET_COUNT, dtype=torch.int32, device=cur.device)
+        return t
+    # a capture that did not provide pools (or more streams than pools): the zero fill becomes a memset node of that graph, replayed in front of
+    # the launch that counts here; the words live in the graph's private memory
+    return torch.zeros(TICKET_COUNT, dtype=torch.int32, device=cur.device)
+
+
+class ticket_pools:
+    """Context manager: launches inside take their arrival counters from `pools` (zeroed int32 [TICKET_COUNT] tensors, one per stream the region
+    launches on, handed out in order of first use) instead of the streams' own pools — what a captured graph needs (see `tickets`)."""
+
+    def __init__(self, pools):
+        self.free, self.assigned, self.all = list(pools), {}, list(pools)
+
+    def __enter__(self):
+        self.prev = getattr(_tls, 'ticket_override', None)
+        _tls.ticket_override = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.ticket_override = self.prev
+        return False
+
+
+def new_ticket_pools(device, count=3):
+    return [torch.zeros(TICKET_COUNT, dtype=torch.int32, device=device) for _ in range(count)]
 
 
 def require_device(*tensors):

@@ -16,6 +16,17 @@
 // the eight partial accumulators are summed through LDS in a fixed order (deterministic) and wave w applies the epilogue to rows r = w (mod 8).
 // The grid is XCD-aware the other way round from the large kernels: a 32-channel weight tile (9 * I * 32 * 4 B = 0.6 MB at I = 512) is
 // re-read by every pixel tile, so all workgroups of one channel tile sit on ONE XCD and its 4 MB L2 holds the two or so tiles it serves.
+//
+// Round 6 — K also split ACROSS workgroups, reduced inside the launch (KS > 1).  With K inside one workgroup a 4 x 4 .. 16 x 16 layer is 16-64
+// workgroups, each streaming 0.6 MB of weight tiles in dependent chunk round trips: 17-44 us for a 9.4 MB weight stream whose HBM time is ~2 us
+// (profiles/r05_layer_trace.txt).  Now the grid is (pixel tile, channel tile, K slice): slice s of KS takes the chunks
+// [(8 s + w) nc, ...) for its wave w, nc = KC / (8 KS) — down to ONE chunk (18 KB of fragments) per wave — so that the whole chip pulls the layer's
+// weights at once.  The slices meet through HBM: every workgroup writes the LDS-reduced sums of its slice as a 4-16 KB slab with write-through (sc1)
+// stores, every wave drains them (s_waitcnt vmcnt(0)), one lane takes a ticket (relaxed agent-scope fetch_add on the tile's arrival counter), and the
+// workgroup that draws KS - 1 — the last arriver, whichever it is — re-arms the counter, issues ONE agent-scope acquire, adds the KS slabs IN SLICE
+// ORDER (bitwise reproducible whatever the arrival order) and applies the epilogue: no second launch, no spin wait, no assumption about dispatch
+// order or placement (cdna_hip_programming.md section 5 item 2 / Guideline 16).  The arrival counters are the CALLER's (n3d_conv2d_desc.tickets:
+// zeroed once, one pool per stream; every launch leaves them zero).
 #include <stdlib.h>
 
 #include "common.h"
@@ -31,8 +42,30 @@ struct SkParams {
     int tiles_p, tiles_m;
     int x_bytes;                          // size of the whole input tensor (buffer descriptor range)
     int64_t xbs, ybs, yrs, style_stride;
+    int KS;                               // K slices over workgroups (1 = the whole K inside one workgroup, no slabs)
+    float* partial; unsigned* tickets;    // KS > 1: slabs [tile][channel tile][slice][PT * 16 items][64 lanes]; arrival counters [tile][channel tile]
     n3d_epilogue epi;
 };
+
+// ---- the seam between the K slices of one output tile (see the header comment)
+typedef __attribute__((address_space(1))) unsigned sk_gu32;
+__device__ __forceinline__ void sk_slab_store(float* p, float v) {          // 4-byte write-through (sc1) store: an accumulator epilogue's natural width
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Every wave calls this after its slab stores.  Returns true in the workgroup that arrived last (then: counter re-armed, acquire done, all waves past a barrier).
+__device__ __forceinline__ bool sk_arrive_last(unsigned* ticket, int KS, unsigned* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                                       // ... before ONE lane takes the ticket
+    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_flag != (unsigned)(KS - 1)) return false;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the stream's next launch (nobody else arrives any more)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // ONE acquire: this CU's L1 holds no stale slab line afterwards
+    }
+    __syncthreads();
+    return true;
+}
 
 constexpr int SK_SLOTS = 128;                                              // patch pixels per wave region (stride 1; the transposed twin below)
 constexpr int SK_WAVE_SLOTS = 2 * 2 * SK_SLOTS;                            // [hi|lo][half][pixel] 16-byte slots = 8 KB
@@ -48,18 +81,20 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
     __shared__ float s_style[2 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    int mt_i, tile;
+    int mt_i, tile, ks;
     {
-        const int b = blockIdx.x;
-        if ((p.tiles_m & 7) == 0) {                                        // one channel tile's workgroups share an XCD (= blockIdx % 8)
-            const int per = p.tiles_m >> 3, q = b >> 3;
-            mt_i = (b & 7) + 8 * (q % per); tile = q / per;
-        } else { mt_i = b % p.tiles_m; tile = b / p.tiles_m; }
+        const int b = blockIdx.x, units = p.tiles_m * p.KS;                // unit = (channel tile, K slice): one slab of weights
+        int u;
+        if ((units & 7) == 0) {                                            // one unit's workgroups (the pixel tiles re-reading its weights) share an XCD (= blockIdx % 8)
+            const int per = units >> 3, q = b >> 3;
+            u = (b & 7) + 8 * (q % per); tile = q / per;
+        } else { u = b % units; tile = b / units; }
+        mt_i = u % p.tiles_m; ks = u / p.tiles_m;
     }
     const int m0 = mt_i * 32;
     const int n0 = p.NS == 1 ? tile / p.tps : tile * p.NS;
     const int y0 = p.NS == 1 ? (tile % p.tps) * p.R : 0;
-    const int KC = p.I / 16, nc = KC / 8, c_begin = wn * nc;
+    const int KC = p.I / 16, nc = KC / (8 * p.KS), c_begin = (ks * 8 + wn) * nc;
     const int PRW = p.PR * p.PW;
 
     for (int i = tid; i < p.NS * p.I; i += 512) {
@@ -165,13 +200,31 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wn * PT + g) * 16 + r) * 64 + lane] = NA == 3 ? (acc[g][0][r] + acc[g][1][r]) + acc[g][NA - 1][r] : acc[g][0][r] + acc[g][NA - 1][r];
     __syncthreads();
+    const float* slabs = nullptr;
+    if (p.KS > 1) {                                                        // this slice's sums -> its slab; the last-arriving slice of the tile goes on
+        slabs = p.partial + (int64_t)(tile * p.tiles_m + mt_i) * p.KS * (PT * 16 * 64);
+        float* slab = const_cast<float*>(slabs) + (int64_t)ks * (PT * 16 * 64);
+#pragma unroll
+        for (int q = 0; q < PT * 2; ++q) {
+            const int item = q * 8 + wn, g = item >> 4, r = item & 15;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[((w * PT + g) * 16 + r) * 64 + lane];
+            sk_slab_store(slab + item * 64 + lane, v);
+        }
+        if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
+    }
 #pragma unroll
     for (int q = 0; q < PT * 2; ++q) {
         const int item = q * 8 + wn, g = item >> 4, r = item & 15;
         const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = 0.f;
+        if (slabs) {
+            for (int k = 0; k < p.KS; ++k) v += slabs[(int64_t)k * (PT * 16 * 64) + item * 64 + lane];        // slice order: reproducible
+        } else {
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[((w * PT + g) * 16 + r) * 64 + lane];
+        }
         int n_, oy_, ox_;                                                  // (g is a run-time value here: select instead of indexing registers)
         n_ = on[0]; oy_ = oy[0]; ox_ = ox[0];
 #pragma unroll
@@ -183,15 +236,27 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
     }
 }
 
+// K slices over workgroups for a launch of `units` = (pixel tiles x channel tiles) single-slice workgroups: double while the grid stays within
+// ~one workgroup per CU and every wave keeps at least one 16-channel chunk.  No arrival counters (desc.tickets) -> 1: the whole K inside the workgroup.
+constexpr int SK_MAX_TICKETS = 4096;
+static int sk_slices(int units, int KC, int target) {
+    int ks = 1;
+    const int forced = n3d_tune("N3D_SK_KS", 0);
+    if (forced > 0) return (KC % (8 * forced) == 0) ? forced : 1;
+    target = n3d_tune("N3D_SK_TARGET", target);
+    while (units * ks * 2 <= target && KC % (16 * ks) == 0) ks *= 2;
+    return ks;
+}
+
 // tile plan; false when the layer is not this kernel's
-static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_out) {
+static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_out, bool seam = false) {
     static const bool enabled = n3d_tune("N3D_CONV_SK", 1) != 0;
     if (!enabled) return false;
     if (N < 1 || I % 128 != 0 || I > 1024 || O % 32 != 0 || O < 32 || H < 2 || W < 2 || W > 32) return false;
     const int HW = H * W;
     const int64_t px = (int64_t)N * HW;
     if (px > 2048 || HW > 1024) return false;                              // every pixel tile re-reads the layer's weights from L2
-    if (I > 512 && px > 256) return false;                                 // (measured: 61 against 45 us at I = 1024, 16 x 16 x 4: 8 chunks per wave in sequence)
+    if (I > 512 && px > n3d_tune("N3D_SK_WIDE_PX", 256)) return false;                                 // (measured: 61 against 45 us at I = 1024, 16 x 16 x 4: 8 chunks per wave in sequence)
     int best = 0;
     SkParams bp;
     for (int pt = 2; pt >= 1; --pt) {
@@ -202,8 +267,11 @@ static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_ou
         if (q.NS > 2) continue;                                            // s_style holds two samples' styles
         q.PR = q.R + 2; q.PW = W + 2; q.nslots = q.NS * q.PR * q.PW;
         if (q.nslots > SK_SLOTS) continue;
-        // 64-pixel tiles (every weight fragment feeds two pixel groups) once they still give the chip a workgroup per CU
-        if (pt == 2 && (int64_t)q.tiles_p * (O / 32) < 256) continue;
+        // 64-pixel tiles (every weight fragment feeds two pixel groups) once they still give the chip a workgroup per CU — counting the K slices
+        // a launch with arrival counters adds (round 6): the weights then cross L2 -> CU once per 64 pixels instead of once per 32
+        const int pt_force = n3d_tune("N3D_SK_PT", 0);
+        if (pt_force && pt != pt_force) continue;
+        if (!pt_force && pt == 2 && (int64_t)q.tiles_p * (O / 32) * (seam ? (I / 16) / 8 : 1) < 256) continue;
         best = pt; bp = q;
         break;
     }
@@ -214,6 +282,16 @@ static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_ou
 }
 
 extern "C" int n3d_conv2d_sk_eligible(int N, int I, int O, int H, int W) { return sk_plan(N, I, O, H, W, nullptr, nullptr) ? 1 : 0; }
+
+// The K slices of one launch, from what the descriptor offers: arrival counters for every output tile (desc.tickets / ticket_count) and a slab
+// workspace of units * KS * slab floats (desc.workspace, sized by n3d_conv2d_sk_workspace).  Without counters: KS = 1, exactly the round-5 launch.
+static void sk_seam(const n3d_conv2d_desc* d, int units, int slab_floats, int target, int* KS, float** partial, unsigned** tickets) {
+    *KS = 1; *partial = nullptr; *tickets = nullptr;
+    if (!d->tickets || !d->workspace || units > d->ticket_count || units > SK_MAX_TICKETS) return;
+    const int ks = sk_slices(units, d->I / 16, target);
+    if (ks <= 1) return;
+    *KS = ks; *partial = d->workspace; *tickets = d->tickets;
+}
 
 // stride 2 (mode 1): input IH x IW = (2 OH + 1) x (2 OW + 1), 32-pixel output tiles of R rows (or two whole samples), patch <= 192 input pixels
 static bool sk_s2_plan(int N, int I, int O, int IH, int IW, SkParams* out) {
@@ -254,10 +332,11 @@ int conv2d_sk_s2_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream)
     N3D_CHECK(p.yrs >= p.W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.epi = d->epi;
+    sk_seam(d, p.tiles_p * p.tiles_m, 1 * 16 * 64, 256, &p.KS, &p.partial, &p.tickets);
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.HW;
     const double bytes = 4.0 * ((double)d->N * d->I * p.HWin + (double)d->N * d->O * p.HW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL((conv2d_sk_bf16x3_kernel<1, 2>), dim3((unsigned)(p.tiles_p * p.tiles_m)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((conv2d_sk_bf16x3_kernel<1, 2>), dim3((unsigned)(p.tiles_p * p.tiles_m * p.KS)), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }
@@ -268,7 +347,7 @@ int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     SkParams p;
     int pt;
     if (d->epi.round_f16 || d->epi.residual_up_filter || d->side_split8 || d->y_layout != N3D_LAYOUT_NCHW_F32) return 1;
-    if (!sk_plan(d->N, d->I, d->O, d->H, d->W, &p, &pt)) return 1;
+    if (!sk_plan(d->N, d->I, d->O, d->H, d->W, &p, &pt, d->tickets && d->workspace)) return 1;
     const int64_t xbs = d->x_batch_stride;                                 // taken literally, like the other float32-input kernels: 0 = one image for the whole batch (the learned constant, expand()ed)
     const int64_t x_bytes = ((int64_t)(d->N - 1) * xbs + (int64_t)d->I * d->H * d->W) * 4;
     if (x_bytes >= (1ll << 31)) return 1;
@@ -282,10 +361,11 @@ int conv2d_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     N3D_CHECK(p.yrs >= d->W, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.epi = d->epi;
+    sk_seam(d, p.tiles_p * p.tiles_m, pt * 16 * 64, 256, &p.KS, &p.partial, &p.tickets);
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.HW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    const dim3 grid((unsigned)(p.tiles_p * p.tiles_m));
+    const dim3 grid((unsigned)(p.tiles_p * p.tiles_m * p.KS));
     if (pt == 2) hipLaunchKernelGGL(conv2d_sk_bf16x3_kernel<2>, grid, dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(conv2d_sk_bf16x3_kernel<1>, grid, dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
@@ -307,6 +387,8 @@ struct SkUpParams {
     int PW, tps, tiles_m;                            // patch pitch W + 2, position tiles per sample
     int x_bytes;
     int64_t xbs, ybs, yrs, style_stride;
+    int KS;                                          // K slices over workgroups, as SkParams
+    float* partial; unsigned* tickets;               // slabs [tile][channel tile][slice][4 phases * 16 items][64 lanes]
     n3d_epilogue epi;
 };
 
@@ -315,16 +397,18 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
     __shared__ float s_style[1024];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    int mt_i, tile;
+    int mt_i, tile, ks;
     {
-        const int b = blockIdx.x;
-        if ((p.tiles_m & 7) == 0) { const int per = p.tiles_m >> 3, q = b >> 3; mt_i = (b & 7) + 8 * (q % per); tile = q / per; }
-        else { mt_i = b % p.tiles_m; tile = b / p.tiles_m; }
+        const int b = blockIdx.x, units = p.tiles_m * p.KS;
+        int u;
+        if ((units & 7) == 0) { const int per = units >> 3, q = b >> 3; u = (b & 7) + 8 * (q % per); tile = q / per; }
+        else { u = b % units; tile = b / units; }
+        mt_i = u % p.tiles_m; ks = u / p.tiles_m;
     }
     const int m0 = mt_i * 32;
     const int n = tile / p.tps, q0 = (tile % p.tps) * 32;                  // sample, first flattened position of the tile
     const int row0 = q0 / p.GW;                                            // first position row: patch row 0 = input row row0 - 1
-    const int KC = p.I / 16, nc = KC / 8, c_begin = wn * nc;
+    const int KC = p.I / 16, nc = KC / (8 * p.KS), c_begin = (ks * 8 + wn) * nc;
     for (int i = tid; i < p.I; i += 512) s_style[i] = p.style ? p.style[(int64_t)n * p.style_stride + i] : 1.f;
 
     const int rows = min(q0 + 31, p.P - 1) / p.GW - row0 + 2, nslots = rows * p.PW;       // patch rows: the position rows + one
@@ -404,6 +488,7 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
 
     // the eight partial sums through LDS in wave order, two phases (one output row pair... the phases pa = 0, then pa = 1) at a time: 8 x 2 x 16 x 64 floats = 64 KB
     float* red = reinterpret_cast<float*>(smem);
+    const float* slabs = p.KS > 1 ? p.partial + (int64_t)(tile * p.tiles_m + mt_i) * p.KS * (4 * 16 * 64) : nullptr;
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
         __syncthreads();                                                   // the patch regions (pa = 0) / the previous round's sums (pa = 1) are dead
@@ -419,11 +504,26 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[((w * 2 + pb) * 16 + r) * 64 + lane];
+            if (slabs) { sk_slab_store(const_cast<float*>(slabs) + ((int64_t)ks * 64 + pa * 32 + item) * 64 + lane, v); continue; }      // this slice's slab
             const int oy = 2 * gy + pa, ox = 2 * gx + pb;
             if (!q_act || o >= p.O || oy >= p.OH || ox >= p.OW) continue;
             p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
         }
     }
+    if (!slabs) return;
+    if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 8 + wn, pb = item >> 4, r = item & 15;
+            const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = 0.f;
+            for (int k = 0; k < p.KS; ++k) v += slabs[((int64_t)k * 64 + pa * 32 + item) * 64 + lane];           // slice order: reproducible
+            const int oy = 2 * gy + pa, ox = 2 * gx + pb;
+            if (!q_act || o >= p.O || oy >= p.OH || ox >= p.OW) continue;
+            p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
+        }
 }
 
 static bool sk_up_plan(int N, int I, int O, int H, int W) {
@@ -432,7 +532,7 @@ static bool sk_up_plan(int N, int I, int O, int H, int W) {
     const int P = (H + 1) * (W + 1);
     // every 32-position tile re-reads the layer's weights from L2: measured (layer trace inside a forward) 4 x 4 at batch 4 53 -> 44 us, 8 x 8 56 -> 41,
     // 16 x 16 at batch 1 61 -> 42 — but 16 x 16 at batch 4 (1156 positions) 77 us against 62 for the pre-split kernel, 32 x 32 at batch 1 76 against 68
-    if ((int64_t)N * P > 512) return false;
+    if ((int64_t)N * P > n3d_tune("N3D_SK_UP_MAXP", 512)) return false;
     // the patch of 32 consecutive positions: at most 32 / (W+1) + 2 position rows + 1, W + 2 wide
     const int rows = (32 + W) / (W + 1) + 2;
     return rows * (W + 2) <= SK_SLOTS;
@@ -458,10 +558,29 @@ int conv2d_up_sk_bf16x3_try_launch(const n3d_conv2d_desc* d, hipStream_t stream)
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
     p.style_stride = d->style_stride ? d->style_stride : d->I;
     p.epi = d->epi;
+    sk_seam(d, d->N * p.tps * p.tiles_m, 4 * 16 * 64, 256, &p.KS, &p.partial, &p.tickets);
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * p.HW + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_up_sk_bf16x3_kernel, dim3((unsigned)(d->N * p.tps * p.tiles_m)), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(conv2d_up_sk_bf16x3_kernel, dim3((unsigned)(d->N * p.tps * p.tiles_m * p.KS)), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
+}
+
+// Floats of slab workspace (desc.workspace) the few-pixel kernels use for this layer when the descriptor carries arrival counters (desc.tickets), and
+// the counters it needs (*tickets_needed): 0 / 0 = the layer is not theirs, or runs with the whole K inside one workgroup.  mode 0 / 1 / 2 as
+// n3d_conv2d_desc.mode (mode 1: H x W = the input image).
+extern "C" int64_t n3d_conv2d_sk_workspace(int N, int I, int O, int H, int W, int mode, int* tickets_needed) {
+    if (tickets_needed) *tickets_needed = 0;
+    int units = 0, slab = 0;
+    SkParams p; int pt;
+    if (mode == 0) { if (!sk_plan(N, I, O, H, W, &p, &pt, true)) return 0; units = p.tiles_p * (O / 32); slab = pt * 16 * 64; }
+    else if (mode == 1) { if (!sk_s2_plan(N, I, O, H, W, &p)) return 0; units = p.tiles_p * (O / 32); slab = 16 * 64; }
+    else if (mode == 2) { if (!sk_up_plan(N, I, O, H, W)) return 0; units = N * (((H + 1) * (W + 1) + 31) / 32) * (O / 32); slab = 4 * 16 * 64; }
+    else return 0;
+    if (units > SK_MAX_TICKETS) return 0;
+    const int ks = sk_slices(units, I / 16, 256);
+    if (ks <= 1) return 0;
+    if (tickets_needed) *tickets_needed = units;
+    return (int64_t)units * ks * slab;
 }

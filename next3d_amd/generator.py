@@ -651,8 +651,12 @@ class TriPlaneGenerator(_Tracked):
             cur.wait_stream(warm)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # the graph's own arrival counters (the few-pixel layers' in-launch split-K reduce, _lib.tickets): allocated and zeroed HERE, eagerly —
+            # a replay may run beside eager launches of the streams it was captured on, so it must not share their pools
+            pools = _lib.ticket_pools(_lib.new_ticket_pools(dev))
+            with torch.cuda.graph(graph), pools:
                 out = call()
+            st['_ticket_pools'] = pools.all
             # the caches the graph reads stay referenced by its entry: they outlive the graph whatever the caller does next
             entry = self._graphs[sig] = (graph, st, out, uses_cache, (self._last_planes, self._identity_cache) if uses_cache else None)
         graph, st, out = entry[:3]

@@ -18,6 +18,7 @@ parameter is re-tiled once; temporaries (Conv2dLayer's `self.weight * self.weigh
 (data_ptr, _version) would hand layer B the tiles of layer A's freed temporary of the same shape.
 Anything else raises RuntimeError (the analogue of ATen's dtype check) — a non-float32 pointer never reaches a float32 kernel."""
 import contextlib
+import ctypes
 
 import os
 
@@ -118,6 +119,15 @@ def sk_s2_eligible(n, i, o, h, w):
 
 
 @_memo
+def sk_workspace(n, i, o, h, w, mode):
+    """n3d_conv2d_sk_workspace: (floats of slab workspace, arrival counters) the few-pixel 3x3 kernels use for this layer when the descriptor carries
+    `tickets` — K sliced over workgroups, reduced by the last arriver inside the launch; (0, 0) = not their layer / no slicing."""
+    need = ctypes.c_int(0)
+    fl = int(_lib.lib().n3d_conv2d_sk_workspace(n, i, o, h, w, mode, ctypes.byref(need)))
+    return fl, need.value
+
+
+@_memo
 def _bf16x3_blocks(n, o, h, w, mode):
     return int(_lib.lib().n3d_conv2d_bf16x3_blocks(n, o, h, w, mode))
 
@@ -151,6 +161,7 @@ def split8_from_nchw(x, scale=None):
     return y
 
 
+SK_SEAM = True       # few-pixel layers: K sliced over workgroups, reduced inside the launch (module constant; tools flip it in-process for A/B runs)
 KSPLIT_MAX = 64      # cap on the split-K factor of the split-bf16 3x3 kernels (module constant; tools sweep it in-process)
 
 
@@ -262,15 +273,22 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
         y = torch.empty([n, o, oh, ow], dtype=torch.float32, device=wt.device)
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
+    sk_layer = False
     if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and sk_eligible(n, i, o, h, w):
-        ksplit = 1                                       # the few-pixel kernel splits K inside its workgroups: no partial-sum workspace
+        ksplit, sk_layer = 1, True                       # the few-pixel kernel splits K inside its workgroups: no split-K reduce launch
     if bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and up_sk_eligible(n, i, o, h, w):
-        ksplit = 1                                       # ... and so does its transposed twin (few-position up-sampling layers)
+        ksplit, sk_layer = 1, True                       # ... and so does its transposed twin (few-position up-sampling layers)
     if bf16x3 and ksize == 3 and mode == 1 and not split8 and not pitched_in and not _wt_batch_stride and out_dtype == torch.float32 and sk_s2_eligible(n, i, o, h, w):
-        ksplit = 1                                       # ... and the few-pixel stride-2 layers
+        ksplit, sk_layer = 1, True                       # ... and the few-pixel stride-2 layers
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)
     ws = torch.empty([ksplit * n * o * oh * ow], dtype=torch.float32, device=wt.device) if ksplit > 1 else None
+    tk = None
+    if SK_SEAM and sk_layer:                             # the few-pixel kernels slice K over the chip when given slabs + this stream's arrival counters
+        sk_floats, sk_need = sk_workspace(n, i, o, h, w, mode)
+        if sk_floats and sk_need <= _lib.TICKET_COUNT:
+            ws = torch.empty([sk_floats], dtype=torch.float32, device=wt.device)
+            tk = _lib.tickets()
     d = _lib.Conv2dDesc()
     d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), (None if rgb is not None else _lib.ptr(c8.data if c8 else (s8.data if s8 else y))), _lib.ptr(ws)
     d.x_layout, d.y_layout = (1 if split8 else 0), (2 if c8 else (1 if s8 else 0))
@@ -282,6 +300,8 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     d.wt_batch_stride = int(_wt_batch_stride)
+    if tk is not None:
+        d.tickets, d.ticket_count = _lib.ptr(tk), tk.numel()
     partial = None
     if rgb is not None:
         rw, rs = rgb

@@ -867,3 +867,57 @@ def test_transposed_conv_channel_interleaved_output(dev, monkeypatch, N, I, OC, 
     ps = cg.conv_launch(xs, wt16, 3, 2, OC, epilogue=_lib.make_epilogue(row_scale=dco), bf16x3=True, out_c8=True)
     print('transposed presplit vs register-staged: max abs diff', float((ps.to_nchw() - ref).abs().max()), 'bit-identical', bool(torch.equal(ps.to_nchw(), ref)))
     _close(ps.to_nchw(), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('N,I,OC,H,W,mode', [(4, 512, 512, 4, 4, 0), (4, 512, 512, 8, 8, 0), (1, 512, 512, 16, 16, 0), (4, 1024, 512, 8, 8, 0), (1, 512, 512, 4, 4, 0),
+                                            (3, 256, 96, 8, 8, 0), (4, 512, 512, 4, 4, 2), (1, 512, 512, 8, 8, 2), (4, 512, 512, 9, 9, 1), (1, 512, 512, 17, 17, 1)])
+def test_few_pixel_split_k_seam(dev, N, I, OC, H, W, mode):
+    """Round 6: the few-pixel 3x3 kernels slice K over WORKGROUPS and reduce inside the launch (conv2d_sk_bf16x3.hip: write-through slabs, one arrival
+    counter per output tile, the last arriver adds the slabs in slice order and applies the epilogue).  Against the same kernel with the whole K inside one
+    workgroup (round 5's launch, SK_SEAM = False) and against float32 ATen; the arrival counters are zero again after every launch; 40 launches in a row and
+    launches on three streams at once BESIDE chip-filling convolutions (uneven load, warm L1s: what an inter-workgroup hand-off has to survive) return the same bits."""
+    import torch.nn.functional as F
+    from next3d_amd import _lib
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    x, w = _gen((N, I, H, W), 190), _gen((OC, I, 3, 3), 191) / np.sqrt(I * 9)
+    s, d, b = _gen((N, I), 192), _gen((N, OC), 193).abs() + 0.5, _gen((OC,), 194)
+    t = lambda a: a.to(dev)
+    wt16 = cg.prep_weight_bf16x3(t(w))
+    xs = x * s[:, :, None, None]
+    ref = {0: lambda: F.conv2d(xs, w, padding=1), 1: lambda: F.conv2d(xs, w, stride=2), 2: lambda: F.conv_transpose2d(xs, w.transpose(0, 1), stride=2)}[mode]()
+    ref = O.bias_act(ref * d[:, :, None, None], b, act='lrelu')
+    fl, need = cg.sk_workspace(N, I, OC, H, W, mode)
+    assert fl > 0 and 0 < need <= _lib.TICKET_COUNT, 'this shape is expected to run with K slices'
+    run = lambda: cg.conv_launch(t(x), wt16, 3, mode, OC, style=t(s), epilogue=_lib.make_epilogue(row_scale=t(d), bias=t(b), act='lrelu'), bf16x3=True)
+    old = cg.SK_SEAM
+    try:
+        cg.SK_SEAM = False
+        y0 = run()
+        cg.SK_SEAM = True
+        y1 = run()
+    finally:
+        cg.SK_SEAM = old
+    scale = max(1.0, float(ref.abs().max()))
+    assert tuple(y1.shape) == tuple(ref.shape)
+    assert float((y1.cpu() - ref).abs().max()) <= 1e-4 * scale
+    assert float((y1 - y0).abs().max()) <= 2e-5 * scale                      # another summation order, the same products
+    assert int(_lib.tickets().abs().sum()) == 0
+    for _ in range(40):
+        assert torch.equal(run(), y1)
+    assert int(_lib.tickets().abs().sum()) == 0
+    # three streams, each beside a chip-filling 3x3 layer of another stream
+    big_x, big_w = torch.randn(2, 128, 128, 128, device=dev), cg.prep_weight_bf16x3(torch.randn(128, 128, 3, 3, device=dev) / 34)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    outs = [[] for _ in streams]
+    torch.cuda.synchronize()
+    for it in range(12):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if (it + k) % 3 != 2:
+                    cg.conv_launch(big_x, big_w, 3, 0, 128, bf16x3=True)
+                outs[k].append(run())
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, y1) for lst in outs for o in lst)
+    for st in streams:
+        with torch.cuda.stream(st):
+            assert int(_lib.tickets().abs().sum()) == 0
