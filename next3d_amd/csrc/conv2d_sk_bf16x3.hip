@@ -48,23 +48,33 @@ struct SkParams {
 };
 
 // ---- the seam between the K slices of one output tile (see the header comment)
-typedef __attribute__((address_space(1))) unsigned sk_gu32;
-__device__ __forceinline__ void sk_slab_store(float* p, float v) {          // 4-byte write-through (sc1) store: an accumulator epilogue's natural width
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef float sk_f32x2 __attribute__((ext_vector_type(2)));
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+typedef int sk_i32x2 __attribute__((ext_vector_type(2)));
+typedef int sk_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int SK_SC1 = 16;                                                 // aux bit of the buffer instructions: sc1 = write-through store / L1-bypassing load
+// VW (2 or 4) floats per lane, write-through; `off` = float index into the slab workspace
+template <int VW>
+__device__ __forceinline__ void sk_slab_store(const __amdgpu_buffer_rsrc_t& r, int off, const float (&v)[VW]) {
+    if constexpr (VW == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sk_i32x2, sk_f32x2{v[0], v[1]}), r, off * 4, 0, SK_SC1);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_i32x4, sk_f32x4{v[0], v[1], v[2], v[3]}), r, off * 4, 0, SK_SC1);
 }
-// Every wave calls this after its slab stores.  Returns true in the workgroup that arrived last (then: counter re-armed, acquire done, all waves past a barrier).
+template <int VW>
+__device__ __forceinline__ void sk_slab_add(const __amdgpu_buffer_rsrc_t& r, int off, float (&v)[VW]) {     // v += slab values (sc1 loads: the slabs were stored sc1, no acquire needed)
+    if constexpr (VW == 2) { const sk_f32x2 t = __builtin_bit_cast(sk_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off * 4, 0, SK_SC1)); v[0] += t[0]; v[1] += t[1]; }
+    else { const sk_f32x4 t = __builtin_bit_cast(sk_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off * 4, 0, SK_SC1)); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+}
+// Every wave calls this after its slab stores.  Returns true in the workgroup that arrived last (the counter is re-armed then, and all waves are past a barrier).
 __device__ __forceinline__ bool sk_arrive_last(unsigned* ticket, int KS, unsigned* s_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                                       // ... before ONE lane takes the ticket
-    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*s_flag != (unsigned)(KS - 1)) return false;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the stream's next launch (nobody else arrives any more)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // ONE acquire: this CU's L1 holds no stale slab line afterwards
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(KS - 1)) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the stream's next launch: nobody else arrives any more
+        *s_flag = old;
     }
     __syncthreads();
-    return true;
+    return *s_flag == (unsigned)(KS - 1);
 }
 
 constexpr int SK_SLOTS = 128;                                              // patch pixels per wave region (stride 1; the transposed twin below)
@@ -136,7 +146,6 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
         for (int k = 0; k < NA; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][k][r] = 0.f;
-    __syncthreads();                                                       // s_style
 
     // software pipeline over the wave's chunks: the activations of chunk c + 1 are requested as soon as chunk c's are converted, and every
     // tap's weight fragments are re-requested for chunk c + 1 right after the MFMAs that consumed them (same registers)
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
     load_raw(c_begin);
 #pragma unroll
     for (int t = 0; t < 9; ++t) { ah[t] = a0[t * a_tap + c_begin * a_chunk]; al[t] = a0[t * a_tap + c_begin * a_chunk + 2 * p.OP64]; }
+    __syncthreads();                                                       // s_style (behind the first chunk's requests: the styles' round trip overlaps theirs)
 
     for (int c = c_begin; c < c_begin + nc; ++c) {
         const bool more = c + 1 < c_begin + nc;
@@ -192,7 +202,8 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
         }
     }
 
-    // the eight partial sums through LDS, summed in wave order (C/D layout: col = lane & 31 = pixel, row = (r&3) + 8*(r>>2) + 4*half = channel)
+    // the eight partial sums through LDS, summed in wave order (C/D layout: col = lane & 31 = pixel, row = (r&3) + 8*(r>>2) + 4*half = channel).  Wave w owns the
+    // items (g, r) = w * VW .. w * VW + VW - 1 of the PT x 16 — VW = 2 PT consecutive registers r = consecutive channels: its share of a slab is ONE 8- / 16-byte store per lane
     __syncthreads();                                                       // every wave is done with its patch region
     float* red = reinterpret_cast<float*>(smem);                           // [wave][group][r][lane]: PT x 32 KB
 #pragma unroll
@@ -200,39 +211,37 @@ __global__ __launch_bounds__(512) void conv2d_sk_bf16x3_kernel(SkParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wn * PT + g) * 16 + r) * 64 + lane] = NA == 3 ? (acc[g][0][r] + acc[g][1][r]) + acc[g][NA - 1][r] : acc[g][0][r] + acc[g][NA - 1][r];
     __syncthreads();
-    const float* slabs = nullptr;
-    if (p.KS > 1) {                                                        // this slice's sums -> its slab; the last-arriving slice of the tile goes on
-        slabs = p.partial + (int64_t)(tile * p.tiles_m + mt_i) * p.KS * (PT * 16 * 64);
-        float* slab = const_cast<float*>(slabs) + (int64_t)ks * (PT * 16 * 64);
+    constexpr int VW = 2 * PT;
+    const int g_w = (wn * VW) >> 4, r_w = (wn * VW) & 15;                  // wave-uniform
+    float v[VW];
 #pragma unroll
-        for (int q = 0; q < PT * 2; ++q) {
-            const int item = q * 8 + wn, g = item >> 4, r = item & 15;
-            float v = 0.f;
+    for (int k = 0; k < VW; ++k) {
+        v[k] = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[((w * PT + g) * 16 + r) * 64 + lane];
-            sk_slab_store(slab + item * 64 + lane, v);
-        }
-        if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
+        for (int w = 0; w < 8; ++w) v[k] += red[((w * PT + g_w) * 16 + r_w + k) * 64 + lane];
     }
+    if (p.KS > 1) {                                                        // this slice's sums -> its slab; the last-arriving slice of the tile goes on
+        constexpr int SLAB = PT * 16 * 64;
+        const int units = p.tiles_p * p.tiles_m;
+        const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, units * p.KS * SLAB * 4, 0x00020000);
+        const int mine = (tile * p.tiles_m + mt_i) * p.KS * SLAB + (wn * 64 + lane) * VW;
+        sk_slab_store<VW>(r_slab, mine + ks * SLAB, v);
+        if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
 #pragma unroll
-    for (int q = 0; q < PT * 2; ++q) {
-        const int item = q * 8 + wn, g = item >> 4, r = item & 15;
-        const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = 0.f;
-        if (slabs) {
-            for (int k = 0; k < p.KS; ++k) v += slabs[(int64_t)k * (PT * 16 * 64) + item * 64 + lane];        // slice order: reproducible
-        } else {
+        for (int k = 0; k < VW; ++k) v[k] = 0.f;
+        for (int k2 = 0; k2 < p.KS; ++k2) sk_slab_add<VW>(r_slab, mine + k2 * SLAB, v);        // slice order: reproducible whatever the arrival order
+    }
+    int n_, oy_, ox_;                                                      // (g_w is a run-time value: select instead of indexing registers)
+    n_ = on[0]; oy_ = oy[0]; ox_ = ox[0];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v += red[((w * PT + g) * 16 + r) * 64 + lane];
-        }
-        int n_, oy_, ox_;                                                  // (g is a run-time value here: select instead of indexing registers)
-        n_ = on[0]; oy_ = oy[0]; ox_ = ox[0];
+    for (int gg = 1; gg < PT; ++gg)
+        if (g_w == gg) { n_ = on[gg]; oy_ = oy[gg]; ox_ = ox[gg]; }
+    if (n_ >= p.N) return;
 #pragma unroll
-        for (int gg = 1; gg < PT; ++gg)
-            if (g == gg) { n_ = on[gg]; oy_ = oy[gg]; ox_ = ox[gg]; }
-        if (n_ >= p.N || o >= p.O) continue;
-        v = n3d_apply_epilogue(v, p.epi, n_, o, p.O, oy_, ox_, p.H, p.W);
-        p.y[(int64_t)n_ * p.ybs + ((int64_t)o * p.H + oy_) * p.yrs + ox_] = v;
+    for (int k = 0; k < VW; ++k) {
+        const int r = r_w + k, o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o >= p.O) continue;
+        p.y[(int64_t)n_ * p.ybs + ((int64_t)o * p.H + oy_) * p.yrs + ox_] = n3d_apply_epilogue(v[k], p.epi, n_, o, p.O, oy_, ox_, p.H, p.W);
     }
 }
 
@@ -267,11 +276,10 @@ static bool sk_plan(int N, int I, int O, int H, int W, SkParams* out, int* pt_ou
         if (q.NS > 2) continue;                                            // s_style holds two samples' styles
         q.PR = q.R + 2; q.PW = W + 2; q.nslots = q.NS * q.PR * q.PW;
         if (q.nslots > SK_SLOTS) continue;
-        // 64-pixel tiles (every weight fragment feeds two pixel groups) once they still give the chip a workgroup per CU — counting the K slices
-        // a launch with arrival counters adds (round 6): the weights then cross L2 -> CU once per 64 pixels instead of once per 32
+        // 64-pixel tiles (every weight fragment feeds two pixel groups) once they still give the chip a workgroup per CU
         const int pt_force = n3d_tune("N3D_SK_PT", 0);
         if (pt_force && pt != pt_force) continue;
-        if (!pt_force && pt == 2 && (int64_t)q.tiles_p * (O / 32) * (seam ? (I / 16) / 8 : 1) < 256) continue;
+        if (!pt_force && pt == 2 && (int64_t)q.tiles_p * (O / 32) < 256) continue;       // (with K slices too: measured, profiles/r06_sk_seam_sweep.txt)
         best = pt; bp = q;
         break;
     }
@@ -432,7 +440,6 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ph][r] = 0.f;
-    __syncthreads();                                                       // s_style
 
     float raw[2][16];
     bf16x8 ah[9], al[9];
@@ -448,6 +455,7 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
     load_raw(c_begin);
 #pragma unroll
     for (int t = 0; t < 9; ++t) { ah[t] = a0[t * a_tap + c_begin * a_chunk]; al[t] = a0[t * a_tap + c_begin * a_chunk + 2 * p.OP64]; }
+    __syncthreads();                                                       // s_style (behind the first chunk's requests)
 
     for (int c = c_begin; c < c_begin + nc; ++c) {
         const bool more = c + 1 < c_begin + nc;
@@ -486,9 +494,14 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
         }
     }
 
-    // the eight partial sums through LDS in wave order, two phases (one output row pair... the phases pa = 0, then pa = 1) at a time: 8 x 2 x 16 x 64 floats = 64 KB
+    // the eight partial sums through LDS in wave order, two phases (one output row pair... the phases pa = 0, then pa = 1) at a time: 8 x 2 x 16 x 64 floats = 64 KB.
+    // Wave w owns (pb, r) = (w >> 2, 4 (w & 3) .. + 3) of each round: four consecutive channels = one 16-byte piece of a slab per lane and round
     float* red = reinterpret_cast<float*>(smem);
-    const float* slabs = p.KS > 1 ? p.partial + (int64_t)(tile * p.tiles_m + mt_i) * p.KS * (4 * 16 * 64) : nullptr;
+    const int pb_w = wn >> 2, r_w = 4 * (wn & 3);
+    constexpr int SLAB = 4 * 16 * 64;
+    const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.KS > 1 ? p.N * p.tps * p.tiles_m * p.KS * SLAB * 4 : 0, 0x00020000);
+    const int mine = (tile * p.tiles_m + mt_i) * p.KS * SLAB + (wn * 64 + lane) * 4;          // + slice * SLAB + pa * (SLAB / 2)
+    float v[2][4];
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
         __syncthreads();                                                   // the patch regions (pa = 0) / the previous round's sums (pa = 1) are dead
@@ -498,31 +511,31 @@ __global__ __launch_bounds__(512) void conv2d_up_sk_bf16x3_kernel(SkUpParams p) 
             for (int r = 0; r < 16; ++r) red[((wn * 2 + pb) * 16 + r) * 64 + lane] = acc[pa * 2 + pb][r];
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {                                   // 2 phases x 16 registers = 32 items over 8 waves
-            const int item = it * 8 + wn, pb = item >> 4, r = item & 15;
-            const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            v[pa][k] = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[((w * 2 + pb) * 16 + r) * 64 + lane];
-            if (slabs) { sk_slab_store(const_cast<float*>(slabs) + ((int64_t)ks * 64 + pa * 32 + item) * 64 + lane, v); continue; }      // this slice's slab
-            const int oy = 2 * gy + pa, ox = 2 * gx + pb;
-            if (!q_act || o >= p.O || oy >= p.OH || ox >= p.OW) continue;
-            p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
+            for (int w = 0; w < 8; ++w) v[pa][k] += red[((w * 2 + pb_w) * 16 + r_w + k) * 64 + lane];
+        }
+        if (p.KS > 1) sk_slab_store<4>(r_slab, mine + ks * SLAB + pa * (SLAB / 2), v[pa]);
+    }
+    if (p.KS > 1) {
+        if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[pa][k] = 0.f;
+            for (int k2 = 0; k2 < p.KS; ++k2) sk_slab_add<4>(r_slab, mine + k2 * SLAB + pa * (SLAB / 2), v[pa]);     // slice order: reproducible
         }
     }
-    if (!slabs) return;
-    if (!sk_arrive_last(p.tickets + tile * p.tiles_m + mt_i, p.KS, reinterpret_cast<unsigned*>(s_style))) return;
+    if (!q_act) return;
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 8 + wn, pb = item >> 4, r = item & 15;
-            const int o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = 0.f;
-            for (int k = 0; k < p.KS; ++k) v += slabs[((int64_t)k * 64 + pa * 32 + item) * 64 + lane];           // slice order: reproducible
-            const int oy = 2 * gy + pa, ox = 2 * gx + pb;
-            if (!q_act || o >= p.O || oy >= p.OH || ox >= p.OW) continue;
-            p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v, p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
+        for (int k = 0; k < 4; ++k) {
+            const int r = r_w + k, o = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oy = 2 * gy + pa, ox = 2 * gx + pb_w;
+            if (o >= p.O || oy >= p.OH || ox >= p.OW) continue;
+            p.y[(int64_t)n * p.ybs + ((int64_t)o * p.OH + oy) * p.yrs + ox] = n3d_apply_epilogue(v[pa][k], p.epi, n, o, p.O, oy, ox, p.OH, p.OW);
         }
 }
 

@@ -44,6 +44,8 @@ def _check_conv_desc(name, d):
     ow = 2 * d.W + 1 if d.mode == 2 else ((d.W - 3) // 2 + 1 if (d.mode == 1 and d.ksize == 3) else d.W)
     assert d.y_row_stride == 0 or d.y_row_stride >= ow, (name, d.mode, d.W, d.y_row_stride)
     assert d.ksplit <= 1 or d.workspace, name
+    if d.tickets:                                        # arrival counters: only the few-pixel 3x3 kernels count on them, and they need their slab workspace
+        assert bf16x3 and d.ksize == 3 and d.x_layout == 0 and d.workspace and d.ticket_count > 0 and d.ksplit <= 1
     assert not d.epi.noise or d.epi.noise_strength
     assert 1 <= d.epi.act <= 9
 
@@ -71,7 +73,7 @@ def patches():
     class Recorder:
         def __getattr__(self, name):
             res, argtypes = _lib._SIGNATURES[name]
-            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_split8_ksplit', 'n3d_conv2d_sk_eligible', 'n3d_conv2d_sk_s2_eligible', 'n3d_conv2d_up_sk_eligible', 'n3d_abi_version', 'n3d_last_error'):
+            if name in ('n3d_conv2d_bf16x3_blocks', 'n3d_conv2d_split8_eligible', 'n3d_conv2d_split8_ksplit', 'n3d_conv2d_sk_eligible', 'n3d_conv2d_sk_s2_eligible', 'n3d_conv2d_up_sk_eligible', 'n3d_conv2d_sk_workspace', 'n3d_abi_version', 'n3d_last_error'):
                 return getattr(real, name)                       # pure host functions: the real ones
 
             def fn(*args):
@@ -87,6 +89,7 @@ def patches():
             return fn
 
     rec = Recorder()
-    return [(_lib, 'lib', lambda: rec), (_lib, 'require_device', lambda *a: None), (_lib, 'stream', lambda: None),
+    pool = torch.zeros(_lib.TICKET_COUNT, dtype=torch.int32)
+    return [(_lib, 'lib', lambda: rec), (_lib, 'require_device', lambda *a: None), (_lib, 'stream', lambda: None), (_lib, 'tickets', lambda: pool),
             (generator, '_require_hip', lambda d: None), (torch.cuda, 'current_stream', lambda *a, **k: _Stream()),
             (torch.cuda, 'Stream', lambda *a, **k: _Stream()), (torch.cuda, 'stream', lambda s: contextlib.nullcontext())], calls

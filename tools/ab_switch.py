@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of one module switch of next3d_amd.layers (GPU box):
 
-    python tools/ab_switch.py SK_S2 True False [--reps 2]
+    python tools/ab_switch.py SK_S2 True False [--reps 2]        (a switch of another module: cg.SK_SEAM, networks.X)
 
 Per value and repetition (alternating, one process): the headline loop of bench.py's shape — batch 4, 512² / 64² / 48 + 48, force_fp32, steps round-robin on three HIP
 streams, 30 timed steps — the same steps on ONE stream, and the scripts' call pattern (batch 1, default route, one eager G.synthesis per frame, 60 frames).  The switch is
@@ -24,7 +24,12 @@ def main():
     ap.add_argument('--reps', type=int, default=2)
     ap.add_argument('--steps', type=int, default=30)
     a = ap.parse_args()
-    from next3d_amd import _lib, demo, layers
+    from next3d_amd import _lib, demo, layers, networks
+    from next3d_amd.torch_utils.ops import conv2d_gradfix as cg
+    mod = layers
+    if '.' in a.name:
+        mod = {'layers': layers, 'cg': cg, 'networks': networks}[a.name.split('.')[0]]
+        a.name = a.name.split('.')[1]
     vals = [ast.literal_eval(v) for v in a.values]
     dev = torch.device('cuda', 0)
     G, _ = demo.build_generator(dev)
@@ -60,14 +65,14 @@ def main():
         step(in4, True); torch.cuda.synchronize()
     for rep in range(a.reps):
         for val in vals:
-            setattr(layers, a.name, val)
+            setattr(mod, a.name, val)
             for k in range(4):
                 step(in4, True, lanes[k % 3]); step(in1, False)
             torch.cuda.synchronize()
             t3 = timed(lambda k: step(in4, True, lanes[k % 3]), a.steps)
             t1 = timed(lambda k: step(in4, True), a.steps)
             tb = timed(lambda k: step(in1, False), 60)
-            print(f'layers.{a.name} = {val!r:6}: batch 4 three lanes {a.steps * 4 / t3:7.1f} frames/s ({1e3 * t3 / a.steps:.3f} ms/step), one stream {a.steps * 4 / t1:7.1f} frames/s '
+            print(f'{mod.__name__.split(".")[-1]}.{a.name} = {val!r:6}: batch 4 three lanes {a.steps * 4 / t3:7.1f} frames/s ({1e3 * t3 / a.steps:.3f} ms/step), one stream {a.steps * 4 / t1:7.1f} frames/s '
                   f'({1e3 * t1 / a.steps:.3f} ms/step); batch 1 default route {1e3 * tb / 60:.3f} ms/frame', flush=True)
 
 
