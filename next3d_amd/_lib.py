@@ -167,10 +167,22 @@ def check(rc):
         raise RuntimeError('libn3d: ' + _handle().n3d_last_error().decode())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_get_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+
+
+def _stream_handle():
+    """torch's current HIP stream of the current device as an integer handle — the raw getter (what torch's own launchers use): `torch.cuda.current_stream()`
+    builds a Stream object through four Python layers, ~3 us of the ~20 us a launch costs the host, once per entry point (163 per batch-1 frame)."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_get_device())
+
+
 def stream():
     """The HIP stream kernels are enqueued on = torch's current stream (as the reference plugins do with
     at::cuda::getCurrentCUDAStream(), bias_act.cpp:88-94)."""
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _stream_handle()
 
 
 def ptr(t):
@@ -190,38 +202,55 @@ def ptr(t):
 
 
 TICKET_COUNT = 4096
-_ticket_pools = {}
+
+
+SLAB_FLOATS = 1 << 21        # 8 MB: the largest slab workspace a few-pixel launch asks for (256 workgroups x 16 KB x 2)
+
+
+class _SeamPool:
+    """Arrival counters + slab workspace of ONE stream (or one captured graph's stream): launches of a stream are serialised, so they share both."""
+
+    def __init__(self, device):
+        self.tickets = torch.zeros(TICKET_COUNT, dtype=torch.int32, device=device)
+        self.slabs = torch.empty(SLAB_FLOATS, dtype=torch.float32, device=device)
+        self.tickets_ptr, self.slabs_ptr = self.tickets.data_ptr(), self.slabs.data_ptr()
+
+
+def seam_pool():
+    """The current stream's arrival counters (n3d_conv2d_desc.tickets: TICKET_COUNT zeroed int32 words) and slab workspace.  Kernels that split K over
+    workgroups and reduce in the last-arriving one (csrc/conv2d_sk_bf16x3.hip) count arrivals per output tile there and leave every word zero, so a
+    pool is zeroed once, when it is created; launches of ONE stream are serialised and share it, different streams (the side stream of the static
+    backbone, the bench's lanes) get their own.  A HIP graph replays on whatever stream its caller picks, possibly beside eager work of the streams
+    it was captured on: `ticket_pools(...)` gives a capture its own pools, allocated eagerly BEFORE the capture begins (generator.synthesis_graph);
+    a capture without them (not ours) allocates inside the capture — the zero fill is then a memset node of that graph."""
+    h = _stream_handle()
+    over = getattr(_tls, 'ticket_override', None)
+    if over is None:
+        t = _seam_pools.get(h)
+        if t is not None:
+            return t
+        if not torch.cuda.is_current_stream_capturing():
+            t = _seam_pools[h] = _SeamPool(torch.device('cuda', torch.cuda.current_device()))
+            return t
+    else:
+        t = over.assigned.get(h)
+        if t is None and over.free:
+            t = over.assigned[h] = over.free.pop()
+        if t is not None:
+            return t
+    return _SeamPool(torch.device('cuda', torch.cuda.current_device()))
 
 
 def tickets():
-    """The current stream's pool of arrival counters (n3d_conv2d_desc.tickets): TICKET_COUNT zeroed int32 words.  Kernels that split K over
-    workgroups and reduce in the last-arriving one (csrc/conv2d_sk_bf16x3.hip) count arrivals per output tile here and leave every word zero, so
-    a pool is zeroed once, when it is created; launches of ONE stream are serialised and may share it, different streams (the side stream of the
-    static backbone, the bench's lanes) get their own.  A HIP graph replays on whatever stream its caller picks, possibly beside eager work of
-    the streams it was captured on: `ticket_pools(...)` gives a capture its own pools, allocated eagerly BEFORE the capture begins
-    (generator.synthesis_graph)."""
-    cur = torch.cuda.current_stream()
-    over = getattr(_tls, 'ticket_override', None)
-    if over is not None:
-        t = over.assigned.get(cur.cuda_stream)
-        if t is None and over.free:
-            t = over.assigned[cur.cuda_stream] = over.free.pop()
-        if t is not None:
-            return t
-    elif not torch.cuda.is_current_stream_capturing():
-        key = (cur.device.index, cur.cuda_stream)
-        t = _ticket_pools.get(key)
-        if t is None:
-            t = _ticket_pools[key] = torch.zeros(TICKET_COUNT, dtype=torch.int32, device=cur.device)
-        return t
-    # a capture that did not provide pools (or more streams than pools): the zero fill becomes a memset node of that graph, replayed in front of
-    # the launch that counts here; the words live in the graph's private memory
-    return torch.zeros(TICKET_COUNT, dtype=torch.int32, device=cur.device)
+    return seam_pool().tickets
+
+
+_seam_pools = {}
 
 
 class ticket_pools:
-    """Context manager: launches inside take their arrival counters from `pools` (zeroed int32 [TICKET_COUNT] tensors, one per stream the region
-    launches on, handed out in order of first use) instead of the streams' own pools — what a captured graph needs (see `tickets`)."""
+    """Context manager: launches inside take their arrival counters and slabs from `pools` (`new_ticket_pools`: one per stream the region
+    launches on, handed out in order of first use) instead of the streams' own pools — what a captured graph needs (see `seam_pool`)."""
 
     def __init__(self, pools):
         self.free, self.assigned, self.all = list(pools), {}, list(pools)
@@ -237,7 +266,7 @@ class ticket_pools:
 
 
 def new_ticket_pools(device, count=3):
-    return [torch.zeros(TICKET_COUNT, dtype=torch.int32, device=device) for _ in range(count)]
+    return [_SeamPool(device) for _ in range(count)]
 
 
 def require_device(*tensors):
@@ -347,25 +376,40 @@ def cast(t, dtype):
     return y
 
 
+_ACT_SPEC = None
+
+
 def make_epilogue(row_scale=None, noise=None, noise_strength=None, bias=None, residual=None, const_scale=1.0,
                   act='linear', alpha=None, gain=None, clamp=None, residual_up_filter=None, round_f16=False):
     """`residual_up_filter` (a [4,4] filter): `residual` is the half-resolution image and is upsampled x2 in the epilogue
     (== upfirdn2d.upsample2d(residual, filter)) instead of being read at full resolution."""
-    from .torch_utils.ops.bias_act import activation_funcs
-    spec = activation_funcs[act]
+    global _ACT_SPEC
+    if _ACT_SPEC is None:
+        from .torch_utils.ops.bias_act import activation_funcs
+        _ACT_SPEC = {k: (ACT_IDS[k], float(v.def_alpha), float(v.def_gain)) for k, v in activation_funcs.items()}
+    act_id, def_alpha, def_gain = _ACT_SPEC[act]
     e = Epilogue()
-    e.row_scale, e.noise, e.noise_strength, e.bias, e.residual = ptr(row_scale), ptr(noise), ptr(noise_strength), ptr(bias), ptr(residual)
-    e.residual_batch_stride = residual.stride(0) if residual is not None else 0
-    e.row_scale_stride = row_scale.stride(0) if row_scale is not None else 0
+    # (pointers straight from the tensors — the struct keeps them alive itself, below — and only the fields that are set: ~120 epilogues per forward)
+    if row_scale is not None:
+        e.row_scale, e.row_scale_stride = row_scale.data_ptr(), row_scale.stride(0)
+    if noise is not None:
+        e.noise, e.noise_strength = noise.data_ptr(), noise_strength.data_ptr() if noise_strength is not None else None
+    elif noise_strength is not None:
+        e.noise_strength = noise_strength.data_ptr()
+    if bias is not None:
+        e.bias = bias.data_ptr()
+    if residual is not None:
+        e.residual, e.residual_batch_stride = residual.data_ptr(), residual.stride(0)
     e.const_scale = float(const_scale)
-    e.act = ACT_IDS[act]
-    e.alpha = float(spec.def_alpha if alpha is None else alpha)
-    e.gain = float(spec.def_gain if gain is None else gain)
-    e.clamp = float(-1 if clamp is None else clamp)
+    e.act = act_id
+    e.alpha = def_alpha if alpha is None else float(alpha)
+    e.gain = def_gain if gain is None else float(gain)
+    e.clamp = -1.0 if clamp is None else float(clamp)
     if residual_up_filter is not None:
         assert residual is not None and residual.is_contiguous() and tuple(residual_up_filter.shape) == (4, 4) and residual_up_filter.is_contiguous()
-    e.residual_up_filter = ptr(residual_up_filter)
-    e.round_f16 = int(round_f16)                 # False / True, or 2 (float16 blocks: the reference's off-GPU bias_act rounding, include/n3d.h)
+        e.residual_up_filter = residual_up_filter.data_ptr()
+    if round_f16:
+        e.round_f16 = int(round_f16)             # False / True, or 2 (float16 blocks: the reference's off-GPU bias_act rounding, include/n3d.h)
     e._keepalive = (row_scale, noise, noise_strength, bias, residual, residual_up_filter)   # the struct only holds raw pointers
     return e
 

@@ -198,6 +198,20 @@ def pick_ksplit_bf16x3(n, i, o, h, w, mode=0):
     return ks
 
 
+class _Dense:
+    """Shape / stride bookkeeping of a dense float32 [N,C,H,W] tensor that does not exist as one (a split8 / c8 operand, an output nobody writes):
+    what conv_launch reads off `x` and `y` — a `torch.empty(..., device='meta')` costs the host ~4 us per layer for the same four numbers."""
+    __slots__ = ('shape', '_st')
+    dtype = torch.float32
+
+    def __init__(self, n, c, h, w):
+        self.shape = (n, c, h, w)
+        self._st = (c * h * w, h * w, w, 1)
+
+    def stride(self, k=None):
+        return self._st if k is None else self._st[k]
+
+
 def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue=None, ksplit=None, bf16x3=False, row_pitch=False,
                 out_c8=False, out_split8=False, side_style=None, _wt_batch_stride=0, _wt_flat=False, rgb=None):
     """x [N,I,H,W] (any batch stride, dense planes), wt prepared weights [k*k,I,OP] (or the split-bf16 tiles when
@@ -219,7 +233,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
             raise RuntimeError('conv2d: a split8 input goes to the 3x3 split-bf16 kernels (stride 1, stride 2, transposed), without a style')
         n, i, h, w = x.shape
         xs = x
-        x = torch.empty([n, i, h, w], dtype=torch.float32, device='meta')      # shape / stride bookkeeping only
+        x = _Dense(n, i, h, w)                                                 # shape / stride bookkeeping only
         if mode == 0:                                                          # the library's own split-K factor for this shape (few tiles, deep K)
             ksplit = max(1, split8_ksplit(n, i, out_channels, h, w))
         elif mode == 2:
@@ -257,14 +271,14 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
             raise RuntimeError('conv2d: the channel-interleaved output is written by the transposed split-bf16 kernel (O % 64 == 0)')
         c8 = _lib.C8(n, o, oh, ow, wt.device)
         ksplit = 1
-        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')
+        y = _Dense(n, o, oh, ow)
     elif out_split8:
         if not (bf16x3 and ksize == 1 and out is None and o % 32 == 0 and out_dtype == torch.float32 and not split8):
             raise RuntimeError('conv2d: the split8 output is written by the 1x1 split-bf16 kernel (O % 32 == 0)')
         s8 = _lib.Split8(n, o, oh, ow, wt.device)
-        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')
+        y = _Dense(n, o, oh, ow)
     elif rgb is not None:
-        y = torch.empty([n, o, oh, ow], dtype=torch.float32, device='meta')      # not written (checked below)
+        y = _Dense(n, o, oh, ow)                                                # not written (checked below)
     elif out is not None:
         y = out
     elif row_pitch:
@@ -286,11 +300,10 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     tk = None
     if SK_SEAM and sk_layer:                             # the few-pixel kernels slice K over the chip when given slabs + this stream's arrival counters
         sk_floats, sk_need = sk_workspace(n, i, o, h, w, mode)
-        if sk_floats and sk_need <= _lib.TICKET_COUNT:
-            ws = torch.empty([sk_floats], dtype=torch.float32, device=wt.device)
-            tk = _lib.tickets()
+        if sk_floats and sk_need <= _lib.TICKET_COUNT and sk_floats <= _lib.SLAB_FLOATS:
+            tk = _lib.seam_pool()
     d = _lib.Conv2dDesc()
-    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), (None if rgb is not None else _lib.ptr(c8.data if c8 else (s8.data if s8 else y))), _lib.ptr(ws)
+    d.x, d.wt, d.style, d.y, d.workspace = _lib.ptr(xs.data if split8 else x), _lib.ptr(wt), _lib.ptr(style), (None if rgb is not None else _lib.ptr(c8.data if c8 else (s8.data if s8 else y))), (tk.slabs_ptr if tk is not None else _lib.ptr(ws))
     d.x_layout, d.y_layout = (1 if split8 else 0), (2 if c8 else (1 if s8 else 0))
     d.N, d.I, d.O, d.H, d.W = n, i, o, h, w
     d.ksize, d.mode, d.ksplit = ksize, mode, ksplit
@@ -301,7 +314,7 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     d.wt_batch_stride = int(_wt_batch_stride)
     if tk is not None:
-        d.tickets, d.ticket_count = _lib.ptr(tk), tk.numel()
+        d.tickets, d.ticket_count = tk.tickets_ptr, _lib.TICKET_COUNT
     partial = None
     if rgb is not None:
         rw, rs = rgb

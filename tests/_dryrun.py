@@ -89,7 +89,10 @@ def patches():
             return fn
 
     rec = Recorder()
-    pool = torch.zeros(_lib.TICKET_COUNT, dtype=torch.int32)
-    return [(_lib, 'lib', lambda: rec), (_lib, 'require_device', lambda *a: None), (_lib, 'stream', lambda: None), (_lib, 'tickets', lambda: pool),
+    class _Pool:
+        tickets, slabs = torch.zeros(_lib.TICKET_COUNT, dtype=torch.int32), torch.empty(16, dtype=torch.float32)
+        tickets_ptr, slabs_ptr = tickets.data_ptr(), slabs.data_ptr()
+    pool = _Pool()
+    return [(_lib, 'lib', lambda: rec), (_lib, 'require_device', lambda *a: None), (_lib, 'stream', lambda: None), (_lib, 'seam_pool', lambda: pool),
             (generator, '_require_hip', lambda d: None), (torch.cuda, 'current_stream', lambda *a, **k: _Stream()),
             (torch.cuda, 'Stream', lambda *a, **k: _Stream()), (torch.cuda, 'stream', lambda s: contextlib.nullcontext())], calls

@@ -29,7 +29,7 @@ def graph_us(fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / REP)
-    assert all(int(p.abs().sum()) == 0 for p in pools.all), 'arrival counters not re-armed'
+    assert all(int(p.tickets.abs().sum()) == 0 for p in pools.all), 'arrival counters not re-armed'
     return best
 
 
