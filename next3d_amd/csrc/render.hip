@@ -292,46 +292,120 @@ __device__ __forceinline__ void pass_blend(const PassFetch& F, float (&f)[16]) {
     for (int c = 0; c < 8; ++c) { f[2 * c] = f2[c].x * (1.f / 3.f); f[2 * c + 1] = f2[c].y * (1.f / 3.f); }   // mean over the planes (triplane_next3d.py:361)
 }
 
+// ---- Round 6: COALESCED gathers.  The pass above lets every lane fetch 64 bytes of ITS sample's texels as four 16-byte loads: a wave load
+// instruction then touches 64 different cache lines (one 16-byte piece each), and the texture path — address processing and tag look-ups at
+// ~0.5 line per clock and CU — is what the kernel waits for: 48 loads x 64 lines x 4 waves = 12,288 line accesses per round of passes against
+// 4,288 cycles of decoder MFMAs (profiles/r05_render_pmc.txt: 58.7 line accesses per wave load, 0.48 per clock, matrix pipe 0.17, one wave per
+// SIMD).  Here EIGHT ADJACENT LANES fetch one texel (128 contiguous bytes): lane l = 8 a + b loads piece b of the texels of the samples
+// s' = 8 j + a, j = 0..3 — the same 48 instructions and bytes per lane, 8 texels (8-16 lines) per instruction instead of 64.  Each lane
+// derives the 12 tap offsets / weights of ITS FOUR samples itself (4 x the address arithmetic of the old pass, VALU work that sits under the
+// decoder's MFMAs; nothing is exchanged between lanes for it: the sample depths are in the ray's LDS arrays anyway), blends in the loaded
+// layout — 4 channels of 4 samples per lane, the same fma chain per channel as pass_blend: bit-identical features — and hands the features to
+// the sample's owner pair (s, s + 32) through the sample's OWN colour row in LDS, which the pass only fills at its end: no extra LDS.
+struct PassFetch2 {
+    float4 v[4][12];          // [sample group j][tap = 4 plane + k]: piece b of the texel
+    float tw[4][12];
+    int row[4];               // LDS float index (from the wave's region) of the colour row of sample 8 j + a, -1 = no such sample
+};
+// taps of one plane as byte offsets into the sample's three planes (taps outside get weight 0 and offset 0: always loadable)
+__device__ __forceinline__ void plane_taps_off(int plane_texel0, int PH, int PW, float gx, float gy, int (&off)[4], float (&tw)[4]) {
+    const float ix = ((gx + 1.f) * (float)PW - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * (float)PH - 1.f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const bool sane = fx0 > -2.f && fx0 < (float)PW + 1.f && fy0 > -2.f && fy0 < (float)PH + 1.f;
+    const int x0 = sane ? (int)fx0 : -4, y0 = sane ? (int)fy0 : -4;
+    const float wx1 = ix - fx0, wy1 = iy - fy0;
+    const float wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy;
+    const float wgt[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};   // nw, ne, sw, se
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        const bool ok = xx >= 0 && xx < PW && yy >= 0 && yy < PH;
+#if defined(RN_ABL) && RN_ABL == 1
+        off[k] = 0;
+#else
+        off[k] = ok ? (plane_texel0 + yy * PW + xx) * (RN_C * 4) : 0;
+#endif
+        tw[k] = ok ? wgt[k] : 0.f;
+    }
+}
+// blend of one sample group in the loaded layout: 4 channels (piece b) of sample 8 j + a; pass_blend's arithmetic per channel
+__device__ __forceinline__ f32x4 pass_blend2(const PassFetch2& F, int j) {
+    f32x2 lo = f32x2{0.f, 0.f}, hi = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        const f32x2 w2 = f32x2{F.tw[j][t], F.tw[j][t]};
+        lo = __builtin_elementwise_fma(w2, f32x2{F.v[j][t].x, F.v[j][t].y}, lo);
+        hi = __builtin_elementwise_fma(w2, f32x2{F.v[j][t].z, F.v[j][t].w}, hi);
+    }
+    return f32x4{lo.x * (1.f / 3.f), lo.y * (1.f / 3.f), hi.x * (1.f / 3.f), hi.y * (1.f / 3.f)};
+}
+
+#ifdef RN_TRACE   // tuning builds only (tools/build_variant.sh trace render.hip -DRN_TRACE): stage time stamps of every wave
+__device__ long long rn_trace_buf[16384 * 16];
+#define RN_STAMP2(k) do { if (g0 == 32 && slot0 == 0) RN_STAMP(k); } while (0)
+#define RN_STAMP3(k) do { if (rn_tr) RN_STAMP(k); } while (0)
+#define RN_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 16384) rn_trace_buf[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
+    static long long host[16384 * 16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rn_trace_buf), sizeof(host)) != hipSuccess) return 1;
+    for (int k = 0; k < 16; ++k) {
+        double sum = 0;
+        for (int w = 0; w < nwg; ++w) sum += (double)(host[w * 16 + k] - host[w * 16]);
+        avg[k] = sum / nwg;
+    }
+    return 0;
+}
+#else
+#define RN_STAMP(k)
+#define RN_STAMP2(k)
+#define RN_STAMP3(k)
+#endif
+
 // second half, part 2: 32 -> 64 softplus -> 33 on the matrix pipe -> rgb[r] = colour channel 8 (r / 4) + 4 hb + r % 4, sigma.
 // Straight-line code, four quarters of 17 / 17 / 16 / 17 dependent MFMAs with the softplus batches between them.  (A pinned
 // sched_group_barrier order that alternates one MFMA with one hidden unit's softplus was measured: no difference — the pass is
 // not bound by the decoder's instruction order.)
 // LOADS: the next pass's 48 texel loads are issued from here (`Fn`), four parts spread over the quarters.
-template <bool LOADS>
+template <bool LOADS, typename LoadFn>
 __device__ __forceinline__ void pass_mlp(const float* wl /* decoder image + lane */, float bsig, int lane, const float (&f)[16], float (&rgb)[16], float& sigma,
-                                         PassFetch& Fn) {
+                                         LoadFn pass_load_part, bool rn_tr = false) {
     const int hb = lane >> 5;
     const float one0 = hb == 0 ? 1.f : 0.f;
     const float* wsig = wl - lane + 67 * 64 + hb * 32;
     f32x16 h0, h1, o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; o[r] = 0.f; }
-    if (LOADS) { pass_load(Fn, 0); pass_load(Fn, 1); }
+    if (LOADS) { pass_load_part(0); pass_load_part(1); }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[kk * 64], f[kk], h0, 0, 0, 0);
     h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[16 * 64], one0, h0, 0, 0, 0);
+    RN_STAMP3(12);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 + kk) * 64], f[kk], h1, 0, 0, 0);
     h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(17 + 16) * 64], one0, h1, 0, 0, 0);
+    RN_STAMP3(13);
     float hs0[16], hs1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hs0[r] = softplus_raw(h0[r]);
-    if (LOADS) pass_load(Fn, 2);
+    if (LOADS) pass_load_part(2);
     float sp = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + r) * 64], hs0[r], o, 0, 0, 0);
         sp = fmaf(wsig[r], hs0[r], sp);
     }
+    RN_STAMP3(14);
 #pragma unroll
     for (int r = 0; r < 16; ++r) hs1[r] = softplus_raw(h1[r]);
-    if (LOADS) pass_load(Fn, 3);
+    if (LOADS) pass_load_part(3);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(34 + 16 + r) * 64], hs1[r], o, 0, 0, 0);
         sp = fmaf(wsig[16 + r], hs1[r], sp);
     }
     o = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[66 * 64], one0, o, 0, 0, 0);
+    RN_STAMP3(15);
     sigma = sp + __shfl_xor(sp, 32, 64) + bsig;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rgb[r] = sigmoid_raw(o[r]) * (1.f + 2.f * 0.001f) - 0.001f;
@@ -432,29 +506,12 @@ __device__ __forceinline__ void march_weights(const RayLds& L, int count, int l3
     wave_sync();
 }
 
-#ifdef RN_TRACE   // tuning builds only (tools/build_variant.sh trace render.hip -DRN_TRACE): stage time stamps of every wave
-__device__ long long rn_trace_buf[16384 * 16];
-#define RN_STAMP2(k) do { if (g0 == 32 && slot0 == 0) RN_STAMP(k); } while (0)
-#define RN_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < 16384) rn_trace_buf[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-extern "C" int n3d_render_trace_dump(double* avg, int nwg) {
-    static long long host[16384 * 16];
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rn_trace_buf), sizeof(host)) != hipSuccess) return 1;
-    for (int k = 0; k < 15; ++k) {
-        double sum = 0;
-        for (int w = 0; w < nwg; ++w) sum += (double)(host[w * 16 + k] - host[w * 16]);
-        avg[k] = sum / nwg;
-    }
-    return 0;
-}
-#else
-#define RN_STAMP(k)
-#define RN_STAMP2(k)
-#endif
 
 // Two rays per wave: no idle lanes in the decode passes; the colours of 2 x (Sc + Sf) samples live in LDS, which leaves room for
 // one wave per SIMD (variants with two waves per SIMD — one ray per wave, or the colours parked in a global workspace — were
 // measured equal or slower in round 2 and are gone: DESIGN.md 3.2).
 constexpr int RPW = 2;
+template <bool COALESCED>
 __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hb = lane >> 5;
     const int n = blockIdx.y;
@@ -533,8 +590,75 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             if (more) taps(g0 + 32, cnt, slot0, F);                       // ... their registers take the next pass's, loaded under the decoder
             RN_STAMP2(11);
             float rgb[16], sigma;
-            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, F);
-            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, F);
+            auto part = [&](int k) { pass_load(F, k); };
+            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            store_pass(slot, q, rgb, sigma);
+            RN_STAMP2(9);
+        }
+    };
+    // the same with coalesced gathers (PassFetch2): sample group j of the NEXT pass = its 12 tap offsets / weights + its 12 loads, issued as part j under this pass's decoder
+    const __amdgpu_buffer_rsrc_t r_planes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.planes + (int64_t)n * 3 * p.PH * p.PW * RN_C), 0, 3 * p.PH * p.PW * RN_C * 4, 0x00020000);
+    const int ga = lane >> 3, gb16 = (lane & 7) * 16;
+    auto fetch_group = [&](int g0, int cnt, int slot0, int j, PassFetch2& F) {
+        const int g = g0 + 8 * j + ga;
+        const bool live = g < nrays * cnt;
+        const int q = live && g >= cnt ? 1 : 0;
+        const int i = live ? g - q * cnt : 0;
+        const float t = (q ? Ls[1] : Ls[0]).dep[slot0 + i];
+        F.row[j] = live ? (q * rlf + (slot0 + i) * cp) : -1;
+        const float dx = q ? rdx[1] : rdx[0], dy = q ? rdy[1] : rdy[0], dz = q ? rdz[1] : rdz[0];
+        const float cx = p.coord_scale * __fadd_rn(ox, __fmul_rn(t, dx)), cy = p.coord_scale * __fadd_rn(oy, __fmul_rn(t, dy)), cz = p.coord_scale * __fadd_rn(oz, __fmul_rn(t, dz));
+        int off[3][4];
+        float tw[3][4];
+        plane_taps_off(0, p.PH, p.PW, cx, cy, off[0], tw[0]);                       // plane 0: (x, y)
+        plane_taps_off(p.PH * p.PW, p.PH, p.PW, cx, cz, off[1], tw[1]);             // plane 1: (x, z)
+        plane_taps_off(2 * p.PH * p.PW, p.PH, p.PW, cz, cy, off[2], tw[2]);         // plane 2: (z, y)   (renderer.py:42-44)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                F.tw[j][4 * pl + k] = live ? tw[pl][k] : 0.f;
+                F.v[j][4 * pl + k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_planes, off[pl][k] + gb16, 0, 0));
+            }
+    };
+    auto decode_all2 = [&](int cnt, int slot0) {
+        const int total = nrays * cnt;
+        PassFetch2 F;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch_group(0, cnt, slot0, j, F);
+        for (int g0 = 0; g0 < total; g0 += 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            // this pass's owner pair: sample g0 + l31 -> (ray q, slot)
+            const int g = g0 + l31;
+            const bool live = g < total;
+            const int q = live && g >= cnt ? 1 : 0;
+            const int slot = live ? slot0 + g - q * cnt : -1;
+            // blend in the loaded layout (waits for the texels), park the features in the samples' own colour rows, read the owner's 16 back
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 f4 = pass_blend2(F, j);
+                if (F.row[j] >= 0) *reinterpret_cast<f32x4*>(wsm + F.row[j] + (lane & 7) * 4) = f4;
+            }
+            wave_sync();
+            float f[16];
+            {
+                const float* own = wsm + q * rlf + max(slot, 0) * cp + 16 * hb;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(own + 4 * a);
+                    f[4 * a] = t4[0]; f[4 * a + 1] = t4[1]; f[4 * a + 2] = t4[2]; f[4 * a + 3] = t4[3];
+                }
+            }
+            wave_sync();                                                  // (the rows are rewritten by store_pass below: reads first)
+            __builtin_amdgcn_sched_barrier(0);
+            RN_STAMP2(10);
+            const bool more = g0 + 32 < total;
+            float rgb[16], sigma;
+            auto part = [&](int k) { fetch_group(g0 + 32, cnt, slot0, k, F); };
+            RN_STAMP2(11);
+            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
             store_pass(slot, q, rgb, sigma);
             RN_STAMP2(9);
         }
@@ -550,7 +674,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         }
     }
     wave_sync();
-    decode_all(Sc, 0);
+    if (COALESCED) decode_all2(Sc, 0); else decode_all(Sc, 0);
     wave_sync();
     RN_STAMP(2);
 
@@ -596,7 +720,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         wave_sync();
         RN_STAMP(4);
         // ---- second decode pass at the importance depths -> slots Sc + j
-        decode_all(Sf, Sc);
+        if (COALESCED) decode_all2(Sf, Sc); else decode_all(Sf, Sc);
         wave_sync();
         RN_STAMP(5);
         // ---- unify_samples: stable rank of every sample in the merged order (renderer.py:164-182)
@@ -654,7 +778,12 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body(p, smem);
+    render_rays_body<false>(p, smem);
+}
+// the coalesced gather (eight lanes per texel): tuning builds only, N3D_RENDER_GATHER=1 — built and measured in round 6, NOT faster (see PassFetch2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_c8_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    render_rays_body<true>(p, smem);
 }
 
 // global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
@@ -862,7 +991,8 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     wpb = wpb > 4 ? 4 : wpb;
     N3D_CHECK(wpb >= 1, "render_rays: %d samples per ray do not fit the LDS", M);
     const size_t lds = image + wpb * per_wave;
-    const void* kfn = (const void*)render_rays_kernel;
+    const bool coalesced = n3d_tune("N3D_RENDER_GATHER", 0) != 0 && (int64_t)3 * PH * PW * RN_C * 4 < (1ll << 31);      // (32-bit texel offsets per sample)
+    const void* kfn = coalesced ? (const void*)render_rays_c8_kernel : (const void*)render_rays_kernel;
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER_RAYS, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));          // bytes: 12 texels x 128 B gathered per point + the outputs
@@ -872,7 +1002,8 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(render_depth_bounds_kernel, dim3(bgrid), dim3(256), 0, stream, p, nrays, keys);
     N3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
+    if (coalesced) hipLaunchKernelGGL(render_rays_c8_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
+    else hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

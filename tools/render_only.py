@@ -38,7 +38,7 @@ def main():
         avg = (ctypes.c_double * 16)()
         h.n3d_render_trace_dump(avg, 2048)
         names = ['start', 'decoder regs + rays', 'coarse decode', 'march 1', 'importance depths', 'fine decode', 'rank', 'march 2', 'composite',
-                 'pass 1: decoded + stored', 'pass 1: blended', 'pass 1: next taps', 'pass 1: layer 1 block 0', 'pass 1: layer 1 block 1', 'pass 1: layer 2 half 0', 'pass 1: layer 2 half 1']
+                 'pass 1: decoded + stored', 'pass 1: blended', 'pass 1: next taps', 'pass 1: layer 1 block 0', 'pass 1: layer 1 block 1', 'pass 1: softplus 0 + layer 2 half 0', 'pass 1: layer 2 done']
         print('cycles since the wave started, mean over workgroups: ' + ', '.join(f'{n} {avg[i]:.0f}' for i, n in enumerate(names)))
     print(f'render (bounds + rays) {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us per call, batch {a.batch}; feat mean {feat.mean().item():.6f} depth mean {depth.mean().item():.6f}')
 
