@@ -416,6 +416,13 @@ typedef struct {
     float density_noise;
     const float* density_noise_coarse;
     const float* density_noise_fine;
+    /* ABI 7 — the seam between the two passes, for verification: the importance depths (sample_importance, vr/renderer.py:209-268) are
+     * DISCONTINUOUS in the coarse pass's weights (a u that falls next to a CDF step lands in another bin for a last-bit difference), so an
+     * end-to-end comparison of two correct implementations differs on a few rays.  fine_depths_out [N,R*R,Sf]: the depths this call sampled;
+     * fine_depths_in [N,R*R,Sf]: use THESE instead of sampling (a checker feeds its own: everything behind the seam — second decode, merge,
+     * march, composite — is then compared on identical samples, every ray).  Both NULL in normal use. */
+    float* fine_depths_out;
+    const float* fine_depths_in;
 } n3d_render_opts;
 int n3d_render_rays_ex(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
                        const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,

@@ -43,7 +43,7 @@ class Conv2dDesc(ctypes.Structure):
 class RenderOpts(ctypes.Structure):
     _fields_ = [('white_back', c_int), ('disparity_space_sampling', c_int), ('ray_start', c_float), ('ray_end', c_float), ('auto_bounds', c_int),
                 ('box_side', c_float), ('ray_bounds_ws', c_void_p), ('density_noise', c_float), ('density_noise_coarse', c_void_p),
-                ('density_noise_fine', c_void_p)]
+                ('density_noise_fine', c_void_p), ('fine_depths_out', c_void_p), ('fine_depths_in', c_void_p)]
 
 
 class ModwJob(ctypes.Structure):

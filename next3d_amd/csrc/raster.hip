@@ -141,10 +141,11 @@ __global__ __launch_bounds__(256) void raster_faces_kernel(const float* tv, cons
         for (int k = 0; k < 9; ++k) o[3 + k] = __float_as_uint(w[k]);
     }
 #endif
-    const float zmax = fmaxf(z0, fmaxf(z1, z2));
+    const float zmax = fmaxf(z0, fmaxf(z1, z2)), zmin = fminf(z0, fminf(z1, z2));
     const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
     const bool zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
-    if (zmax < 0.0f || (cull && face_area < 0.0f) || zero_area) return;      // cull_backfaces (renderer.py:397: True)
+    // zmin < kEpsilon: PyTorch3D's CheckPointOutsideBoundingBox ("z_invalid") puts every pixel outside the box of a face with a vertex at / behind the camera plane
+    if (zmax < 0.0f || (cull && face_area < 0.0f) || zero_area || zmin < K_EPS) return;      // cull_backfaces (renderer.py:397: True)
     const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
     const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
     if (!(xmax >= -2.f && xmin <= 2.f && ymax >= -2.f && ymin <= 2.f)) return;   // far off-screen / NaN

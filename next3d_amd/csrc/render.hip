@@ -53,6 +53,8 @@ struct RenderParams {
     const float* noise_c;     // density noise draws [N,R*R,Sc] / [N,R*R,Sf] (renderer.py:152-153: sigma += randn_like * density_noise) or NULL
     const float* noise_f;
     float noise_scale;
+    float* fine_out;          // n3d_render_opts.fine_depths_out / fine_depths_in (verification seam) or NULL
+    const float* fine_in;
 };
 
 // total order on floats as unsigned keys (negative depths are possible with 'auto' bounds when the camera sits inside the box)
@@ -715,7 +717,10 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             const float c0 = L.cdf[below], c1 = L.cdf[above], b0 = L.bins[below], b1 = L.bins[above];
             float denom = c1 - c0;
             if (denom < 1e-5f) denom = 1.f;
-            L.dep[Sc + j] = __fadd_rn(b0, __fmul_rn((u - c0) / denom, (b1 - b0)));
+            float dj = __fadd_rn(b0, __fmul_rn((u - c0) / denom, (b1 - b0)));
+            if (p.fine_out && store) p.fine_out[((int64_t)n * RR + ray) * Sf + j] = dj;
+            if (p.fine_in) dj = p.fine_in[((int64_t)n * RR + ray) * Sf + j];
+            L.dep[Sc + j] = dj;
         }
         wave_sync();
         RN_STAMP(4);
@@ -961,11 +966,13 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.bounds = bounds_ws; p.feat = feat; p.depth = depth; p.wsum = wsum;
     p.N = N; p.R = R; p.Sc = Sc; p.Sf = Sf; p.PH = PH; p.PW = PW; p.depth_delta = depth_delta; p.coord_scale = coord_scale;
     p.depth_mode = 0; p.inv_start = p.inv_end = 0.f; p.ray_bounds = nullptr; p.white_back = 0; p.noise_c = p.noise_f = nullptr; p.noise_scale = 0.f;
+    p.fine_out = nullptr; p.fine_in = nullptr;
     const int64_t nrays = (int64_t)N * R * R;
     const unsigned bgrid = (unsigned)(cdiv64(nrays, 256) > 256 ? 256 : cdiv64(nrays, 256));
     unsigned int* keys = reinterpret_cast<unsigned int*>(bounds_ws);
     if (opts) {
         p.white_back = opts->white_back != 0;
+        p.fine_out = opts->fine_depths_out; p.fine_in = opts->fine_depths_in;
         if (opts->density_noise > 0.f) {
             N3D_CHECK(opts->density_noise_coarse && (opts->density_noise_fine || Sf == 0), "render_rays: density_noise > 0 needs the normal draws (density_noise_coarse / _fine)");
             p.noise_c = opts->density_noise_coarse; p.noise_f = opts->density_noise_fine; p.noise_scale = opts->density_noise;

@@ -4,6 +4,7 @@ fixtures (TEST INFRASTRUCTURE; runs only in the build container, where /root/ref
 
   python oracle/pin_against_reference.py                      # compare + (re)write tests/golden/*.npz
   python oracle/pin_against_reference.py --only case_r64_s96  # one case; the shared fixtures are left untouched
+  python oracle/pin_against_reference.py --orbit              # gen_videos_next3d.py's render loop, frames 0 / 60 / 119 -> tests/golden/orbit_frames.npz
 
 What it does, per case:
   1. builds the reference TriPlaneGenerator from its own constructors (oracle/ref_shims.py),
@@ -370,7 +371,90 @@ def mapping_depth():
     return 0 if ok else 1
 
 
+ORBIT_FRAMES = (0, 60, 119)
+
+
+def orbit():
+    """--orbit: gen_videos_next3d.py's render loop (:96-158) with the argument values the script itself computes — grid 1 x 1, one seed = one keyframe,
+    w_frames = 120 (120-frame camera orbit: BASELINE.json configs[2]), --trunc 0.7, --sample_mult 2 (96 + 96 samples, :288-289), the scipy cubic
+    interpolation of the tiled keyframe latents (float64, :112-120, :140-141), the per-frame LookAtPoseSampler pose (:131-137) and
+    `G.synthesis(ws=w.unsqueeze(0), c=c[0:1], v=verts[0:1], noise_mode='const')` (:153) — run on the REAL reference for frames 0 / 60 / 119, the renderer's
+    random draws injected as everywhere else.  Stores the frames' inputs and the reference's outputs in tests/golden/orbit_frames.npz
+    (tests/test_generator_gpu.py::test_orbit_frames_match_reference_golden replays the same expressions through next3d_amd)."""
+    import scipy.interpolate
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    uv_mask = n3d_mesh.synthetic_uv_face_mask()
+    ref_shims.install(uv_mask[0, 0].numpy())
+    import camera_utils as ref_cam
+    from camera_utils import LookAtPoseSampler
+    G = ref_shims.build_reference_generator(RENDERING_KWARGS)
+    sd = n3d_spec.synthetic_state_dict(seed=0)
+    verts_, faces, uvs, uvfaces = n3d_mesh.parse_obj(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    sd.update(n3d_mesh.mesh_buffers(faces, uvs, uvfaces))
+    G.load_state_dict(sd, strict=True)
+    v_demo = n3d_mesh.parse_obj_vertices(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
+    lms = n3d_mesh.parse_landmarks(os.path.join(ref_shims.REF, 'data/demo/demo_kpt2d.txt'))
+    device = torch.device('cpu')
+    # ---- the script's own lines from here on (gen_videos_next3d.py), device = cpu
+    seeds, grid_w, grid_h, w_frames, wraps, kind, psi, truncation_cutoff, sampling_multiplier = [0], 1, 1, 120, 2, 'cubic', 0.7, 14, 2
+    G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * sampling_multiplier)                        # :288
+    G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * sampling_multiplier)  # :289
+    verts = torch.cat((v_demo, lms), 1)                                              # :291-316 (v from the .obj, landmarks appended)
+    num_keyframes = len(seeds) // (grid_w * grid_h)
+    all_seeds = np.zeros(num_keyframes * grid_h * grid_w, dtype=np.int64)
+    for idx in range(num_keyframes * grid_h * grid_w):
+        all_seeds[idx] = seeds[idx % len(seeds)]
+    camera_lookat_point = torch.tensor(G.rendering_kwargs['avg_camera_pivot'], device=device)
+    zs = torch.from_numpy(np.stack([np.random.RandomState(seed).randn(G.z_dim) for seed in all_seeds])).to(device)
+    cam2world_pose = LookAtPoseSampler.sample(3.14 / 2, 3.14 / 2, camera_lookat_point, radius=G.rendering_kwargs['avg_camera_radius'], device=device)
+    focal_length = 4.2647
+    intrinsics = torch.tensor([[focal_length, 0, 0.5], [0, focal_length, 0.5], [0, 0, 1]], device=device)
+    c = torch.cat([cam2world_pose.reshape(-1, 16), intrinsics.reshape(-1, 9)], 1)
+    c = c.repeat(len(zs), 1)
+    verts = verts.repeat(len(zs), 1, 1)
+    ws = G.mapping(z=zs, c=c, truncation_psi=psi, truncation_cutoff=truncation_cutoff)
+    ws_map, c_cond = ws.clone(), c.clone()
+    ws = ws.reshape(grid_h, grid_w, num_keyframes, *ws.shape[1:])
+    x = np.arange(-num_keyframes * wraps, num_keyframes * (wraps + 1))
+    y = np.tile(ws[0][0].cpu().numpy(), [wraps * 2 + 1, 1, 1])
+    interp = scipy.interpolate.interp1d(x, y, kind=kind, axis=0)
+    R, Sc, Sf = G.neural_rendering_resolution, G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance']
+    rk = dict(RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    out, ok = {}, True
+    for frame_idx in ORBIT_FRAMES:
+        pitch_range = 0.25
+        yaw_range = 0.35
+        cam2world_pose = LookAtPoseSampler.sample(3.14 / 2 + yaw_range * np.sin(2 * 3.14 * frame_idx / (num_keyframes * w_frames // 2)),
+                                                  3.14 / 2 - 0.05 + pitch_range * np.cos(2 * 3.14 * frame_idx / (num_keyframes * w_frames // 2)),
+                                                  camera_lookat_point, radius=G.rendering_kwargs['avg_camera_radius'], device=device)
+        c = torch.cat([cam2world_pose.reshape(-1, 16), intrinsics.reshape(-1, 9)], 1)
+        w = torch.from_numpy(interp(frame_idx / w_frames)).to(device)
+        orig_rand, orig_rand_like = torch.rand, torch.rand_like
+        torch.rand_like = lambda t, *a, **k: jitter.clone() if tuple(t.shape) == tuple(jitter.shape) else orig_rand_like(t, *a, **k)
+        torch.rand = lambda *a, **k: u.clone() if (tuple(a) == tuple(u.shape) or (len(a) == 1 and tuple(a[0]) == tuple(u.shape))) else orig_rand(*a, **k)
+        try:
+            t0 = time.time()
+            o = G.synthesis(ws=w.unsqueeze(0), c=c[0:1], v=verts[0:1], noise_mode='const')
+            t_ref = time.time() - t0
+        finally:
+            torch.rand, torch.rand_like = orig_rand, orig_rand_like
+        o_or = ogen.synthesis(sd, w.unsqueeze(0).to(torch.float32), c[0:1], verts[0:1], uv_mask, rk, jitter, u, neural_rendering_resolution=R)
+        d = {k: float((o[k] - o_or[k]).abs().max()) for k in ('image', 'image_raw', 'image_depth')}
+        print(f'[orbit frame {frame_idx}] w dtype {w.dtype}, reference {t_ref:.1f}s, max-abs(ref - oracle): ' + ' '.join(f'{k}={x_:.2e}' for k, x_ in d.items()))
+        ok &= all(x_ <= 1e-4 for x_ in d.values())
+        out.update({f'c_{frame_idx}': c.numpy(), f'image_{frame_idx}_sub2': sub(o['image'], 2), f'image_raw_{frame_idx}': o['image_raw'].numpy(),
+                    f'image_depth_{frame_idx}': o['image_depth'].numpy(), f'image_mean_{frame_idx}': o['image'].mean(dim=(2, 3)).numpy()})
+    np.savez_compressed(os.path.join(GOLDEN, 'orbit_frames.npz'), frames=np.array(ORBIT_FRAMES), seed=seeds[0], w_frames=w_frames, wraps=wraps, psi=psi,
+                        cutoff=truncation_cutoff, z=zs.numpy(), c_cond=c_cond.numpy(), ws=ws_map.numpy(), v=verts.numpy(), R=R, Sc=Sc, Sf=Sf, **out)
+    print('PIN', 'OK' if ok else 'FAILED')
+    return 0 if ok else 1
+
+
 def main():
+    if '--orbit' in sys.argv:
+        return orbit()
     if '--mapping-depth' in sys.argv:
         return mapping_depth()
     if '--sr-modules' in sys.argv:

@@ -56,16 +56,20 @@ def main():
         torch.rand_like = lambda t, *a, **k: jitter.clone() if tuple(t.shape) == tuple(jitter.shape) else o_rand_like(t, *a, **k)
         torch.rand = lambda *a, **k: u.clone() if (tuple(a) == tuple(u.shape) or (len(a) == 1 and tuple(a[0]) == tuple(u.shape))) else o_rand(*a, **k)
         torch.randn_like = lambda t, *a, **k: next(draws).clone()
+        ir, fine_ref = ImportanceRenderer(), []
+        ref_sample_importance = ir.sample_importance                     # the reference's own importance depths (:209-268): stored, so that a kernel under test can be teacher-forced with them
+        ir.sample_importance = lambda *a, **k: (fine_ref.append(ref_sample_importance(*a, **k)) or fine_ref[-1])
         try:
-            rgb, depth, wsum = ImportanceRenderer()(planes, dec, ro, rd, opts)
+            rgb, depth, wsum = ir(planes, dec, ro, rd, opts)
         finally:
             torch.rand, torch.rand_like, torch.randn_like = o_rand, o_rand_like, o_randn_like
         o_ro, o_rd = oren.ray_sampler(c2w, K, R)
-        rgb_o, depth_o, wsum_o = oren.importance_renderer(P, 'decoder', planes, o_ro, o_rd, opts, jitter, u, noise=nz)
-        d = [float((a - b).abs().max()) for a, b in ((rgb, rgb_o), (depth, depth_o), (wsum, wsum_o))]
-        print(f'[{name}] max-abs(ref - oracle): rgb {d[0]:.2e} depth {d[1]:.2e} wsum {d[2]:.2e}')
+        fine_o = []
+        rgb_o, depth_o, wsum_o = oren.importance_renderer(P, 'decoder', planes, o_ro, o_rd, opts, jitter, u, noise=nz, fine_depths_out=fine_o)
+        d = [float((a - b).abs().max()) for a, b in ((rgb, rgb_o), (depth, depth_o), (wsum, wsum_o), (fine_ref[0], fine_o[0]))]
+        print(f'[{name}] max-abs(ref - oracle): rgb {d[0]:.2e} depth {d[1]:.2e} wsum {d[2]:.2e} importance depths {d[3]:.2e}')
         ok &= all(x <= 1e-6 for x in d)
-        out.update({f'{name}_rgb': rgb.numpy(), f'{name}_depth': depth.numpy(), f'{name}_wsum': wsum.numpy(), f'{name}_cams': cams.numpy()})
+        out.update({f'{name}_rgb': rgb.numpy(), f'{name}_depth': depth.numpy(), f'{name}_wsum': wsum.numpy(), f'{name}_cams': cams.numpy(), f'{name}_fine': fine_ref[0].numpy()})
     np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'render_opts.npz'), planes=planes.numpy(), jitter=jitter.numpy(), u=u.numpy(),
                         noise_c=nz[0].numpy(), noise_f=nz[1].numpy(), R=R, Sc=Sc, Sf=Sf, cases=np.array(list(CASES)),
                         **{k.replace('.', '__'): v.numpy() for k, v in P.items()}, **out)

@@ -63,10 +63,16 @@ void oracle_rasterize_meshes(const float* verts, const int32_t* faces, int N, in
             const float x1 = v1[0], y1 = v1[1], z1 = v1[2];
             const float x2 = v2[0], y2 = v2[1], z2 = v2[2];
             const float zmax = fmaxf(z0, fmaxf(z1, z2));
+            const float zmin = fminf(z0, fminf(z1, z2));
             const float face_area = edge_fn(x0, y0, x1, y1, x2, y2); /* EdgeFunctionForward(v0,v1,v2) */
             const int is_back = face_area < 0.0f;
             const int zero_area = (face_area <= K_EPS) && (face_area >= -K_EPS);
-            if (zmax < 0.0f || (cull_backfaces && is_back) || zero_area) continue;
+            /* z_invalid: PyTorch3D's CheckPointOutsideBoundingBox also reports EVERY pixel as outside the box of a face with a vertex at or behind the
+             * camera plane (zlims.x < kEpsilon: "faces with at least one vertex behind the camera won't render correctly and should be removed or
+             * clipped before calling the rasterizer") — such a face never covers a pixel.  Irrelevant on the Next3D path (z += 10,
+             * triplane_next3d.py:201) but part of rasterize_meshes' published behaviour. */
+            const int z_invalid = zmin < K_EPS;
+            if (zmax < 0.0f || (cull_backfaces && is_back) || zero_area || z_invalid) continue;
 
             const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
             const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));

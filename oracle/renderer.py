@@ -142,7 +142,7 @@ def sample_importance(z_vals, weights, u):
     return sample_pdf(z_mid, w[:, 1:-1], u).reshape(B, R, u.shape[1], 1)
 
 
-def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u, noise=None):
+def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u, noise=None, fine_depths_out=None):
     """vr/renderer.py:95-147 (ImportanceRenderer.forward): fixed ray_start / ray_end, or both 'auto' (:98-106); sample_stratified with
     or without disparity_space_sampling (:184-207); white_back (ray_marcher.py:56-57); density_noise (:152-153).
 
@@ -186,6 +186,8 @@ def importance_renderer(P, decoder_prefix, planes, ray_o, ray_d, opts, jitter, u
     if Sf > 0:
         _, _, w = ray_march_(col_c, den_c, depths_c)
         depths_f = sample_importance(depths_c, w, u)
+        if fine_depths_out is not None:          # (tests: the importance depths, to teacher-force the kernel under test with — n3d_render_opts.fine_depths_in)
+            fine_depths_out.append(depths_f)
         col_f, den_f = run(depths_f, Sf, noise[1] if amp > 0 else None)
         all_d = torch.cat([depths_c, depths_f], -2)
         all_c = torch.cat([col_c, col_f], -2)

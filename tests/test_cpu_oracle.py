@@ -101,6 +101,13 @@ def test_rasterizer_and_floodfill_closed_form():
     if big:   # +Y is UP in PyTorch3D NDC: the apex (y=+0.5) lands in the top rows (fewer covered pixels there)
         rows = hit.any(dim=1).nonzero().flatten()
         assert hit[rows.min()].sum() < hit[rows.max()].sum()
+    # z_invalid (PyTorch3D CheckPointOutsideBoundingBox: zlims.x < kEpsilon): a face with ONE vertex at / behind the camera plane covers nothing
+    # although its zmax is positive; the same face moved in front of the plane is drawn
+    vz, fv = verts.clone(), int(faces[front[0]][0])                        # one vertex of the face that IS drawn
+    vz[0, fv, 2] = -0.25
+    assert int((raster.rasterize_meshes(vz, faces, image_size=64)[0] >= 0).sum()) == 0
+    vz[0, fv, 2] = 2e-8
+    assert int((raster.rasterize_meshes(vz, faces, image_size=64)[0] >= 0).sum()) == int(hit.sum())
     img = np.zeros((8, 8), np.float32)
     img[2:6, 2:6] = 255.0
     img[3:5, 3:5] = 0.0                                                     # enclosed hole must NOT be filled
@@ -156,6 +163,7 @@ def load_render_opts_golden():
         opts = dict(dict(depth_resolution=Sc, depth_resolution_importance=Sf, box_warp=1), **RENDER_OPT_CASES[name])
         out[name] = (opts, torch.from_numpy(g[name + '_cams']), torch.from_numpy(g[name + '_rgb']), torch.from_numpy(g[name + '_depth']),
                      torch.from_numpy(g[name + '_wsum']))
+    inp['fine'] = {name: torch.from_numpy(g[name + '_fine']) for name in out}        # the REFERENCE's importance depths [N, R*R, Sf, 1] (round 6: teacher forcing)
     return inp, out
 
 
@@ -166,8 +174,10 @@ def test_renderer_options_match_reference_golden():
     N = inp['planes'].shape[0]
     for name, (opts, cams, rgb, depth, wsum) in cases_.items():
         ro, rd = renderer.ray_sampler(cams[:, :16].reshape(N, 4, 4), cams[:, 16:25].reshape(N, 3, 3), inp['R'])
-        o = renderer.importance_renderer(inp['P'], 'decoder', inp['planes'], ro, rd, opts, inp['jitter'], inp['u'], noise=inp['noise'])
+        fine = []
+        o = renderer.importance_renderer(inp['P'], 'decoder', inp['planes'], ro, rd, opts, inp['jitter'], inp['u'], noise=inp['noise'], fine_depths_out=fine)
         d = [float((a - b).abs().max()) for a, b in zip(o, (rgb, depth, wsum))]
+        assert torch.equal(fine[0], inp['fine'][name])                   # the importance depths themselves: the reference's, bit for bit
         assert max(d) <= 1e-5, (name, d)
         if name == 'auto_wide_fov':
             rs, re = renderer.ray_limits_box(ro, rd, 1)

@@ -789,3 +789,56 @@ def test_other_superresolution_modules_match_reference_golden(dev, cls, res):
         assert 1e-5 < e16 <= 2e-2 and not w                              # float16 blocks on the f16 kernels
     else:
         assert e16 == 0.0 and len(w) == 1                                # SynthesisBlockNoUp has no float16 form here: float32 arithmetic, one warning
+
+
+@pytest.mark.gpu
+def test_orbit_frames_match_reference_golden(G, dev):
+    """VERDICT r5 4c — the closest thing to "gen_videos_next3d.py on hardware" this environment allows: the script's render loop (:96-158) with the argument
+    values the script itself computes — one seed = one keyframe, w_frames = 120, --trunc 0.7, --sample_mult 2 (96 + 96 samples), the float64 scipy cubic
+    interpolation of the tiled keyframe latents, `G.synthesis(ws=w.unsqueeze(0), c=c[0:1], v=verts[0:1], noise_mode='const')` — for frames 0 / 60 / 119 of the
+    120-frame orbit, against the REAL reference's outputs for the same frames (tests/golden/orbit_frames.npz, oracle/pin_against_reference.py --orbit; the
+    renderer's random draws injected on both sides).  Run the way the script runs it (plane caching off, `cache_backbone` pattern on: the orbit never changes
+    the latents or the mesh, so the second form must return the same frames), on both precisions of the float32 route and on the scripts' default route."""
+    import scipy.interpolate
+    from next3d_amd import layers
+    d = np.load(os.path.join(GOLDEN, 'orbit_frames.npz'))
+    R, Sc, Sf, w_frames, wraps = int(d['R']), int(d['Sc']), int(d['Sf']), int(d['w_frames']), int(d['wraps'])
+    assert (R, Sc, Sf) == (G.neural_rendering_resolution, 96, 96)
+    G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = Sc, Sf       # gen_videos_next3d.py:288-289
+    jitter, u = cases.rng_inputs(1, R, Sc, Sf)
+    device = dev
+    zs = torch.from_numpy(np.stack([np.random.RandomState(int(d['seed'])).randn(G.z_dim)])).to(device)         # :95 (float64, as the script builds it)
+    c = torch.from_numpy(d['c_cond']).to(device)
+    verts = torch.from_numpy(d['v']).to(device)
+    worst = {}
+    try:
+        for precision in ('fp32', 'bf16x3'):
+            layers.set_precision(precision)
+            ws = G.mapping(z=zs, c=c, truncation_psi=float(d['psi']), truncation_cutoff=int(d['cutoff']))      # :104
+            assert _md(ws, d['ws']) <= 1e-4
+            _ = G.synthesis(ws[:1], c[:1], verts[:1])                                                          # :105 warm up (its own random draws)
+            ws_g = ws.reshape(1, 1, 1, *ws.shape[1:])
+            x = np.arange(-1 * wraps, 1 * (wraps + 1))                                                         # :113-116, num_keyframes = 1
+            y = np.tile(ws_g[0][0].cpu().numpy(), [wraps * 2 + 1, 1, 1])
+            interp = scipy.interpolate.interp1d(x, y, kind='cubic', axis=0)
+            for route, kw in (('float32 route', dict(force_fp32=True)), ('default route', {})):
+                for cached in (False, True):
+                    for k, frame_idx in enumerate(int(f) for f in d['frames']):
+                        cf = torch.from_numpy(d[f'c_{frame_idx}']).to(device)                                  # the script's own LookAtPoseSampler pose of this frame (:131-137)
+                        w = torch.from_numpy(interp(frame_idx / w_frames)).to(device)                          # :140-141: float64
+                        assert w.dtype == torch.float64
+                        ckw = dict(cache_backbone=(k == 0), use_cached_backbone=(k > 0)) if cached else {}
+                        o = G.synthesis(ws=w.unsqueeze(0), c=cf[0:1], v=verts[0:1], noise_mode='const', depth_jitter=jitter, importance_u=u, **kw, **ckw)      # :153
+                        e = (_md(o['image'][..., ::2, ::2], d[f'image_{frame_idx}_sub2']), _md(o['image_raw'], d[f'image_raw_{frame_idx}']),
+                             _md(o['image_depth'], d[f'image_depth_{frame_idx}']), _md(o['image'].mean(dim=(2, 3)), d[f'image_mean_{frame_idx}']))
+                        key = (precision, route)
+                        worst[key] = tuple(max(a, b) for a, b in zip(worst.get(key, (0, 0, 0, 0)), e))
+                        if route == 'float32 route':
+                            assert e[0] <= 1e-3 and e[1] <= 1e-3 and e[2] <= 1e-3, (precision, route, cached, frame_idx, e)           # north_star
+                        else:      # float16 super-resolution blocks against the reference's float32 run of the same frames: the documented bound of that route
+                            assert e[0] <= 1.2e-2 and e[3] <= 1.2e-3 and e[1] <= 1e-3 and e[2] <= 1e-3, (precision, route, cached, frame_idx, e)
+    finally:
+        layers.set_precision('bf16x3')
+        G.rendering_kwargs['depth_resolution'], G.rendering_kwargs['depth_resolution_importance'] = 48, 48
+    for key, e in worst.items():
+        print(f'orbit {key}: image {e[0]:.2e} image_raw {e[1]:.2e} image_depth {e[2]:.2e} image mean {e[3]:.2e}')

@@ -375,8 +375,9 @@ def _channels_last(planes):
 def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
     """Ray sampler + two-pass importance renderer + decoder + ray marcher (vr/renderer.py:95-268, vr/ray_marcher.py:27-66)
     on random tri-planes: 48+48 (the headline configuration), 24+24, 96+96 (gen_videos' sampling multiplier 2), coarse only,
-    and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star); the importance pass is
-    discontinuous in the coarse weights, so at most 1 % of the rays may exceed it."""
+    and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star) at EVERY ray with the importance depths teacher-forced
+    (n3d_render_opts.fine_depths_in = the oracle's own); free-running, the importance pass is discontinuous in the coarse weights: the rays whose sampled
+    depths agree (all but a handful, counted) are held to 1e-3 as well."""
     from next3d_amd import _lib, demo as camera_utils
     N = 2
     planes = _gen((N, 3, 32, PH, PW), 60 + R, 2.0)
@@ -386,21 +387,46 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
     jitter, u = cases.rng_inputs(N, R, Sc, max(Sf, 1))
     u = u[:, :Sf]
     opts = dict(depth_resolution=Sc, depth_resolution_importance=Sf, ray_start=2.25, ray_end=3.3, box_warp=1)
-    rgb, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, opts, jitter, u)
+    fine = []
+    rgb, depth, wsum = renderer.importance_renderer(P, 'decoder', planes, ray_o, ray_d, opts, jitter, u, fine_depths_out=fine)
     t = dict(dtype=torch.float32, device=dev)
-    feat, dep, ws_, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(N, R * R, **t), torch.empty(2, **t)
     d = [x.contiguous().to(dev) for x in (_channels_last(planes), c[:, :16], c[:, 16:25], torch.linspace(2.25, 3.3, Sc), jitter,
                                            u if Sf else torch.zeros(1), w1, b1, w2t, b2)]
-    _lib.check(_lib.lib().n3d_render_rays(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
-                                          Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, _lib.stream()))
-    e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
-    e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
-    e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
+
+    def run(fine_in=None, fine_out=None):
+        feat, dep, ws_, bounds = torch.empty(N, 32, R, R, **t), torch.empty(N, 1, R, R, **t), torch.empty(N, R * R, **t), torch.empty(2, **t)
+        ro = _lib.RenderOpts()
+        ro.ray_start, ro.ray_end, ro.box_side = 2.25, 3.3, 1.0
+        ro.fine_depths_in, ro.fine_depths_out = _lib.ptr(fine_in), _lib.ptr(fine_out)
+        _lib.check(_lib.lib().n3d_render_rays_ex(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
+                                                 Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, ro, _lib.stream()))
+        e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
+        e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
+        e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
+        return e_rgb, e_dep, e_w
+
+    # (1) teacher-forced: the oracle's importance depths go in — second decode, merge, march and composite on IDENTICAL samples: EVERY ray within 1e-3
+    if Sf:
+        e_rgb, e_dep, e_w = run(fine_in=fine[0].reshape(N, R * R, Sf).contiguous().to(dev))
+        print(f'R{R} {Sc}+{Sf} teacher-forced: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, wsum max {float(e_w.max()):.2e}')
+        for e in (e_rgb, e_dep, e_w):
+            assert float(e.max()) <= 1e-3 and float(e.median()) <= 1e-4
+    # (2) free-running: the kernel's own importance depths against the oracle's — equal to float32 rounding on all but the few samples whose u sits on a CDF step
+    # (the seam is discontinuous there), and the composite within 1e-3 on all but those rays
+    own = torch.zeros(N, R * R, max(Sf, 1), **t)
+    e_rgb, e_dep, e_w = run(fine_out=own if Sf else None)
     print(f'R{R} {Sc}+{Sf}: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, '
           f'wsum max {float(e_w.max()):.2e}')
+    bad_rays = torch.zeros(N, R * R, dtype=torch.bool)
+    if Sf:
+        dd = (own.cpu() - fine[0].reshape(N, R * R, Sf)).abs()
+        bad = dd > 1e-5
+        bad_rays = bad.any(-1)
+        print(f'   importance depths: {int(bad.sum())} of {bad.numel()} samples off by more than 1e-5 (max {float(dd.max()):.2e}) on {int(bad_rays.sum())} rays')
+        assert float(bad.float().mean()) <= 2e-3
     for e in (e_rgb, e_dep, e_w):
-        assert float((e > 1e-3).float().mean()) <= 0.01
-        assert float(e.median()) <= 1e-4
+        assert float(e[~bad_rays].max()) <= 1e-3                          # every ray whose samples agree
+        assert float((e > 1e-3).float().mean()) <= 0.01 and float(e.median()) <= 1e-4
 
 
 @pytest.mark.parametrize('name', ['white_back', 'disparity', 'auto', 'auto_wide_fov', 'density_noise', 'all'])
@@ -433,14 +459,24 @@ def test_render_rays_options_match_reference_golden(dev, name):
         ro.ray_start, ro.ray_end = opts['ray_start'], opts['ray_end']
     if opts.get('density_noise', 0) > 0:
         ro.density_noise, ro.density_noise_coarse, ro.density_noise_fine = opts['density_noise'], _lib.ptr(nc), _lib.ptr(nf)
-    _lib.check(_lib.lib().n3d_render_rays_ex(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
-                                             float((hi - lo) / (Sc - 1)), 2.0, ro, _lib.stream()))
-    e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
-    e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
-    e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
-    print(f'{name}: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, wsum max {float(e_w.max()):.2e}')
-    for e in (e_rgb, e_dep, e_w):                                         # the importance pass is discontinuous in the coarse weights (as in test_render_rays_matches_oracle)
-        assert float((e > 1e-3).float().mean()) <= 0.01 and float(e.median()) <= 1e-4
+    fine_ref = inp['fine'][name].reshape(N, R * R, Sf).contiguous().to(dev)      # the REFERENCE's own importance depths
+    own = torch.zeros(N, R * R, Sf, **t)
+    for forced in (True, False):
+        ro.fine_depths_in, ro.fine_depths_out = (_lib.ptr(fine_ref), None) if forced else (None, _lib.ptr(own))
+        _lib.check(_lib.lib().n3d_render_rays_ex(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc, Sf, PH, PW,
+                                                 float((hi - lo) / (Sc - 1)), 2.0, ro, _lib.stream()))
+        e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
+        e_dep = (dep.cpu().reshape(N, R * R) - depth[..., 0]).abs()
+        e_w = (ws_.cpu() - wsum.reshape(N, R * R)).abs()
+        print(f'{name}{" teacher-forced" if forced else ""}: rgb max {float(e_rgb.max()):.2e} median {float(e_rgb.median()):.2e}, depth max {float(e_dep.max()):.2e}, wsum max {float(e_w.max()):.2e}')
+        if forced:                                                        # identical samples behind the seam: EVERY ray within the tolerance
+            for e in (e_rgb, e_dep, e_w):
+                assert float(e.max()) <= 1e-3 and float(e.median()) <= 1e-4
+        else:                                                             # free-running: the importance pass is discontinuous in the coarse weights — the rays whose sampled depths agree are held to 1e-3
+            bad = (own.cpu() - fine_ref.cpu()).abs() > 1e-5 * max(1.0, float(fine_ref.abs().max()))
+            assert float(bad.float().mean()) <= 5e-3
+            for e in (e_rgb, e_dep, e_w):
+                assert float(e[~bad.any(-1)].max()) <= 1e-3 and float((e > 1e-3).float().mean()) <= 0.01 and float(e.median()) <= 1e-4
     if auto:                                                              # the per-ray limits themselves: exactly the reference's slab test + repair
         o_ro, o_rd = renderer.ray_sampler(cams[:, :16].reshape(N, 4, 4), cams[:, 16:25].reshape(N, 3, 3), R)
         rs, re = renderer.ray_limits_box(o_ro, o_rd, 1)
@@ -603,6 +639,26 @@ def test_third_party_shims_rasterize_meshes_matches_oracle(dev, shims, cull):
         assert torch.equal(p.cpu(), p_ref) and torch.equal(z.cpu(), z_ref) and torch.equal(b.cpu(), b_ref)
     with pytest.raises(RuntimeError):
         rasterize_meshes(Meshes(verts=v.to(dev), faces=faces[None].expand(2, -1, -1).to(dev)), image_size=128, blur_radius=0.0, faces_per_pixel=2)
+
+
+def test_third_party_shims_rasterize_meshes_rejects_faces_behind_the_camera_plane(dev, shims):
+    """PyTorch3D's `z_invalid`: CheckPointOutsideBoundingBox reports every pixel outside the box of a face whose MINIMUM z is below kEpsilon = 1e-8
+    (a vertex at or behind the camera plane), so such a face covers nothing — also when its other vertices are in front (zmax >= 0 alone would keep it).
+    A soup pushed across z = 0: faces straddling the plane vanish in the kernel exactly as in oracle/raster_ref.c; the rest is bit-equal."""
+    from pytorch3d.renderer.mesh import rasterize_meshes
+    from pytorch3d.structures import Meshes
+    v0, faces, _ = _soup(78)
+    v = v0 * 5.0
+    v[..., 2] = v[..., 2] * 6.0 + 0.05                                    # z roughly in [-0.5, 0.6]: behind, straddling and in front of the plane
+    zf = v[0][faces][..., 2]                                              # [F, 3]
+    straddle = (zf.min(1).values < 1e-8) & (zf.max(1).values >= 0)
+    assert int(straddle.sum()) >= 5 and int((zf.min(1).values >= 1e-8).sum()) >= 5
+    p_ref, z_ref, b_ref = raster.rasterize_meshes(v, faces, image_size=128, cull_backfaces=False)
+    p, z, b, _ = rasterize_meshes(Meshes(verts=v.to(dev), faces=faces[None].to(dev)), image_size=128, blur_radius=0.0, faces_per_pixel=1, bin_size=None,
+                                  max_faces_per_bin=None, perspective_correct=False, cull_backfaces=False)
+    drawn = set(p_ref[p_ref >= 0].unique().tolist())
+    assert len(drawn) >= 3 and not (drawn & set(straddle.nonzero().flatten().tolist()))            # no face with a vertex behind the plane is ever drawn
+    assert torch.equal(p.cpu(), p_ref) and torch.equal(z.cpu(), z_ref) and torch.equal(b.cpu(), b_ref)
 
 
 def test_third_party_shims_reference_call_sequence_equals_fused_kernel(dev, shims):
