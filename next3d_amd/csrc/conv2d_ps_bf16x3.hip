@@ -514,6 +514,42 @@ __global__ __launch_bounds__(512, 4) void conv2d_ps1p_bf16x3_kernel(ConvPsParams
         __syncthreads();                                                  // the epilogue's LDS factors are rewritten by the next tile
     }
 }
+// DYNAMIC persistent form (round 6; tuning builds: N3D_PS_PERSIST=2): the resident workgroups PULL tiles from a queue instead of
+// walking a static share — blockIdx & 7 (the XCD a workgroup is observed to run on: a speed assumption only) selects one of eight queues, each covering the
+// contiguous eighth of the logical tile order the launch-per-tile form would have given that XCD (same L2 locality), one relaxed agent-scope fetch_add per tile
+// (MI355X_MICROARCH.md "dequeue": 0.3-1.3 us, shared per XCD).  A workgroup that finishes early takes the next tile at once: no lockstep, no static imbalance;
+// its stores drain under the next tile's first DMA.  q[0..7] = the queues' heads, q[8] = workgroups that have left: the last one re-arms all nine words
+// (the caller's zeroed per-stream pool, n3d_conv2d_desc.tickets).
+__device__ __forceinline__ int ps_dequeue(unsigned* q, int xcd, int* s_slot) {
+    if (threadIdx.x == 0) *s_slot = (int)__hip_atomic_fetch_add(q + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*s_slot);
+    __syncthreads();                                                      // (the slot is rewritten by the next dequeue)
+    return t;
+}
+__device__ __forceinline__ void ps_queue_leave(unsigned* q) {
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(q + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(q + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void ps_queue_share(int total, int& first, int& count) {
+    const int q8 = total >> 3, r = total & 7, xcd = blockIdx.x & 7;
+    first = xcd < r ? xcd * (q8 + 1) : r * (q8 + 1) + (xcd - r) * q8;
+    count = q8 + (xcd < r ? 1 : 0);
+}
+__global__ __launch_bounds__(512, 4) void conv2d_ps1d_bf16x3_kernel(ConvPsParams p, int total, unsigned* q) {
+    __shared__ bf16x8 smem[ps_smem_slots(1, false) + 1];
+    int* s_slot = reinterpret_cast<int*>(smem + ps_smem_slots(1, false));
+    int first, count;
+    ps_queue_share(total, first, count);
+    for (;;) {
+        const int t = ps_dequeue(q, blockIdx.x & 7, s_slot);
+        if (t >= count) break;
+        conv2d_ps_bf16x3_body<1, 0>(p, smem, first + t);
+    }
+    ps_queue_leave(q);
+}
 __global__ __launch_bounds__(512, 2) void conv2d_ps2_bf16x3_kernel(ConvPsParams p) {         // two buffers, one workgroup per CU
     __shared__ bf16x8 smem[ps_smem_slots(2, false)];
     conv2d_ps_bf16x3_body<2, 0>(p, smem);
@@ -612,7 +648,8 @@ int conv2d_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
       else if (rgb && nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (rgb) hipLaunchKernelGGL(conv2d_ps1_rgb_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
       else if (nbuf == 2) hipLaunchKernelGGL(conv2d_ps2_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
-      else if (n3d_tune("N3D_PS_PERSIST", 0) && p.ksplit == 1 && nblk > 512) hipLaunchKernelGGL(conv2d_ps1p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
+      else if (n3d_tune("N3D_PS_PERSIST", 0) == 2 && p.ksplit == 1 && nblk > 512 && d->tickets && d->ticket_count >= 9) hipLaunchKernelGGL(conv2d_ps1d_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk, d->tickets);
+      else if (n3d_tune("N3D_PS_PERSIST", 0) == 1 && p.ksplit == 1 && nblk > 512) hipLaunchKernelGGL(conv2d_ps1p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
       else hipLaunchKernelGGL(conv2d_ps1_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p); }
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.H, p.W, p.ybs, p.yrs, p.epi, stream);
@@ -906,6 +943,19 @@ __global__ __launch_bounds__(512, 4) void conv2d_up_ps32p_bf16x3_kernel(ConvUpPs
     }
 }
 
+__global__ __launch_bounds__(512, 4) void conv2d_up_ps32d_bf16x3_kernel(ConvUpPsParams p, int total, unsigned* q) {      // dynamic persistent form (see conv2d_ps1d_bf16x3_kernel)
+    __shared__ bf16x8 smem[up_ps_smem_slots(1) + 1];
+    int* s_slot = reinterpret_cast<int*>(smem + up_ps_smem_slots(1));
+    int first, count;
+    ps_queue_share(total, first, count);
+    for (;;) {
+        const int t = ps_dequeue(q, blockIdx.x & 7, s_slot);
+        if (t >= count) break;
+        conv2d_up_ps_body<1, 8, 1>(p, smem, first + t);
+    }
+    ps_queue_leave(q);
+}
+
 int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const bool nchw = d->y_layout == N3D_LAYOUT_NCHW_F32;
     N3D_CHECK(d->ksize == 3 && d->mode == 2 && (d->y_layout == N3D_LAYOUT_C8_F32 || nchw), "conv2d_bf16x3: a split8 input to the transposed kernel: c8 or float32 NCHW output");
@@ -937,7 +987,9 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)d->H * d->W;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    if (n3d_tune("N3D_PS_PERSIST", 0) && nblk > 512) hipLaunchKernelGGL(conv2d_up_ps32p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
+    const int persist = n3d_tune("N3D_PS_PERSIST", 0);
+    if (persist == 2 && nblk > 512 && d->tickets && d->ticket_count >= 9) hipLaunchKernelGGL(conv2d_up_ps32d_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk, d->tickets);
+    else if (persist == 1 && nblk > 512) hipLaunchKernelGGL(conv2d_up_ps32p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
     else hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;

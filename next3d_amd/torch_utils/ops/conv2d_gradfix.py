@@ -161,6 +161,7 @@ def split8_from_nchw(x, scale=None):
     return y
 
 
+PS_TICKETS = False   # hand the stream's arrival counters to the pre-split 3x3 kernels too (tuning builds: N3D_PS_PERSIST=2, tools/ps_persist_ab.py)
 SK_SEAM = True       # few-pixel layers: K sliced over workgroups, reduced inside the launch (module constant; tools flip it in-process for A/B runs)
 KSPLIT_MAX = 64      # cap on the split-K factor of the split-bf16 3x3 kernels (module constant; tools sweep it in-process)
 
@@ -313,7 +314,10 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     d.x_row_stride = x.stride(2)
     d.epi = epilogue if epilogue is not None else _lib.make_epilogue()
     d.wt_batch_stride = int(_wt_batch_stride)
-    if tk is not None:
+    if tk is None and PS_TICKETS and split8:              # tools: the dynamic-queue persistent kernels of tuning builds draw their tiles through the stream's counters
+        tk = _lib.seam_pool()
+        d.tickets, d.ticket_count = tk.tickets_ptr, _lib.TICKET_COUNT
+    elif tk is not None:
         d.tickets, d.ticket_count = tk.tickets_ptr, _lib.TICKET_COUNT
     partial = None
     if rgb is not None:

@@ -22,15 +22,21 @@ def t_us(fn, iters=40):
 
 
 def ab(tag, fn, out, gf):
+    """N3D_PS_PERSIST: 0 = one launch-time workgroup per tile (shipped), 1 = static persistent (round 5), 2 = dynamic queue (round 6)"""
     res = {}
-    for v in ('0', '1', '0', '1'):
+    for v in ('0', '1', '2', '0', '1', '2'):
         os.environ['N3D_PS_PERSIST'] = v
         y = out(fn())
         res.setdefault(v, []).append((t_us(fn), y.clone()))
-    same = torch.equal(res['0'][0][1], res['1'][0][1])
-    a, b = min(t for t, _ in res['0']), min(t for t, _ in res['1'])
-    print(f'{tag} ({gf:.0f} GF): launch per tile {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  persistent {b:7.1f} us ({gf / b * 1e3:4.0f} TF)  {100 * (a / b - 1):+5.1f} %  bitwise equal: {same}', flush=True)
+    same = torch.equal(res['0'][0][1], res['1'][0][1]) and torch.equal(res['0'][0][1], res['2'][0][1])
+    a, b, c = (min(t for t, _ in res[k]) for k in ('0', '1', '2'))
+    print(f'{tag} ({gf:.0f} GF): launch per tile {a:7.1f} us ({gf / a * 1e3:4.0f} TF)  static persistent {b:7.1f} us ({100 * (a / b - 1):+5.1f} %)  dynamic queue {c:7.1f} us ({gf / c * 1e3:4.0f} TF, {100 * (a / c - 1):+5.1f} %)'
+          f'  bitwise equal: {same}', flush=True)
     os.environ['N3D_PS_PERSIST'] = '0'
+    assert int(_lib.tickets().abs().sum()) == 0, 'queue words not re-armed'
+
+
+cg.PS_TICKETS = True
 
 
 for (N, I, O, H) in [(4, 256, 256, 128), (4, 128, 128, 256), (4, 256, 256, 256), (4, 128, 128, 512)]:
