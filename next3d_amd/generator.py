@@ -97,6 +97,16 @@ class TriPlaneGenerator(_Tracked):
         self.mapping_layers = int(mapping_kwargs.get('num_layers', 8))
         if not 1 <= self.mapping_layers <= 16:
             raise RuntimeError(f'mapping_kwargs.num_layers = {self.mapping_layers}: 1..16 expected')
+        # ... and the other options MappingNetwork honours (tat/networks_stylegan2.py:196-209) only at the values `mapping()` implements: a pickle built with another
+        # one would produce other ws — refuse it instead of ignoring the key; unknown keys raise as the reference's constructor would
+        mk_fixed = dict(embed_features=None, layer_features=None, activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998)
+        for key, val in mapping_kwargs.items():
+            if key == 'num_layers':
+                continue
+            if key not in mk_fixed:
+                raise TypeError(f'TriPlaneGenerator: unexpected mapping keyword argument {key!r} (MappingNetwork takes num_layers, ' + ', '.join(mk_fixed) + ')')
+            if val is not None and val != mk_fixed[key] and not (key in ('embed_features', 'layer_features') and val == 512):
+                raise RuntimeError(f'mapping_kwargs[{key!r}] = {val!r}: this build implements the reference default ({mk_fixed[key]!r}) only')
         # the backbones' widths: channels_dict of `channel_base` / `channel_max` (tat/networks_stylegan2.py:614; ffhq-512: 32768 / 512) — RuntimeError for
         # widths the matrix-core kernels do not tile (spec.check_channels)
         self.channel_base, self.channel_max = int(synthesis_kwargs.get('channel_base', 32768)), int(synthesis_kwargs.get('channel_max', 512))
@@ -106,7 +116,7 @@ class TriPlaneGenerator(_Tracked):
         # fp16_resolution run on the f16 matrix-core kernels unless force_fp32 is passed (tat/networks_stylegan2.py:615-621, :548-562)
         # the block options this build implements are the next3d ones; anything else must not be ignored silently (the reference would build another network,
         # or raise TypeError for a key its blocks do not take)
-        fixed = dict(architecture='skip', use_noise=True, activation='lrelu', resample_filter=[1, 3, 3, 1])
+        fixed = dict(architecture='skip', use_noise=True, activation='lrelu', resample_filter=[1, 3, 3, 1], kernel_size=3)     # (kernel_size: SynthesisLayer's, through layer_kwargs)
         for key, want in fixed.items():
             got = synthesis_kwargs.get(key, want)
             if (list(got) if key == 'resample_filter' else got) != want:
@@ -589,6 +599,8 @@ class TriPlaneGenerator(_Tracked):
             raise RuntimeError(f"sr_antialias=False with a {feature_image.shape[-1]} x {feature_image.shape[-1]} render above the super-resolution input "
                                f'({S.sr.input_resolution}): the non-antialiased down-scaling is not implemented')
         sr_image = S.sr(rgb_image, feature_image, eg3d_ws, _resize_aa, noise_mode=sr_noise, fp16=sr_fp16, bank=bank)
+        if getattr(S.sr, 'aliased_raw', None) is not None:       # SuperresolutionHybrid4X / 2X without a resize: the reference's in-place update of its own view (networks.SuperRes8XDC)
+            rgb_image = S.sr.aliased_raw
         return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image}
 
     # ------------------------------------------------------------------ HIP-graph replay of the steady-state loops

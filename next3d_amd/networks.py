@@ -354,8 +354,10 @@ class SuperRes8XDC:
                   for b, hh in ((self.block0, h), (self.block1, 2 * h))))
         if not ok and not getattr(self, '_warned32', False):
             self._warned32 = True
-            warnings.warn('float16 super-resolution blocks are not available for this configuration (filter / shapes): '
-                          'running them in float32 (the force_fp32=True arithmetic)')
+            why = ('this super-resolution module has a block without up-sampling (SynthesisBlockNoUp: SuperresolutionHybrid4X / 2X), which has no float16 form here'
+                   if not self.all_up else 'resampling filter / layer shapes outside the f16 kernels')
+            warnings.warn(f'float16 super-resolution blocks are not available for this configuration ({why}): '
+                          'running the whole module in float32 (the force_fp32=True arithmetic)')
         return ok
 
     def _forward_f16(self, x, rgb, bank, noise_mode):
@@ -392,7 +394,9 @@ class SuperRes8XDC:
             if last not in self._banks:
                 self._banks[last] = L.StyleBank(self.bank_entries(last), self.fir.device)
             bank = self._banks[last].compute(ws)
-        if (x.shape[-1] != self.input_resolution) if self.resize_rule == 'ne' else (x.shape[-1] < self.input_resolution):     # (4X resizes only a SMALLER render, :82)
+        self.aliased_raw = None
+        resized = (x.shape[-1] != self.input_resolution) if self.resize_rule == 'ne' else (x.shape[-1] < self.input_resolution)     # (4X resizes only a SMALLER render, :82)
+        if resized:
             x = resize_fn(x, self.input_resolution)
             rgb = resize_fn(rgb, self.input_resolution)
         if not rgb.is_contiguous():                                  # (no resize: the caller's channel-slice view of the feature image)
@@ -400,5 +404,10 @@ class SuperRes8XDC:
         if fp16 and self._f16_ok(x, noise_mode):
             return self._forward_f16(x, rgb, bank, noise_mode)
         x0, rgb, xs = self.block0(x, rgb, bank, ws.shape[0], self.fir, noise_mode, next_block=self.block1)
+        if isinstance(self.block0, _BlockNoUp) and not resized:
+            # SynthesisBlockNoUp adds toRGB's output IN PLACE (`img = img.add_(y)`, tat/superresolution.py:250) and without a resize `img` IS the caller's
+            # `rgb_image = feature_image[:, :3]` view (triplane_next3d.py:185): the 'image_raw' the reference returns is rgb + toRGB(block0) — handed to synthesis()
+            # (pinned: oracle/pin_against_reference.py --sr-noresize, 0.0 against the reference)
+            self.aliased_raw = rgb
         x1, rgb, _ = self.block1(x0, rgb, bank, ws.shape[0], self.fir, noise_mode, x_split8=xs, last=True)
         return rgb

@@ -289,11 +289,16 @@ def conv_launch(x, wt, ksize, mode, out_channels, out=None, style=None, epilogue
     assert tuple(y.shape) == (n, o, oh, ow) and y.stride(3) == 1 and y.stride(2) >= ow and y.stride(1) == oh * y.stride(2)
     gh, gw = (h + 1, w + 1) if mode == 2 else (oh, ow)
     sk_layer = False
-    if bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and sk_eligible(n, i, o, h, w):
+    # (the few-pixel launchers decline a layer whose epilogue rounds to float16 or up-samples its residual, and every side output: mirrored here so that the split-K
+    #  choice below and the library's dispatch cannot diverge — ADVICE r5)
+    sk_epi_ok = (epilogue is None or (not epilogue.round_f16 and not epilogue.residual_up_filter)) and side_style is None and s8 is None
+    if not sk_epi_ok:
+        pass
+    elif bf16x3 and ksize == 3 and mode == 0 and not split8 and c8 is None and not _wt_batch_stride and sk_eligible(n, i, o, h, w):
         ksplit, sk_layer = 1, True                       # the few-pixel kernel splits K inside its workgroups: no split-K reduce launch
-    if bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and up_sk_eligible(n, i, o, h, w):
+    elif bf16x3 and ksize == 3 and mode == 2 and not split8 and c8 is None and not _wt_batch_stride and out_dtype == torch.float32 and (epilogue is None or not epilogue.residual) and up_sk_eligible(n, i, o, h, w):
         ksplit, sk_layer = 1, True                       # ... and so does its transposed twin (few-position up-sampling layers)
-    if bf16x3 and ksize == 3 and mode == 1 and not split8 and not pitched_in and not _wt_batch_stride and out_dtype == torch.float32 and sk_s2_eligible(n, i, o, h, w):
+    elif bf16x3 and ksize == 3 and mode == 1 and not split8 and not pitched_in and not _wt_batch_stride and out_dtype == torch.float32 and sk_s2_eligible(n, i, o, h, w):
         ksplit, sk_layer = 1, True                       # ... and the few-pixel stride-2 layers
     if ksplit is None:
         ksplit = (1 if ksize == 1 else pick_ksplit_bf16x3(n, i, o, h, w, mode)) if bf16x3 else pick_ksplit(n, i, o, gh, gw, ksize, mode)

@@ -88,7 +88,7 @@ FIR_SEP = True             # separable evaluation of separable 4x4 filters (modu
 
 
 def fir_factor(fir):
-    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter TENSOR (one host read; the networks call this
+    """4 device taps `a` with fir == outer(a, a), or None — decided once per filter TENSOR, inference tensors included (one host read; the networks call this
     at model preparation, networks.py, so that no forward — and no HIP-graph capture — ever does it).  The entry is tied to the
     tensor object by a weak reference and dropped with it: a later tensor at the same address never sees a stale factor.
     The model's filter is setup_filter([1,3,3,1]) = outer(v, v) with v = [1,3,3,1] / 8 (:96-116): the separable kernels
@@ -96,9 +96,14 @@ def fir_factor(fir):
     import weakref
     from .conv2d_gradfix import _tensor_version
     key = id(fir)
-    version = _tensor_version(fir)            # None for inference tensors (no version counter): decided again on every call
+    # inference tensors keep no version counter (a model built or loaded under torch.inference_mode()): their entry is tied to the tensor object and its storage
+    # address instead — the filter is a registered buffer that nothing rewrites in place, and re-deciding it per call would cost a blocking device-to-host read
+    # on every filtered layer (and is illegal inside a HIP-graph capture: ADVICE r5)
+    version = _tensor_version(fir)
+    if version is None:
+        version = ('inference', fir.data_ptr())
     hit = _FIR1D.get(key)
-    if version is not None and hit is not None and hit[0]() is fir and hit[1] == version:
+    if hit is not None and hit[0]() is fir and hit[1] == version:
         return hit[2]
     f = fir.detach().to('cpu', torch.float64)
     a = None
@@ -106,8 +111,6 @@ def fir_factor(fir):
         v = f.sum(1) / f.sum().sqrt()
         if torch.equal(torch.outer(v, v).to(torch.float32), f.to(torch.float32)):
             a = v.to(torch.float32).to(fir.device).contiguous()
-    if version is None:
-        return a
     _FIR1D[key] = (weakref.ref(fir), version, a)
     weakref.finalize(fir, lambda k=key: _FIR1D.pop(k, None) if (_FIR1D.get(k) and _FIR1D[k][0]() is None) else None)
     return a

@@ -135,6 +135,7 @@ def synthesis(P, ws, c, v, uv_face_mask, rendering_kwargs, jitter, u, neural_ren
     rgb = feature_image[:, :3]
     st['feature_image'] = feature_image
     sr_class = str(rendering_kwargs.get('superresolution_module', 'SuperresolutionHybrid8XDC')).rsplit('.', 1)[-1]       # tat/triplane_next3d.py:66
-    sr = networks.superresolution(P, 'superresolution', rgb, feature_image, eg3d_ws, force_fp32=force_fp32, sr_class=sr_class)
-    out = {'image': sr, 'image_raw': rgb, 'image_depth': depth_image}
+    alias = {}
+    sr = networks.superresolution(P, 'superresolution', rgb, feature_image, eg3d_ws, force_fp32=force_fp32, sr_class=sr_class, aliased_raw=alias)
+    out = {'image': sr, 'image_raw': alias.get('image_raw', rgb), 'image_depth': depth_image}       # (4X / 2X without a resize: see networks.superresolution)
     return (out, st) if return_stages else out

@@ -241,7 +241,7 @@ _SR = {'SuperresolutionHybrid8XDC': (128, 'ne', False), 'SuperresolutionHybrid8X
        'SuperresolutionHybrid4X': (128, 'lt', True), 'SuperresolutionHybrid2X': (64, 'ne', True)}
 
 
-def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False, sr_class='SuperresolutionHybrid8XDC'):
+def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False, sr_class='SuperresolutionHybrid8XDC', aliased_raw=None):
     """tat/superresolution.py:279-290 (SuperresolutionHybrid8XDC.forward; :46-58 8X, :79-91 4X, :113-124 2X), noise_mode='none'; fp32 path (what the
     reference runs off-GPU and what the goldens pin) or, with force_fp32=False (8XDC / 8X), its fp16 blocks emulated (synthesis_block_fp16).
     conv_clamp=256 because the module is built with use_fp16 = sr_num_fp16_res > 0 (:269-275).  Channel counts come from the parameters' shapes."""
@@ -250,13 +250,20 @@ def superresolution(P, prefix, rgb, x, ws, force_fp32=True, cpu_rounding=False, 
     if (x.shape[-1] != res_in) if rule == 'ne' else (x.shape[-1] < res_in):
         x = F.interpolate(x, size=(res_in, res_in), mode='bilinear', align_corners=False, antialias=True)
         rgb = F.interpolate(rgb, size=(res_in, res_in), mode='bilinear', align_corners=False, antialias=True)
+        if aliased_raw is not None:
+            aliased_raw['resized'] = True
     if not force_fp32:      # the reference's default on a GPU (use_fp16 = sr_num_fp16_res > 0): emulated float16 storage
         assert not noup, 'float16 emulation of SynthesisBlockNoUp is not restated'
         x, rgb = synthesis_block_fp16(P, f'{prefix}.block0', x, rgb, ws, cpu_rounding=cpu_rounding)
         x, rgb = synthesis_block_fp16(P, f'{prefix}.block1', x, rgb, ws, cpu_rounding=cpu_rounding)
         return rgb
     if noup:
+        resized = aliased_raw is not None and aliased_raw.get('resized', False)
         x, rgb = synthesis_block_noup(P, f'{prefix}.block0', x, rgb, ws, noise_mode='none', conv_clamp=256)
+        # SynthesisBlockNoUp adds toRGB's output IN PLACE (`img = img.add_(y)`, tat/superresolution.py:250): when the module did not resize, `img` is the caller's
+        # `rgb_image = feature_image[:, :3]` view (triplane_next3d.py:185), so the 'image_raw' the reference RETURNS is rgb + toRGB(block0) — reported to the caller here
+        if aliased_raw is not None and not resized:
+            aliased_raw['image_raw'] = rgb
     else:
         x, rgb = synthesis_block(P, f'{prefix}.block0', x, rgb, ws, P[f'{prefix}.block0.conv0.weight'].shape[1], noise_mode='none', conv_clamp=256)
     x, rgb = synthesis_block(P, f'{prefix}.block1', x, rgb, ws, P[f'{prefix}.block1.conv0.weight'].shape[1], noise_mode='none', conv_clamp=256)

@@ -278,6 +278,9 @@ def fp16_blocks():
 VARIANTS_SR = [('SuperresolutionHybrid8X', 32768, 512, 'sr8X'), ('SuperresolutionHybrid4X', 32768, 512, 'sr4X'), ('SuperresolutionHybrid2X', 32768, 512, 'sr2X')]
 # (SuperresolutionHybridDeepfp32, :127-154, cannot be constructed by the reference's own TriPlaneGenerator: triplane_next3d.py:66 passes sr_antialias=..., which that class does
 #  not take and forwards to SynthesisLayer -> TypeError.  Tried here in round 5; the generator of this package raises for it too.)
+# ... and the two modules with a SynthesisBlockNoUp at a render that needs NO resize (2X at 64 x 64, 4X at 128 x 128): the reference's in-place `img.add_(y)` then lands in
+# the returned 'image_raw' (ADVICE r5): tests/golden/case_r32_s24_sr2X_r64.npz / _sr4X_r128.npz (the case's inputs at another neural rendering resolution)
+VARIANTS_SR_NORESIZE = [('SuperresolutionHybrid2X', 32768, 512, 'sr2X_r64', 64), ('SuperresolutionHybrid4X', 32768, 512, 'sr4X_r128', 128)]
 VARIANTS_WIDTH = [('SuperresolutionHybrid8XDC', 16384, 512, 'cb16384'), ('SuperresolutionHybrid8XDC', 16384, 256, 'cb16384_cm256')]
 
 
@@ -298,9 +301,9 @@ def sr_modules(variants=VARIANTS_SR, what='sr modules'):
     v_demo = n3d_mesh.parse_obj_vertices(os.path.join(ref_shims.REF, 'data/demo/demo.obj'))
     lms = n3d_mesh.parse_landmarks(os.path.join(ref_shims.REF, 'data/demo/demo_kpt2d.txt'))
     cfg = CASES['case_r32_s24']
-    R, Sc, Sf = cfg['R'], cfg['Sc'], cfg['Sf']
     ok = True
-    for cls, cb, cm, suffix in variants:
+    for cls, cb, cm, suffix, *r_over in variants:
+        R, Sc, Sf = (r_over[0] if r_over else cfg['R']), cfg['Sc'], cfg['Sf']
         rk = dict(RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, superresolution_module=f'training_avatar_texture.superresolution.{cls}')
         G = ref_shims.build_reference_generator(rk, channel_base=cb, channel_max=cm)
         ref_sd = G.state_dict()
@@ -461,6 +464,8 @@ def main():
         return sr_modules()
     if '--channel-widths' in sys.argv:
         return sr_modules(VARIANTS_WIDTH, 'channel widths')
+    if '--sr-noresize' in sys.argv:
+        return sr_modules(VARIANTS_SR_NORESIZE, 'sr modules without a resize (in-place image_raw)')
     if '--fp16-backbones' in sys.argv:
         return fp16_backbones()
     if '--fp16-blocks' in sys.argv:

@@ -60,6 +60,14 @@ def test_generator_module_state_dict_names():
     assert set(G8.state_dict()) == set(spec.build_spec(mapping_layers=8)) and 'neural_blending.mapping.fc7.weight' in G8.state_dict() and G8.backbone.mapping.num_layers == 8
     with pytest.raises(RuntimeError, match='num_layers'):
         TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=0))
+    # the other MappingNetwork options: their reference defaults pass, another value is refused (mapping() hard-codes it), an unknown key raises
+    TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(),
+                      mapping_kwargs=dict(num_layers=2, lr_multiplier=0.01, activation='lrelu', w_avg_beta=0.998, embed_features=None), kernel_size=3)
+    for bad in (dict(lr_multiplier=0.1), dict(activation='relu'), dict(layer_features=256)):
+        with pytest.raises(RuntimeError, match='implements the reference default'):
+            TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=2, **bad))
+    with pytest.raises(TypeError, match='unexpected mapping'):
+        TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(depth=2))
     G = TriPlaneGenerator(512, 25, 512, 512, 3, topo, rendering_kwargs=dict(demo.RENDERING_KWARGS), uv_face_mask=mesh.synthetic_uv_face_mask(), mapping_kwargs=dict(num_layers=2))
     assert G.sr_conv_clamp is None                                           # sr_num_fp16_res == 0 -> no clamp (superresolution.py:273)
     # absent synthesis kwargs take the reference classes' defaults: float16 in the 4 highest resolutions of the backbones (fp16_resolution 32), conv_clamp 256
@@ -420,8 +428,12 @@ def test_prepared_weight_cache_skips_inference_tensors_and_can_be_cleared():
         w = torch.randn(4, 4, 3, 3) * 0.5
         f = uf.setup_filter([1, 3, 3, 1])
         assert cg._tensor_version(w) is None
-        a = uf.fir_factor(f)                                                # must not raise; not cached
-        assert a is not None and id(f) not in uf._FIR1D
+        a = uf.fir_factor(f)                                                # must not raise
+        # round 6: the FILTER of an inference-mode model IS cached — tied to the tensor object and its storage address — so that no forward (and no
+        # HIP-graph capture) re-reads it from the device; a new tensor object never sees the entry
+        assert a is not None and id(f) in uf._FIR1D and uf.fir_factor(f) is a
+        f2 = f.clone()
+        assert uf.fir_factor(f2) is not a
     p = torch.nn.Parameter(torch.randn(4, 4, 3, 3))
     assert cg._tensor_version(p) == p._version
     cg._PREP_CACHE[12345] = {}

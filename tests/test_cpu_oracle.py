@@ -261,7 +261,7 @@ def test_oracle_fp16_backbones_against_reference_fp16_run():
     check_fp16_backbone_outputs(g, st, out, 'oracle')
 
 
-@pytest.mark.parametrize('suffix', ['sr4X', 'cb16384', 'cb16384_cm256'])
+@pytest.mark.parametrize('suffix', ['sr4X', 'cb16384', 'cb16384_cm256', 'sr2X_r64'])
 def test_oracle_reproduces_reference_golden_of_other_architectures(suffix):
     """The reference's other architectures — super-resolution modules (tat/superresolution.py:29-124) and backbone widths (`--cbase` / `--cmax`,
     train_next3d.py:199-200) — run by the reference's own constructors (oracle/pin_against_reference.py --sr-modules / --channel-widths): the oracle
