@@ -299,9 +299,10 @@ __device__ __forceinline__ void pass_blend(const PassFetch& F, float (&f)[16]) {
 // ~0.5 line per clock and CU — is what the kernel waits for: 48 loads x 64 lines x 4 waves = 12,288 line accesses per round of passes against
 // 4,288 cycles of decoder MFMAs (profiles/r05_render_pmc.txt: 58.7 line accesses per wave load, 0.48 per clock, matrix pipe 0.17, one wave per
 // SIMD).  Here EIGHT ADJACENT LANES fetch one texel (128 contiguous bytes): lane l = 8 a + b loads piece b of the texels of the samples
-// s' = 8 j + a, j = 0..3 — the same 48 instructions and bytes per lane, 8 texels (8-16 lines) per instruction instead of 64.  Each lane
-// derives the 12 tap offsets / weights of ITS FOUR samples itself (4 x the address arithmetic of the old pass, VALU work that sits under the
-// decoder's MFMAs; nothing is exchanged between lanes for it: the sample depths are in the ray's LDS arrays anyway), blends in the loaded
+// s' = 8 j + a, j = 0..3 — the same 48 instructions and bytes per lane, 8 texels (8-16 lines) per instruction instead of 64.  The 12 tap
+// offsets / weights of a sample are computed ONCE by its owner pair (the old pass's arithmetic) and handed to the eight loading lanes through
+// the sample's own colour row in LDS (free until the sample's pass blends; a first version let every lane derive the taps of its four
+// samples itself: +51 % VALU instructions, profiles/r06_render_gather_pmc.txt); the loading lanes blend in the loaded
 // layout — 4 channels of 4 samples per lane, the same fma chain per channel as pass_blend: bit-identical features — and hands the features to
 // the sample's owner pair (s, s + 32) through the sample's OWN colour row in LDS, which the pass only fills at its end: no extra LDS.
 struct PassFetch2 {
@@ -457,24 +458,39 @@ __device__ __forceinline__ void scan_half(const float* src, float* dst, int n, i
 // order[rank] = sample.  Lane l31 ranks samples l31 + 32 m; one broadcast LDS read per compared sample serves all of them.
 template <int KP>
 __device__ __forceinline__ void rank_half(const RayLds& L, int M, int l31) {
+    // Round 6: ONE strict count per sample (no second "<=" count: a tie shows up as an order slot nobody wrote), FOUR partial counters per sample so that the
+    // sixteen compare-and-add steps of a batch are four dependent chains of four instead of one of sixteen (the wave has its SIMD to itself: the chain length is
+    // the stage's time — 13.3 k of a wave's 133 k cycles before, profiles/r06_render_gather_pmc.txt), and the rank of every sample kept (rank[]: the composite's coefficients)
     float d[KP];
-    int lt[KP], le[KP];
+    int c0[KP], c1[KP], c2[KP], c3[KP];
+    int* rank = reinterpret_cast<int*>(L.bins);                            // (bins is dead behind the importance depths)
 #pragma unroll
-    for (int m = 0; m < KP; ++m) { d[m] = l31 + 32 * m < M ? L.dep[l31 + 32 * m] : INFINITY; lt[m] = 0; le[m] = 0; }
+    for (int m = 0; m < KP; ++m) {
+        d[m] = l31 + 32 * m < M ? L.dep[l31 + 32 * m] : INFINITY; c0[m] = 0; c1[m] = 0; c2[m] = 0; c3[m] = 0;
+        if (l31 + 32 * m < M) L.order[l31 + 32 * m] = -1;
+    }
     for (int q0 = 0; q0 < M; q0 += 16) {                                  // sixteen compared samples per LDS round trip
         float dq[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) dq[k] = q0 + k < M ? L.dep[q0 + k] : INFINITY;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < 16; k += 4)
 #pragma unroll
-            for (int m = 0; m < KP; ++m) { lt[m] += dq[k] < d[m] ? 1 : 0; le[m] += dq[k] <= d[m] ? 1 : 0; }      // two compare + add-carry pairs
+            for (int m = 0; m < KP; ++m) { c0[m] += dq[k] < d[m] ? 1 : 0; c1[m] += dq[k + 1] < d[m] ? 1 : 0; c2[m] += dq[k + 2] < d[m] ? 1 : 0; c3[m] += dq[k + 3] < d[m] ? 1 : 0; }
     }
-    // no two samples of the ray at the same depth (the normal case): rank = number of smaller depths.  Equal depths are ordered by
-    // sample index (torch.sort is stable there), counted exactly in a second pass only when some lane saw a tie.
+    int lt[KP];
+#pragma unroll
+    for (int m = 0; m < KP; ++m) lt[m] = (c0[m] + c1[m]) + (c2[m] + c3[m]);
+    wave_sync();                                                          // (order[] = -1 everywhere)
+#pragma unroll
+    for (int m = 0; m < KP; ++m)
+        if (l31 + 32 * m < M) L.order[lt[m]] = l31 + 32 * m;
+    wave_sync();
+    // no two samples of the ray at the same depth (the normal case): every slot is written.  Equal depths are ordered by sample index (torch.sort is stable there):
+    // counted exactly in a second pass only when some slot stayed empty
     bool tie = false;
 #pragma unroll
-    for (int m = 0; m < KP; ++m) tie = tie || (l31 + 32 * m < M && le[m] - lt[m] != 1);
+    for (int m = 0; m < KP; ++m) tie = tie || (l31 + 32 * m < M && L.order[l31 + 32 * m] < 0);
     if (__any(tie)) {
 #pragma unroll
         for (int m = 0; m < KP; ++m) lt[m] = 0;
@@ -483,10 +499,14 @@ __device__ __forceinline__ void rank_half(const RayLds& L, int M, int l31) {
 #pragma unroll
             for (int m = 0; m < KP; ++m) lt[m] += (dq < d[m] || (dq == d[m] && q < l31 + 32 * m)) ? 1 : 0;
         }
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < KP; ++m)
+            if (l31 + 32 * m < M) L.order[lt[m]] = l31 + 32 * m;
     }
 #pragma unroll
     for (int m = 0; m < KP; ++m)
-        if (l31 + 32 * m < M) L.order[lt[m]] = l31 + 32 * m;
+        if (l31 + 32 * m < M) rank[l31 + 32 * m] = lt[m];
 }
 
 // mid-point ray march over `count` samples addressed through idx(i) (ray_marcher.py:28-46); fills wgt[0..count-2].  Every ray
@@ -602,13 +622,14 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     // the same with coalesced gathers (PassFetch2): sample group j of the NEXT pass = its 12 tap offsets / weights + its 12 loads, issued as part j under this pass's decoder
     const __amdgpu_buffer_rsrc_t r_planes = __builtin_amdgcn_make_buffer_rsrc((void*)(p.planes + (int64_t)n * 3 * p.PH * p.PW * RN_C), 0, 3 * p.PH * p.PW * RN_C * 4, 0x00020000);
     const int ga = lane >> 3, gb16 = (lane & 7) * 16;
-    auto fetch_group = [&](int g0, int cnt, int slot0, int j, PassFetch2& F) {
-        const int g = g0 + 8 * j + ga;
+    // owner pair (s, s + 32) of sample gF + s: the 12 tap offsets / weights ONCE per sample (round 5's arithmetic), parked in the sample's OWN colour row
+    // (unwritten until its pass blends): offsets in floats 0..11 (written by the lane of half 0), weights in 12..23 (half 1)
+    auto stage_taps = [&](int gF, int cnt, int slot0) {
+        const int g = gF + l31;
         const bool live = g < nrays * cnt;
         const int q = live && g >= cnt ? 1 : 0;
         const int i = live ? g - q * cnt : 0;
         const float t = (q ? Ls[1] : Ls[0]).dep[slot0 + i];
-        F.row[j] = live ? (q * rlf + (slot0 + i) * cp) : -1;
         const float dx = q ? rdx[1] : rdx[0], dy = q ? rdy[1] : rdy[0], dz = q ? rdz[1] : rdz[0];
         const float cx = p.coord_scale * __fadd_rn(ox, __fmul_rn(t, dx)), cy = p.coord_scale * __fadd_rn(oy, __fmul_rn(t, dy)), cz = p.coord_scale * __fadd_rn(oz, __fmul_rn(t, dz));
         int off[3][4];
@@ -616,19 +637,40 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         plane_taps_off(0, p.PH, p.PW, cx, cy, off[0], tw[0]);                       // plane 0: (x, y)
         plane_taps_off(p.PH * p.PW, p.PH, p.PW, cx, cz, off[1], tw[1]);             // plane 1: (x, z)
         plane_taps_off(2 * p.PH * p.PW, p.PH, p.PW, cz, cy, off[2], tw[2]);         // plane 2: (z, y)   (renderer.py:42-44)
+        if (live) {
+            float* row = wsm + q * rlf + (slot0 + i) * cp + 12 * hb;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<f32x4*>(row + 4 * pl) = hb ? f32x4{tw[pl][0], tw[pl][1], tw[pl][2], tw[pl][3]}
+                                                             : f32x4{__int_as_float(off[pl][0]), __int_as_float(off[pl][1]), __int_as_float(off[pl][2]), __int_as_float(off[pl][3])};
+        }
+        wave_sync();
+    };
+    // reader lane 8 a + b: sample group j = the sample gF + 8 j + a; its taps come out of the sample's row, its 12 loads fetch piece b of the 12 texels
+    auto fetch_group = [&](int g0, int cnt, int slot0, int j, PassFetch2& F) {
+        const int g = g0 + 8 * j + ga;
+        const bool live = g < nrays * cnt;
+        const int q = live && g >= cnt ? 1 : 0;
+        const int i = live ? g - q * cnt : 0;
+        const int row = q * rlf + (slot0 + i) * cp;
+        F.row[j] = live ? row : -1;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(wsm + row + 4 * pl), w4 = *reinterpret_cast<const f32x4*>(wsm + row + 12 + 4 * pl);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                F.tw[j][4 * pl + k] = live ? tw[pl][k] : 0.f;
-                F.v[j][4 * pl + k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_planes, off[pl][k] + gb16, 0, 0));
+                F.tw[j][4 * pl + k] = live ? w4[k] : 0.f;
+                F.v[j][4 * pl + k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_planes, (live ? __float_as_int(o4[k]) : 0) + gb16, 0, 0));
             }
+        }
     };
     auto decode_all2 = [&](int cnt, int slot0) {
         const int total = nrays * cnt;
         PassFetch2 F;
+        stage_taps(0, cnt, slot0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fetch_group(0, cnt, slot0, j, F);
+        if (32 < total) stage_taps(32, cnt, slot0);                       // taps run ONE pass ahead of the loads that use them: the LDS round trip is off the decoder's path
         for (int g0 = 0; g0 < total; g0 += 32) {
             __builtin_amdgcn_sched_barrier(0);
             // this pass's owner pair: sample g0 + l31 -> (ray q, slot)
@@ -657,7 +699,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             RN_STAMP2(10);
             const bool more = g0 + 32 < total;
             float rgb[16], sigma;
-            auto part = [&](int k) { fetch_group(g0 + 32, cnt, slot0, k, F); };
+            auto part = [&](int k) { fetch_group(g0 + 32, cnt, slot0, k, F); if (k == 3 && g0 + 64 < total) stage_taps(g0 + 64, cnt, slot0); };
             RN_STAMP2(11);
             if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
             else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
@@ -708,19 +750,30 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         scan_half<false>(L.trn, L.cdf, Np + 1, l31);                    // cdf[0] = 0, cdf[k + 1] = pdf[0] + .. + pdf[k] (:244-245)
         wave_sync();
         const float* uu = p.u + ((int64_t)n * RR + ray) * Sf;
-        for (int j = l31; j < Sf; j += 32) {
-            const float u = uu[j];
-            int ind = 0;                                             // searchsorted(cdf, u, right=True)
-#pragma unroll 8
-            for (int k = 0; k <= Np; ++k) ind += (L.cdf[k] <= u) ? 1 : 0;
+        for (int jb = 0; jb < Sf; jb += 64) {                         // two draws per lane at once: one walk over the cdf serves both (round 6)
+          const int ja = jb + l31, jc = jb + 32 + l31;
+          const float ua = ja < Sf ? uu[ja] : 0.f, uc = jc < Sf ? uu[jc] : 0.f;
+          int a0 = 0, a1 = 0, c0 = 0, c1 = 0;                         // searchsorted(cdf, u, right=True): two partial counts per draw
+          int k = 0;
+          for (; k + 1 <= Np; k += 2) {
+              const float e0 = L.cdf[k], e1 = L.cdf[k + 1];
+              a0 += (e0 <= ua) ? 1 : 0; a1 += (e1 <= ua) ? 1 : 0; c0 += (e0 <= uc) ? 1 : 0; c1 += (e1 <= uc) ? 1 : 0;
+          }
+          for (; k <= Np; ++k) { const float e0 = L.cdf[k]; a0 += (e0 <= ua) ? 1 : 0; c0 += (e0 <= uc) ? 1 : 0; }
+          for (int half2 = 0; half2 < 2; ++half2) {
+            const int j = half2 ? jc : ja;
+            if (j >= Sf) continue;
+            const float u = half2 ? uc : ua;
+            const int ind = half2 ? c0 + c1 : a0 + a1;
             const int below = max(ind - 1, 0), above = min(ind, Np);
-            const float c0 = L.cdf[below], c1 = L.cdf[above], b0 = L.bins[below], b1 = L.bins[above];
-            float denom = c1 - c0;
+            const float cc0 = L.cdf[below], cc1 = L.cdf[above], b0 = L.bins[below], b1 = L.bins[above];
+            float denom = cc1 - cc0;
             if (denom < 1e-5f) denom = 1.f;
-            float dj = __fadd_rn(b0, __fmul_rn((u - c0) / denom, (b1 - b0)));
+            float dj = __fadd_rn(b0, __fmul_rn((u - cc0) / denom, (b1 - b0)));
             if (p.fine_out && store) p.fine_out[((int64_t)n * RR + ray) * Sf + j] = dj;
             if (p.fine_in) dj = p.fine_in[((int64_t)n * RR + ray) * Sf + j];
             L.dep[Sc + j] = dj;
+          }
         }
         wave_sync();
         RN_STAMP(4);
@@ -737,7 +790,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         march_weights(L, M, l31, [ord](int i) { return ord[i]; });
         RN_STAMP(7);
     } else {
-        for (int k = l31; k < Sc; k += 32) L.order[k] = k;
+        for (int k = l31; k < Sc; k += 32) { L.order[k] = k; reinterpret_cast<int*>(L.bins)[k] = k; }
         wave_sync();
         march_weights(L, Sc, l31, [](int i) { return i; });
     }
@@ -746,19 +799,27 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     // lane-strided partial sums
     float acc = 0.f, dacc = 0.f, wt = 0.f;
     {
-        float cprev = L.col[L.order[0] * cp + l31];
-        for (int i0 = 0; i0 < count - 1; i0 += 16) {                      // sixteen (weight, next colour) pairs per LDS round trip
+        // Round 6: sum_i w_i (c_ord(i) + c_ord(i+1)) / 2 regrouped PER SAMPLE: the sample of rank r carries (w_{r-1} + w_r) / 2 — the coefficients are computed once by the
+        // ray's lanes (three samples each), and the channel sum walks the samples in storage order with independent LDS reads instead of chasing order[] -> colour row
+        // sixteen dependent round trips at a time (8.8 k cycles per wave before).  Same products; another summation order (differences of float32 rounding).
+        const int* rank = reinterpret_cast<const int*>(L.bins);
+        float* coef = L.cdf;                                               // (dead behind the importance depths)
+        for (int sI = l31; sI < count; sI += 32) {
+            const int r = rank[sI];
+            coef[sI] = 0.5f * ((r > 0 ? L.wgt[r - 1] : 0.f) + (r < count - 1 ? L.wgt[r] : 0.f));
+        }
+        wave_sync();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int sI = 0;
+        for (; sI + 16 <= count; sI += 16) {
             float w[16], cn[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int i = min(i0 + k, count - 2);
-                w[k] = L.wgt[i];
-                cn[k] = L.col[L.order[i + 1] * cp + l31];
-            }
+            for (int k = 0; k < 16; ++k) { w[k] = coef[sI + k]; cn[k] = L.col[(sI + k) * cp + l31]; }
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (i0 + k < count - 1) { acc += w[k] * ((cprev + cn[k]) / 2.f); cprev = cn[k]; }
+            for (int k = 0; k < 16; k += 4) { a0 = fmaf(w[k], cn[k], a0); a1 = fmaf(w[k + 1], cn[k + 1], a1); a2 = fmaf(w[k + 2], cn[k + 2], a2); a3 = fmaf(w[k + 3], cn[k + 3], a3); }
         }
+        for (; sI < count; ++sI) a0 = fmaf(coef[sI], L.col[sI * cp + l31], a0);
+        acc = (a0 + a1) + (a2 + a3);
     }
     for (int i = l31; i < count - 1; i += 32) {
         const int a = L.order[i], b = L.order[i + 1];
@@ -785,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     render_rays_body<false>(p, smem);
 }
-// the coalesced gather (eight lanes per texel): tuning builds only, N3D_RENDER_GATHER=1 — built and measured in round 6, NOT faster (see PassFetch2)
+// the coalesced gather (eight lanes per texel, PassFetch2): the launcher picks it where four waves share a CU (n3d_render_rays_ex)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_c8_kernel(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     render_rays_body<true>(p, smem);
@@ -998,7 +1059,10 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     wpb = wpb > 4 ? 4 : wpb;
     N3D_CHECK(wpb >= 1, "render_rays: %d samples per ray do not fit the LDS", M);
     const size_t lds = image + wpb * per_wave;
-    const bool coalesced = n3d_tune("N3D_RENDER_GATHER", 0) != 0 && (int64_t)3 * PH * PW * RN_C * 4 < (1ll << 31);      // (32-bit texel offsets per sample)
+    // the gather: eight lanes per texel (render_rays_c8_kernel) where four waves share a CU's texture path — there the address / tag rate of 64 scattered 16-byte
+    // accesses per load instruction is what a pass waits for (510 -> 453 us on the benchmark shape); with two or three waves per CU (more than 96 samples per ray:
+    // the colour rows fill the LDS) round 5's 64-bytes-per-lane gather is the faster one (1.76 against 1.85 ms at 96 + 96): profiles/r06_render_gather_pmc.txt
+    const bool coalesced = n3d_tune("N3D_RENDER_GATHER", wpb >= 4 ? 1 : 0) != 0 && (int64_t)3 * PH * PW * RN_C * 4 < (1ll << 31);      // (32-bit texel offsets per sample)
     const void* kfn = coalesced ? (const void*)render_rays_c8_kernel : (const void*)render_rays_kernel;
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER_RAYS, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
