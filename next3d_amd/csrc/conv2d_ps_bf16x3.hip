@@ -933,6 +933,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_up_ps32_bf16x3_kernel(ConvUpPsP
     conv2d_up_ps_body<1, 8, 1>(p, smem);
 }
 
+// tuning builds (N3D_UP_WIDE=1): four waves per workgroup, each 64 positions x 32 channels x 4 phases — the weight fragments a wave reads serve two position
+// groups (34 fragment reads per 54 MFMAs instead of 26 per 27), 128 accumulators per lane, two workgroups = eight waves per CU
+__global__ __launch_bounds__(256, 2) void conv2d_up_ps32w_bf16x3_kernel(ConvUpPsParams p) {
+    __shared__ bf16x8 smem[up_ps_smem_slots(1)];
+    conv2d_up_ps_body<1, 4, 2>(p, smem);
+}
 __global__ __launch_bounds__(512, 4) void conv2d_up_ps32p_bf16x3_kernel(ConvUpPsParams p, int total) {      // persistent form (see conv2d_ps1p_bf16x3_kernel)
     __shared__ bf16x8 smem[up_ps_smem_slots(1)];
     int first, count, step;
@@ -988,7 +994,8 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
     const int persist = n3d_tune("N3D_PS_PERSIST", 0);
-    if (persist == 2 && nblk > 512 && d->tickets && d->ticket_count >= 9) hipLaunchKernelGGL(conv2d_up_ps32d_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk, d->tickets);
+    if (n3d_tune("N3D_UP_WIDE", 0)) hipLaunchKernelGGL(conv2d_up_ps32w_bf16x3_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    else if (persist == 2 && nblk > 512 && d->tickets && d->ticket_count >= 9) hipLaunchKernelGGL(conv2d_up_ps32d_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk, d->tickets);
     else if (persist == 1 && nblk > 512) hipLaunchKernelGGL(conv2d_up_ps32p_bf16x3_kernel, dim3(512), dim3(512), 0, stream, p, (int)nblk);
     else hipLaunchKernelGGL(conv2d_up_ps32_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
