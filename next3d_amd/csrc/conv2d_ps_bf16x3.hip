@@ -587,6 +587,7 @@ extern "C" int n3d_conv2d_split8_ksplit(int N, int I, int O, int H, int W) {
     if (I % 16 != 0 || I < 16 || H < 16 || W < 32 || N < 1 || O < 1) return 0;
     const int64_t blocks = (int64_t)cdiv(W, PS_TW) * cdiv(H, PS_TH) * cdiv(O, PS_BM) * N;
     if ((int64_t)(I / 8) * H * W * 16 >= (1ll << 31)) return 0;           // 32-bit buffer offsets per plane
+    { const int force = n3d_tune("N3D_PS_KS", 0); if (force > 0 && (I / 16) % force == 0) return force; }      // (tuning builds: tools/ps_b1_sweep.py)
     if (blocks >= 256) return 1;
     static const int on = n3d_tune("N3D_PS_SPLITK", 1);
     int ks = 1;
