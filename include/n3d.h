@@ -23,7 +23,7 @@ extern "C" {
 
 typedef void* n3d_stream_t; /* hipStream_t */
 
-#define N3D_ABI_VERSION 7
+#define N3D_ABI_VERSION 8
 
 /* activation ids = the reference's cuda_idx (torch_utils/ops/bias_act.py:23-33) */
 enum { N3D_ACT_LINEAR = 1, N3D_ACT_RELU = 2, N3D_ACT_LRELU = 3, N3D_ACT_TANH = 4, N3D_ACT_SIGMOID = 5,
@@ -423,6 +423,9 @@ typedef struct {
      * march, composite — is then compared on identical samples, every ray).  Both NULL in normal use. */
     float* fine_depths_out;
     const float* fine_depths_in;
+    /* ABI 8 — the decoder (OSGDecoder, tat/triplane_next3d.py:359-371) in the convolutions' split-bf16 arithmetic (three v_mfma_f32_32x32x16_bf16 per MAC, operand
+     * truncation 2^-17) instead of float32-input MFMAs (bitwise an fmaf chain): 24 MFMAs of 8 passes per 32 samples instead of 67 of 16.  0 (and opts NULL): float32. */
+    int decoder_split_bf16;
 } n3d_render_opts;
 int n3d_render_rays_ex(const float* planes_cl, const float* cam2world, const float* intrinsics, const float* tlin,
                        const float* jitter, const float* u, const float* w1, const float* b1, const float* w2,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('N3D_LIB') or os.path.join(_HERE, 'libn3d.so')     # N3D_LIB: A/B-compare two builds on one box
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -43,7 +43,7 @@ class Conv2dDesc(ctypes.Structure):
 class RenderOpts(ctypes.Structure):
     _fields_ = [('white_back', c_int), ('disparity_space_sampling', c_int), ('ray_start', c_float), ('ray_end', c_float), ('auto_bounds', c_int),
                 ('box_side', c_float), ('ray_bounds_ws', c_void_p), ('density_noise', c_float), ('density_noise_coarse', c_void_p),
-                ('density_noise_fine', c_void_p), ('fine_depths_out', c_void_p), ('fine_depths_in', c_void_p)]
+                ('density_noise_fine', c_void_p), ('fine_depths_out', c_void_p), ('fine_depths_in', c_void_p), ('decoder_split_bf16', c_int)]
 
 
 class ModwJob(ctypes.Structure):

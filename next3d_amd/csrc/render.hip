@@ -228,6 +228,54 @@ __device__ __forceinline__ void stage_decoder(const RenderParams& p, float* wimg
     }
 }
 
+// The same decoder for the SPLIT-bf16 route (n3d_render_opts.decoder_split_bf16; the convolutions' arithmetic): every fp32 operand as
+// hi = bf16(x), lo = bf16(x - hi) and a . b = a_hi b_lo + a_lo b_hi + a_hi b_hi on v_mfma_f32_32x32x16_bf16 — 24 instructions of 8 passes per 32 samples
+// instead of 67 of 16 passes (the f32-input MFMA runs at 1/16 of the bf16 rate; three split instructions are 5.3x cheaper per MAC).  Same M / N / K
+// assignment as above; a K step is 16 values, lane half hb supplying slots 8 hb .. 8 hb + 7:
+//   layer 1, step s: slot (hb, j) = channel 16 hb + 8 s + j — the 16 features a lane holds are its B operands of the two steps as they are;
+//   layer 2, step t: slot (hb, q) = hidden unit 32 (t / 2) + 16 (t % 2) + 8 (q / 4) + 4 hb + q % 4 — the accumulator registers 8 (t % 2) .. + 7 of block t / 2
+//                    ARE the B operand (after softplus and the split), no cross-lane traffic; the weights are arranged to match.
+// Biases enter as the accumulators' initial values (exact).  Image: 16 rows of 64 x 16 bytes (bf16x8 per lane), then 160 floats:
+//   rows 0..7 : layer 1 [jb][step][hi|lo];  rows 8..15 : layer 2 [t][hi|lo];  floats: b1 [hb][jb][16], b2 colours [hb][16], sigma weights [hb][jb][16]
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define RN_SPLIT_ROWS 16
+static_assert(RN_SPLIT_ROWS * 64 * 4 + 160 <= RN_WROWS * 64, "the split image fits the fp32 image's LDS");
+__device__ __forceinline__ void split8_rn(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+__device__ __forceinline__ void stage_decoder_split(const RenderParams& p, float* wimg, int tid, int nthreads) {
+    bf16x8* img = reinterpret_cast<bf16x8*>(wimg);
+    for (int e = tid; e < RN_SPLIT_ROWS * 64; e += nthreads) {
+        const int row = e >> 6, l = e & 63, l31 = l & 31, hb = l >> 5;
+        float v[8];
+        if (row < 8) {
+            const int jb = row >> 2, step = (row >> 1) & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p.w1[(32 * jb + l31) * RN_C + 16 * hb + 8 * step + j];
+        } else {
+            const int t = (row - 8) >> 1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = p.w2[(32 * (t >> 1) + 16 * (t & 1) + 8 * (q >> 2) + 4 * hb + (q & 3)) * 34 + 1 + l31];
+        }
+        bf16x8 hi, lo;
+        split8_rn(v, hi, lo);
+        img[e] = (row & 1) ? lo : hi;
+    }
+    float* fb = wimg + RN_SPLIT_ROWS * 64 * 4;
+    for (int e = tid; e < 160; e += nthreads) {
+        float v;
+        if (e < 64) { const int hb = e >> 5, jb = (e >> 4) & 1, r = e & 15; v = p.b1[32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
+        else if (e < 96) { const int k = e - 64, hb = k >> 4, r = k & 15; v = p.b2[1 + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
+        else { const int k = e - 96, hb = k >> 5, jb = (k >> 4) & 1, r = k & 15; v = p.w2[(32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)) * 34]; }
+        fb[e] = v;
+    }
+}
+
 // The waves of a workgroup share nothing but the decoder image; inside a wave LDS operations execute in issue order, so the
 // stages of a ray need a compiler-level fence only, not an s_barrier across the workgroup.
 __device__ __forceinline__ void wave_sync() {
@@ -414,6 +462,72 @@ __device__ __forceinline__ void pass_mlp(const float* wl /* decoder image + lane
     for (int r = 0; r < 16; ++r) rgb[r] = sigmoid_raw(o[r]) * (1.f + 2.f * 0.001f) - 0.001f;
 }
 
+// the split-bf16 decoder (stage_decoder_split's image): same interface, same interleaving of the next pass's loads
+template <bool LOADS, typename LoadFn>
+__device__ __forceinline__ void pass_mlp_split(const float* wimg, float bsig, int lane, const float (&f)[16], float (&rgb)[16], float& sigma,
+                                               LoadFn pass_load_part, bool rn_tr = false) {
+    const int hb = lane >> 5;
+    const bf16x8* A = reinterpret_cast<const bf16x8*>(wimg) + lane;        // + row * 64
+    const float* fb = wimg + RN_SPLIT_ROWS * 64 * 4;
+    const f32x4* b1p = reinterpret_cast<const f32x4*>(fb + hb * 32);
+    const f32x4* b2p = reinterpret_cast<const f32x4*>(fb + 64 + hb * 16);
+    const float* wsig = fb + 96 + hb * 32;
+    f32x16 h0, h1, o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t0 = b1p[q], t1 = b1p[4 + q], t2 = b2p[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h0[4 * q + k] = t0[k]; h1[4 * q + k] = t1[k]; o[4 * q + k] = t2[k]; }
+    }
+    if (LOADS) { pass_load_part(0); pass_load_part(1); }
+    bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f[8 * st + j];
+        split8_rn(v, xh[st], xl[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const bf16x8 a0h = A[(st * 2) * 64], a0l = A[(st * 2 + 1) * 64], a1h = A[(4 + st * 2) * 64], a1l = A[(4 + st * 2 + 1) * 64];
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, xh[st], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, xh[st], h1, 0, 0, 0);
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, xl[st], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, xl[st], h1, 0, 0, 0);
+        h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, xh[st], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, xh[st], h1, 0, 0, 0);
+    }
+    RN_STAMP3(13);
+    float sp = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+        float hs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hs[r] = softplus_raw(jb ? h1[r] : h0[r]);
+        if (LOADS) pass_load_part(2 + jb);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = hs[8 * tt + q];
+            bf16x8 bh, bl;
+            split8_rn(v, bh, bl);
+            const int t = 2 * jb + tt;
+            const bf16x8 ah = A[(8 + 2 * t) * 64], al = A[(8 + 2 * t + 1) * 64];
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sp = fmaf(wsig[16 * jb + r], hs[r], sp);
+        RN_STAMP3(14 + jb);
+    }
+    sigma = sp + __shfl_xor(sp, 32, 64) + bsig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rgb[r] = sigmoid_raw(o[r]) * (1.f + 2.f * 0.001f) - 0.001f;
+}
+
 // LDS of one ray: arrays sized for M = Sc + Sf samples
 struct RayLds {
     float* col;     // [M][RN_CP]  colour rows
@@ -533,12 +647,13 @@ __device__ __forceinline__ void march_weights(const RayLds& L, int count, int l3
 // one wave per SIMD (variants with two waves per SIMD — one ray per wave, or the colours parked in a global workspace — were
 // measured equal or slower in round 2 and are gone: DESIGN.md 3.2).
 constexpr int RPW = 2;
-template <bool COALESCED>
+template <bool COALESCED, bool SPLIT>
 __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hb = lane >> 5;
     const int n = blockIdx.y;
     const int R = p.R, RR = R * R, Sc = p.Sc, Sf = p.Sf, M = Sc + Sf;
-    stage_decoder(p, smem, threadIdx.x, blockDim.x);
+    if (SPLIT) stage_decoder_split(p, smem, threadIdx.x, blockDim.x);
+    else stage_decoder(p, smem, threadIdx.x, blockDim.x);
     __syncthreads();                                                      // the only workgroup-wide barrier
     const int ray0 = (blockIdx.x * (blockDim.x >> 6) + wave) * RPW;       // this wave's rays: ray0 (, ray0 + 1: may not exist)
     if (ray0 >= RR) return;
@@ -613,8 +728,13 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             RN_STAMP2(11);
             float rgb[16], sigma;
             auto part = [&](int k) { pass_load(F, k); };
-            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
-            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            if (SPLIT) {
+                if (more) pass_mlp_split<true>(smem, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+                else pass_mlp_split<false>(smem, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            } else {
+                if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+                else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            }
             store_pass(slot, q, rgb, sigma);
             RN_STAMP2(9);
         }
@@ -701,8 +821,13 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
             float rgb[16], sigma;
             auto part = [&](int k) { fetch_group(g0 + 32, cnt, slot0, k, F); if (k == 3 && g0 + 64 < total) stage_taps(g0 + 64, cnt, slot0); };
             RN_STAMP2(11);
-            if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
-            else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            if (SPLIT) {
+                if (more) pass_mlp_split<true>(smem, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+                else pass_mlp_split<false>(smem, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            } else {
+                if (more) pass_mlp<true>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+                else pass_mlp<false>(wl, bsig, lane, f, rgb, sigma, part, g0 == 32 && slot0 == 0);
+            }
             store_pass(slot, q, rgb, sigma);
             RN_STAMP2(9);
         }
@@ -844,12 +969,21 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_kernel(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body<false>(p, smem);
+    render_rays_body<false, false>(p, smem);
 }
 // the coalesced gather (eight lanes per texel, PassFetch2): the launcher picks it where four waves share a CU (n3d_render_rays_ex)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_c8_kernel(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    render_rays_body<true>(p, smem);
+    render_rays_body<true, false>(p, smem);
+}
+// the same two with the decoder on split-bf16 MFMAs (n3d_render_opts.decoder_split_bf16)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_s_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    render_rays_body<false, true>(p, smem);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void render_rays_c8s_kernel(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    render_rays_body<true, true>(p, smem);
 }
 
 // global min / max of the coarse depths over the whole batch (ray_marcher.py:54 clamps against them).  Multi-block: every
@@ -1063,7 +1197,9 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     // accesses per load instruction is what a pass waits for (510 -> 453 us on the benchmark shape); with two or three waves per CU (more than 96 samples per ray:
     // the colour rows fill the LDS) round 5's 64-bytes-per-lane gather is the faster one (1.76 against 1.85 ms at 96 + 96): profiles/r06_render_gather_pmc.txt
     const bool coalesced = n3d_tune("N3D_RENDER_GATHER", wpb >= 4 ? 1 : 0) != 0 && (int64_t)3 * PH * PW * RN_C * 4 < (1ll << 31);      // (32-bit texel offsets per sample)
-    const void* kfn = coalesced ? (const void*)render_rays_c8_kernel : (const void*)render_rays_kernel;
+    const bool split = n3d_tune("N3D_RENDER_SPLIT", opts && opts->decoder_split_bf16 ? 1 : 0) != 0;
+    const void* kfn = split ? (coalesced ? (const void*)render_rays_c8s_kernel : (const void*)render_rays_s_kernel)
+                            : (coalesced ? (const void*)render_rays_c8_kernel : (const void*)render_rays_kernel);
     const double pts = (double)N * R * R * M;
     N3dProfScope prof(N3D_K_RENDER_RAYS, stream, pts * 2.0 * (RN_C * RN_HID + RN_HID * (RN_C + 1)),
                       pts * 12.0 * RN_C * 4.0 + 4.0 * N * R * R * (RN_C + 1));          // bytes: 12 texels x 128 B gathered per point + the outputs
@@ -1073,8 +1209,14 @@ extern "C" int n3d_render_rays_ex(const float* planes_cl, const float* cam2world
     N3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(render_depth_bounds_kernel, dim3(bgrid), dim3(256), 0, stream, p, nrays, keys);
     N3D_LAUNCH_CHECK();
-    if (coalesced) hipLaunchKernelGGL(render_rays_c8_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
-    else hipLaunchKernelGGL(render_rays_kernel, dim3(cdiv((R * R + 1) / 2, wpb), N), dim3(64 * wpb), lds, stream, p);
+    const dim3 rgrid(cdiv((R * R + 1) / 2, wpb), N), rblock(64 * wpb);
+    if (split) {
+        if (coalesced) hipLaunchKernelGGL(render_rays_c8s_kernel, rgrid, rblock, lds, stream, p);
+        else hipLaunchKernelGGL(render_rays_s_kernel, rgrid, rblock, lds, stream, p);
+    } else {
+        if (coalesced) hipLaunchKernelGGL(render_rays_c8_kernel, rgrid, rblock, lds, stream, p);
+        else hipLaunchKernelGGL(render_rays_kernel, rgrid, rblock, lds, stream, p);
+    }
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,7 @@ from . import _lib, layers, mesh, networks, spec
 
 _BUFFER_LEAVES = ('noise_const', 'resample_filter', 'w_avg', 'dense_faces', 'faces', 'raw_uvcoords', 'uvcoords', 'uvfaces',
                   'face_uvcoords')
+RENDER_DECODER_SPLIT = True        # render: with layers.PRECISION == 'bf16x3' the OSGDecoder runs on split-bf16 MFMAs too (n3d_render_opts.decoder_split_bf16; False: float32-input MFMAs)
 RASTER_ON_SIDE_STREAM = 1          # _planes: batch sizes up to which the mesh rasterisation runs in front of the static backbone on the side stream (0 = never)
 RENDERING_VIEWS = [[0, 0, 0], [0, 90, 0], [0, -90, 0], [90, 0, 0]]        # reference triplane_next3d.py:140-145
 
@@ -506,8 +507,10 @@ class TriPlaneGenerator(_Tracked):
                                '[N, M, S, 1] depths (renderer.py:193) does not run either')
         noise_amp = float(rk.get('density_noise', 0) or 0)
         opts = None
-        if auto or disparity or rk.get('white_back', False) or noise_amp > 0:
+        split = RENDER_DECODER_SPLIT and layers.PRECISION == 'bf16x3'          # the decoder in the convolutions' arithmetic (fp32 route: float32-input MFMAs)
+        if auto or disparity or rk.get('white_back', False) or noise_amp > 0 or split:
             opts = _lib.RenderOpts()
+            opts.decoder_split_bf16 = 1 if split else 0
             opts.white_back = 1 if rk.get('white_back', False) else 0
             opts.disparity_space_sampling = 1 if disparity else 0
             opts.auto_bounds = 1 if auto else 0

@@ -371,13 +371,15 @@ def _channels_last(planes):
     return planes.permute(0, 1, 3, 4, 2).contiguous()
 
 
+@pytest.mark.parametrize('split', [0, 1], ids=['decoder_f32', 'decoder_split_bf16'])
 @pytest.mark.parametrize('R,Sc,Sf,PH,PW', [(8, 48, 48, 32, 32), (6, 24, 24, 16, 40), (5, 96, 96, 32, 32), (4, 12, 0, 8, 8), (4, 64, 17, 24, 24)])
-def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
+def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW, split):
     """Ray sampler + two-pass importance renderer + decoder + ray marcher (vr/renderer.py:95-268, vr/ray_marcher.py:27-66)
     on random tri-planes: 48+48 (the headline configuration), 24+24, 96+96 (gen_videos' sampling multiplier 2), coarse only,
     and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star) at EVERY ray with the importance depths teacher-forced
     (n3d_render_opts.fine_depths_in = the oracle's own); free-running, the importance pass is discontinuous in the coarse weights: the rays whose sampled
-    depths agree (all but a handful, counted) are held to 1e-3 as well."""
+    depths agree (all but a handful, counted) are held to 1e-3 as well.  Both decoders: float32-input MFMAs and the split-bf16 form the default route uses
+    (n3d_render_opts.decoder_split_bf16, ABI 8), same bounds."""
     from next3d_amd import _lib, demo as camera_utils
     N = 2
     planes = _gen((N, 3, 32, PH, PW), 60 + R, 2.0)
@@ -398,6 +400,7 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
         ro = _lib.RenderOpts()
         ro.ray_start, ro.ray_end, ro.box_side = 2.25, 3.3, 1.0
         ro.fine_depths_in, ro.fine_depths_out = _lib.ptr(fine_in), _lib.ptr(fine_out)
+        ro.decoder_split_bf16 = split
         _lib.check(_lib.lib().n3d_render_rays_ex(*[_lib.ptr(x) for x in d], _lib.ptr(feat), _lib.ptr(dep), _lib.ptr(ws_), _lib.ptr(bounds), N, R, Sc,
                                                  Sf, PH, PW, float((3.3 - 2.25) / (Sc - 1)), 2.0, ro, _lib.stream()))
         e_rgb = (feat.cpu().reshape(N, 32, R * R).permute(0, 2, 1) - rgb).abs().amax(-1)
@@ -430,7 +433,8 @@ def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW):
 
 
 @pytest.mark.parametrize('name', ['white_back', 'disparity', 'auto', 'auto_wide_fov', 'density_noise', 'all'])
-def test_render_rays_options_match_reference_golden(dev, name):
+@pytest.mark.parametrize('split', [0, 1], ids=['decoder_f32', 'decoder_split_bf16'])
+def test_render_rays_options_match_reference_golden(dev, name, split):
     """n3d_render_rays_ex — 'auto' ray bounds (per-ray box limits + the reference's repair of the rays that miss the box),
     disparity-space sampling, white_back, density noise — against the REFERENCE's own ImportanceRenderer outputs
     (tests/golden/render_opts.npz, oracle/pin_renderer_options.py), and through generator.render's reading of rendering_kwargs."""
@@ -450,6 +454,7 @@ def test_render_rays_options_match_reference_golden(dev, name):
     d = [x.contiguous().to(dev) for x in (_channels_last(planes), cams[:, :16], cams[:, 16:25], torch.linspace(lo, hi, Sc), inp['jitter'], inp['u'], w1,
                                            P['decoder.net.0.bias'], w2t, P['decoder.net.2.bias'])]
     ro = _lib.RenderOpts()
+    ro.decoder_split_bf16 = split
     ro.white_back, ro.disparity_space_sampling, ro.auto_bounds, ro.box_side = int(opts.get('white_back', False)), int(disp), int(auto), 1.0
     rb = torch.empty(N * R * R * 2, **t)
     nc, nf = (x.reshape(N, R * R, -1).contiguous().to(dev) for x in inp['noise'])
