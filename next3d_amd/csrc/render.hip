@@ -235,10 +235,15 @@ __device__ __forceinline__ void stage_decoder(const RenderParams& p, float* wimg
 //   layer 1, step s: slot (hb, j) = channel 16 hb + 8 s + j — the 16 features a lane holds are its B operands of the two steps as they are;
 //   layer 2, step t: slot (hb, q) = hidden unit 32 (t / 2) + 16 (t % 2) + 8 (q / 4) + 4 hb + q % 4 — the accumulator registers 8 (t % 2) .. + 7 of block t / 2
 //                    ARE the B operand (after softplus and the split), no cross-lane traffic; the weights are arranged to match.
-// Biases enter as the accumulators' initial values (exact).  Image: 16 rows of 64 x 16 bytes (bf16x8 per lane), then 160 floats:
+// Biases enter as the accumulators' initial values (exact).  The base-2 constants of softplus / sigmoid are folded into the weights: layer 1 computes
+// h' = log2(e) h, the hidden activation is a = log2(1 + 2^h') = softplus(h) / ln 2, the colour rows of layer 2 are NEGATED and their bias scaled by -log2(e)
+// (ln 2 log2(e) = 1: o' = -log2(e) o exactly as the sigmoid's exponent wants it), the sigma row is scaled by ln 2: two multiplies less per hidden unit, one per colour
+// (with the MFMAs cheap the kernel is VALU-bound: 341 -> 321 us).  Image: 16 rows of 64 x 16 bytes (bf16x8 per lane), then 160 floats:
 //   rows 0..7 : layer 1 [jb][step][hi|lo];  rows 8..15 : layer 2 [t][hi|lo];  floats: b1 [hb][jb][16], b2 colours [hb][16], sigma weights [hb][jb][16]
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RN_SPLIT_ROWS 16
+#define RN_LOG2E 1.44269504f
+#define RN_LN2 0.693147181f
 static_assert(RN_SPLIT_ROWS * 64 * 4 + 160 <= RN_WROWS * 64, "the split image fits the fp32 image's LDS");
 __device__ __forceinline__ void split8_rn(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -256,11 +261,11 @@ __device__ __forceinline__ void stage_decoder_split(const RenderParams& p, float
         if (row < 8) {
             const int jb = row >> 2, step = (row >> 1) & 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = p.w1[(32 * jb + l31) * RN_C + 16 * hb + 8 * step + j];
+            for (int j = 0; j < 8; ++j) v[j] = RN_LOG2E * p.w1[(32 * jb + l31) * RN_C + 16 * hb + 8 * step + j];
         } else {
             const int t = (row - 8) >> 1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = p.w2[(32 * (t >> 1) + 16 * (t & 1) + 8 * (q >> 2) + 4 * hb + (q & 3)) * 34 + 1 + l31];
+            for (int q = 0; q < 8; ++q) v[q] = -p.w2[(32 * (t >> 1) + 16 * (t & 1) + 8 * (q >> 2) + 4 * hb + (q & 3)) * 34 + 1 + l31];
         }
         bf16x8 hi, lo;
         split8_rn(v, hi, lo);
@@ -269,9 +274,9 @@ __device__ __forceinline__ void stage_decoder_split(const RenderParams& p, float
     float* fb = wimg + RN_SPLIT_ROWS * 64 * 4;
     for (int e = tid; e < 160; e += nthreads) {
         float v;
-        if (e < 64) { const int hb = e >> 5, jb = (e >> 4) & 1, r = e & 15; v = p.b1[32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
-        else if (e < 96) { const int k = e - 64, hb = k >> 4, r = k & 15; v = p.b2[1 + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
-        else { const int k = e - 96, hb = k >> 5, jb = (k >> 4) & 1, r = k & 15; v = p.w2[(32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)) * 34]; }
+        if (e < 64) { const int hb = e >> 5, jb = (e >> 4) & 1, r = e & 15; v = RN_LOG2E * p.b1[32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
+        else if (e < 96) { const int k = e - 64, hb = k >> 4, r = k & 15; v = -RN_LOG2E * p.b2[1 + 8 * (r >> 2) + 4 * hb + (r & 3)]; }
+        else { const int k = e - 96, hb = k >> 5, jb = (k >> 4) & 1, r = k & 15; v = RN_LN2 * p.w2[(32 * jb + 8 * (r >> 2) + 4 * hb + (r & 3)) * 34]; }
         fb[e] = v;
     }
 }
@@ -504,7 +509,10 @@ __device__ __forceinline__ void pass_mlp_split(const float* wimg, float bsig, in
     for (int jb = 0; jb < 2; ++jb) {
         float hs[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hs[r] = softplus_raw(jb ? h1[r] : h0[r]);
+        for (int r = 0; r < 16; ++r) {                                     // log2(1 + 2^h'), = h' beyond softplus' threshold 20 (torch.nn.Softplus' default)
+            const float x = jb ? h1[r] : h0[r];
+            hs[r] = x > 20.f * RN_LOG2E ? x : __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(x));
+        }
         if (LOADS) pass_load_part(2 + jb);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -525,7 +533,7 @@ __device__ __forceinline__ void pass_mlp_split(const float* wimg, float bsig, in
     }
     sigma = sp + __shfl_xor(sp, 32, 64) + bsig;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rgb[r] = sigmoid_raw(o[r]) * (1.f + 2.f * 0.001f) - 0.001f;
+    for (int r = 0; r < 16; ++r) rgb[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o[r])) * (1.f + 2.f * 0.001f) - 0.001f;      // o = -log2(e) x (folded): sigmoid(x)
 }
 
 // LDS of one ray: arrays sized for M = Sc + Sf samples
@@ -686,17 +694,16 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     // decode `cnt` samples per ray, slots slot0 .. slot0 + cnt - 1, whose depths are in the rays' dep[] arrays.  Passes of 32 samples
     // over the concatenated sample lists of the wave's rays; pass k + 1's gathers are issued before pass k's decoder runs.
     auto taps = [&](int g0, int cnt, int slot0, PassFetch& F) {
-        const int g = g0 + l31;
-        const bool live = g < nrays * cnt;
-        F.q = live && g >= cnt ? 1 : 0;
-        const int i = live ? g - F.q * cnt : 0;
-        F.slot = live ? slot0 + i : -1;
+        const int g = min(g0 + l31, nrays * cnt - 1);                     // (lanes beyond the last sample REPEAT it: see decode_all2)
+        F.q = g >= cnt ? 1 : 0;
+        const int i = g - F.q * cnt;
+        F.slot = slot0 + i;
         const float t = (F.q ? Ls[1] : Ls[0]).dep[slot0 + i];
         const float dx = F.q ? rdx[1] : rdx[0], dy = F.q ? rdy[1] : rdy[0], dz = F.q ? rdz[1] : rdz[0];
         pass_taps(p, n, hb, __fadd_rn(ox, __fmul_rn(t, dx)), __fadd_rn(oy, __fmul_rn(t, dy)), __fadd_rn(oz, __fmul_rn(t, dz)), F);
     };
     auto store_pass = [&](int slot, int q, const float (&rgb)[16], float sigma) {
-        if (slot >= 0) {
+        {                                                                 // (every lane owns a sample: the lanes beyond the last one repeat it, and store the same words again)
             const RayLds& L = q ? Ls[1] : Ls[0];
             if (hb == 0) {
                 if (p.noise_c) {                                          // density noise (renderer.py:152-153): one draw per decoded sample
@@ -745,10 +752,9 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     // owner pair (s, s + 32) of sample gF + s: the 12 tap offsets / weights ONCE per sample (round 5's arithmetic), parked in the sample's OWN colour row
     // (unwritten until its pass blends): offsets in floats 0..11 (written by the lane of half 0), weights in 12..23 (half 1)
     auto stage_taps = [&](int gF, int cnt, int slot0) {
-        const int g = gF + l31;
-        const bool live = g < nrays * cnt;
-        const int q = live && g >= cnt ? 1 : 0;
-        const int i = live ? g - q * cnt : 0;
+        const int g = min(gF + l31, nrays * cnt - 1);
+        const int q = g >= cnt ? 1 : 0;
+        const int i = g - q * cnt;
         const float t = (q ? Ls[1] : Ls[0]).dep[slot0 + i];
         const float dx = q ? rdx[1] : rdx[0], dy = q ? rdy[1] : rdy[0], dz = q ? rdz[1] : rdz[0];
         const float cx = p.coord_scale * __fadd_rn(ox, __fmul_rn(t, dx)), cy = p.coord_scale * __fadd_rn(oy, __fmul_rn(t, dy)), cz = p.coord_scale * __fadd_rn(oz, __fmul_rn(t, dz));
@@ -757,7 +763,7 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         plane_taps_off(0, p.PH, p.PW, cx, cy, off[0], tw[0]);                       // plane 0: (x, y)
         plane_taps_off(p.PH * p.PW, p.PH, p.PW, cx, cz, off[1], tw[1]);             // plane 1: (x, z)
         plane_taps_off(2 * p.PH * p.PW, p.PH, p.PW, cz, cy, off[2], tw[2]);         // plane 2: (z, y)   (renderer.py:42-44)
-        if (live) {
+        {
             float* row = wsm + q * rlf + (slot0 + i) * cp + 12 * hb;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
@@ -768,22 +774,24 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
     };
     // reader lane 8 a + b: sample group j = the sample gF + 8 j + a; its taps come out of the sample's row, its 12 loads fetch piece b of the 12 texels
     auto fetch_group = [&](int g0, int cnt, int slot0, int j, PassFetch2& F) {
-        const int g = g0 + 8 * j + ga;
-        const bool live = g < nrays * cnt;
-        const int q = live && g >= cnt ? 1 : 0;
-        const int i = live ? g - q * cnt : 0;
+        const int g = min(g0 + 8 * j + ga, nrays * cnt - 1);
+        const int q = g >= cnt ? 1 : 0;
+        const int i = g - q * cnt;
         const int row = q * rlf + (slot0 + i) * cp;
-        F.row[j] = live ? row : -1;
+        F.row[j] = row;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const f32x4 o4 = *reinterpret_cast<const f32x4*>(wsm + row + 4 * pl), w4 = *reinterpret_cast<const f32x4*>(wsm + row + 12 + 4 * pl);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                F.tw[j][4 * pl + k] = live ? w4[k] : 0.f;
-                F.v[j][4 * pl + k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_planes, (live ? __float_as_int(o4[k]) : 0) + gb16, 0, 0));
+                F.tw[j][4 * pl + k] = w4[k];
+                F.v[j][4 * pl + k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_planes, __float_as_int(o4[k]) + gb16, 0, 0));
             }
         }
     };
+    // A partly filled last pass has NO idle lanes: the lanes beyond the last sample repeat it (g = min(g, total - 1) everywhere — taps, loads, blend, decoder, store: the same words
+    // written twice).  The decode loop then has no lane-dependent branch at all: an MFMA takes its A rows from all 64 lanes and honours EXEC, and builds of this kernel whose
+    // partly filled passes ran under lane-dependent control flow returned wrong colours on 24 + 24 / 64 + 17 / 8 + 8 samples (profiles/r06_render_split_ab.txt).
     auto decode_all2 = [&](int cnt, int slot0) {
         const int total = nrays * cnt;
         PassFetch2 F;
@@ -794,20 +802,19 @@ __device__ __forceinline__ void render_rays_body(const RenderParams& p, float* s
         for (int g0 = 0; g0 < total; g0 += 32) {
             __builtin_amdgcn_sched_barrier(0);
             // this pass's owner pair: sample g0 + l31 -> (ray q, slot)
-            const int g = g0 + l31;
-            const bool live = g < total;
-            const int q = live && g >= cnt ? 1 : 0;
-            const int slot = live ? slot0 + g - q * cnt : -1;
+            const int g = min(g0 + l31, total - 1);
+            const int q = g >= cnt ? 1 : 0;
+            const int slot = slot0 + g - q * cnt;
             // blend in the loaded layout (waits for the texels), park the features in the samples' own colour rows, read the owner's 16 back
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 f4 = pass_blend2(F, j);
-                if (F.row[j] >= 0) *reinterpret_cast<f32x4*>(wsm + F.row[j] + (lane & 7) * 4) = f4;
+                *reinterpret_cast<f32x4*>(wsm + F.row[j] + (lane & 7) * 4) = f4;
             }
             wave_sync();
             float f[16];
             {
-                const float* own = wsm + q * rlf + max(slot, 0) * cp + 16 * hb;
+                const float* own = wsm + q * rlf + slot * cp + 16 * hb;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(own + 4 * a);

@@ -372,11 +372,13 @@ def _channels_last(planes):
 
 
 @pytest.mark.parametrize('split', [0, 1], ids=['decoder_f32', 'decoder_split_bf16'])
-@pytest.mark.parametrize('R,Sc,Sf,PH,PW', [(8, 48, 48, 32, 32), (6, 24, 24, 16, 40), (5, 96, 96, 32, 32), (4, 12, 0, 8, 8), (4, 64, 17, 24, 24)])
+@pytest.mark.parametrize('R,Sc,Sf,PH,PW', [(8, 48, 48, 32, 32), (6, 24, 24, 16, 40), (5, 96, 96, 32, 32), (4, 12, 0, 8, 8), (4, 64, 17, 24, 24),
+                                          (6, 8, 8, 16, 16), (3, 47, 2, 16, 16), (1, 48, 48, 16, 16), (3, 20, 12, 24, 24), (4, 33, 31, 24, 24), (7, 40, 8, 32, 32)])
 def test_render_rays_matches_oracle(dev, R, Sc, Sf, PH, PW, split):
     """Ray sampler + two-pass importance renderer + decoder + ray marcher (vr/renderer.py:95-268, vr/ray_marcher.py:27-66)
     on random tri-planes: 48+48 (the headline configuration), 24+24, 96+96 (gen_videos' sampling multiplier 2), coarse only,
-    and an odd split.  Tolerance 1e-3 max-abs on the composited features / depth (north_star) at EVERY ray with the importance depths teacher-forced
+    an odd split, and shapes whose LAST decode pass is partly filled in every way (few samples, one ray per wave, a two-sample importance pass: the lanes beyond the last
+    sample repeat it — builds that left them idle miscomputed exactly these).  Tolerance 1e-3 max-abs on the composited features / depth (north_star) at EVERY ray with the importance depths teacher-forced
     (n3d_render_opts.fine_depths_in = the oracle's own); free-running, the importance pass is discontinuous in the coarse weights: the rays whose sampled
     depths agree (all but a handful, counted) are held to 1e-3 as well.  Both decoders: float32-input MFMAs and the split-bf16 form the default route uses
     (n3d_render_opts.decoder_split_bf16, ABI 8), same bounds."""
