@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Renderer time per call on four shapes with fixed inputs and a checksum; run once per library (N3D_LIB=tools/probe/libn3d_<tag>.so, tools/build_variant.sh) alternating in ONE gpurun
+call — the A/B form used for every renderer change of round 6 (boxes of the pool differ by more than the effects measured)."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from next3d_amd import demo, generator
 dev = torch.device('cuda', 0)
 G, _ = demo.build_generator(dev)

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""The renderer against the oracle (teacher-forced importance depths) over shapes whose LAST decode pass is partly filled in every way — few samples, one ray per wave, a
+two-sample importance pass — for both decoders; prints the rays beyond 1e-3 and their per-channel errors.  The sweep that exposed (and now guards) the tail handling of round 6:
+profiles/r06_render_split_ab.txt.  GPU box: python tools/render_tail_sweep.py"""
 import sys, os, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from next3d_amd import _lib, demo as camera_utils
 from oracle import renderer, cases
 dev = torch.device('cuda', 0)
