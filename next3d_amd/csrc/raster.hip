@@ -405,6 +405,35 @@ __global__ __launch_bounds__(1024) void fill_holes_kernel(float* __restrict__ al
     }
 }
 
+// the four taps of a pixel as two 8-byte pairs (row 0: taps 0 / 1, row 1: taps 2 / 3): byte offset of the pair inside a channel plane and which half holds which tap
+struct TexPairs { int boff[2]; bool first_in_y[2], second_in_x[2]; };
+__device__ __forceinline__ TexPairs tex_pairs(const BilinearTaps& t) {
+    TexPairs q;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const bool ok0 = t.ok[2 * r], ok1 = t.ok[2 * r + 1];
+        // both inside: the pair starts at tap 0.  Only tap 0 inside (x = TW - 1): the pair (x - 1, x), tap 0 in its second half.  Only tap 1 inside (x = 0): the pair (0, 1), tap 1
+        // in its first half.  Neither: any legal pair (its values are not used).
+        const int first = ok0 ? (ok1 ? t.off[2 * r] : t.off[2 * r] - 1) : (ok1 ? t.off[2 * r + 1] : 0);
+        q.boff[r] = first * 4;
+        q.first_in_y[r] = ok0 && !ok1;
+        q.second_in_x[r] = !ok0 && ok1;
+    }
+    return q;
+}
+__device__ __forceinline__ float tex_pairs_apply(__amdgpu_buffer_rsrc_t r_tex, const TexPairs& q, const BilinearTaps& t, int plane_off) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const f32x2v pr = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r_tex, q.boff[r] + plane_off, 0, TEXPROJ_AGENT ? 16 : 0));
+        const float v0 = q.first_in_y[r] ? pr.y : pr.x, v1 = q.second_in_x[r] ? pr.x : pr.y;
+        if (t.ok[2 * r]) acc += v0 * t.w[2 * r];
+        if (t.ok[2 * r + 1]) acc += v1 * t.w[2 * r + 1];
+    }
+    return acc;
+}
+
 // out_plane[n][c][y][x] = sum over the plane's views of grid_sample(textures[n][c], grid[n*views+view][y][x])
 // `planes` > 1: the caller's plane list (view_a[k], view_b[k], out[k]) is processed in ONE launch (blockIdx.y = plane).
 struct TexProjPlanes { float* out[4]; int view_a[4]; int view_b[4]; };
@@ -425,10 +454,24 @@ __global__ __launch_bounds__(256) void texture_project_kernel(const float* __res
     }
     // tap offsets and weights once per pixel (bilinear_1ch's arithmetic, same accumulation order nw, ne, sw, se)
     BilinearTaps ta = bilinear_setup(TH, TW, ua, va), tb = bilinear_setup(TH, TW, ub, vb);
+    if (TW < 2 || (int64_t)C * TH * TW * 4 >= (1ll << 31)) {               // (degenerate widths / planes beyond 32-bit buffer offsets: one load per tap)
+        for (int c = 0; c < C; ++c) {
+            const float* tc = tn + (int64_t)c * TH * TW;
+            float v = bilinear_apply_tex(ta, tc);
+            if (view_b >= 0) v = v + bilinear_apply_tex(tb, tc);
+            on[(int64_t)c * H * W] = v;
+        }
+        return;
+    }
+    // Round 6: the two x-adjacent taps of a row are 8 contiguous bytes: ONE 8-byte load per tap row (buffer loads need dword alignment only) instead of two dword gathers —
+    // the kernel is bound by the texture path's per-lane address rate (64 scattered addresses per load instruction), and this halves the instructions: 138 -> 93 us per
+    // 3-plane batch-4 call (profiles/r06_texproj_pairs_ab.txt).  A row with one tap outside the texture loads the pair that holds its inside tap; same values, same sums in the same order.
+    const __amdgpu_buffer_rsrc_t r_tex = __builtin_amdgcn_make_buffer_rsrc((void*)tn, 0, C * TH * TW * 4, 0x00020000);
+    TexPairs pa = tex_pairs(ta), pb = tex_pairs(tb);
+    const int plane_bytes = TH * TW * 4;
     for (int c = 0; c < C; ++c) {
-        const float* tc = tn + (int64_t)c * TH * TW;
-        float v = bilinear_apply_tex(ta, tc);
-        if (view_b >= 0) v = v + bilinear_apply_tex(tb, tc);
+        float v = tex_pairs_apply(r_tex, pa, ta, c * plane_bytes);
+        if (view_b >= 0) v = v + tex_pairs_apply(r_tex, pb, tb, c * plane_bytes);
         on[(int64_t)c * H * W] = v;
     }
 }
