@@ -572,6 +572,77 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(ResizeParams p) {
     p.dst[((int64_t)n * p.C + c) * p.DH * p.DW + (int64_t)dy * p.DW + dx] = acc;
 }
 
+// The same resize with a DESTINATION box (the paste of the mouth plane back into the front plane: 256^2 -> an s x s box, s ~ 40, known on the device only).  resize_aa_kernel
+// spends a thread on every pixel of the destination tensor (8.4 M for batch 4, 2 % of them inside the boxes, 20 active lanes per wave) and lets each of them derive its own
+// 2 x ~13 normalised weights (26 divisions): 109 us per call.  Here a workgroup owns a band of box rows of one (sample, channel), derives the weights of its rows and of all box
+// columns ONCE into LDS, and its 256 threads walk the band's pixels: the same weights (same expressions), the same sums in the same order — identical results.
+// grid (RS_BANDS, N * C).  Falls back to the per-pixel form (weights on the fly) when the box's weight tables would not fit (RS_TAPS floats per axis).
+constexpr int RS_BANDS = 4, RS_TAPS = 3072, RS_DIM = 512;
+__global__ __launch_bounds__(256) void resize_aa_paste_kernel(ResizeParams p) {
+    __shared__ float s_wx[RS_TAPS], s_wy[RS_TAPS];
+    __shared__ int s_x0[RS_DIM], s_xn[RS_DIM], s_y0[RS_DIM], s_yn[RS_DIM];
+    const int tid = threadIdx.x, band = blockIdx.x, n = blockIdx.y / p.C, c = blockIdx.y % p.C;
+    const int* b = p.dst_box + n * 4;
+    const int oy0 = b[0], ox0 = b[2], oh = b[1] - b[0], ow = p.dst_square ? oh : b[3] - b[2];
+    int sy0 = 0, sx0 = 0, sh = p.SH, sw = p.SW;
+    if (p.src_box) { const int* sb = p.src_box + n * 4; sy0 = sb[0]; sx0 = sb[2]; sh = sb[1] - sb[0]; sw = sb[3] - sb[2]; }
+    if (oh <= 0 || ow <= 0 || sh <= 0 || sw <= 0) return;
+    const int cy0 = max(sy0, 0), cx0 = max(sx0, 0);                       // clamp the source box to the tensor (python slicing semantics)
+    sh = min(sy0 + sh, p.SH) - cy0; sw = min(sx0 + sw, p.SW) - cx0;
+    if (sh <= 0 || sw <= 0) return;
+    const int r0 = (int)((int64_t)oh * band / RS_BANDS), r1 = (int)((int64_t)oh * (band + 1) / RS_BANDS);      // this workgroup's box rows
+    if (r1 <= r0) return;
+    const float* src = p.src + (int64_t)n * p.src_bs + (int64_t)c * p.SH * p.SW;
+    float* dst = p.dst + ((int64_t)n * p.C + c) * p.DH * p.DW;
+    // support of an axis: 2 * max(scale, 1) + 1 taps per pixel at most
+    const float scx = (float)sw / (float)ow, scy = (float)sh / (float)oh;
+    const int tx_max = (int)(2.f * fmaxf(scx, 1.f)) + 2, ty_max = (int)(2.f * fmaxf(scy, 1.f)) + 2;
+    const bool tables = ow <= RS_DIM && (r1 - r0) <= RS_DIM && (int64_t)ow * tx_max <= RS_TAPS && (int64_t)(r1 - r0) * ty_max <= RS_TAPS;
+    if (tables) {
+        for (int rx = tid; rx < ow; rx += 256) {
+            int xmin, xsize; float cxc, xinv, xtot;
+            aa_range(rx, sw, ow, xmin, xsize, cxc, xinv, xtot);
+            s_x0[rx] = xmin; s_xn[rx] = xsize;
+            for (int jx = 0; jx < xsize; ++jx) s_wx[rx * tx_max + jx] = tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot;
+        }
+        for (int ry = r0 + tid; ry < r1; ry += 256) {
+            int ymin, ysize; float cyc, yinv, ytot;
+            aa_range(ry, sh, oh, ymin, ysize, cyc, yinv, ytot);
+            s_y0[ry - r0] = ymin; s_yn[ry - r0] = ysize;
+            for (int jy = 0; jy < ysize; ++jy) s_wy[(ry - r0) * ty_max + jy] = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < (r1 - r0) * ow; e += 256) {
+        const int ry = r0 + e / ow, rx = e % ow, dy = oy0 + ry, dx = ox0 + rx;
+        if (dy < 0 || dy >= p.DH || dx < 0 || dx >= p.DW) continue;       // the part of the box outside the tensor is not written
+        float acc = 0.f;
+        if (tables) {
+            const int xmin = s_x0[rx], xsize = s_xn[rx], ymin = s_y0[ry - r0], ysize = s_yn[ry - r0];
+            const float* wx = s_wx + rx * tx_max, *wy = s_wy + (ry - r0) * ty_max;
+            for (int jy = 0; jy < ysize; ++jy) {
+                const float* row = src + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
+                float h = 0.f;
+                for (int jx = 0; jx < xsize; ++jx) h += row[jx] * wx[jx];
+                acc += h * wy[jy];
+            }
+        } else {
+            int ymin, ysize, xmin, xsize;
+            float cyc, cxc, yinv, xinv, ytot, xtot;
+            aa_range(ry, sh, oh, ymin, ysize, cyc, yinv, ytot);
+            aa_range(rx, sw, ow, xmin, xsize, cxc, xinv, xtot);
+            for (int jy = 0; jy < ysize; ++jy) {
+                const float wyv = tri_filter(((float)(jy + ymin) - cyc + 0.5f) * yinv) / ytot;
+                const float* row = src + (int64_t)(cy0 + ymin + jy) * p.SW + cx0 + xmin;
+                float h = 0.f;
+                for (int jx = 0; jx < xsize; ++jx) h += row[jx] * (tri_filter(((float)(jx + xmin) - cxc + 0.5f) * xinv) / xtot);
+                acc += h * wyv;
+            }
+        }
+        dst[(int64_t)dy * p.DW + dx] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void raster_clear_kernel(unsigned long long* __restrict__ zbuf, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -784,7 +855,10 @@ int n3d_resize_aa_strided(const float* src, int64_t src_batch_stride, float* dst
     p.dst_square = dst_square;
     p.src_bs = src_batch_stride ? src_batch_stride : (int64_t)C * SH * SW;
     N3dProfScope prof(N3D_K_MISC, stream, 0.0, 4.0 * N * C * ((double)SH * SW + (double)DH * DW));
-    hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)cdiv64((int64_t)N * C * DH * DW, 256)), dim3(256), 0, stream, p);
+    if (dst_box && (int64_t)N * C < 65536)                                // a destination box: one workgroup per band of box rows of a (sample, channel)
+        hipLaunchKernelGGL(resize_aa_paste_kernel, dim3(RS_BANDS, (unsigned)(N * C)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(resize_aa_kernel, dim3((unsigned)cdiv64((int64_t)N * C * DH * DW, 256)), dim3(256), 0, stream, p);
     N3D_LAUNCH_CHECK();
     return 0;
 }

@@ -307,6 +307,17 @@ def test_resize_aa_crop_and_paste_boxes(dev):
         assert _md(dst[i:i + 1], ref) <= 5e-6
         outside = torch.ones(256, 256, dtype=torch.bool); outside[y0:y1, x0:x1] = False
         assert torch.equal(dst[i].cpu()[:, outside], dst0[i][:, outside])
+    # the paste kernel's other regimes: a tiny box (66 taps per axis), a box wider than its LDS weight tables (weights on the fly), a box that sticks out of the tensor
+    for (SH, DH, box) in [(256, 64, [20, 28, 30, 38]), (1024, 800, [20, 720, 30, 730]), (256, 256, [200, 300, -20, 80])]:
+        src, dst0 = _gen((1, 2, SH, SH), 45), _gen((1, 2, DH, DH), 46)
+        y0, y1, x0, x1 = box
+        s = y1 - y0
+        dst = _resize(dev, src.to(dev), dst0.clone().to(dev), None, torch.tensor([box], dtype=torch.int32).to(dev), 1)
+        full = F.interpolate(src, size=(s, s), mode='bilinear', antialias=True)
+        ref = dst0.clone()
+        ys, xs = slice(max(y0, 0), min(y1, DH)), slice(max(x0, 0), min(x1, DH))
+        ref[:, :, ys, xs] = full[:, :, ys.start - y0:ys.stop - y0, xs.start - x0:xs.stop - x0]
+        assert _md(dst, ref) <= 5e-6, (SH, DH, box)
 
 
 # ------------------------------------------------------------------------------------------------ blend + renderer
