@@ -1017,13 +1017,16 @@ int conv2d_up_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
 // epilogue of conv2d_ps_bf16x3_body; optional split-K like the register-staged kernel.
 // Patch pixels beyond the image (only ever feeding outputs beyond OH x OW, which are not stored) read whatever follows in
 // the sample, or zeros beyond its end (descriptor range check).
-constexpr int S2_BM = 64, S2_TH = 16, S2_TW = 32;
+constexpr int S2_BM = 64, S2_TH = 16, S2_TW = 32;                                     // (S2_BM: the shipped kernel's channels per workgroup; the body is a template over it)
 constexpr int S2_PH = S2_TH + 1, S2_PW = S2_TW + 1, S2_PPIX = S2_PH * S2_PW;         // 17 x 33 = 561
 constexpr int S2_BCH = (S2_PPIX + 63) / 64, S2_BPAD = S2_BCH * 64;                    // 9 pieces = 576 slots per (hi|lo, half)
-constexpr int S2_A_SZ = 4 * 2 * S2_BM, S2_B_SZ = 2 * S2_BPAD;                          // per hi|lo: [slot 4][half][row], [half][pixel]
-constexpr int S2_BUF = 2 * S2_A_SZ + 2 * S2_B_SZ;                                      // 3328 slots = 53,248 B
+constexpr int S2_B_SZ = 2 * S2_BPAD;                                                  // per hi|lo: [half][pixel]
+constexpr int s2_a_sz(int bm) { return 4 * 2 * bm; }                                   // per hi|lo: [slot 4][half][row]
+constexpr int s2_buf(int bm) { return 2 * s2_a_sz(bm) + 2 * S2_B_SZ; }                 // BM 64: 3328 slots = 53,248 B; BM 128: 4352 slots = 69,632 B
 constexpr int S2_B_PIECES = 2 * 2 * S2_BCH;                                            // 36
-constexpr int S2_NBUF = 3;
+// MTW = 32-channel groups per workgroup, NBUF LDS buffers.  <2, 3>: shipped (64 channels, the DMA of stage s + 2 in flight).  <4, 2> (tuning builds, N3D_S2_WIDE=1; VERDICT r5
+// item 1c): 128 channels per workgroup — the patch is staged once per 128 output channels instead of per 64, each patch fragment a wave reads feeds twice the MFMAs (12 fragment
+// reads per 24 MFMAs and tap instead of 8 per 12), 128 accumulators per lane — but only TWO 68 KB buffers fit: the DMA queue is one stage deep.
 
 struct ConvS2PsParams {
     const bf16x8* x; const bf16x8* wt16; float* y; float* partial;
@@ -1033,8 +1036,9 @@ struct ConvS2PsParams {
     n3d_epilogue epi;
 };
 
-__global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsParams p) {
-    __shared__ bf16x8 smem[S2_NBUF * S2_BUF + 2 * S2_BM * 4 / 16];
+template <int MTW, int NBUF>
+__device__ __forceinline__ void conv2d_s2_ps_body(const ConvS2PsParams& p, bf16x8* smem) {
+    constexpr int BM = 32 * MTW, A_SZ = s2_a_sz(BM), BUF = s2_buf(BM), AW = BM / 64;      // AW: 64-row weight pieces per (slot, hi|lo, half)
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     int lb;
@@ -1042,7 +1046,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int m0 = (lb % p.tiles_m) * S2_BM; lb /= p.tiles_m;
+    const int m0 = (lb % p.tiles_m) * BM; lb /= p.tiles_m;
     const int tile_i = lb % (p.tiles_x * p.tiles_y); lb /= (p.tiles_x * p.tiles_y);
     const int ks = lb % p.ksplit, n = lb / p.ksplit;
     const int y0 = (tile_i / p.tiles_x) * S2_TH, x0 = (tile_i % p.tiles_x) * S2_TW;
@@ -1061,7 +1065,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int q = wn + 8 * j, hl = q / (2 * S2_BCH), hf = (q / S2_BCH) & 1, c = q % S2_BCH;
-        ldsB[j] = 2 * S2_A_SZ + hl * S2_B_SZ + hf * S2_BPAD + c * 64;
+        ldsB[j] = 2 * A_SZ + hl * S2_B_SZ + hf * S2_BPAD + c * 64;
         sofB[j] = hl * plane_bytes + hf * HW * 16;
         const int pp = c * 64 + lane;
         const int iy = 2 * (y0 + pp / S2_PW), ix = 2 * (x0 + pp % S2_PW);   // phase (0, 0) pixel; the phase adds (py W + px) * 16 to the scalar offset
@@ -1073,14 +1077,14 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
     auto copy_stage = [&](int st) {
         const int c = c_begin + (st >> 2), g = st & 3, py = g >> 1, px = g & 1;
         const int nx = px ? 1 : 2, nt = (py ? 1 : 2) * nx;
-        bf16x8* base = smem + (st % S2_NBUF) * S2_BUF;
+        bf16x8* base = smem + (st % NBUF) * BUF;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int a = wn + 8 * j;
-            if (a < 4 * nt) {
-                const int slot = a >> 2, hl = (a >> 1) & 1, hf = a & 1;
+        for (int j = 0; j < 2 * AW; ++j) {
+            const int a = wn + 8 * j;                                     // piece a = (slot, hi|lo, half, 64-row part)
+            if (a < 4 * nt * AW) {
+                const int mh = a % AW, a4 = a / AW, slot = a4 >> 2, hl = (a4 >> 1) & 1, hf = a4 & 1;
                 const int ky = py ? 1 : 2 * (slot / nx), kx = px ? 1 : 2 * (slot % nx);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + hl * S2_A_SZ + (slot * 2 + hf) * S2_BM), 16, voffA,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void*)(base + hl * A_SZ + (slot * 2 + hf) * BM + mh * 64), 16, voffA + mh * 64 * 16,
                                                          ((((ky * 3 + kx) * KC + c) * 2 + hl) * 2 + hf) * p.OP64 * 16, 0, 0);
             }
         }
@@ -1091,53 +1095,73 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x, (lds_void*)(base + ldsB[j]), 16, voffB[j], sofB[j] + sph, 0, 0);
     };
     // DMA instructions this wave issues for a stage of phase g: patch 5 (waves 0-3) or 4, weights 2 / 1 / 1 / (waves 0-3: 1, else 0)
-    auto dma_count = [&](int g) { return (wn < 4 ? 5 : 4) + (g == 0 ? 2 : (g == 3 ? (wn < 4 ? 1 : 0) : 1)); };
+    auto dma_count = [&](int g) { return (wn < 4 ? 5 : 4) + (g == 0 ? 2 : (g == 3 ? (wn < 4 ? 1 : 0) : 1)); };      // (MTW = 2: the three-buffer pipeline's wait counts)
 
-    f32x16 acc[2][2];
+    f32x16 acc[MTW][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    const int a_frag = half * S2_BM + l31;                                // + slot*2*BM + mt*32
+    const int a_frag = half * BM + l31;                                   // + slot*2*BM + mt*32
     const int b_frag = half * S2_BPAD + (wn * 2) * S2_PW + l31;           // + nt*PW + dy*PW + dx
     auto mfma_taps = [&](int st, auto ny_c, auto nx_c) {                  // taps (dy, dx), dy < NY, dx < NX; slot = dy*NX + dx
         constexpr int NY = decltype(ny_c)::value, NX = decltype(nx_c)::value;
-        const bf16x8* A_hi = smem + (st % S2_NBUF) * S2_BUF, *A_lo = A_hi + S2_A_SZ, *B_hi = A_hi + 2 * S2_A_SZ, *B_lo = B_hi + S2_B_SZ;
+        const bf16x8* A_hi = smem + (st % NBUF) * BUF, *A_lo = A_hi + A_SZ, *B_hi = A_hi + 2 * A_SZ, *B_lo = B_hi + S2_B_SZ;
         __builtin_amdgcn_s_setprio(1);
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        bf16x8 ah[2], al[2], bh[2], bl[2];                                // (weight fragments two channel groups at a time: MTW = 4 has 128 accumulators and 256 registers)
 #pragma unroll
         for (int dy = 0; dy < NY; ++dy)
 #pragma unroll
             for (int dx = 0; dx < NX; ++dx) {
                 const int slot = dy * NX + dx, boff = dy * S2_PW + dx;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) { ah[mt] = A_hi[slot * 2 * S2_BM + a_frag + mt * 32]; al[mt] = A_lo[slot * 2 * S2_BM + a_frag + mt * 32]; }
-#pragma unroll
                 for (int nt = 0; nt < 2; ++nt) { bh[nt] = B_hi[b_frag + nt * S2_PW + boff]; bl[nt] = B_lo[b_frag + nt * S2_PW + boff]; }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mp = 0; mp < MTW; mp += 2) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {                      // pixels = matrix rows, as conv2d_ps_bf16x3_body
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-                    }
+                    for (int m = 0; m < 2; ++m) { ah[m] = A_hi[slot * 2 * BM + a_frag + (mp + m) * 32]; al[m] = A_lo[slot * 2 * BM + a_frag + (mp + m) * 32]; }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {                  // pixels = matrix rows, as conv2d_ps_bf16x3_body
+                            acc[mp + m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[m], acc[mp + m][nt], 0, 0, 0);
+                            acc[mp + m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[m], acc[mp + m][nt], 0, 0, 0);
+                            acc[mp + m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[m], acc[mp + m][nt], 0, 0, 0);
+                        }
+                    if (MTW > 2) __builtin_amdgcn_sched_barrier(0);       // (keeps the scheduler from hoisting every tap's fragment reads: 128 accumulators leave no room for them)
+                }
             }
         __builtin_amdgcn_s_setprio(0);
     };
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
 
-    float* s_rs = reinterpret_cast<float*>(smem + S2_NBUF * S2_BUF), *s_bs = s_rs + S2_BM;
+    float* s_rs = reinterpret_cast<float*>(smem + NBUF * BUF), *s_bs = s_rs + BM;
     const n3d_epilogue& E = p.epi;
-    if (tid < S2_BM) {
+    if (tid < BM) {
         const int o = min(m0 + tid, p.O - 1);
         s_rs[tid] = E.const_scale * (E.row_scale ? E.row_scale[(int64_t)n * (E.row_scale_stride ? E.row_scale_stride : p.O) + o] : 1.f);
         s_bs[tid] = E.bias ? E.bias[o] : 0.f;
     }
 
+    if (NBUF == 2) {                                                      // two buffers: stage st + 1 lands under the MFMAs of stage st
+        if (nstage > 0) copy_stage(0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        for (int st = 0; st < nstage; ++st) {
+            if (st + 1 < nstage) copy_stage(st + 1);                      // its buffer's last readers passed the barrier of iteration st - 1
+            switch (st & 3) {
+                case 0: mfma_taps(st, I2{}, I2{}); break;
+                case 1: mfma_taps(st, I2{}, I1{}); break;
+                case 2: mfma_taps(st, I1{}, I2{}); break;
+                default: mfma_taps(st, I1{}, I1{}); break;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
     if (nstage > 0) copy_stage(0);
     if (nstage > 1) copy_stage(1);
     // stage 0 must be complete: at most the pieces of stage 1 may still be in flight (vmcnt counts in order)
@@ -1163,6 +1187,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
         }
         __builtin_amdgcn_s_barrier();
     }
+    }
 
     // epilogue (conv2d_ps_bf16x3_body's): lane = one channel of group mt, 16 pixels of the wave's row nt in 4 runs of 4
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1170,7 +1195,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
     if (p.partial) {                                                      // split-K: raw sums, reduced by conv16_splitk_epilogue_kernel
         const bool vec4 = (p.OW & 3) == 0;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
             const int o = m0 + mt * 32 + l31;
             if (o >= p.O) continue;
 #pragma unroll
@@ -1197,7 +1222,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
     const bool vec = ((p.OW | p.yrs | p.ybs) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 &&
                      (!E.residual || ((E.residual_batch_stride & 3) == 0 && ((uintptr_t)E.residual & 15) == 0)) && (!E.noise || ((uintptr_t)E.noise & 15) == 0);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
         const int o = m0 + mt * 32 + l31;
         if (o >= p.O) continue;
         const float rs = s_rs[mt * 32 + l31], bs = s_bs[mt * 32 + l31];
@@ -1243,6 +1268,15 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsPar
     }
 }
 
+__global__ __launch_bounds__(512, 2) void conv2d_s2_ps_bf16x3_kernel(ConvS2PsParams p) {
+    __shared__ bf16x8 smem[3 * s2_buf(64) + 2 * 64 * 4 / 16];
+    conv2d_s2_ps_body<2, 3>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv2d_s2_ps128_bf16x3_kernel(ConvS2PsParams p) {                   // tuning builds: N3D_S2_WIDE=1
+    __shared__ bf16x8 smem[2 * s2_buf(128) + 2 * 128 * 4 / 16];
+    conv2d_s2_ps_body<4, 2>(p, smem);
+}
+
 int conv16_splitk_epilogue_launch(const float* partial, float* y, int ksplit, int N, int O, int OH, int OW, int64_t ybs, int64_t yrs,
                                   const n3d_epilogue& epi, hipStream_t stream);          // conv2d_bf16x3.hip
 
@@ -1259,7 +1293,8 @@ int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     p.x = (const bf16x8*)d->x; p.wt16 = (const bf16x8*)d->wt; p.y = d->y; p.partial = d->workspace;
     p.N = d->N; p.I = d->I; p.O = d->O; p.OP64 = (d->O + 63) / 64 * 64; p.H = d->H; p.W = d->W;
     p.OH = (d->H - 3) / 2 + 1; p.OW = (d->W - 3) / 2 + 1;
-    p.tiles_x = cdiv(p.OW, S2_TW); p.tiles_y = cdiv(p.OH, S2_TH); p.tiles_m = cdiv(p.O, S2_BM);
+    const bool wide = n3d_tune("N3D_S2_WIDE", 0) != 0 && p.O % 128 == 0;
+    p.tiles_x = cdiv(p.OW, S2_TW); p.tiles_y = cdiv(p.OH, S2_TH); p.tiles_m = cdiv(p.O, wide ? 128 : S2_BM);
     p.xbs = d->x_batch_stride ? d->x_batch_stride / 4 : (int64_t)2 * (d->I / 8) * d->H * d->W;
     p.ybs = d->y_batch_stride; p.yrs = d->y_row_stride ? d->y_row_stride : p.OW;
     N3D_CHECK(p.yrs >= p.OW, "conv2d_bf16x3: y_row_stride smaller than the output width");
@@ -1275,7 +1310,8 @@ int conv2d_s2_ps_bf16x3_launch(const n3d_conv2d_desc* d, hipStream_t stream) {
     const double flops = 2.0 * d->N * (double)d->O * d->I * 9 * (double)p.OH * p.OW;
     const double bytes = 4.0 * ((double)d->N * d->I * d->H * d->W + (double)d->N * d->O * p.OH * p.OW + (double)d->O * d->I * 9);
     N3dProfScope prof(N3D_K_CONV2D_BF16X3, stream, flops, bytes);
-    hipLaunchKernelGGL(conv2d_s2_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    if (wide) hipLaunchKernelGGL(conv2d_s2_ps128_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv2d_s2_ps_bf16x3_kernel, dim3((unsigned)nblk), dim3(512), 0, stream, p);
     N3D_LAUNCH_CHECK();
     if (p.ksplit > 1) return conv16_splitk_epilogue_launch(p.partial, p.y, p.ksplit, p.N, p.O, p.OH, p.OW, p.ybs, p.yrs, p.epi, stream);
     return 0;
