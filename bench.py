@@ -46,7 +46,7 @@ sys.path.insert(0, REPO)
 PEAK_L2_TBPS = 34.5                 # aggregate L2 bandwidth, /opt/skills/guides/MI355X_MICROARCH.md (L2 per XCD)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 matrix peak (same guide); bf16x3 spends 3 bf16 MFMAs per algorithmic MAC
-TRAFFIC_PROFILE = os.path.join(REPO, "profiles", "r05_traffic_pmc.json")
+TRAFFIC_PROFILE = os.path.join(REPO, "profiles", "r06_traffic_pmc.json")
 CPU_REFERENCE_PROFILE = os.path.join(REPO, 'profiles', 'r03_cpu_reference.json')
 # what the bf16 matrix pipe sustains with the kernels' instruction mix and RANDOM operands (tools/mfma_peak.hip, profiles/r02_mfma_peak_probe.txt:
 # 1850-1950 TFLOP/s bf16 = 617-650 fp32-equivalent; the chip power-limits to ~1.8 GHz under this load)
@@ -347,7 +347,7 @@ def main():
         # ---- the volume renderer (n3d_render_rays_ex: depth-bounds pre-pass + render_rays_kernel) against what bounds it: the texel gathers.
         # Algorithmic bytes = 12 texels x 128 B per sample point (3 planes x 4 bilinear taps x 32 float32 channels; nothing is shared between
         # points in the accounting) over the HIP-event time of the entry point.  The planes (25 MB per sample) are L2 / Infinity-Cache resident:
-        # the bound is the L2 -> L1 -> register gather path, not HBM.  PMC of this kernel: profiles/r05_render_pmc.txt.
+        # the bound is the L2 -> L1 -> register gather path, not HBM.  PMC of this kernel: profiles/r06_render_pmc_final.txt.
         rr = prof.get('render_rays')
         if rr and rr['ms'] > 0:
             tb = rr['bytes'] / (rr['ms'] * 1e-3) / 1e12
@@ -356,7 +356,7 @@ def main():
                                        'decoder_tflops': rr['flops'] / (rr['ms'] * 1e-3) / 1e12,
                                        'note': 'achieved = 12 texels x 128 B per sample point / HIP-event time of n3d_render_rays_ex (batch of rays: N x 64 x 64 x (48 + 48)); '
                                                'peak = aggregate L2 bandwidth of /opt/skills/guides/MI355X_MICROARCH.md (34.5 TB/s); measured L1 / L2 request rates and the '
-                                               'reason the kernel sits where it does: profiles/r05_render_pmc.txt, DESIGN.md 3.2'}
+                                               'reason the kernel sits where it does: profiles/r06_render_pmc_final.txt, DESIGN.md 3.2'}
 
     extras = {}
     frames_total, elapsed_total = args.steps * B * world, elapsed
